@@ -1,0 +1,149 @@
+/*
+ * mvoracle.h -- CPU restatement (plain C99) of the mvtools hot path:
+ *   mv.Super -> mv.Analyse -> mv.DegrainN / mv.Compensate.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as the
+ * checker / reported CPU baseline.  The product (libmvtools_amd.so) never links or calls it.
+ *
+ * Every function cites the reference file:line (relative to /root/reference/src) it restates.
+ *
+ * PINNING STATUS (see oracle/README.md and DESIGN.md):
+ *   - kernel level (SAD, SATD, overlap windows, overlaps accumulate, ToPixels, 8-bit Wiener/bilinear
+ *     refine, block copy): checked against oracle/_ref, the reference's own translation units
+ *     compiled unmodified from /root/reference (the ones that need no absent header).
+ *   - Super+Analyse end to end: checked against the three vector-blob hashes SURVEY.md 8(c) records
+ *     from the reference (6d02e770, b899c7de, 9ee5c88e).
+ *   - MVFrame.cpp / PlaneOfBlocks.cpp / GroupOfPlanes.c / Fakery.c / MVDegrains.h cannot be compiled
+ *     here without stand-ins for the absent VapourSynth headers, so beyond the two items above the
+ *     pyramid, the search driver, Degrain weights and Compensate are "parity unpinned".
+ */
+#ifndef MVORACLE_H
+#define MVORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVO_UNSET (-2147483647 - 1) /* "argument not passed" sentinel for optional filter args */
+#define MVO_MAX_LEVELS 32
+#define MVO_ERR 256
+
+/* wire types: MVAnalysisData.h:40-44, :83-134 */
+typedef struct mvo_vector { int x, y; int64_t sad; } mvo_vector;
+
+typedef struct mvo_analysis_data {
+    int nMagicKey, nVersion, nBlkSizeX, nBlkSizeY, nPel, nLvCount, nDeltaFrame, isBackward, nCPUFlags,
+        nMotionFlags, nWidth, nHeight, nOverlapX, nOverlapY, nBlkX, nBlkY, bitsPerSample, yRatioUV,
+        xRatioUV, nHPadding, nVPadding;
+} mvo_analysis_data;
+
+/* ---- geometry: MVFrame.cpp:1209-1247 ---- */
+int mvo_plane_height_luma(int src_height, int level, int yRatioUV, int vpad);
+int mvo_plane_width_luma(int src_width, int level, int xRatioUV, int hpad);
+unsigned mvo_plane_super_offset(int chroma, int src_height, int level, int pel, int vpad, int plane_pitch, int yRatioUV);
+
+/* ---- mv.Super: MVSuper.c ---- */
+typedef struct mvo_super {
+    /* clip */
+    int width, height, bits, xRatioUV, yRatioUV, gray;
+    /* resolved args */
+    int hpad, vpad, pel, levels, chroma, sharp, rfilter;
+    int modeYUV;                 /* 1 = Y only, 7 = YUV */
+    int superWidth, superHeight; /* luma dims of the super frame */
+} mvo_super;
+
+/* args may be MVO_UNSET; returns 0 or -1 with message in err (same strings as MVSuper.c:179-206) */
+int mvo_super_init(mvo_super *s, int width, int height, int bits, int subW, int subH, int gray,
+                   int hpad, int vpad, int pel, int levels, int chroma, int sharp, int rfilter, char *err);
+/* dst planes: pitch[p] * (superHeight >> (p?subH:0)) bytes each; zero-filled inside (MVSuper.c:75) */
+void mvo_super_frame(const mvo_super *s, const uint8_t *const src[3], const int srcPitch[3],
+                     uint8_t *const dst[3], const int dstPitch[3]);
+
+/* ---- mv.Analyse: MVAnalyse.c, GroupOfPlanes.c, PlaneOfBlocks.cpp ---- */
+typedef struct mvo_analyse_args { /* every field may be MVO_UNSET */
+    int blksize, blksizev, levels, search, searchparam, pelsearch, isb, lambda, chroma, delta, truemotion,
+        lsad, plevel, global, pnew, pzero, pglobal, overlap, overlapv, divide, badsad, badrange, opt,
+        meander, trymany, fields, tff, search_coarse, dct;
+} mvo_analyse_args;
+
+typedef struct mvo_analyse {
+    mvo_analysis_data ad;
+    int searchType, searchTypeCoarse, nSearchParam, nPelSearch, nLambda, lsad, pnew, plevel, global, pglobal,
+        pzero, divideExtra, badrange, meander, tryMany, dctmode, chroma, fields, tff, tff_exists, opt;
+    int64_t badSAD;
+    int nSuperLevels, nSuperHPad, nSuperVPad, nSuperPel, nSuperModeYUV;
+    int numFrames;
+} mvo_analyse;
+
+void mvo_analyse_args_default(mvo_analyse_args *a); /* all MVO_UNSET */
+int mvo_analyse_init(mvo_analyse *d, const mvo_analyse_args *a, const mvo_super *s, int numFrames, char *err);
+int mvo_analyse_blob_size(const mvo_analyse *d);
+/* ref == NULL -> "too close to the clip boundary": default (invalid) blob. fieldShift normally 0. */
+void mvo_analyse_frame(const mvo_analyse *d, const uint8_t *const src[3], const int srcPitch[3],
+                       const uint8_t *const ref[3], const int refPitch[3], int fieldShift, uint8_t *blob);
+
+/* ---- vector blob reader: Fakery.c, MVAnalysisData.c:7-31 ---- */
+void mvo_scale_thscd(int64_t *thscd1, int *thscd2, const mvo_analysis_data *ad);
+int mvo_blob_is_usable(const mvo_analysis_data *ad, const uint8_t *blob, int64_t thscd1, int thscd2);
+const mvo_vector *mvo_blob_level0(const mvo_analysis_data *ad, const uint8_t *blob);
+
+/* ---- overlap windows: Overlap.cpp:40-125 ---- */
+void mvo_over_init(int16_t *win9, int nx, int ny, int ox, int oy); /* win9: 9*nx*ny */
+
+/* ---- mv.DegrainN: MVDegrains.cpp/.h ---- */
+typedef struct mvo_degrain {
+    int radius;
+    mvo_analysis_data ad; /* vectors_data[0] */
+    int64_t thSAD[3];
+    int64_t nSCD1; int nSCD2;
+    int nLimit[3];
+    int process[3];
+    int nSuperHPad, nSuperVPad, nSuperPel, nSuperModeYUV, nSuperLevels;
+    int bits, numPlanes, xSubUV, ySubUV;
+    int nWidth[3], nHeight[3], nOverlapX[3], nOverlapY[3], nBlkSizeX[3], nBlkSizeY[3], nWidth_B[3], nHeight_B[3];
+} mvo_degrain;
+
+int mvo_degrain_init(mvo_degrain *d, int radius, const mvo_analysis_data *ad, const mvo_super *s,
+                     int64_t thsad, int64_t thsadc, int plane, int limit, int limitc, int64_t thscd1, int thscd2, char *err);
+/* refs[r] = super frame planes of frame n+/-delta_r (may be NULL if out of clip); blobs[r] = MVTools_vectors
+ * of vector clip r at frame n; order mvbw, mvfw, mvbw2, mvfw2 ... (MVDegrains.h:10-23) */
+void mvo_degrain_frame(const mvo_degrain *d, const uint8_t *const src[3], const int srcPitch[3],
+                       const uint8_t *const (*refs)[3], const int (*refPitch)[3], const uint8_t *const *blobs,
+                       uint8_t *const dst[3], const int dstPitch[3]);
+
+/* ---- mv.Compensate: MVCompensate.c ---- */
+typedef struct mvo_compensate {
+    mvo_analysis_data ad;
+    int64_t thSAD, nSCD1; int nSCD2;
+    int scBehavior, time256, fields;
+    int nSuperHPad, nSuperVPad, nSuperPel, nSuperModeYUV, nSuperLevels;
+    int bits, numPlanes;
+} mvo_compensate;
+
+int mvo_compensate_init(mvo_compensate *d, const mvo_analysis_data *ad, const mvo_super *s, int scbehavior,
+                        int64_t thsad, double time, int64_t thscd1, int thscd2, char *err);
+/* srcSuper = super frame n, refSuper = super frame nref (NULL if out of range), blob = vectors at n */
+void mvo_compensate_frame(const mvo_compensate *d, const uint8_t *const srcSuper[3], const int srcPitch[3],
+                          const uint8_t *const refSuper[3], const int refPitch[3], const uint8_t *blob,
+                          uint8_t *const dst[3], const int dstPitch[3]);
+
+/* ---- kernel-level entry points (for pinning against oracle/_ref) ---- */
+unsigned mvo_sad(int w, int h, int bits, const uint8_t *src, intptr_t srcPitch, const uint8_t *ref, intptr_t refPitch);
+unsigned mvo_satd(int w, int h, int bits, const uint8_t *src, intptr_t srcPitch, const uint8_t *ref, intptr_t refPitch);
+void mvo_overlaps(int w, int h, int bits, uint8_t *dst, intptr_t dstPitch, const uint8_t *src, intptr_t srcPitch,
+                  const int16_t *win, intptr_t winPitch);
+void mvo_to_pixels(int bits, uint8_t *dst, int dstPitch, const uint8_t *src, int srcPitch, int w, int h);
+/* kind: 0 H-bilinear 1 V-bilinear 2 D-bilinear 3 H-bicubic 4 V-bicubic 5 H-wiener 6 V-wiener */
+void mvo_refine_plane(int kind, int bits, uint8_t *dst, const uint8_t *src, intptr_t pitch, intptr_t w, intptr_t h);
+void mvo_average2(int bits, uint8_t *dst, const uint8_t *a, const uint8_t *b, intptr_t pitch, intptr_t w, intptr_t h);
+
+uint32_t mvo_fnv1a(const uint8_t *p, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
