@@ -1,0 +1,182 @@
+/*
+ * mvtools_amd.h -- C ABI of libmvtools_amd.so, the MI355X (gfx950) implementation of the mvtools hot path
+ *   mv.Super -> mv.Analyse -> mv.Degrain1..6 / mv.Compensate.
+ *
+ * This is the drop-in boundary: a VapourSynth filter shell (or any other host) binds exactly these entry
+ * points.  Plain pointers and sizes only.  Each entry point names the reference interface it replaces
+ * (paths relative to dubhater/vapoursynth-mvtools src/).
+ *
+ * Conventions
+ *   - every image pointer is a DEVICE pointer (HBM) unless the function name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work is enqueued
+ *     asynchronously on it, the caller synchronises;
+ *   - optional filter arguments take MVX_UNSET to mean "not passed" (the reference's defaults apply);
+ *   - functions return 0 on success, a negative code on failure; mvx_*_create additionally write the
+ *     reference's user-visible error string (e.g. "Super: pel must be 1, 2, or 4.") into `err`.
+ *   - there is NO CPU fallback: if no gfx950 device / kernel image is available the call fails.
+ */
+#ifndef MVTOOLS_AMD_H
+#define MVTOOLS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVX_UNSET (-2147483647 - 1)
+#define MVX_ERRLEN 256
+
+#define MVX_OK 0
+#define MVX_E_ARG (-1)     /* invalid filter argument (message in err) */
+#define MVX_E_DEVICE (-2)  /* HIP error (message from mvx_last_error) */
+#define MVX_E_NOMEM (-3)
+
+const char *mvx_last_error(void);   /* thread-local text of the last failure */
+int mvx_device_count(void);         /* number of visible gfx950 devices, <0 on error */
+const char *mvx_version(void);
+
+/* ---- wire formats (byte-identical to the reference) -------------------------------------------- */
+
+/* VECTOR, MVAnalysisData.h:40-44 */
+typedef struct mvx_vector { int32_t x, y; int64_t sad; } mvx_vector;
+
+/* MVAnalysisData, MVAnalysisData.h:83-134 == the MVTools_MVAnalysisData frame property (84 bytes) */
+typedef struct mvx_analysis_data {
+    int32_t nMagicKey, nVersion, nBlkSizeX, nBlkSizeY, nPel, nLvCount, nDeltaFrame, isBackward, nCPUFlags,
+        nMotionFlags, nWidth, nHeight, nOverlapX, nOverlapY, nBlkX, nBlkY, bitsPerSample, yRatioUV, xRatioUV,
+        nHPadding, nVPadding;
+} mvx_analysis_data;
+
+/* ---- mv.Super ------------------------------------------------------------------------------------
+ * replaces mvsuperCreate / mvsuperGetFrame, MVSuper.c:140-275 / :43-126 (argument string :279-291)   */
+
+typedef struct mvx_super_args {
+    /* the input clip's format (VSVideoInfo) */
+    int32_t width, height, bits, subsampling_w, subsampling_h, gray;
+    /* filter arguments, MVX_UNSET = default: hpad=16 vpad=16 pel=2 levels=0 chroma=1 sharp=2 rfilter=2 */
+    int32_t hpad, vpad, pel, levels, chroma, sharp, rfilter;
+} mvx_super_args;
+
+typedef struct mvx_super_info {
+    int32_t width, height, bits, xRatioUV, yRatioUV, gray;
+    int32_t hpad, vpad, pel, levels, chroma, sharp, rfilter;
+    int32_t modeYUV;                    /* Super_modeyuv */
+    int32_t super_width, super_height;  /* luma dimensions of the super clip's frames */
+    int32_t num_planes;
+    int32_t plane_width[3], plane_height[3]; /* samples */
+} mvx_super_info;
+
+typedef struct mvx_super mvx_super;
+
+int mvx_super_create(const mvx_super_args *args, mvx_super **out, char *err /* MVX_ERRLEN or NULL */);
+void mvx_super_destroy(mvx_super *s);
+void mvx_super_get_info(const mvx_super *s, mvx_super_info *info);
+
+/* Builds `nframes` super frames.  src[f*3+p] / dst[f*3+p] are device pointers to plane p of frame f
+ * (p >= num_planes ignored); pitches in bytes, shared by all frames.  dst planes must have been
+ * zero-filled once by the caller when allocated: only the defined rectangles (every level's padded
+ * plane, every sub-pel plane) are written, bytes outside them are never touched.
+ * dst pitch must be a multiple of 16 bytes. */
+int mvx_super_frames(mvx_super *s, int nframes, const void *const *src, const ptrdiff_t src_pitch[3],
+                     void *const *dst, const ptrdiff_t dst_pitch[3], void *stream);
+
+/* ---- mv.Analyse ----------------------------------------------------------------------------------
+ * replaces mvanalyseCreate / mvanalyseGetFrame, MVAnalyse.c:267-635 / :76-254 (argument string :639-671);
+ * the search itself is GroupOfPlanes.c:69-125 + PlaneOfBlocks.cpp:419-1131,1447-1636.                */
+
+typedef struct mvx_analyse_args { /* MVX_UNSET = not passed */
+    int32_t blksize, blksizev, levels, search, searchparam, pelsearch, isb, lambda, chroma, delta, truemotion,
+        lsad, plevel, global, pnew, pzero, pglobal, overlap, overlapv, divide, badsad, badrange, opt, meander,
+        trymany, fields, tff, search_coarse, dct;
+} mvx_analyse_args;
+
+typedef struct mvx_analyse mvx_analyse;
+
+int mvx_analyse_create(const mvx_analyse_args *args, const mvx_super *super_clip, int num_frames,
+                       const ptrdiff_t super_pitch[3], mvx_analyse **out, char *err);
+void mvx_analyse_destroy(mvx_analyse *a);
+void mvx_analyse_get_data(const mvx_analyse *a, mvx_analysis_data *out); /* MVTools_MVAnalysisData */
+int mvx_analyse_blob_size(const mvx_analyse *a);                          /* bytes of MVTools_vectors */
+
+typedef struct mvx_analyse_job {
+    const void *src[3]; /* super frame n (device) */
+    const void *ref[3]; /* super frame n +/- delta (device); ref[0]==NULL -> frame too close to the clip
+                           boundary: the invalid/default blob is written (GroupOfPlanes.c:150-164) */
+    void *blob;         /* device, mvx_analyse_blob_size() bytes, 16-byte aligned */
+    int32_t field_shift;/* MVAnalyse.c:172-176; 0 unless fields=1 */
+    int32_t reserved;
+} mvx_analyse_job;
+
+/* One chain (frame, direction) per job; all jobs run concurrently in one launch. `jobs` is a HOST array. */
+int mvx_analyse_frames(mvx_analyse *a, int njobs, const mvx_analyse_job *jobs, void *stream);
+
+/* ---- mv.Degrain1..6 ------------------------------------------------------------------------------
+ * replaces mvdegrainCreate<r> / mvdegrainGetFrame<r>, MVDegrains.cpp:511-809 / :85-330 (arg strings :813-932) */
+
+typedef struct mvx_degrain_args {
+    int32_t radius;           /* 1..6 */
+    int64_t thsad, thsadc;    /* MVX_UNSET -> 400 / thsad */
+    int32_t plane, limit, limitc;
+    int64_t thscd1; int32_t thscd2;
+} mvx_degrain_args;
+
+typedef struct mvx_degrain mvx_degrain;
+
+int mvx_degrain_create(const mvx_degrain_args *args, const mvx_analysis_data *vectors_data /* of mvbw */,
+                       const mvx_super *super_clip, const ptrdiff_t src_pitch[3], const ptrdiff_t super_pitch[3],
+                       const ptrdiff_t dst_pitch[3], mvx_degrain **out, char *err);
+void mvx_degrain_destroy(mvx_degrain *d);
+
+typedef struct mvx_degrain_job {
+    const void *src[3];          /* clip frame n */
+    const void *refs[12][3];     /* super frame n+delta (mvbw), n-delta (mvfw), ... order mvbw,mvfw,mvbw2,mvfw2..;
+                                    refs[r][0] may be NULL when that frame is outside the clip */
+    const void *blobs[12];       /* MVTools_vectors of vector clip r at frame n (device) */
+    void *dst[3];
+} mvx_degrain_job;
+
+int mvx_degrain_frames(mvx_degrain *d, int nframes, const mvx_degrain_job *jobs, void *stream);
+
+/* ---- mv.Compensate -------------------------------------------------------------------------------
+ * replaces mvcompensateCreate / mvcompensateGetFrame, MVCompensate.c:419-575 / :73-374 (arg string :579-592) */
+
+typedef struct mvx_compensate_args {
+    int32_t scbehavior;  /* MVX_UNSET -> 1 */
+    int64_t thsad;       /* MVX_UNSET -> 10000 */
+    double time;         /* 0..100, pass 100.0 for the default */
+    int64_t thscd1; int32_t thscd2;
+} mvx_compensate_args;
+
+typedef struct mvx_compensate mvx_compensate;
+
+int mvx_compensate_create(const mvx_compensate_args *args, const mvx_analysis_data *vectors_data,
+                          const mvx_super *super_clip, const ptrdiff_t super_pitch[3], const ptrdiff_t dst_pitch[3],
+                          mvx_compensate **out, char *err);
+void mvx_compensate_destroy(mvx_compensate *c);
+
+typedef struct mvx_compensate_job {
+    const void *src_super[3]; /* super frame n */
+    const void *ref_super[3]; /* super frame nref; [0]==NULL if outside the clip */
+    const void *blob;         /* MVTools_vectors at frame n */
+    void *dst[3];
+} mvx_compensate_job;
+
+int mvx_compensate_frames(mvx_compensate *c, int nframes, const mvx_compensate_job *jobs, void *stream);
+
+/* ---- vector blob helpers (reader side: Fakery.c, MVAnalysisData.c:7-31) -------------------------- */
+void mvx_scale_thscd(int64_t *thscd1, int32_t *thscd2, const mvx_analysis_data *ad);
+
+/* ---- small device-memory helpers so that a C host (e.g. the VapourSynth shell) needs no HIP headers */
+void *mvx_dev_alloc(size_t bytes);            /* zero-filled */
+void mvx_dev_free(void *p);
+int mvx_copy_to_device(void *dst, ptrdiff_t dst_pitch, const void *src_host, ptrdiff_t src_pitch, size_t row_bytes, size_t rows, void *stream);
+int mvx_copy_to_host(void *dst_host, ptrdiff_t dst_pitch, const void *src, ptrdiff_t src_pitch, size_t row_bytes, size_t rows, void *stream);
+int mvx_stream_sync(void *stream);
+int mvx_set_device(int ordinal);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVTOOLS_AMD_H */

@@ -1,0 +1,575 @@
+// mvx_degrain.hip -- mv.Degrain1..6 and mv.Compensate on gfx950.
+//
+// The reference walks blocks, blends each block into a temp (Degrain_C, MVDegrains.h:30-53), scatters it times a
+// raised-cosine window into a 16/32-bit accumulator (overlaps_c, Overlap.cpp:143-158) and finally normalises
+// (ToPixels, Overlap.cpp:335-356).  The accumulator never saturates, so the sum is order-free and the GPU form is
+// a GATHER: one thread per output sample visits the <=4 blocks covering it, recomputes that block's blended sample
+// and accumulates it times the window tap.  No accumulator plane, no atomics, one pass over HBM:
+//   plan kernel   : per (frame, block) -> per-reference weights (fp64 exactly as MVDegrains.h:184-223) and the byte
+//                   offset of the motion-compensated block inside the reference super frame (MVDegrains.h:192-206)
+//   gather kernel : per output sample  -> blend + window + normalise + uncovered strips + LimitChanges.
+#include "mvx_common.h"
+
+#define MOTION_USE_CHROMA_MOTION 8
+
+struct __attribute__((packed, aligned(4))) GVecD { int x, y; long long sad; };
+
+// ------------------------------------------------------------------------------------------------ host helpers
+
+// Overlap.cpp:40-125 overInit.  M_PI is the double constant; the cosf argument is formed in double.
+static void win1d(float *w, float *first, float *last, int n, int o) {
+    for (int i = 0; i < o; i++) {
+        w[i] = cosf((float)(M_PI * (i - o + 0.5f) / (o * 2)));
+        w[i] = w[i] * w[i];
+        first[i] = 1; last[i] = w[i];
+    }
+    for (int i = o; i < n - o; i++) { w[i] = 1; first[i] = 1; last[i] = 1; }
+    for (int i = n - o; i < n; i++) {
+        w[i] = cosf((float)(M_PI * (i - n + o + 0.5f) / (o * 2)));
+        w[i] = w[i] * w[i];
+        first[i] = w[i]; last[i] = 1;
+    }
+}
+
+void mvx_over_windows(int16_t *win9, int nx, int ny, int ox, int oy) {
+    std::vector<float> fx(nx * 3), fy(ny * 3);
+    win1d(&fx[0], &fx[nx], &fx[2 * nx], nx, ox);
+    win1d(&fy[0], &fy[ny], &fy[2 * ny], ny, oy);
+    const float *x[3] = { &fx[nx], &fx[0], &fx[2 * nx] }; // first, middle, last
+    const float *y[3] = { &fy[ny], &fy[0], &fy[2 * ny] };
+    for (int wy = 0; wy < 3; wy++)
+        for (int wx = 0; wx < 3; wx++) {
+            int16_t *w = win9 + nx * ny * (wy * 3 + wx);
+            for (int j = 0; j < ny; j++)
+                for (int i = 0; i < nx; i++) w[j * nx + i] = (int16_t)(int)(y[wy][j] * x[wx][i] * 2048 + 0.5f);
+        }
+}
+
+extern "C" __attribute__((visibility("default"))) void mvx_scale_thscd(int64_t *thscd1, int32_t *thscd2, const mvx_analysis_data *ad) { // MVAnalysisData.c:7-31
+    *thscd1 = *thscd1 * (ad->nBlkSizeX * ad->nBlkSizeY) / (8 * 8);
+    if (ad->nMotionFlags & MOTION_USE_CHROMA_MOTION) *thscd1 += *thscd1 / (ad->xRatioUV * ad->yRatioUV) * 2;
+    const int pixelMax = (1 << ad->bitsPerSample) - 1;
+    *thscd1 = (int64_t)((double)*thscd1 * pixelMax / 255.0 + 0.5);
+    *thscd2 = *thscd2 * ad->nBlkX * ad->nBlkY / 256;
+}
+
+// ------------------------------------------------------------------------------------------------ shared device structs
+
+struct PlaneG { // one plane of the clip / of level 0 of the super frame
+    int W, H, WB, HB;        // frame dims, block-covered dims
+    int blkW, blkH, ovX, ovY, stepX, stepY;
+    int hpadPel, vpadPel;    // super padding * pel, in sub-pel units
+    int subX, subY;          // log2 subsampling of this plane relative to luma
+    long long srcPitch, supPitch, dstPitch, supPlaneStride; // bytes
+    int thIdx;               // 0 luma threshold, 1 chroma threshold
+    int process;
+    int limit;
+};
+
+struct DGParams {
+    int nRefs, nBlkX, nBlkY, nBlk, pel, logPel, bits, bps, nplanes, overlap;
+    int lastLevelOff;        // byte offset of the level-0 record inside a blob
+    long long thSAD[2];
+    long long thscd1; int thscd2;
+    PlaneG pl[3];
+    const int16_t *win[3];
+    // compensate only
+    long long cthSAD; int time256, scBehavior;
+};
+
+struct DGJob {
+    const unsigned char *src[3];
+    const unsigned char *refs[12][3];
+    const unsigned char *blobs[12];
+    unsigned char *dst[3];
+};
+
+// plan record: one per (frame, plane class luma/chroma, block)
+struct PlanRec {
+    unsigned off[12];  // byte offset of the compensated block's first sample inside the reference super plane
+    short w[12];
+    short wsrc;
+    short pad;
+};
+
+// ------------------------------------------------------------------------------------------------ kernels
+
+// Fakery.c:52-58,103-107,144-146: usable = validity==1 && !(count(sad > thscd1) > thscd2)
+__global__ __launch_bounds__(256) void usable_kernel(const DGParams *Pp, const DGJob *jobs, int *usable, int single) {
+    const DGParams &P = *Pp;
+    const int f = blockIdx.y, r = blockIdx.x;
+    const unsigned char *blob = single ? jobs[f].blobs[0] : jobs[f].blobs[r];
+    const bool haveRef = single ? true : jobs[f].refs[r][0] != nullptr;
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    int c = 0;
+    const GVecD *v = (const GVecD *)(blob + P.lastLevelOff + 4);
+    for (int i = threadIdx.x; i < P.nBlk; i += 256) c += v[i].sad > P.thscd1 ? 1 : 0;
+    atomicAdd(&cnt, c);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int validity = ((const int *)blob)[1];
+        usable[f * 12 + r] = haveRef && validity == 1 && !(cnt > P.thscd2);
+    }
+}
+
+// MVDegrains.h:184-189
+__device__ __forceinline__ int degrain_weight(long long thSAD, long long blockSAD) {
+    if (blockSAD >= thSAD) return 0;
+    return (int)((double)((thSAD - blockSAD) * (thSAD + blockSAD) * 256) / (double)(thSAD * thSAD + blockSAD * blockSAD));
+}
+
+// MVFrame.cpp:1686-1704,1732-1734 mvpGetPointer as a byte offset inside the super plane (level 0)
+__device__ __forceinline__ unsigned sup_offset(const PlaneG &g, int pel, int logPel, int bps, int nX, int nY) {
+    nX += g.hpadPel; nY += g.vpadPel;
+    const int m = pel - 1;
+    const int idx = (nX & m) | ((nY & m) << logPel);
+    return (unsigned)(idx * g.supPlaneStride + (long long)(nY >> logPel) * g.supPitch + (long long)(nX >> logPel) * bps);
+}
+
+__global__ __launch_bounds__(256) void degrain_plan_kernel(const DGParams *Pp, const DGJob *jobs, const int *usable, PlanRec *plan) {
+    const DGParams &P = *Pp;
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.nBlk) return;
+    const int by = i / P.nBlkX, bx = i - by * P.nBlkX;
+    const DGJob &J = jobs[f];
+    const int n = P.nRefs;
+    int vx[12], vy[12]; long long sad[12]; int us[12];
+    for (int r = 0; r < n; r++) {
+        us[r] = usable[f * 12 + r];
+        if (us[r]) {
+            const GVecD *v = (const GVecD *)(J.blobs[r] + P.lastLevelOff + 4);
+            vx[r] = v[i].x; vy[r] = v[i].y; sad[r] = v[i].sad;
+        }
+    }
+    const int ncls = P.nplanes > 1 ? 2 : 1;
+    for (int c = 0; c < ncls; c++) {
+        const PlaneG &g = P.pl[c];
+        PlanRec rec;
+        int W[12], WSum = 256 + 1;
+        for (int r = 0; r < n; r++) {
+            W[r] = 0; rec.off[r] = 0;
+            if (us[r]) { // MVDegrains.h:192-200 useBlock; block origin Fakery.c:31-32
+                const int blx = ((bx * P.pl[0].stepX) << P.logPel) + vx[r], bly = ((by * P.pl[0].stepY) << P.logPel) + vy[r];
+                rec.off[r] = sup_offset(g, P.pel, P.logPel, P.bps, c ? blx >> g.subX : blx, c ? bly >> g.subY : bly);
+                W[r] = degrain_weight(P.thSAD[g.thIdx], sad[r]);
+            }
+            WSum += W[r];
+        }
+        const double scale = 256.0 / WSum; // MVDegrains.h:208-223 normaliseWeights
+        int WSrc = 256;
+        for (int r = 0; r < n; r++) { W[r] = (int)(W[r] * scale); WSrc -= W[r]; rec.w[r] = (short)W[r]; }
+        for (int r = n; r < 12; r++) { rec.w[r] = 0; rec.off[r] = 0; }
+        rec.wsrc = (short)WSrc; rec.pad = 0;
+        plan[((size_t)f * 2 + c) * P.nBlk + i] = rec;
+    }
+}
+
+template <typename T, int NR>
+__global__ __launch_bounds__(256) void degrain_kernel(const DGParams *Pp, const DGJob *jobs, const PlanRec *plan) {
+    const DGParams &P = *Pp;
+    const int z = blockIdx.z, f = z / 3, p = z % 3;
+    if (p >= P.nplanes) return;
+    const PlaneG &g = P.pl[p];
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= g.W || y >= g.H) return;
+    const DGJob &J = jobs[f];
+    const T *srow = (const T *)(J.src[p] + (long long)y * g.srcPitch);
+    T *drow = (T *)(J.dst[p] + (long long)y * g.dstPitch);
+    const int s = srow[x];
+    if (!g.process || x >= g.WB || y >= g.HB) { drow[x] = (T)s; return; } // MVDegrains.cpp:211-214,238-249,290-298
+    const PlanRec *pl = plan + ((size_t)f * 2 + (p ? 1 : 0)) * P.nBlk;
+    int out;
+    if (!P.overlap) {
+        const int bx = x / g.blkW, by = y / g.blkH;
+        const int px = x - bx * g.blkW, py = y - by * g.blkH;
+        const PlanRec &R = pl[by * P.nBlkX + bx];
+        int sum = 128 + s * R.wsrc;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int w = R.w[r];
+            if (w) sum += (int)((const T *)(J.refs[r][p] + R.off[r] + (long long)py * g.supPitch))[px] * w;
+        }
+        out = (T)(sum >> 8);
+    } else {
+        // blocks covering this sample: bx in [bx0, bx1], by in [by0, by1]
+        int bx1 = x / g.stepX; if (bx1 > P.nBlkX - 1) bx1 = P.nBlkX - 1;
+        int bx0 = x - g.blkW + 1 <= 0 ? 0 : (x - g.blkW + g.stepX) / g.stepX;
+        int by1 = y / g.stepY; if (by1 > P.nBlkY - 1) by1 = P.nBlkY - 1;
+        int by0 = y - g.blkH + 1 <= 0 ? 0 : (y - g.blkH + g.stepY) / g.stepY;
+        unsigned acc = 0;
+        const int16_t *win = P.win[p];
+        for (int by = by0; by <= by1; by++) {
+            const int py = y - by * g.stepY;
+            const int wby = by == 0 ? 0 : (by == P.nBlkY - 1 ? 6 : 3); // ((by + nBlkY - 3) / (nBlkY - 2)) * 3, MVDegrains.cpp:256
+            for (int bx = bx0; bx <= bx1; bx++) {
+                const int px = x - bx * g.stepX;
+                const int wbx = bx == P.nBlkX - 1 ? 2 : (bx == 0 ? 0 : 1); // :260-262,285
+                const PlanRec &R = pl[by * P.nBlkX + bx];
+                int sum = 128 + s * R.wsrc;
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    const int w = R.w[r];
+                    if (w) sum += (int)((const T *)(J.refs[r][p] + R.off[r] + (long long)py * g.supPitch))[px] * w;
+                }
+                const int val = (T)(sum >> 8);
+                acc += (unsigned)((val * (int)win[(wby + wbx) * g.blkW * g.blkH + py * g.blkW + px]) >> 6);
+            }
+        }
+        if (sizeof(T) == 1) acc &= 0xffffu; // 16-bit accumulator of the 8-bit path (Overlap.cpp:254-256); never overflows in practice
+        const int a = (int)((acc + 16) >> 5); // Overlap.cpp:335-356
+        const int pm = (1 << P.bits) - 1;
+        out = a > pm ? pm : a;
+    }
+    if (g.limit < (1 << P.bits) - 1) { // MVDegrains.h:163-181
+        int lo = s - g.limit, hi = s + g.limit;
+        out = out < lo ? lo : out;
+        out = out > hi ? hi : out;
+    }
+    drow[x] = (T)out;
+}
+
+// ---- compensate
+
+struct CPlanRec { unsigned off[2]; int fromRef; }; // off[0] luma, off[1] chroma
+
+__global__ __launch_bounds__(256) void compensate_plan_kernel(const DGParams *Pp, const DGJob *jobs, const int *usable, CPlanRec *plan) {
+    const DGParams &P = *Pp;
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.nBlk || !usable[f * 12]) return;
+    const int by = i / P.nBlkX, bx = i - by * P.nBlkX;
+    const GVecD *v = (const GVecD *)(jobs[f].blobs[0] + P.lastLevelOff + 4);
+    const GVecD b = v[i];
+    int blx, bly;
+    CPlanRec rec;
+    if (b.sad < P.cthSAD) { // MVCompensate.c:238-242,286-290
+        blx = bx * P.pl[0].stepX * P.pel + b.x * P.time256 / 256;
+        bly = by * P.pl[0].stepY * P.pel + b.y * P.time256 / 256;
+        rec.fromRef = 1;
+    } else { // :243-247,291-295 (no-overlap: stepX == blkW)
+        blx = bx * P.pl[0].stepX * P.pel;
+        bly = by * P.pl[0].stepY * P.pel;
+        rec.fromRef = 0;
+    }
+    rec.off[0] = sup_offset(P.pl[0], P.pel, P.logPel, P.bps, blx, bly);
+    rec.off[1] = P.nplanes > 1 ? sup_offset(P.pl[1], P.pel, P.logPel, P.bps, blx >> P.pl[1].subX, bly >> P.pl[1].subY) : 0;
+    plan[(size_t)f * P.nBlk + i] = rec;
+}
+
+// job layout for compensate: src[] = super frame n, refs[0][] = super frame nref (may be null), blobs[0], dst[]
+template <typename T>
+__global__ __launch_bounds__(256) void compensate_kernel(const DGParams *Pp, const DGJob *jobs, const int *usable, const CPlanRec *plan) {
+    const DGParams &P = *Pp;
+    const int z = blockIdx.z, f = z / 3, p = z % 3;
+    if (p >= P.nplanes) return;
+    const PlaneG &g = P.pl[p];
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= g.W || y >= g.H) return;
+    const DGJob &J = jobs[f];
+    T *drow = (T *)(J.dst[p] + (long long)y * g.dstPitch);
+    const unsigned char *srcSup = J.src[p], *refSup = J.refs[0][p];
+    // interior (pel plane 0) sample of a super frame
+    const long long inner = (long long)(g.vpadPel / P.pel + y) * g.supPitch + (long long)(g.hpadPel / P.pel + x) * (long long)sizeof(T);
+    if (!usable[f * 12]) { // MVCompensate.c:348-364
+        const unsigned char *s = (!P.scBehavior && refSup) ? refSup : srcSup;
+        drow[x] = *(const T *)(s + inner);
+        return;
+    }
+    if (x >= g.WB || y >= g.HB) { // :319-342
+        const unsigned char *s = P.scBehavior ? srcSup : refSup;
+        drow[x] = *(const T *)(s + inner);
+        return;
+    }
+    const CPlanRec *pl = plan + (size_t)f * P.nBlk;
+    const int c = p ? 1 : 0;
+    if (!P.overlap) {
+        const int bx = x / g.blkW, by = y / g.blkH;
+        const int px = x - bx * g.blkW, py = y - by * g.blkH;
+        const CPlanRec R = pl[by * P.nBlkX + bx];
+        drow[x] = ((const T *)((R.fromRef ? refSup : srcSup) + R.off[c] + (long long)py * g.supPitch))[px];
+        return;
+    }
+    int bx1 = x / g.stepX; if (bx1 > P.nBlkX - 1) bx1 = P.nBlkX - 1;
+    int bx0 = x - g.blkW + 1 <= 0 ? 0 : (x - g.blkW + g.stepX) / g.stepX;
+    int by1 = y / g.stepY; if (by1 > P.nBlkY - 1) by1 = P.nBlkY - 1;
+    int by0 = y - g.blkH + 1 <= 0 ? 0 : (y - g.blkH + g.stepY) / g.stepY;
+    unsigned acc = 0;
+    const int16_t *win = P.win[p];
+    for (int by = by0; by <= by1; by++) {
+        const int py = y - by * g.stepY;
+        const int wby = by == 0 ? 0 : (by == P.nBlkY - 1 ? 6 : 3);
+        for (int bx = bx0; bx <= bx1; bx++) {
+            const int px = x - bx * g.stepX;
+            const int wbx = bx == P.nBlkX - 1 ? 2 : (bx == 0 ? 0 : 1);
+            const CPlanRec R = pl[by * P.nBlkX + bx];
+            const int val = ((const T *)((R.fromRef ? refSup : srcSup) + R.off[c] + (long long)py * g.supPitch))[px];
+            acc += (unsigned)((val * (int)win[(wby + wbx) * g.blkW * g.blkH + py * g.blkW + px]) >> 6);
+        }
+    }
+    if (sizeof(T) == 1) acc &= 0xffffu;
+    const int a = (int)((acc + 16) >> 5);
+    const int pm = (1 << P.bits) - 1;
+    drow[x] = (T)(a > pm ? pm : a);
+}
+
+// ------------------------------------------------------------------------------------------------ host objects
+
+struct DGCommon {
+    DGParams P;
+    DGParams *dP = nullptr;
+    DGJob *dJobs = nullptr;
+    size_t jobsCap = 0;
+    int *dUsable = nullptr;
+    void *dPlan = nullptr;
+    size_t planCap = 0;
+    int16_t *dWin[2] = { nullptr, nullptr };
+    int nWinClasses = 1;
+    ~DGCommon() {
+        if (dP) (void)hipFree(dP);
+        if (dJobs) (void)hipFree(dJobs);
+        if (dUsable) (void)hipFree(dUsable);
+        if (dPlan) (void)hipFree(dPlan);
+        if (dWin[0]) (void)hipFree(dWin[0]);
+        if (dWin[1]) (void)hipFree(dWin[1]);
+    }
+};
+struct mvx_degrain : DGCommon { int radius; };
+struct mvx_compensate : DGCommon {};
+
+#define DFAIL(...) do { snprintf(err, MVX_ERRLEN, __VA_ARGS__); mvx_set_error("%s", err); return MVX_E_ARG; } while (0)
+
+static int fill_common(DGCommon *h, const mvx_analysis_data *ad, const mvx_super_info &si, const ptrdiff_t src_pitch[3],
+                       const ptrdiff_t super_pitch[3], const ptrdiff_t dst_pitch[3], char *err) {
+    DGParams &P = h->P;
+    P.nBlkX = ad->nBlkX; P.nBlkY = ad->nBlkY; P.nBlk = ad->nBlkX * ad->nBlkY;
+    P.pel = ad->nPel; P.logPel = ad->nPel == 4 ? 2 : ad->nPel == 2 ? 1 : 0;
+    P.bits = si.bits; P.bps = (si.bits + 7) / 8; P.nplanes = si.num_planes;
+    P.overlap = ad->nOverlapX > 0 || ad->nOverlapY > 0;
+    if (P.overlap && (ad->nBlkX < 3 || ad->nBlkY < 3)) DFAIL("overlap needs at least 3x3 blocks (window selection divides by nBlk-2).");
+    // level-0 record is the last one in the blob (Fakery.c:110-121)
+    {
+        const int nWidth_B = (ad->nBlkSizeX - ad->nOverlapX) * ad->nBlkX + ad->nOverlapX;
+        const int nHeight_B = (ad->nBlkSizeY - ad->nOverlapY) * ad->nBlkY + ad->nOverlapY;
+        int off = 8;
+        for (int i = ad->nLvCount - 1; i > 0; i--) {
+            int bx = ((nWidth_B >> i) - ad->nOverlapX) / (ad->nBlkSizeX - ad->nOverlapX);
+            int by = ((nHeight_B >> i) - ad->nOverlapY) / (ad->nBlkSizeY - ad->nOverlapY);
+            off += 4 + bx * by * 16;
+        }
+        P.lastLevelOff = off;
+    }
+    const int xSub = mvx_ilog2(si.xRatioUV), ySub = mvx_ilog2(si.yRatioUV);
+    for (int p = 0; p < 3; p++) {
+        PlaneG &g = P.pl[p];
+        const int sx = p ? xSub : 0, sy = p ? ySub : 0;
+        g.subX = sx; g.subY = sy;
+        g.W = ad->nWidth >> sx; g.H = ad->nHeight >> sy;
+        g.blkW = ad->nBlkSizeX >> sx; g.blkH = ad->nBlkSizeY >> sy;
+        g.ovX = ad->nOverlapX >> sx; g.ovY = ad->nOverlapY >> sy;
+        g.stepX = g.blkW - g.ovX; g.stepY = g.blkH - g.ovY;
+        g.WB = (ad->nBlkX * (ad->nBlkSizeX - ad->nOverlapX) + ad->nOverlapX) >> sx;
+        g.HB = (ad->nBlkY * (ad->nBlkSizeY - ad->nOverlapY) + ad->nOverlapY) >> sy;
+        g.hpadPel = (si.hpad >> sx) * si.pel; g.vpadPel = (si.vpad >> sy) * si.pel; // MVFrame.cpp:1334-1335,1775-1779
+        g.srcPitch = src_pitch ? src_pitch[p < si.num_planes ? p : 0] : 0;
+        g.supPitch = super_pitch[p < si.num_planes ? p : 0];
+        g.dstPitch = dst_pitch[p < si.num_planes ? p : 0];
+        g.supPlaneStride = g.supPitch * (long long)((si.height >> sy) + 2 * (si.vpad >> sy));
+        g.thIdx = p ? 1 : 0;
+        g.process = 1; g.limit = (1 << si.bits) - 1;
+    }
+    if (si.num_planes > 1 && super_pitch[1] != super_pitch[2]) DFAIL("U and V super planes must share one pitch.");
+    h->nWinClasses = si.num_planes > 1 ? 2 : 1;
+    return MVX_OK;
+}
+
+// device state is created on first use so that argument validation works without a GPU
+static int finish_common(DGCommon *h) {
+    if (h->dP) return MVX_OK;
+    DGParams &P = h->P;
+    if (P.overlap) {
+        for (int c = 0; c < h->nWinClasses; c++) {
+            const PlaneG &g = P.pl[c];
+            std::vector<int16_t> w(9 * g.blkW * g.blkH);
+            mvx_over_windows(w.data(), g.blkW, g.blkH, g.ovX, g.ovY);
+            HIP_CHECK(hipMalloc((void **)&h->dWin[c], w.size() * 2));
+            HIP_CHECK(hipMemcpy(h->dWin[c], w.data(), w.size() * 2, hipMemcpyHostToDevice));
+        }
+        P.win[0] = h->dWin[0]; P.win[1] = P.win[2] = h->dWin[1];
+    }
+    HIP_CHECK(hipMalloc((void **)&h->dP, sizeof(DGParams)));
+    HIP_CHECK(hipMemcpy(h->dP, &h->P, sizeof(DGParams), hipMemcpyHostToDevice));
+    return MVX_OK;
+}
+
+static int ensure_jobs(DGCommon *h, int nframes, size_t planBytesPerFrame) {
+    if ((size_t)nframes > h->jobsCap) {
+        if (h->dJobs) (void)hipFree(h->dJobs);
+        if (h->dUsable) (void)hipFree(h->dUsable);
+        h->jobsCap = (size_t)nframes * 2;
+        HIP_CHECK(hipMalloc((void **)&h->dJobs, h->jobsCap * sizeof(DGJob)));
+        HIP_CHECK(hipMalloc((void **)&h->dUsable, h->jobsCap * 12 * sizeof(int)));
+    }
+    size_t need = planBytesPerFrame * nframes;
+    if (need > h->planCap) {
+        if (h->dPlan) (void)hipFree(h->dPlan);
+        h->planCap = need + need / 2;
+        HIP_CHECK(hipMalloc(&h->dPlan, h->planCap));
+    }
+    return MVX_OK;
+}
+
+// MVDegrains.cpp:511-809 mvdegrainCreate
+extern "C" __attribute__((visibility("default"))) int mvx_degrain_create(const mvx_degrain_args *a, const mvx_analysis_data *ad, const mvx_super *sup, const ptrdiff_t src_pitch[3],
+                                  const ptrdiff_t super_pitch[3], const ptrdiff_t dst_pitch[3], mvx_degrain **out, char *err) {
+    char dummy[MVX_ERRLEN];
+    if (!err) err = dummy;
+    err[0] = 0;
+    *out = nullptr;
+    const mvx_super_info &si = sup->info;
+    const int radius = a->radius;
+    if (radius < 1 || radius > 6) DFAIL("Degrain: radius must be between 1 and 6.");
+    long long thSAD0 = a->thsad == MVX_UNSET ? 400 : a->thsad;
+    long long thSAD1 = a->thsadc == MVX_UNSET ? thSAD0 : a->thsadc;
+    int plane = a->plane == MVX_UNSET ? 4 : a->plane;
+    long long nSCD1 = a->thscd1 == MVX_UNSET ? 400 : a->thscd1; // MV_DEFAULT_SCD1
+    int nSCD2 = a->thscd2 == MVX_UNSET ? 130 : a->thscd2;
+    if (plane < 0 || plane > 4) DFAIL("Degrain%d: plane must be between 0 and 4 (inclusive).", radius);
+    static const int planes[5] = { 1, 2, 4, 6, 7 };
+    const int YUVplanes = planes[plane];
+    if (nSCD1 > 8 * 8 * 255) DFAIL("Degrain%d: thscd1 can be at most %d.", radius, 8 * 8 * 255);
+    const long long nSCD1_old = nSCD1;
+    int64_t s1 = nSCD1; int32_t s2 = nSCD2;
+    mvx_scale_thscd(&s1, &s2, ad);
+    nSCD1 = s1; nSCD2 = s2;
+    thSAD0 = thSAD0 * nSCD1 / nSCD1_old; // :658-659
+    thSAD1 = thSAD1 * nSCD1 / nSCD1_old;
+    if (thSAD0 >= 2147483647LL || thSAD1 >= 2147483647LL) {
+        const bool c = thSAD0 < 2147483647LL;
+        DFAIL("Degrain%d: with this block size and video format, thsad%s must not exceed %lld or some calculations would overflow.", radius,
+              c ? "c" : "", (long long)(2147483647LL * nSCD1_old / nSCD1));
+    }
+    if (ad->nHeight != si.height || ad->nWidth != si.super_width - si.hpad * 2 || ad->nWidth != si.width || ad->nPel != si.pel)
+        DFAIL("Degrain%d: wrong source or super clip frame size.", radius);
+    const int pixelMax = (1 << si.bits) - 1;
+    int limit = a->limit == MVX_UNSET ? pixelMax : a->limit;
+    int limitc = a->limitc == MVX_UNSET ? limit : a->limitc;
+    if (limit < 0 || limit > pixelMax) DFAIL("Degrain%d: limit must be between 0 and %d (inclusive).", radius, pixelMax);
+    if (limitc < 0 || limitc > pixelMax) DFAIL("Degrain%d: limitc must be between 0 and %d (inclusive).", radius, pixelMax);
+
+    mvx_degrain *h = new mvx_degrain();
+    h->radius = radius;
+    memset(&h->P, 0, sizeof(h->P));
+    int rc = fill_common(h, ad, si, src_pitch, super_pitch, dst_pitch, err);
+    if (rc) { delete h; return rc; }
+    DGParams &P = h->P;
+    P.nRefs = 2 * radius;
+    P.thSAD[0] = thSAD0; P.thSAD[1] = thSAD1; P.thscd1 = nSCD1; P.thscd2 = nSCD2;
+    P.pl[0].process = !!(YUVplanes & 1);
+    P.pl[1].process = !!(YUVplanes & 2 & si.modeYUV);
+    P.pl[2].process = !!(YUVplanes & 4 & si.modeYUV);
+    P.pl[0].limit = limit; P.pl[1].limit = P.pl[2].limit = limitc;
+    *out = h;
+    return MVX_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) void mvx_degrain_destroy(mvx_degrain *d) { delete d; }
+
+template <typename T> static void launch_degrain(int nr, dim3 grid, hipStream_t st, const DGParams *dP, const DGJob *dJ, const PlanRec *plan) {
+#define DG(N) hipLaunchKernelGGL((degrain_kernel<T, N>), grid, dim3(256), 0, st, dP, dJ, plan)
+    switch (nr) { case 2: DG(2); break; case 4: DG(4); break; case 6: DG(6); break; case 8: DG(8); break; case 10: DG(10); break; default: DG(12); break; }
+#undef DG
+}
+
+extern "C" __attribute__((visibility("default"))) int mvx_degrain_frames(mvx_degrain *d, int nframes, const mvx_degrain_job *jobs, void *stream) {
+    if (nframes <= 0) return MVX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = finish_common(d);
+    if (rc) return rc;
+    const DGParams &P = d->P;
+    if ((rc = ensure_jobs(d, nframes, sizeof(PlanRec) * 2 * (size_t)P.nBlk))) return rc;
+    std::vector<DGJob> hj(nframes);
+    for (int f = 0; f < nframes; f++) {
+        memset(&hj[f], 0, sizeof(DGJob));
+        for (int p = 0; p < 3; p++) { hj[f].src[p] = (const unsigned char *)jobs[f].src[p]; hj[f].dst[p] = (unsigned char *)jobs[f].dst[p]; }
+        for (int r = 0; r < P.nRefs; r++) {
+            for (int p = 0; p < 3; p++) hj[f].refs[r][p] = (const unsigned char *)jobs[f].refs[r][p];
+            hj[f].blobs[r] = (const unsigned char *)jobs[f].blobs[r];
+        }
+    }
+    HIP_CHECK(hipMemcpyAsync(d->dJobs, hj.data(), sizeof(DGJob) * nframes, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(usable_kernel, dim3(P.nRefs, nframes), dim3(256), 0, st, d->dP, d->dJobs, d->dUsable, 0);
+    hipLaunchKernelGGL(degrain_plan_kernel, dim3((P.nBlk + 255) / 256, nframes), dim3(256), 0, st, d->dP, d->dJobs, d->dUsable, (PlanRec *)d->dPlan);
+    dim3 grid((P.pl[0].W + 63) / 64, (P.pl[0].H + 3) / 4, nframes * 3);
+    if (P.bps == 1) launch_degrain<uint8_t>(P.nRefs, grid, st, d->dP, d->dJobs, (const PlanRec *)d->dPlan);
+    else launch_degrain<uint16_t>(P.nRefs, grid, st, d->dP, d->dJobs, (const PlanRec *)d->dPlan);
+    HIP_CHECK(hipGetLastError());
+    return MVX_OK;
+}
+
+// MVCompensate.c:419-575 mvcompensateCreate
+extern "C" __attribute__((visibility("default"))) int mvx_compensate_create(const mvx_compensate_args *a, const mvx_analysis_data *ad, const mvx_super *sup,
+                                     const ptrdiff_t super_pitch[3], const ptrdiff_t dst_pitch[3], mvx_compensate **out, char *err) {
+    char dummy[MVX_ERRLEN];
+    if (!err) err = dummy;
+    err[0] = 0;
+    *out = nullptr;
+    const mvx_super_info &si = sup->info;
+    const int scBehavior = a->scbehavior == MVX_UNSET ? 1 : !!a->scbehavior;
+    long long thSAD = a->thsad == MVX_UNSET ? 10000 : a->thsad;
+    const double time = a->time;
+    if (time < 0.0 || time > 100.0) DFAIL("Compensate: time must be between 0.0 and 100.0 (inclusive).");
+    long long nSCD1 = a->thscd1 == MVX_UNSET ? 400 : a->thscd1;
+    int nSCD2 = a->thscd2 == MVX_UNSET ? 130 : a->thscd2;
+    if (nSCD1 > 8 * 8 * 255) DFAIL("Compensate: thscd1 can be at most %d.", 8 * 8 * 255);
+    const long long nSCD1_old = nSCD1;
+    int64_t s1 = nSCD1; int32_t s2 = nSCD2;
+    mvx_scale_thscd(&s1, &s2, ad);
+    nSCD1 = s1; nSCD2 = s2;
+    thSAD = thSAD * nSCD1 / nSCD1_old; // :521
+    if (ad->nHeight != si.height || ad->nWidth != si.super_width - si.hpad * 2 || ad->nWidth != si.width || ad->nPel != si.pel)
+        DFAIL("Compensate: wrong source or super clip frame size.");
+    mvx_compensate *h = new mvx_compensate();
+    memset(&h->P, 0, sizeof(h->P));
+    int rc = fill_common(h, ad, si, nullptr, super_pitch, dst_pitch, err);
+    if (rc) { delete h; return rc; }
+    DGParams &P = h->P;
+    P.nRefs = 1;
+    P.thscd1 = nSCD1; P.thscd2 = nSCD2; P.cthSAD = thSAD;
+    P.time256 = (int)(time * 256 / 100); // :560
+    P.scBehavior = scBehavior;
+    if (!(si.modeYUV & 6)) P.nplanes = 1; // num_planes :147-149
+    *out = h;
+    return MVX_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) void mvx_compensate_destroy(mvx_compensate *c) { delete c; }
+
+extern "C" __attribute__((visibility("default"))) int mvx_compensate_frames(mvx_compensate *c, int nframes, const mvx_compensate_job *jobs, void *stream) {
+    if (nframes <= 0) return MVX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = finish_common(c);
+    if (rc) return rc;
+    const DGParams &P = c->P;
+    if ((rc = ensure_jobs(c, nframes, sizeof(CPlanRec) * (size_t)P.nBlk))) return rc;
+    std::vector<DGJob> hj(nframes);
+    for (int f = 0; f < nframes; f++) {
+        memset(&hj[f], 0, sizeof(DGJob));
+        for (int p = 0; p < 3; p++) {
+            hj[f].src[p] = (const unsigned char *)jobs[f].src_super[p];
+            hj[f].refs[0][p] = (const unsigned char *)jobs[f].ref_super[p];
+            hj[f].dst[p] = (unsigned char *)jobs[f].dst[p];
+        }
+        hj[f].blobs[0] = (const unsigned char *)jobs[f].blob;
+    }
+    HIP_CHECK(hipMemcpyAsync(c->dJobs, hj.data(), sizeof(DGJob) * nframes, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(usable_kernel, dim3(1, nframes), dim3(256), 0, st, c->dP, c->dJobs, c->dUsable, 0);
+    hipLaunchKernelGGL(compensate_plan_kernel, dim3((P.nBlk + 255) / 256, nframes), dim3(256), 0, st, c->dP, c->dJobs, c->dUsable, (CPlanRec *)c->dPlan);
+    dim3 grid((P.pl[0].W + 63) / 64, (P.pl[0].H + 3) / 4, nframes * 3);
+    if (P.bps == 1) hipLaunchKernelGGL(compensate_kernel<uint8_t>, grid, dim3(256), 0, st, c->dP, c->dJobs, c->dUsable, (const CPlanRec *)c->dPlan);
+    else hipLaunchKernelGGL(compensate_kernel<uint16_t>, grid, dim3(256), 0, st, c->dP, c->dJobs, c->dUsable, (const CPlanRec *)c->dPlan);
+    HIP_CHECK(hipGetLastError());
+    return MVX_OK;
+}

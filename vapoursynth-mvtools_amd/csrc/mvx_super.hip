@@ -1,0 +1,422 @@
+// mvx_super.hip -- mv.Super on gfx950: padded hierarchical pyramid + sub-pel planes.
+//
+// What it computes is fixed by the reference (MVSuper.c:43-126, MVFrame.cpp:508-1197,1264-1318,1386-1527,1634-1683);
+// how it is computed is not: instead of fill -> reduce chain -> pad -> three whole-plane refine passes, every output
+// sample is produced directly from the source frame:
+//   * level 0: one LDS-tiled kernel reads the source tile (+2/+3 halo, coordinates clamped = the reference's edge
+//     replication) once and writes the padded plane and its H / V / HV half-pel planes (pel 2; pel 4 adds averages);
+//   * level L+1: one kernel per level evaluates the separable 2x decimation filter at the clamped interior coordinate
+//     of every sample of the padded rectangle (the padding is just the clamped coordinate, no separate pad pass).
+// Both are HBM streaming kernels: algorithmic bytes = S_src read + S_super written.
+#include "mvx_common.h"
+
+// ------------------------------------------------------------------------------------------------ host: geometry
+
+int mvx_plane_height_luma(int src_height, int level, int yRatioUV, int vpad) { // MVFrame.cpp:1209-1216
+    int height = src_height;
+    for (int i = 1; i <= level; i++)
+        height = vpad >= yRatioUV ? ((height / yRatioUV + 1) / 2) * yRatioUV : ((height / yRatioUV) / 2) * yRatioUV;
+    return height;
+}
+
+int mvx_plane_width_luma(int src_width, int level, int xRatioUV, int hpad) { // MVFrame.cpp:1219-1226
+    int width = src_width;
+    for (int i = 1; i <= level; i++)
+        width = hpad >= xRatioUV ? ((width / xRatioUV + 1) / 2) * xRatioUV : ((width / xRatioUV) / 2) * xRatioUV;
+    return width;
+}
+
+unsigned mvx_plane_super_offset(int chroma, int src_height, int level, int pel, int vpad, int plane_pitch, int yRatioUV) { // :1229-1247
+    int height = src_height;
+    unsigned offset = 0;
+    if (level > 0) {
+        offset = pel * pel * plane_pitch * (src_height + vpad * 2);
+        for (int i = 1; i < level; i++) {
+            height = chroma ? mvx_plane_height_luma(src_height * yRatioUV, i, yRatioUV, vpad * yRatioUV) / yRatioUV
+                            : mvx_plane_height_luma(src_height, i, yRatioUV, vpad);
+            offset += plane_pitch * (height + vpad * 2);
+        }
+    }
+    return offset;
+}
+
+void mvx_level_plane(const mvx_super_info &si, int level, int plane, long long pitch, LevelPlane *o) {
+    int xr = plane ? si.xRatioUV : 1, yr = plane ? si.yRatioUV : 1;
+    o->w = mvx_plane_width_luma(si.width, level, si.xRatioUV, si.hpad) / xr;   // mvgofInit MVFrame.cpp:1871-1877 + mvfInit :1769-1779
+    o->h = mvx_plane_height_luma(si.height, level, si.yRatioUV, si.vpad) / yr;
+    o->hpad = si.hpad / xr;
+    o->vpad = si.vpad / yr;
+    o->pw = o->w + 2 * o->hpad;
+    o->ph = o->h + 2 * o->vpad;
+    // mvgofUpdate MVFrame.cpp:1898: the plane index is passed as the `chroma` flag, level-0 plane height/vpad
+    o->off = (long long)mvx_plane_super_offset(plane, si.height / yr, level, si.pel, o->vpad, 1, si.yRatioUV) * pitch;
+}
+
+static int argdef(int v, int d) { return v == MVX_UNSET ? d : v; }
+
+extern "C" __attribute__((visibility("default"))) int mvx_super_create(const mvx_super_args *a, mvx_super **out, char *err) { // MVSuper.c:140-264
+    char dummy[MVX_ERRLEN];
+    if (!err) err = dummy;
+    err[0] = 0;
+    *out = nullptr;
+    mvx_super_info si;
+    memset(&si, 0, sizeof(si));
+    si.hpad = argdef(a->hpad, 16);
+    si.vpad = argdef(a->vpad, 16);
+    si.pel = argdef(a->pel, 2);
+    si.levels = argdef(a->levels, 0);
+    si.chroma = !!argdef(a->chroma, 1);
+    si.sharp = argdef(a->sharp, 2);
+    si.rfilter = argdef(a->rfilter, 2);
+#define SFAIL(msg) do { snprintf(err, MVX_ERRLEN, "%s", msg); mvx_set_error("%s", msg); return MVX_E_ARG; } while (0)
+    if (si.pel != 1 && si.pel != 2 && si.pel != 4) SFAIL("Super: pel must be 1, 2, or 4.");
+    if (si.sharp < 0 || si.sharp > 2) SFAIL("Super: sharp must be between 0 and 2 (inclusive).");
+    if (si.rfilter < 0 || si.rfilter > 4) SFAIL("Super: rfilter must be between 0 and 4 (inclusive).");
+    if (a->bits < 8 || a->bits > 16 || a->subsampling_w < 0 || a->subsampling_w > 1 || a->subsampling_h < 0 || a->subsampling_h > 1 ||
+        a->width <= 0 || a->height <= 0)
+        SFAIL("Super: input clip must be GRAY, 420, 422, 440, or 444, up to 16 bits, with constant dimensions.");
+    if (si.hpad < 0 || si.vpad < 0) SFAIL("Super: hpad and vpad must not be negative.");
+    si.width = a->width; si.height = a->height; si.bits = a->bits; si.gray = !!a->gray;
+    if (si.gray) si.chroma = 0;
+    si.modeYUV = si.chroma ? 7 : 1;
+    si.xRatioUV = 1 << a->subsampling_w;
+    si.yRatioUV = 1 << a->subsampling_h;
+    int nLevelsMax = 0; // :220-227
+    while (mvx_plane_height_luma(si.height, nLevelsMax, si.yRatioUV, si.vpad) >= si.yRatioUV * 2 &&
+           mvx_plane_width_luma(si.width, nLevelsMax, si.xRatioUV, si.hpad) >= si.xRatioUV * 2)
+        nLevelsMax++;
+    if (si.levels <= 0 || si.levels > nLevelsMax) si.levels = nLevelsMax;
+    if (si.levels > MVX_MAX_LEVELS) SFAIL("Super: too many levels.");
+    si.super_width = si.width + 2 * si.hpad; // :257-264
+    si.super_height = mvx_plane_super_offset(0, si.height, si.levels, si.pel, si.vpad, si.super_width, si.yRatioUV) / si.super_width;
+    if (si.yRatioUV == 2 && (si.super_height & 1)) si.super_height++;
+    if (si.xRatioUV == 2 && (si.super_width & 1)) si.super_width++;
+    si.num_planes = si.gray ? 1 : 3;
+    for (int p = 0; p < 3; p++) {
+        si.plane_width[p] = p ? si.super_width / si.xRatioUV : si.super_width;
+        si.plane_height[p] = p ? si.super_height / si.yRatioUV : si.super_height;
+    }
+    mvx_super *s = new mvx_super();
+    s->info = si;
+    *out = s;
+    return MVX_OK;
+#undef SFAIL
+}
+
+extern "C" __attribute__((visibility("default"))) void mvx_super_destroy(mvx_super *s) { delete s; }
+extern "C" __attribute__((visibility("default"))) void mvx_super_get_info(const mvx_super *s, mvx_super_info *info) { *info = s->info; }
+
+// ------------------------------------------------------------------------------------------------ device kernels
+
+struct SuperPlaneGeom {
+    int w, h, hpad, vpad, pw, ph; // level-0 plane
+    long long src_pitch, dst_pitch;
+};
+
+struct SuperL0Args {
+    const void *const *src; // [nframes*3]
+    void *const *dst;       // [nframes*3]
+    SuperPlaneGeom g[3];
+    int pel, bits, modeYUV, nplanes;
+};
+
+template <typename T> __device__ __forceinline__ int ldT(const void *p, long long i) { return ((const T *)p)[i]; }
+__device__ __forceinline__ int iclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// horizontal / vertical half-pel rule at absolute padded coordinate X of a line of length n; s(i) reads sample i.
+// SHARP 0: MVFrame.cpp:530-548 / :508-527; 1: :1153-1176 / :1115-1150; 2: :1071-1111 / :1019-1068
+template <int SHARP, typename F> __device__ __forceinline__ int half_rule(F s, int X, int n, int pm) {
+    if (X == n - 1) return s(X);
+    if (SHARP == 0) return (s(X) + s(X + 1) + 1) >> 1;
+    if (SHARP == 1) {
+        if (X < 1 || X >= n - 3) return (s(X) + s(X + 1) + 1) >> 1;
+        int v = (-(s(X - 1) + s(X + 2)) + (s(X) + s(X + 1)) * 9 + 8) >> 4;
+        return min(pm, max(0, v));
+    }
+    if (X < 2 || X >= n - 4) return (s(X) + s(X + 1) + 1) >> 1;
+    int m0 = s(X - 2), m1 = s(X - 1), m2 = s(X), m3 = s(X + 1), m4 = s(X + 2), m5 = s(X + 3);
+    m2 = (m2 + m3) * 4; m2 -= m1 + m4; m2 *= 5; m0 += m5 + m2 + 16; m0 >>= 5;
+    return max(0, min(m0, pm));
+}
+
+#define L0_TW 128
+#define L0_TH 16
+#define L0_HL 2 // halo before
+#define L0_HR 3 // halo after
+#define L0_LW (L0_TW + L0_HL + L0_HR)
+#define L0_LH (L0_TH + L0_HL + L0_HR)
+
+template <typename T, int SHARP, int PEL>
+__global__ __launch_bounds__(256) void super_level0_kernel(SuperL0Args A) {
+    __shared__ unsigned short sp0[L0_LH][L0_LW + 1];
+    __shared__ unsigned short sv[L0_TH][L0_LW + 1];
+    const int z = blockIdx.z, f = z / 3, p = z % 3;
+    if (p >= A.nplanes || !(A.modeYUV & (1 << p))) return;
+    const SuperPlaneGeom g = A.g[p];
+    const int X0 = blockIdx.x * L0_TW, Y0 = blockIdx.y * L0_TH;
+    if (X0 >= g.pw || Y0 >= g.ph) return;
+    const unsigned char *src = (const unsigned char *)A.src[f * 3 + p];
+    unsigned char *dst = (unsigned char *)A.dst[f * 3 + p];
+    const int pm = (1 << A.bits) - 1;
+    const int tid = threadIdx.x;
+
+    // phase 1: padded plane tile (+halo) from the source frame, coordinates clamped (== PadReferenceFrame, MVFrame.cpp:1264-1318)
+    for (int i = tid; i < L0_LH * L0_LW; i += 256) {
+        int ly = i / L0_LW, lx = i - ly * L0_LW;
+        int X = iclamp(X0 - L0_HL + lx, 0, g.pw - 1), Y = iclamp(Y0 - L0_HL + ly, 0, g.ph - 1);
+        int sx = iclamp(X - g.hpad, 0, g.w - 1), sy = iclamp(Y - g.vpad, 0, g.h - 1);
+        sp0[ly][lx] = (unsigned short)((const T *)(src + (long long)sy * g.src_pitch))[sx];
+    }
+    __syncthreads();
+    if (PEL > 1) { // phase 2: vertical half-pel plane for the tile rows, all tile columns incl. halo
+        for (int i = tid; i < L0_TH * L0_LW; i += 256) {
+            int ty = i / L0_LW, lx = i - ty * L0_LW;
+            int Y = Y0 + ty;
+            int v = 0;
+            if (Y < g.ph) v = half_rule<SHARP>([&](int yy) { return (int)sp0[yy - Y0 + L0_HL][lx]; }, Y, g.ph, pm);
+            sv[ty][lx] = (unsigned short)v;
+        }
+        __syncthreads();
+    }
+    // phase 3: 8 consecutive samples per thread
+    const int ty = tid >> 4, tx8 = (tid & 15) * 8;
+    const int Y = Y0 + ty;
+    if (Y >= g.ph) return;
+    const long long planeStride = g.dst_pitch * g.ph;
+    const int idxH = PEL == 2 ? 1 : 2, idxV = PEL == 2 ? 2 : 8, idxHV = PEL == 2 ? 3 : 10;
+    T *r0 = (T *)(dst + (long long)Y * g.dst_pitch);
+    T *rH = (T *)(dst + idxH * planeStride + (long long)Y * g.dst_pitch);
+    T *rV = (T *)(dst + idxV * planeStride + (long long)Y * g.dst_pitch);
+    T *rHV = (T *)(dst + idxHV * planeStride + (long long)Y * g.dst_pitch);
+    T o0[8], oH[8], oV[8], oHV[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        int X = X0 + tx8 + k;
+        int lx = tx8 + k + L0_HL;
+        o0[k] = (T)sp0[ty + L0_HL][lx];
+        if (PEL > 1) {
+            int Xc = min(X, g.pw - 1); // keeps LDS indices in range for the (unstored) overhang of the last tile
+            oH[k] = (T)half_rule<SHARP>([&](int xx) { return (int)sp0[ty + L0_HL][xx - X0 + L0_HL]; }, Xc, g.pw, pm);
+            oV[k] = (T)sv[ty][lx];
+            if (SHARP == 0) { // DiagonalBilinear MVFrame.cpp:551-572
+                int a = sp0[ty + L0_HL][lx], b = sp0[ty + L0_HL][lx + 1], c = sp0[ty + L0_HL + 1][lx], d = sp0[ty + L0_HL + 1][lx + 1];
+                int v;
+                if (Y < g.ph - 1) v = (Xc < g.pw - 1) ? (a + b + c + d + 2) >> 2 : (a + c + 1) >> 1;
+                else v = (Xc < g.pw - 1) ? (a + b + 1) >> 1 : a;
+                oHV[k] = (T)v;
+            } else
+                oHV[k] = (T)half_rule<SHARP>([&](int xx) { return (int)sv[ty][xx - X0 + L0_HL]; }, Xc, g.pw, pm);
+        }
+    }
+    const int Xs = X0 + tx8;
+    if (Xs + 8 <= g.pw) {
+        typedef T vec8 __attribute__((ext_vector_type(8)));
+        vec8 v0, vH, vV, vHV;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { v0[k] = o0[k]; if (PEL > 1) { vH[k] = oH[k]; vV[k] = oV[k]; vHV[k] = oHV[k]; } }
+        *(vec8 *)(r0 + Xs) = v0;
+        if (PEL > 1) { *(vec8 *)(rH + Xs) = vH; *(vec8 *)(rV + Xs) = vV; *(vec8 *)(rHV + Xs) = vHV; }
+    } else {
+        for (int k = 0; k < 8 && Xs + k < g.pw; k++) {
+            r0[Xs + k] = o0[k];
+            if (PEL > 1) { rH[Xs + k] = oH[k]; rV[Xs + k] = oV[k]; rHV[Xs + k] = oHV[k]; }
+        }
+    }
+}
+
+// pel 4: the twelve averaged planes, MVFrame.cpp:1489-1524.  dst = (a[shifted by ax,ay] + b + 1) >> 1 over (pw-ax) x (ph-ay);
+// the untouched last column / row stays 0 as in the reference (frame memset, MVSuper.c:75).
+struct AvgOp { int d, a, b, ax, ay; };
+struct SuperAvgArgs {
+    void *const *dst;
+    SuperPlaneGeom g[3];
+    int modeYUV, nplanes;
+    AvgOp ops[8];
+    int nops;
+};
+
+template <typename T> __global__ __launch_bounds__(256) void super_avg_kernel(SuperAvgArgs A) {
+    const int z = blockIdx.z, f = z / 3, p = z % 3;
+    if (p >= A.nplanes || !(A.modeYUV & (1 << p))) return;
+    const SuperPlaneGeom g = A.g[p];
+    const int X = blockIdx.x * 256 + threadIdx.x, Y = blockIdx.y;
+    if (X >= g.pw) return;
+    unsigned char *dst = (unsigned char *)A.dst[f * 3 + p];
+    const long long ps = g.dst_pitch * g.ph;
+    for (int k = 0; k < A.nops; k++) {
+        const AvgOp o = A.ops[k];
+        T *d = (T *)(dst + o.d * ps + (long long)Y * g.dst_pitch);
+        int v = 0;
+        if (X < g.pw - o.ax && Y < g.ph - o.ay) {
+            const T *a = (const T *)(dst + o.a * ps + (long long)(Y + o.ay) * g.dst_pitch);
+            const T *b = (const T *)(dst + o.b * ps + (long long)Y * g.dst_pitch);
+            v = (a[X + o.ax] + b[X] + 1) >> 1;
+        }
+        d[X] = (T)v;
+    }
+}
+
+// 2x reduction of level L into the padded rectangle of level L+1.  MVFrame.cpp:575-1014 + pad :1264-1318.
+struct SuperReduceArgs {
+    const void *const *src; // FROM_SRC: source frames [nframes*3]; else unused
+    void *const *dst;       // super frames [nframes*3]
+    long long src_pitch[3], dst_pitch[3];
+    long long in_off[3], out_off[3]; // byte offsets of level L / L+1 (sub-pel plane 0) in the super plane
+    int in_w[3], in_h[3], in_hpad[3], in_vpad[3];
+    int out_w[3], out_h[3], out_hpad[3], out_vpad[3];
+    int modeYUV, nplanes;
+};
+
+template <typename T, int RF, bool FROM_SRC>
+__global__ __launch_bounds__(256) void super_reduce_kernel(SuperReduceArgs A) {
+    const int z = blockIdx.z, f = z / 3, p = z % 3;
+    if (p >= A.nplanes || !(A.modeYUV & (1 << p))) return;
+    const int ow = A.out_w[p], oh = A.out_h[p], ohp = A.out_hpad[p], ovp = A.out_vpad[p];
+    const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (X >= ow + 2 * ohp || Y >= oh + 2 * ovp) return;
+    const int x = iclamp(X - ohp, 0, ow - 1), y = iclamp(Y - ovp, 0, oh - 1);
+    unsigned char *dplane = (unsigned char *)A.dst[f * 3 + p];
+    const unsigned char *sbase;
+    long long sp;
+    const int iw = A.in_w[p], ih = A.in_h[p];
+    if (FROM_SRC) { sbase = (const unsigned char *)A.src[f * 3 + p]; sp = A.src_pitch[p]; }
+    else { sp = A.dst_pitch[p]; sbase = dplane + A.in_off[p] + (long long)A.in_vpad[p] * sp + (long long)A.in_hpad[p] * (long long)sizeof(T); }
+    // level 0 is reduced BEFORE it is padded (mvgofReduce then mvgofPad, MVSuper.c:88-89): outside the interior the
+    // reference reads the zero-filled frame; deeper levels were padded right after they were produced (MVFrame.cpp:1931).
+    auto S = [&](int xx, int yy) -> int {
+        if (FROM_SRC && (xx >= iw || yy >= ih)) return 0;
+        return (int)((const T *)(sbase + (long long)yy * sp))[xx];
+    };
+    int out;
+    if (RF == 0) {
+        out = (S(2 * x, 2 * y) + S(2 * x + 1, 2 * y) + S(2 * x + 1, 2 * y + 1) + S(2 * x, 2 * y + 1) + 2) / 4;
+    } else {
+        auto V = [&](int XX) -> int { // vertical pass at intermediate column XX
+            if (RF == 1) {
+                if (y == 0) return (S(XX, 0) + S(XX, 1) + 1) / 2;
+                return (S(XX, 2 * y - 1) + S(XX, 2 * y) * 2 + S(XX, 2 * y + 1) + 2) / 4;
+            }
+            if (y == 0 || y == oh - 1) return (S(XX, 2 * y) + S(XX, 2 * y + 1) + 1) / 2;
+            if (RF == 2) return (S(XX, 2 * y - 1) + (S(XX, 2 * y) + S(XX, 2 * y + 1)) * 3 + S(XX, 2 * y + 2) + 4) / 8;
+            int m0 = S(XX, 2 * y - 2), m1 = S(XX, 2 * y - 1), m2 = S(XX, 2 * y), m3 = S(XX, 2 * y + 1), m4 = S(XX, 2 * y + 2), m5 = S(XX, 2 * y + 3);
+            if (RF == 3) { m2 = (m2 + m3) * 22; m1 = (m1 + m4) * 9; m0 += m5 + m2 + m1 + 32; return m0 >> 6; }
+            m2 = (m2 + m3) * 10; m1 = (m1 + m4) * 5; m0 += m5 + m2 + m1 + 16; return m0 >> 5;
+        };
+        if (x == 0) out = (V(0) + V(1) + 1) / 2;
+        else if (RF == 1) out = (V(2 * x - 1) + V(2 * x) * 2 + V(2 * x + 1) + 2) / 4;
+        else if (x == ow - 1) out = (V(2 * x) + V(2 * x + 1) + 1) / 2;
+        else if (RF == 2) out = (V(2 * x - 1) + (V(2 * x) + V(2 * x + 1)) * 3 + V(2 * x + 2) + 4) / 8;
+        else {
+            int m0 = V(2 * x - 2), m1 = V(2 * x - 1), m2 = V(2 * x), m3 = V(2 * x + 1), m4 = V(2 * x + 2), m5 = V(2 * x + 3);
+            if (RF == 3) { m2 = (m2 + m3) * 22; m1 = (m1 + m4) * 9; m0 += m5 + m2 + m1 + 32; out = m0 >> 6; }
+            else { m2 = (m2 + m3) * 10; m1 = (m1 + m4) * 5; m0 += m5 + m2 + m1 + 16; out = m0 >> 5; }
+        }
+    }
+    ((T *)(dplane + A.out_off[p] + (long long)Y * A.dst_pitch[p]))[X] = (T)out;
+}
+
+// ------------------------------------------------------------------------------------------------ host: launch
+
+struct PtrScratch { // per-thread device scratch for the frame-pointer tables
+    void *d = nullptr;
+    size_t cap = 0;
+    int dev = -1;
+};
+static thread_local PtrScratch g_scratch[2];
+
+static int upload_ptrs(int which, const void *const *host, size_t n, hipStream_t st, void **dev_out) {
+    PtrScratch &s = g_scratch[which];
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    size_t bytes = n * sizeof(void *);
+    if (s.cap < bytes || s.dev != dev) {
+        if (s.d) (void)hipFree(s.d);
+        s.cap = bytes < 4096 ? 4096 : bytes * 2;
+        HIP_CHECK(hipMalloc(&s.d, s.cap));
+        s.dev = dev;
+    }
+    HIP_CHECK(hipMemcpyAsync(s.d, host, bytes, hipMemcpyHostToDevice, st));
+    *dev_out = s.d;
+    return MVX_OK;
+}
+
+template <typename T> static void launch_level0(const SuperL0Args &A, int sharp, int pel, dim3 grid, hipStream_t st) {
+#define L0(S, P) hipLaunchKernelGGL((super_level0_kernel<T, S, P>), grid, dim3(256), 0, st, A)
+    if (pel == 1) L0(2, 1);
+    else if (pel == 2) { if (sharp == 0) L0(0, 2); else if (sharp == 1) L0(1, 2); else L0(2, 2); }
+    else { if (sharp == 0) L0(0, 4); else if (sharp == 1) L0(1, 4); else L0(2, 4); }
+#undef L0
+}
+
+template <typename T, bool FS> static void launch_reduce(const SuperReduceArgs &A, int rf, dim3 grid, hipStream_t st) {
+#define RD(R) hipLaunchKernelGGL((super_reduce_kernel<T, R, FS>), grid, dim3(256), 0, st, A)
+    switch (rf) { case 0: RD(0); break; case 1: RD(1); break; case 2: RD(2); break; case 3: RD(3); break; default: RD(4); break; }
+#undef RD
+}
+
+extern "C" __attribute__((visibility("default"))) int mvx_super_frames(mvx_super *s, int nframes, const void *const *src, const ptrdiff_t src_pitch[3],
+                                void *const *dst, const ptrdiff_t dst_pitch[3], void *stream) {
+    if (nframes <= 0) return MVX_OK;
+    const mvx_super_info &si = s->info;
+    hipStream_t st = (hipStream_t)stream;
+    for (int p = 0; p < si.num_planes; p++)
+        if (dst_pitch[p] % 16) { mvx_set_error("mvx_super_frames: dst pitch must be a multiple of 16 bytes"); return MVX_E_ARG; }
+    void *dsrc = nullptr, *ddst = nullptr;
+    int rc;
+    if ((rc = upload_ptrs(0, src, (size_t)nframes * 3, st, &dsrc))) return rc;
+    if ((rc = upload_ptrs(1, (const void *const *)dst, (size_t)nframes * 3, st, &ddst))) return rc;
+    const bool u8 = si.bits <= 8;
+
+    SuperL0Args A;
+    memset(&A, 0, sizeof(A));
+    A.src = (const void *const *)dsrc; A.dst = (void *const *)ddst;
+    A.pel = si.pel; A.bits = si.bits; A.modeYUV = si.modeYUV; A.nplanes = si.num_planes;
+    int maxpw = 0, maxph = 0;
+    for (int p = 0; p < si.num_planes; p++) {
+        LevelPlane lp;
+        mvx_level_plane(si, 0, p, dst_pitch[p], &lp);
+        A.g[p] = { lp.w, lp.h, lp.hpad, lp.vpad, lp.pw, lp.ph, (long long)src_pitch[p], (long long)dst_pitch[p] };
+        if (lp.pw > maxpw) maxpw = lp.pw;
+        if (lp.ph > maxph) maxph = lp.ph;
+    }
+    dim3 grid((maxpw + L0_TW - 1) / L0_TW, (maxph + L0_TH - 1) / L0_TH, nframes * 3);
+    if (u8) launch_level0<uint8_t>(A, si.sharp, si.pel, grid, st); else launch_level0<uint16_t>(A, si.sharp, si.pel, grid, st);
+
+    if (si.pel == 4) { // MVFrame.cpp:1511-1523, two dependent passes
+        SuperAvgArgs B;
+        memset(&B, 0, sizeof(B));
+        B.dst = (void *const *)ddst; B.modeYUV = si.modeYUV; B.nplanes = si.num_planes;
+        for (int p = 0; p < 3; p++) B.g[p] = A.g[p];
+        dim3 g2((maxpw + 255) / 256, maxph, nframes * 3);
+        const AvgOp pass1[8] = { { 1, 0, 2, 0, 0 }, { 9, 8, 10, 0, 0 }, { 4, 0, 8, 0, 0 }, { 6, 2, 10, 0, 0 },
+                                 { 3, 0, 2, 1, 0 }, { 11, 8, 10, 1, 0 }, { 12, 0, 8, 0, 1 }, { 14, 2, 10, 0, 1 } };
+        const AvgOp pass2[4] = { { 5, 4, 6, 0, 0 }, { 13, 12, 14, 0, 0 }, { 7, 4, 6, 1, 0 }, { 15, 12, 14, 1, 0 } };
+        memcpy(B.ops, pass1, sizeof(pass1)); B.nops = 8;
+        if (u8) hipLaunchKernelGGL(super_avg_kernel<uint8_t>, g2, dim3(256), 0, st, B); else hipLaunchKernelGGL(super_avg_kernel<uint16_t>, g2, dim3(256), 0, st, B);
+        memcpy(B.ops, pass2, sizeof(pass2)); B.nops = 4;
+        if (u8) hipLaunchKernelGGL(super_avg_kernel<uint8_t>, g2, dim3(256), 0, st, B); else hipLaunchKernelGGL(super_avg_kernel<uint16_t>, g2, dim3(256), 0, st, B);
+    }
+
+    for (int L = 0; L + 1 < si.levels; L++) {
+        SuperReduceArgs R;
+        memset(&R, 0, sizeof(R));
+        R.src = (const void *const *)dsrc; R.dst = (void *const *)ddst; R.modeYUV = si.modeYUV; R.nplanes = si.num_planes;
+        int mw = 0, mh = 0;
+        for (int p = 0; p < si.num_planes; p++) {
+            LevelPlane a, b;
+            mvx_level_plane(si, L, p, dst_pitch[p], &a);
+            mvx_level_plane(si, L + 1, p, dst_pitch[p], &b);
+            R.src_pitch[p] = src_pitch[p]; R.dst_pitch[p] = dst_pitch[p];
+            R.in_off[p] = a.off; R.out_off[p] = b.off;
+            R.in_w[p] = a.w; R.in_h[p] = a.h; R.in_hpad[p] = a.hpad; R.in_vpad[p] = a.vpad;
+            R.out_w[p] = b.w; R.out_h[p] = b.h; R.out_hpad[p] = b.hpad; R.out_vpad[p] = b.vpad;
+            if (b.pw > mw) mw = b.pw;
+            if (b.ph > mh) mh = b.ph;
+        }
+        dim3 g3((mw + 63) / 64, (mh + 3) / 4, nframes * 3);
+        if (L == 0) { if (u8) launch_reduce<uint8_t, true>(R, si.rfilter, g3, st); else launch_reduce<uint16_t, true>(R, si.rfilter, g3, st); }
+        else { if (u8) launch_reduce<uint8_t, false>(R, si.rfilter, g3, st); else launch_reduce<uint16_t, false>(R, si.rfilter, g3, st); }
+    }
+    HIP_CHECK(hipGetLastError());
+    return MVX_OK;
+}

@@ -1,0 +1,346 @@
+"""Host-side mirror of the reference's filter interface over the C ABI of libmvtools_amd.so.
+
+    core.mv.Super(clip, ...)            -> Super(width, height, bits, ...)       .build(frames)
+    core.mv.Analyse(super, ...)         -> Analyse(super, num_frames, ...)       .run(jobs)
+    core.mv.Degrain1..6(clip, super, mvbw, mvfw, ...) -> Degrain(radius, super, analysis_data, ...) .run(jobs)
+    core.mv.Compensate(clip, super, vectors, ...)     -> Compensate(super, analysis_data, ...)      .run(jobs)
+
+Argument names, defaults and error strings are the reference's (MVSuper.c:279-291, MVAnalyse.c:639-671,
+MVDegrains.cpp:813-932, MVCompensate.c:579-592); they are resolved inside the library, not here.
+PyTorch is only plumbing: device memory (uint8 tensors, one per plane, row stride = pitch) and the HIP stream.
+All pixel work happens in the hand-written HIP kernels; there is no CPU fallback -- a missing library or a missing
+GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBPATH = os.path.join(os.path.dirname(_HERE), "libmvtools_amd.so")
+UNSET = -2147483648
+ERRLEN = 256
+
+
+class MvtoolsError(Exception):
+    pass
+
+
+class AnalysisData(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "nMagicKey", "nVersion", "nBlkSizeX", "nBlkSizeY", "nPel", "nLvCount", "nDeltaFrame", "isBackward", "nCPUFlags",
+        "nMotionFlags", "nWidth", "nHeight", "nOverlapX", "nOverlapY", "nBlkX", "nBlkY", "bitsPerSample", "yRatioUV",
+        "xRatioUV", "nHPadding", "nVPadding")]
+
+
+class SuperArgs(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("width", "height", "bits", "subsampling_w", "subsampling_h", "gray", "hpad", "vpad",
+                                         "pel", "levels", "chroma", "sharp", "rfilter")]
+
+
+class SuperInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("width", "height", "bits", "xRatioUV", "yRatioUV", "gray", "hpad", "vpad", "pel",
+                                         "levels", "chroma", "sharp", "rfilter", "modeYUV", "super_width", "super_height",
+                                         "num_planes")] + [("plane_width", C.c_int32 * 3), ("plane_height", C.c_int32 * 3)]
+
+
+ANALYSE_ARGS = ("blksize", "blksizev", "levels", "search", "searchparam", "pelsearch", "isb", "lambda_", "chroma", "delta",
+                "truemotion", "lsad", "plevel", "global_", "pnew", "pzero", "pglobal", "overlap", "overlapv", "divide", "badsad",
+                "badrange", "opt", "meander", "trymany", "fields", "tff", "search_coarse", "dct")
+
+
+class AnalyseArgs(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ANALYSE_ARGS]
+
+
+class AnalyseJob(C.Structure):
+    _fields_ = [("src", C.c_void_p * 3), ("ref", C.c_void_p * 3), ("blob", C.c_void_p), ("field_shift", C.c_int32), ("reserved", C.c_int32)]
+
+
+class DegrainArgs(C.Structure):
+    _fields_ = [("radius", C.c_int32), ("thsad", C.c_int64), ("thsadc", C.c_int64), ("plane", C.c_int32), ("limit", C.c_int32),
+                ("limitc", C.c_int32), ("thscd1", C.c_int64), ("thscd2", C.c_int32)]
+
+
+class DegrainJob(C.Structure):
+    _fields_ = [("src", C.c_void_p * 3), ("refs", (C.c_void_p * 3) * 12), ("blobs", C.c_void_p * 12), ("dst", C.c_void_p * 3)]
+
+
+class CompensateArgs(C.Structure):
+    _fields_ = [("scbehavior", C.c_int32), ("thsad", C.c_int64), ("time", C.c_double), ("thscd1", C.c_int64), ("thscd2", C.c_int32)]
+
+
+class CompensateJob(C.Structure):
+    _fields_ = [("src_super", C.c_void_p * 3), ("ref_super", C.c_void_p * 3), ("blob", C.c_void_p), ("dst", C.c_void_p * 3)]
+
+
+_lib = None
+
+
+def lib():
+    """Loads libmvtools_amd.so (built by vapoursynth-mvtools_amd/build.py).  Fails loudly when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIBPATH):
+            raise MvtoolsError("libmvtools_amd.so not built (%s): run `python vapoursynth-mvtools_amd/build.py`; "
+                               "there is no CPU fallback" % _LIBPATH)
+        L = C.CDLL(_LIBPATH)
+        P = C.POINTER
+        L.mvx_last_error.restype = C.c_char_p
+        L.mvx_version.restype = C.c_char_p
+        L.mvx_super_create.argtypes = [P(SuperArgs), P(C.c_void_p), C.c_char_p]
+        L.mvx_super_destroy.argtypes = [C.c_void_p]
+        L.mvx_super_get_info.argtypes = [C.c_void_p, P(SuperInfo)]
+        L.mvx_super_frames.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p), P(C.c_ssize_t), P(C.c_void_p), P(C.c_ssize_t), C.c_void_p]
+        L.mvx_analyse_create.argtypes = [P(AnalyseArgs), C.c_void_p, C.c_int, P(C.c_ssize_t), P(C.c_void_p), C.c_char_p]
+        L.mvx_analyse_destroy.argtypes = [C.c_void_p]
+        L.mvx_analyse_get_data.argtypes = [C.c_void_p, P(AnalysisData)]
+        L.mvx_analyse_blob_size.argtypes = [C.c_void_p]
+        L.mvx_analyse_frames.argtypes = [C.c_void_p, C.c_int, P(AnalyseJob), C.c_void_p]
+        L.mvx_degrain_create.argtypes = [P(DegrainArgs), P(AnalysisData), C.c_void_p, P(C.c_ssize_t), P(C.c_ssize_t), P(C.c_ssize_t),
+                                         P(C.c_void_p), C.c_char_p]
+        L.mvx_degrain_destroy.argtypes = [C.c_void_p]
+        L.mvx_degrain_frames.argtypes = [C.c_void_p, C.c_int, P(DegrainJob), C.c_void_p]
+        L.mvx_compensate_create.argtypes = [P(CompensateArgs), P(AnalysisData), C.c_void_p, P(C.c_ssize_t), P(C.c_ssize_t),
+                                            P(C.c_void_p), C.c_char_p]
+        L.mvx_compensate_destroy.argtypes = [C.c_void_p]
+        L.mvx_compensate_frames.argtypes = [C.c_void_p, C.c_int, P(CompensateJob), C.c_void_p]
+        L.mvx_scale_thscd.argtypes = [P(C.c_int64), P(C.c_int32), P(AnalysisData)]
+        _lib = L
+    return _lib
+
+
+def _u(v):
+    return UNSET if v is None else int(v)
+
+
+def _check(rc, err=None):
+    if rc:
+        msg = err.value.decode() if err is not None and err.value else lib().mvx_last_error().decode()
+        raise MvtoolsError(msg)
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise MvtoolsError("no HIP device visible: mvtools_amd has no CPU path")
+    return torch
+
+
+def _stream():
+    return C.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+
+def _pitches(planes):
+    a = (C.c_ssize_t * 3)()
+    for i, p in enumerate(planes):
+        a[i] = p.stride(0)
+    return a
+
+
+# ---------------------------------------------------------------------------------------------- frame helpers
+
+def plane_to_device(arr, pitch_align=256, device="cuda"):
+    """numpy 2-D uint8/uint16 plane -> torch.uint8 [h, pitch] tensor (row stride = pitch bytes)."""
+    torch = _torch()
+    a = np.ascontiguousarray(arr)
+    h, w = a.shape
+    rowbytes = w * a.dtype.itemsize
+    pitch = (rowbytes + pitch_align - 1) // pitch_align * pitch_align
+    t = torch.zeros((h, pitch), dtype=torch.uint8, device=device)
+    t[:, :rowbytes] = torch.from_numpy(a.view(np.uint8).reshape(h, rowbytes)).to(device)
+    return t
+
+
+def frame_to_device(planes, **kw):
+    return [plane_to_device(p, **kw) for p in planes]
+
+
+def plane_to_numpy(t, width, dtype):
+    item = np.dtype(dtype).itemsize
+    a = t[:, :width * item].contiguous().cpu().numpy()
+    return a.view(dtype).reshape(t.shape[0], width)
+
+
+class Super:
+    """mv.Super -- MVSuper.c:140-275."""
+
+    def __init__(self, width, height, bits=8, subsampling=(1, 1), gray=False, hpad=None, vpad=None, pel=None, levels=None,
+                 chroma=None, sharp=None, rfilter=None):
+        a = SuperArgs(width, height, bits, subsampling[0], subsampling[1], int(gray), _u(hpad), _u(vpad), _u(pel), _u(levels),
+                      _u(chroma), _u(sharp), _u(rfilter))
+        self.h = C.c_void_p()
+        err = C.create_string_buffer(ERRLEN)
+        _check(lib().mvx_super_create(C.byref(a), C.byref(self.h), err), err)
+        self.info = SuperInfo()
+        lib().mvx_super_get_info(self.h, C.byref(self.info))
+        self.dtype = np.uint8 if bits <= 8 else np.uint16
+        self.bps = 1 if bits <= 8 else 2
+        self.nplanes = self.info.num_planes
+        self.pitch = [((self.info.plane_width[p] * self.bps + 255) // 256) * 256 for p in range(self.nplanes)]
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().mvx_super_destroy(self.h)
+        except Exception:
+            pass
+
+    def alloc(self, n=1, device="cuda"):
+        """n zero-filled super frames (the library only ever writes the defined rectangles)."""
+        torch = _torch()
+        return [[torch.zeros((self.info.plane_height[p], self.pitch[p]), dtype=torch.uint8, device=device) for p in range(self.nplanes)]
+                for _ in range(n)]
+
+    def build(self, frames, out=None):
+        """frames: list of device frames (list of plane tensors sharing pitches) -> list of super frames."""
+        n = len(frames)
+        if out is None:
+            out = self.alloc(n, device=frames[0][0].device)
+        src = (C.c_void_p * (3 * n))()
+        dst = (C.c_void_p * (3 * n))()
+        for f in range(n):
+            for p in range(self.nplanes):
+                src[f * 3 + p] = frames[f][p].data_ptr()
+                dst[f * 3 + p] = out[f][p].data_ptr()
+                assert frames[f][p].stride(0) == frames[0][p].stride(0) and out[f][p].stride(0) == out[0][p].stride(0)
+        _check(lib().mvx_super_frames(self.h, n, src, _pitches(frames[0]), dst, _pitches(out[0]), _stream()))
+        return out
+
+
+class Analyse:
+    """mv.Analyse -- MVAnalyse.c:267-635; keyword names are the reference's argument names."""
+
+    def __init__(self, sup, num_frames=1 << 30, **kw):
+        self.sup = sup
+        a = AnalyseArgs(*([UNSET] * len(ANALYSE_ARGS)))
+        for k, v in kw.items():
+            k2 = {"lambda": "lambda_", "global": "global_"}.get(k, k)
+            if k2 not in ANALYSE_ARGS:
+                raise TypeError("Analyse: unknown argument " + k)
+            if v is not None:
+                setattr(a, k2, int(v))
+        pitch = (C.c_ssize_t * 3)(*(sup.pitch + [0] * (3 - len(sup.pitch))))
+        self.h = C.c_void_p()
+        err = C.create_string_buffer(ERRLEN)
+        _check(lib().mvx_analyse_create(C.byref(a), sup.h, int(num_frames), pitch, C.byref(self.h), err), err)
+        self.ad = AnalysisData()
+        lib().mvx_analyse_get_data(self.h, C.byref(self.ad))
+        self.blob_size = lib().mvx_analyse_blob_size(self.h)
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().mvx_analyse_destroy(self.h)
+        except Exception:
+            pass
+
+    def alloc_blobs(self, n, device="cuda"):
+        torch = _torch()
+        stride = (self.blob_size + 255) // 256 * 256
+        buf = torch.zeros((n, stride), dtype=torch.uint8, device=device)
+        return [buf[i, :self.blob_size] for i in range(n)]
+
+    def run(self, jobs, blobs=None, field_shift=0):
+        """jobs: list of (src_super_frame, ref_super_frame_or_None) -> list of device blobs (MVTools_vectors)."""
+        n = len(jobs)
+        if blobs is None:
+            blobs = self.alloc_blobs(n, device=jobs[0][0][0].device)
+        arr = (AnalyseJob * n)()
+        for i, (s, r) in enumerate(jobs):
+            for p in range(self.sup.nplanes):
+                assert s[p].stride(0) == self.sup.pitch[p]
+                arr[i].src[p] = s[p].data_ptr()
+                arr[i].ref[p] = r[p].data_ptr() if r is not None else None
+            arr[i].blob = blobs[i].data_ptr()
+            arr[i].field_shift = field_shift
+        _check(lib().mvx_analyse_frames(self.h, n, arr, _stream()))
+        return blobs
+
+
+class Degrain:
+    """mv.Degrain1..6 -- MVDegrains.cpp:511-809.  analysis_data = the vector clips' MVTools_MVAnalysisData."""
+
+    def __init__(self, radius, sup, analysis_data, src_pitch, dst_pitch=None, thsad=None, thsadc=None, plane=None, limit=None,
+                 limitc=None, thscd1=None, thscd2=None):
+        self.sup = sup
+        self.radius = radius
+        a = DegrainArgs(radius, _u(thsad), _u(thsadc), _u(plane), _u(limit), _u(limitc), _u(thscd1), _u(thscd2))
+        ad = AnalysisData.from_buffer_copy(bytes(analysis_data))
+        dst_pitch = dst_pitch or src_pitch
+        pad = lambda l: (C.c_ssize_t * 3)(*(list(l) + [0] * (3 - len(l))))
+        self.h = C.c_void_p()
+        err = C.create_string_buffer(ERRLEN)
+        _check(lib().mvx_degrain_create(C.byref(a), C.byref(ad), sup.h, pad(src_pitch), pad(sup.pitch), pad(dst_pitch), C.byref(self.h), err), err)
+        self.src_pitch, self.dst_pitch = list(src_pitch), list(dst_pitch)
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().mvx_degrain_destroy(self.h)
+        except Exception:
+            pass
+
+    def run(self, jobs, out=None):
+        """jobs: list of (src_frame, [ref_super or None]*2r, [blob]*2r) ordered mvbw, mvfw, mvbw2, mvfw2, ..."""
+        torch = _torch()
+        n = len(jobs)
+        if out is None:
+            out = [[torch.empty_like(p) for p in j[0]] for j in jobs]
+        arr = (DegrainJob * n)()
+        for i, (src, refs, blobs) in enumerate(jobs):
+            for p in range(self.sup.nplanes):
+                assert src[p].stride(0) == self.src_pitch[p] and out[i][p].stride(0) == self.dst_pitch[p]
+                arr[i].src[p] = src[p].data_ptr()
+                arr[i].dst[p] = out[i][p].data_ptr()
+            for r in range(2 * self.radius):
+                if refs[r] is not None:
+                    for p in range(self.sup.nplanes):
+                        arr[i].refs[r][p] = refs[r][p].data_ptr()
+                arr[i].blobs[r] = blobs[r].data_ptr()
+        _check(lib().mvx_degrain_frames(self.h, n, arr, _stream()))
+        return out
+
+
+class Compensate:
+    """mv.Compensate -- MVCompensate.c:419-575."""
+
+    def __init__(self, sup, analysis_data, dst_pitch=None, scbehavior=None, thsad=None, time=100.0, thscd1=None, thscd2=None):
+        self.sup = sup
+        a = CompensateArgs(_u(scbehavior), _u(thsad), float(time), _u(thscd1), _u(thscd2))
+        ad = AnalysisData.from_buffer_copy(bytes(analysis_data))
+        i = sup.info
+        if dst_pitch is None:
+            w = [i.width] + [i.width // i.xRatioUV] * 2
+            dst_pitch = [((w[p] * sup.bps + 255) // 256) * 256 for p in range(sup.nplanes)]
+        pad = lambda l: (C.c_ssize_t * 3)(*(list(l) + [0] * (3 - len(l))))
+        self.h = C.c_void_p()
+        err = C.create_string_buffer(ERRLEN)
+        _check(lib().mvx_compensate_create(C.byref(a), C.byref(ad), sup.h, pad(sup.pitch), pad(dst_pitch), C.byref(self.h), err), err)
+        self.dst_pitch = list(dst_pitch)
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().mvx_compensate_destroy(self.h)
+        except Exception:
+            pass
+
+    def run(self, jobs, out=None):
+        """jobs: list of (src_super, ref_super_or_None, blob)."""
+        torch = _torch()
+        i = self.sup.info
+        n = len(jobs)
+        hs = [i.height] + [i.height // i.yRatioUV] * 2
+        if out is None:
+            dev = jobs[0][0][0].device
+            out = [[torch.zeros((hs[p], self.dst_pitch[p]), dtype=torch.uint8, device=dev) for p in range(self.sup.nplanes)] for _ in range(n)]
+        arr = (CompensateJob * n)()
+        for k, (s, r, blob) in enumerate(jobs):
+            for p in range(self.sup.nplanes):
+                arr[k].src_super[p] = s[p].data_ptr()
+                arr[k].ref_super[p] = r[p].data_ptr() if r is not None else None
+                arr[k].dst[p] = out[k][p].data_ptr()
+            arr[k].blob = blob.data_ptr()
+        _check(lib().mvx_compensate_frames(self.h, n, arr, _stream()))
+        return out
