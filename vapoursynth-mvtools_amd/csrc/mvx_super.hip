@@ -240,7 +240,7 @@ template <typename T> __global__ __launch_bounds__(256) void super_avg_kernel(Su
     if (p >= A.nplanes || !(A.modeYUV & (1 << p))) return;
     const SuperPlaneGeom g = A.g[p];
     const int X = blockIdx.x * 256 + threadIdx.x, Y = blockIdx.y;
-    if (X >= g.pw) return;
+    if (X >= g.pw || Y >= g.ph) return;
     unsigned char *dst = (unsigned char *)A.dst[f * 3 + p];
     const long long ps = g.dst_pitch * g.ph;
     for (int k = 0; k < A.nops; k++) {

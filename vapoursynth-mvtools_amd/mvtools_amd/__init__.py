@@ -84,6 +84,13 @@ def lib():
         if not os.path.exists(_LIBPATH):
             raise MvtoolsError("libmvtools_amd.so not built (%s): run `python vapoursynth-mvtools_amd/build.py`; "
                                "there is no CPU fallback" % _LIBPATH)
+        # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.7.  Importing torch first makes the
+        # dynamic loader bind our DT_NEEDED libamdhip64.so.7 to that already-loaded copy instead of pulling a second
+        # runtime from /opt/rocm (two HSA runtimes in one process cannot both open the device).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(_LIBPATH)
         P = C.POINTER
         L.mvx_last_error.restype = C.c_char_p
