@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""bench.py -- end-to-end mv.Super + mv.Analyse(x2*tr) + mv.DegrainN throughput on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3|cfg2|cfg1|cfg5] [--batch B] [--no-cpu]
+
+A "step" is one pass of the hot path over one batch of B synthetic frames already resident in HBM:
+Super of the B+2*tr frames (batch + temporal halo), 2*tr*B motion searches (one chain per frame and direction, all in
+one launch per vector clip), DegrainN of the B frames.  value = frames/s over all ranks (frames are independent, so
+N GPUs = N disjoint frame ranges, no data-path collective: weak scaling).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "vapoursynth-mvtools_amd"), os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+CONFIGS = {
+    # name: (width, height, bits, radius, analyse kwargs, super kwargs, default batch, BASELINE.json config string)
+    "cfg1": (640, 360, 8, 1, dict(blksize=8), dict(pel=1), 64, "640x360 YUV420P8 Degrain1 blksize=8 pel=1"),
+    "cfg2": (1920, 1080, 8, 1, dict(blksize=8, overlap=4, search=4), dict(pel=2), 64, "1080p YUV420P8 Degrain1 blksize=8 overlap=4 pel=2 search=4"),
+    "cfg3": (3840, 2160, 16, 3, dict(blksize=16, overlap=8), dict(pel=2), 48, "4K YUV420P16 Degrain3 blksize=16 overlap=8 pel=2"),
+    "cfg5": (7680, 4320, 16, 6, dict(blksize=32, overlap=16), dict(pel=2), 8, "8K YUV420P16 Degrain6 blksize=32 overlap=16 pel=2"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def synth_clip_device(torch, width, height, bits, nframes, seed, device):
+    """Textured 4:2:0 clip generated on the device: band-limited texture + 8x8 checker translating (+3,-1) px/frame,
+    a rectangle of different texture moving (-2,+2), +-2 LSB (8-bit scale) noise.  SURVEY.md 8(d)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    scale = 1 << (bits - 8)
+    pm = (1 << bits) - 1
+    margin = 32 + 4 * nframes
+    H, W = height + 2 * margin, width + 2 * margin
+    yy = torch.arange(H, device=device, dtype=torch.float32)[:, None]
+    xx = torch.arange(W, device=device, dtype=torch.float32)[None, :]
+    tex = (40 * torch.sin(xx * 0.21 + yy * 0.07) + 30 * torch.sin(xx * 0.05 - yy * 0.13) + 20 * torch.sin(xx * 0.33 + 1.3) * torch.cos(yy * 0.27)
+           + 25 * (((xx.long() // 8) + (yy.long() // 8)) & 1).float() + 120)
+    texc = [20 * torch.sin(xx * 0.11 + yy * 0.05 + k) + 128 for k in (0.3, 1.7)]
+    frames = []
+    for f in range(nframes):
+        ox, oy = margin + 3 * f, margin - 1 * f
+        planes = []
+        for p in range(3):
+            s = 2 if p else 1
+            base = tex if p == 0 else texc[p - 1]
+            img = base[oy:oy + height:s, ox:ox + width:s].clone()
+            h, w = img.shape
+            rx, ry = (width // 2 - 2 * f) // s, (height // 3 + 2 * f) // s
+            rw, rh = (width // 4) // s, (height // 4) // s
+            img[ry:ry + rh, rx:rx + rw] = base[8:8 + rh * s:s, 8:8 + rw * s:s] * 0.8 + (35 if p == 0 else 10)
+            img = img + torch.randint(-2, 3, img.shape, generator=g, device=device).float()
+            v = torch.clamp(torch.round(img * scale), 0, pm).to(torch.int32)
+            rowbytes = w * (2 if bits > 8 else 1)
+            pitch = (rowbytes + 255) // 256 * 256
+            t = torch.zeros((h, pitch), dtype=torch.uint8, device=device)
+            if bits > 8:
+                t[:, :rowbytes] = torch.stack([(v & 0xFF), (v >> 8)], dim=-1).to(torch.uint8).reshape(h, rowbytes)
+            else:
+                t[:, :rowbytes] = v.to(torch.uint8)
+            planes.append(t)
+        frames.append(planes)
+    return frames
+
+
+class Pipeline:
+    """Super -> Analyse x 2tr -> DegrainN over a resident batch, all on the current HIP stream."""
+
+    def __init__(self, mv, torch, cfg, batch, device, seed):
+        (self.w, self.h, self.bits, self.tr, akw, skw, _, self.label) = cfg
+        self.mv, self.torch, self.B, self.device = mv, torch, batch, device
+        tr = self.tr
+        self.n = batch + 2 * tr
+        self.src = synth_clip_device(torch, self.w, self.h, self.bits, self.n, seed, device)
+        self.sup = mv.Super(self.w, self.h, self.bits, **skw)
+        self.supers = self.sup.alloc(self.n, device=device)
+        self.an = {}
+        for d in range(1, tr + 1):
+            for isb in (1, 0):
+                self.an[(d, isb)] = mv.Analyse(self.sup, isb=isb, delta=d, **akw)
+        a0 = self.an[(1, 1)]
+        self.blobs = {k: a.alloc_blobs(batch, device=device) for k, a in self.an.items()}
+        self.dg = mv.Degrain(tr, self.sup, a0.ad, [p.stride(0) for p in self.src[0]])
+        self.out = [[torch.empty_like(p) for p in self.src[0]] for _ in range(batch)]
+        self.ev = []  # (start, end) events around the search launches
+
+    def step(self, time_search=False):
+        torch, tr, B = self.torch, self.tr, self.B
+        self.sup.build(self.src, out=self.supers)
+        # all 2*tr vector clips share one parameter block (delta / isb only pick the reference frame), so every chain
+        # of the step goes into ONE launch: 2*tr*B chains resident at once
+        jobs, blobs = [], []
+        for (d, isb), a in self.an.items():
+            for i in range(B):
+                n = tr + i
+                nref = n + d if isb else n - d
+                jobs.append((self.supers[n], self.supers[nref]))
+            blobs += self.blobs[(d, isb)]
+        if time_search:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self.an[(1, 1)].run(jobs, blobs=blobs)
+        if time_search:
+            e1.record()
+            self.ev.append((e0, e1))
+        djobs = []
+        for i in range(B):
+            n = tr + i
+            refs, blobs = [], []
+            for d in range(1, tr + 1):
+                for isb in (1, 0):
+                    refs.append(self.supers[n + d if isb else n - d])
+                    blobs.append(self.blobs[(d, isb)][i])
+            djobs.append((self.src[n], refs, blobs))
+        self.dg.run(djobs, out=self.out)
+
+    def algorithmic_bytes_per_chain(self):
+        """one chain reads the current frame's pyramid (sub-pel plane 0 of every level), the whole
+        reference super frame once, and writes the vector blob."""
+        i = self.sup.info
+        bps = self.sup.bps
+        import mvtools_amd as mv
+        full, pyr0 = 0, 0
+        import ctypes as C
+        L = mv.lib()
+        for p in range(i.num_planes):
+            xr, yr = (i.xRatioUV, i.yRatioUV) if p else (1, 1)
+            for lv in range(i.levels):
+                # level dims (MVFrame.cpp:1209-1226)
+                wl, hl = i.width, i.height
+                for _ in range(lv):
+                    wl = ((wl // i.xRatioUV + 1) // 2) * i.xRatioUV if i.hpad >= i.xRatioUV else ((wl // i.xRatioUV) // 2) * i.xRatioUV
+                    hl = ((hl // i.yRatioUV + 1) // 2) * i.yRatioUV if i.vpad >= i.yRatioUV else ((hl // i.yRatioUV) // 2) * i.yRatioUV
+                pw, ph = wl // xr + 2 * (i.hpad // xr), hl // yr + 2 * (i.vpad // yr)
+                npl = i.pel * i.pel if lv == 0 else 1
+                full += pw * ph * bps * npl
+                pyr0 += pw * ph * bps
+        return pyr0 + full + self.an[(1, 1)].blob_size, full
+
+
+def cpu_baseline(cfg, threads):
+    """The oracle (CPU restatement, kind 'port') on a bounded sample of the same workload: F output frames, F = worker
+    threads, each thread owning whole frames (VapourSynth fmParallel style); supers are shared."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    import mvoracle as mo
+    import pipeline as pl
+    (w, h, bits, tr, akw, skw, _, label) = cfg
+    F = threads
+    n = F + 2 * tr
+    frames = pl.moving_clip(w, h, bits, n, seed=5, noise=2)
+    sup = mo.Super(w, h, bits, **skw)
+    ans = {(d, isb): mo.Analyse(sup, isb=isb, delta=d, **akw) for d in range(1, tr + 1) for isb in (1, 0)}
+    dg = mo.Degrain(tr, sup, ans[(1, 1)].ad)
+    t0 = time.time()
+    with ThreadPoolExecutor(threads) as ex:
+        supers = list(ex.map(sup.frame, frames))
+
+        def one(i):
+            nn = tr + i
+            refs, blobs = [], []
+            for d in range(1, tr + 1):
+                for isb in (1, 0):
+                    r = supers[nn + d if isb else nn - d]
+                    refs.append(r)
+                    blobs.append(ans[(d, isb)].frame(supers[nn], r))
+            return dg.frame(frames[nn], refs, blobs)
+        list(ex.map(one, range(F)))
+    dt = time.time() - t0
+    return {"value": F / dt, "unit": "fps", "cores": threads, "kind": "port",
+            "sample": "%d output frames of %s (%d Super + %d Analyse + %d Degrain%d), %d threads each owning whole frames, %.1f s wall; scalar C oracle (-O2), not the reference's SIMD build" % (
+                F, label, n, 2 * tr * F, F, tr, threads, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import mvtools_amd as mv
+    mv.lib()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    cfg = CONFIGS[args.config]
+    B = args.batch or cfg[6]
+    pipe = Pipeline(mv, torch, cfg, B, device, seed=1000 + rank)  # every rank owns a different frame range
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pipe.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.step(time_search=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        search_ms = [a.elapsed_time(b) for a, b in pipe.ev]
+        avg_launch_ms = sum(search_ms) / len(search_ms)
+        bytes_chain, full = pipe.algorithmic_bytes_per_chain()
+        chains = 2 * cfg[3] * B
+        achieved = bytes_chain * chains / (avg_launch_ms * 1e-3) / 1e9
+        out = {
+            "metric": "MDegrain%d %s fps (Super+Analyse+Degrain end-to-end)" % (cfg[3], args.config),
+            "value": world * B * args.steps / dt, "unit": "fps", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u16" if cfg[2] > 8 else "u8", "data": "synthetic",
+            "config": {"workload": cfg[7], "frames_per_step_per_gpu": B, "chains_per_step_per_gpu": 2 * cfg[3] * B,
+                       "sharding": "frame ranges, no collective"},
+            "roofline": {"bound": "hbm", "kernel": "analyse_kernel (one launch = %d chains)" % chains, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": bytes_chain * chains, "avg_launch_ms": avg_launch_ms,
+                         "search_share_of_step": sum(search_ms) / (dt * 1e3)},
+        }
+        if not args.no_cpu and world == 1:
+            th = args.cpu_threads or min(os.cpu_count() or 1, 16)
+            out["cpu_baseline"] = cpu_baseline(cfg, th)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
