@@ -16,6 +16,7 @@
 // Integer SAD reduction: no MFMA.  All double arithmetic of the reference (lambda scaling :461-462, predictor
 // interpolation :1457,1500-1502) is done in IEEE fp64 with contraction off.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "mvx_common.h"
 
@@ -45,6 +46,7 @@ struct AParams {
     long long pitch[3];
     int blobSize;
     int superHPad, superVPad;
+    int ablate; // developer-only (MVX_ABLATE env): 1 = skip the search, 2 = predictor round only; results are then WRONG
     ALevel lv[MVX_MAX_LEVELS];
 };
 
@@ -108,6 +110,37 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
     v = min(v, DPP(v, 0x143, 0xc));
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
+// same reduction with the DPP modifier fused into v_min_u32 (the s_nop covers the VALU-write -> DPP-read hazard)
+__device__ __forceinline__ unsigned wave_min_u32_fused(unsigned v) {
+    asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// ordered arg-min of signed 32-bit costs (0x7fffffff = not a candidate): lowest lane holding the minimum, or -1
+__device__ __forceinline__ int wave_argmin_i32(int cost, int *minOut) {
+    const unsigned u = (unsigned)cost ^ 0x80000000u;
+    const unsigned m = wave_min_u32_fused(u);
+    if (m == 0xffffffffu) return -1;
+    const unsigned long long mask = __ballot(u == m);
+    *minOut = (int)(m ^ 0x80000000u);
+    return __ffsll((long long)mask) - 1;
+}
+template <int LOGG> __device__ __forceinline__ unsigned group_sum_c(unsigned v) {
+    if (LOGG >= 1) v += DPP(v, 0xB1, 0xf);
+    if (LOGG >= 2) v += DPP(v, 0x4E, 0xf);
+    if (LOGG >= 3) v += DPP(v, 0x141, 0xf);
+    if (LOGG >= 4) v += DPP(v, 0x140, 0xf);
+    if (LOGG >= 5) v += (unsigned)__shfl_xor((int)v, 16);
+    if (LOGG >= 6) v += (unsigned)__shfl_xor((int)v, 32);
+    return v;
+}
+
 __device__ __forceinline__ int wave_sum_i32(int v) {
     for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
     return v;
@@ -565,7 +598,7 @@ template <int BPS, typename GEO> struct Searcher {
             }
             unsigned aL = 0, aC = 0;
             const long long pt0 = PROF_T();
-            if (ok) eval_cand(s, logG, vx, vy, vyc, aL, aC);
+            if (ok && P.ablate != 3) eval_cand(s, logG, vx, vy, vyc, aL, aC);
             const long long pt1 = PROF_T();
             aL = group_sum(aL, logG);
             aC = group_sum(aC, logG);
@@ -619,10 +652,122 @@ template <int BPS, typename GEO> struct Searcher {
         nLambda = uni((long long)((double)nLambda * scale * scale));
     }
 
+    // ---- fast path -----------------------------------------------------------------------------------------------
+    // The default search (predictor set, then Hex2 hexagon + square at level 0 or the 24-point exhaustive rings at the
+    // coarse levels, no tryMany) as straight-line code with compile-time candidate tables; semantics identical to the
+    // general state machine below, which still handles every other pattern and the bad-block rescue.
+    enum { FR_A, FR_HEX6, FR_SQUARE, FR_EXH2 };
+    // block SADs bounded by 2^27 -> costs fit 32 bits once the (already int) motion distortion is added with saturation:
+    // a saturated cost can never beat nMinCost, which is at most the zero candidate's cost.
+    static constexpr bool COST32 = GEO::BW != 0 && GEO::BW * GEO::BH <= 1024;
+
+    template <int KIND> __device__ __forceinline__ int round_fast(int cx, int cy) {
+        constexpr int LOGG = KIND == FR_EXH2 ? 1 : 3;
+        constexpr int TOTAL = KIND == FR_A ? 7 : KIND == FR_HEX6 ? 6 : KIND == FR_SQUARE ? 8 : 24;
+        const int lane = lane_id();
+        const int g = lane >> LOGG, s = lane & ((1 << LOGG) - 1);
+        int vx, vy, vyc;
+        bool ok = g < TOTAL;
+        if (KIND == FR_A) {
+            vx = 0; vy = zeroMVfieldShifted.y;
+            vx = g == 1 ? globalMVPredictor.x : vx; vy = g == 1 ? globalMVPredictor.y : vy;
+            vx = g == 2 ? predictor.x : vx; vy = g == 2 ? predictor.y : vy;
+            vx = g == 3 ? predictors[0].x : vx; vy = g == 3 ? predictors[0].y : vy;
+            vx = g == 4 ? predictors[1].x : vx; vy = g == 4 ? predictors[1].y : vy;
+            vx = g == 5 ? predictors[2].x : vx; vy = g == 5 ? predictors[2].y : vy;
+            vx = g == 6 ? predictors[3].x : vx; vy = g == 6 ? predictors[3].y : vy;
+            vyc = g == 0 ? 0 : vy; // chroma of the zero candidate ignores fieldShift (:836-839)
+        } else {
+            int dx, dy;
+            if (KIND == FR_HEX6) { dx = tab8(HEX2X >> 8, g & 7); dy = tab8(HEX2Y >> 8, g & 7); }                  // hex2[g+1], :682-687
+            else if (KIND == FR_SQUARE) { dx = tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), g & 7); dy = tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), g & 7); } // :636-658 r=1
+            else { // rings 1 and 2 (:786-791): 8 + 16 candidates in reference order
+                const int k = g < 8 ? g : g - 8;
+                if (g < 8) { dx = tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), k); dy = tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), k); }
+                else if (k < 8) { dx = tab8(PACK8(-1, -1, 0, 0, 1, 1, -2, 2), k); dy = tab8(PACK8(-2, 2, -2, 2, -2, 2, -1, -1), k); }
+                else { dx = tab8(PACK8(-2, 2, -2, 2, -2, -2, 2, 2), k - 8); dy = tab8(PACK8(0, 0, 1, 1, -2, 2, -2, 2), k - 8); }
+            }
+            vx = cx + dx; vy = cy + dy; vyc = vy;
+            ok = ok && vector_ok(vx, vy);
+        }
+        unsigned aL = 0, aC = 0;
+        if (ok) {
+            if (GEO::BW != 0) eval_fixed<LOGG>(s, vx, vy, vyc, aL, aC);
+            else eval_cand(s, LOGG, vx, vy, vyc, aL, aC);
+        }
+        aL = group_sum_c<LOGG>(aL);
+        aC = group_sum_c<LOGG>(aC);
+        int w;
+        if (COST32) {
+            const int tot = (int)aL + (chroma ? (int)aC : 0);
+            int cc;
+            if (KIND == FR_A) {
+                const int pen = g == 0 ? penaltyZero : (g == 1 ? pglobal : 0);
+                const int md = g >= 3 ? motion_distortion(vx, vy) : 0;
+                cc = tot + (int)(((long long)pen * tot) >> 8);
+                cc = sat_add(md, cc);
+            } else {
+                cc = (int)aL + ((penaltyNew * (int)aL) >> 8);
+                if (chroma) cc += (int)aC + ((penaltyNew * (int)aC) >> 8);
+                cc = sat_add(motion_distortion(vx, vy), cc);
+            }
+            const int lim = nMinCost > 0x7fffffffLL ? 0x7fffffff : (int)nMinCost;
+            const int cost = (ok && cc < lim) ? cc : 0x7fffffff;
+            int mc;
+            w = wave_argmin_i32(cost, &mc);
+            if (w >= 0) {
+                nMinCost = mc;
+                bestMV.sad = (long long)bcast_i(tot, w);
+                if (KIND != FR_HEX6) { bestMV.x = bcast_i(vx, w); bestMV.y = bcast_i(vy, w); }
+            }
+        } else {
+            const long long tot = (long long)aL + (chroma ? (long long)aC : 0);
+            long long cc;
+            if (KIND == FR_A) {
+                const long long pen = g == 0 ? penaltyZero : (g == 1 ? pglobal : 0);
+                cc = tot + ((pen * tot) >> 8) + (g >= 3 ? (long long)motion_distortion(vx, vy) : 0);
+            } else {
+                cc = (long long)motion_distortion(vx, vy) + aL + ((penaltyNew * (long long)aL) >> 8);
+                if (chroma) cc += (long long)aC + ((penaltyNew * (long long)aC) >> 8);
+            }
+            const long long cost = (ok && cc < nMinCost) ? cc : BIG64;
+            long long mc;
+            w = wave_argmin_ll(cost, &mc);
+            if (w >= 0) {
+                nMinCost = mc;
+                bestMV.sad = bcast_ll(tot, w);
+                if (KIND != FR_HEX6) { bestMV.x = bcast_i(vx, w); bestMV.y = bcast_i(vy, w); }
+            }
+        }
+        return w >= 0 ? (w >> LOGG) : -1;
+    }
+    __device__ __forceinline__ static int sat_add(int a, int b) { // b >= 0
+        const long long r = (long long)a + b;
+        return r > 0x7fffffffLL ? 0x7fffffff : (int)r;
+    }
+
+    // returns true when the block is finished; false -> continue in the general state machine at the bad-block check
+    __device__ __forceinline__ bool search_block_fast() {
+        globalMVPredictor = clip_mv(globalMVPredictor); // cumulative clip (:859)
+        nMinCost = BIG64;
+        round_fast<FR_A>(0, 0);
+        if (searchType == SearchHex2) { // pobHex2Search :667-724 with i_me_range <= 3: no half-hexagon iterations
+            int bmx = bestMV.x, bmy = bestMV.y;
+            if (nSearchParam > 1) {
+                const int dir = round_fast<FR_HEX6>(bmx, bmy);
+                if (dir >= 0) { bmx += tab8(HEX2X, dir + 1); bmy += tab8(HEX2Y, dir + 1); }
+                bestMV.x = bmx; bestMV.y = bmy;
+            }
+            round_fast<FR_SQUARE>(bmx, bmy);
+        } else
+            round_fast<FR_EXH2>(bestMV.x, bestMV.y);
+        return !(blkIdx > 1 && bestMV.sad > (badSAD + badSAD * badcount / 16)); // :942
+    }
+
     // pobPseudoEPZSearch (PlaneOfBlocks.cpp:819-968) with pobRefine (:773-816) and every search pattern (:466-769)
     // flattened into one state machine around a SINGLE round() call site, so that the whole block state stays in
     // registers (a pattern-per-function structure would force it into scratch memory).
-    __device__ __forceinline__ void search_block() {
+    __device__ __forceinline__ void search_block(bool fromBadCheck) {
         enum { PC_ROUNDA, PC_TRY_NEXT, PC_REFINE, PC_EXH, PC_LINE, PC_NSTEP, PC_UMH, PC_UMH_HEX4, PC_HEX, PC_HEX3, PC_SQUARE,
                PC_OT_BEGIN, PC_OT_H0, PC_OT_HLOOP, PC_OT_V0, PC_OT_VLOOP, PC_DM_BEGIN, PC_DM_LOOP, PC_DM_SECOND, PC_DM_DIAG,
                PC_REFINE_END, PC_BADCHECK, PC_BADEXP, PC_FINAL, PC_FINAL_EXP, PC_DONE };
@@ -631,9 +776,11 @@ template <int BPS, typename GEO> struct Searcher {
         enum { Right = 1, Left = 2, Down = 4, Up = 8 };
 
         // ---- round A: zero, global, predictor, predictors[0..3]
-        globalMVPredictor = clip_mv(globalMVPredictor); // cumulative clip (:859)
         CandGen gen = { G_ROUNDA, 0, 0, 0, 0, 0, 0 };
-        nMinCost = BIG64;
+        if (!fromBadCheck) {
+            globalMVPredictor = clip_mv(globalMVPredictor); // cumulative clip (:859)
+            nMinCost = BIG64;
+        }
         long long aCost = 0, aTot = 0; // per-candidate values of round A stay in lanes 8*i (tryMany)
         int aVx = 0, aVy = 0;
 
@@ -645,7 +792,7 @@ template <int BPS, typename GEO> struct Searcher {
         int tryIdx = 0; Vec bestAll; bestAll.x = 0; bestAll.y = 0; bestAll.sad = 0; long long costAll = verybig + 1;
         long long foundSAD = 0; int expI = 0, mvx = 0, mvy = 0;
 
-        pc = PC_ROUNDA;
+        pc = fromBadCheck ? PC_BADCHECK : PC_ROUNDA;
         while (pc != PC_DONE) {
             const long long st0 = PROF_T();
             int total = 0; bool upd = true;
@@ -782,7 +929,7 @@ template <int BPS, typename GEO> struct Searcher {
             PROF_ADD(10, st1 - st0); PROF_ADD(11, st2 - st1);
 
             switch (post) {
-            case POST_ROUNDA: aCost = rCost; aTot = rTot; aVx = rVx; aVy = rVy; pc = tryMany ? PC_TRY_NEXT : PC_REFINE; break;
+            case POST_ROUNDA: aCost = rCost; aTot = rTot; aVx = rVx; aVy = rVy; pc = tryMany ? PC_TRY_NEXT : PC_REFINE; if (P.ablate == 2) pc = PC_DONE; break;
             case POST_HEX6:
                 if (w >= 0) dir = w;
                 if (dir != -2) { bmx += tab8(HEX2X, dir + 1); bmy += tab8(HEX2Y, dir + 1); it = 1; pc = PC_HEX3; }
@@ -1018,7 +1165,10 @@ template <int BPS, typename GEO> struct Searcher {
 
             __builtin_amdgcn_wave_barrier(); // single wave: DS ops are in order; keep the compiler from moving LDS reads above the staging writes
             const long long bt1 = PROF_T();
-            search_block();
+            const bool fast = !tryMany && ((searchType == SearchHex2 && nSearchParam <= 3) || (searchType == SearchExhaustive && nSearchParam == 2));
+            if (P.ablate == 1) { bestMV = predictor; bestMV.sad = 0; }
+            else if (fast) { if (!search_block_fast()) search_block(true); }
+            else search_block(false);
             const long long bt2 = PROF_T();
             __builtin_amdgcn_wave_barrier();
 
@@ -1250,6 +1400,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_create(const m
     P.lambda = nLambda; P.lsad = lsad; P.badSAD = badSAD;
     P.verybigSAD = (long long)P.blkX * P.blkY * (1 << si.bits);
     P.superHPad = si.hpad; P.superVPad = si.vpad;
+    P.ablate = getenv("MVX_ABLATE") ? atoi(getenv("MVX_ABLATE")) : 0;
     for (int p = 0; p < 3; p++) P.pitch[p] = p < si.num_planes ? super_pitch[p] : 0;
     if (si.num_planes > 1 && super_pitch[1] != super_pitch[2]) AFAIL("Analyse: the U and V planes of the super clip must share one pitch.");
     int blobOff = 8;
