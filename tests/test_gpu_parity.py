@@ -241,3 +241,68 @@ def test_compensate_parity(oracle, mv, w, h, bits, skw, akw, ckw):
         for p in range(3):
             g = mv.plane_to_numpy(got[p], want[p].shape[1], want[p].dtype)
             assert np.array_equal(g, want[p]), "compensate plane %d differs (%d samples)" % (p, int((g != want[p]).sum()))
+
+
+def _golden_cases():
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden.json")) as f:
+        return json.load(f)["cases"]
+
+
+@pytest.mark.parametrize("case", _golden_cases(), ids=lambda c: c["name"])
+def test_gpu_against_golden_fixtures(oracle, mv, case):
+    """the HIP path against the committed golden vectors (tests/golden/golden.json) -- no oracle computation involved,
+    mvoracle is only used for its FNV-1a hash helper and the list of defined super-frame rectangles"""
+    import torch
+    c = case["params"]
+    w, h, bits, radius = c["w"], c["h"], c["bits"], c["radius"]
+    frames = pl.moving_clip(w, h, bits, 2 * radius + 1, seed=99, noise=3)
+    gsup = mv.Super(w, h, bits, **c["skw"])
+    gsrc = [mv.frame_to_device(f) for f in frames]
+    gsf = gsup.build(gsrc)
+    osup = oracle.Super(w, h, bits, **c["skw"])  # geometry only
+    sf_np = _sup_to_numpy(mv, gsup, gsf[radius])
+    hs = [oracle.fnv1a(np.ascontiguousarray(sf_np[p][y0:y0 + hh, x0:x0 + ww])) for (p, lv, k, y0, x0, hh, ww) in osup.defined_regions()]
+    assert "%08x" % oracle.fnv1a(np.array(hs, dtype=np.uint32)) == case["expect"]["super_regions_fnv"]
+    blobs, refs = [], []
+    for d in range(1, radius + 1):
+        for isb in (1, 0):
+            gan = mv.Analyse(gsup, isb=isb, delta=d, **c["akw"])
+            nref = radius + (d if isb else -d)
+            blobs.append(gan.run([(gsf[radius], gsf[nref])])[0])
+            refs.append(gsf[nref])
+    assert ["%08x" % oracle.fnv1a(b.cpu().numpy()) for b in blobs] == case["expect"]["blobs_fnv"]
+    out = mv.Degrain(radius, gsup, gan.ad, [p.stride(0) for p in gsrc[0]]).run([(gsrc[radius], refs, blobs)])[0]
+    widths = [w, w // 2, w // 2]
+    got = ["%08x" % oracle.fnv1a(mv.plane_to_numpy(out[p], widths[p], gsup.dtype)) for p in range(3)]
+    assert got == case["expect"]["degrain_fnv"]
+    out = mv.Compensate(gsup, gan.ad).run([(gsf[radius], refs[0], blobs[0])])[0]
+    got = ["%08x" % oracle.fnv1a(mv.plane_to_numpy(out[p], widths[p], gsup.dtype)) for p in range(3)]
+    assert got == case["expect"]["compensate_fnv"]
+
+
+def test_full_size_properties_cfg2(mv):
+    """BASELINE cfg2 at full size (1080p P8 Degrain1 blk 8 ov 4 pel 2) through size-independent properties:
+    (1) a clip of identical frames has all-zero vectors and Degrain returns the input unchanged; (2) a pure integer
+    translation is recovered exactly by the interior blocks; (3) the blob header / validity / sizes are self-consistent."""
+    import torch
+    w, h, bits = 1920, 1080, 8
+    base = pl.moving_clip(w + 16, h + 16, bits, 1, seed=8, noise=0)[0]
+    f0 = [base[0][8:8 + h, 8:8 + w], base[1][4:4 + h // 2, 4:4 + w // 2], base[2][4:4 + h // 2, 4:4 + w // 2]]
+    f1 = [base[0][8:8 + h, 6:6 + w], base[1][4:4 + h // 2, 3:3 + w // 2], base[2][4:4 + h // 2, 3:3 + w // 2]]  # content moves +2 px
+    sup = mv.Super(w, h, bits)
+    src = [mv.frame_to_device([np.ascontiguousarray(p) for p in f]) for f in (f0, f0, f1)]
+    sf = sup.build(src)
+    an = mv.Analyse(sup, blksize=8, overlap=4, search=4, isb=1)
+    b_same, b_shift = an.run([(sf[0], sf[1]), (sf[0], sf[2])])
+    torch.cuda.synchronize()
+    bs = b_same.cpu().numpy()
+    assert bs[:8].view(np.int32).tolist() == [an.blob_size, 1] and an.blob_size == 2738792
+    x, y, sad = pl.blob_vectors(bs, an.ad, 0)
+    assert not x.any() and not y.any() and not sad.any()
+    x, y, sad = pl.blob_vectors(b_shift.cpu().numpy(), an.ad, 0)
+    inner = (slice(4, -4), slice(4, -4))
+    assert (x[inner] == 4).mean() > 0.99 and (y[inner] == 0).mean() > 0.99  # +2 px == +4 half-pel
+    out = mv.Degrain(1, sup, an.ad, [p.stride(0) for p in src[0]]).run([(src[0], [sf[1], sf[1]], [b_same, b_same])])[0]
+    for p in range(3):
+        assert torch.equal(out[p][:, :f0[p].shape[1]], src[0][p][:, :f0[p].shape[1]])
