@@ -21,10 +21,10 @@ for _p in (os.path.join(ROOT, "vapoursynth-mvtools_amd"), os.path.join(ROOT, "te
 
 CONFIGS = {
     # name: (width, height, bits, radius, analyse kwargs, super kwargs, default batch, BASELINE.json config string)
-    "cfg1": (640, 360, 8, 1, dict(blksize=8), dict(pel=1), 64, "640x360 YUV420P8 Degrain1 blksize=8 pel=1"),
-    "cfg2": (1920, 1080, 8, 1, dict(blksize=8, overlap=4, search=4), dict(pel=2), 64, "1080p YUV420P8 Degrain1 blksize=8 overlap=4 pel=2 search=4"),
-    "cfg3": (3840, 2160, 16, 3, dict(blksize=16, overlap=8), dict(pel=2), 48, "4K YUV420P16 Degrain3 blksize=16 overlap=8 pel=2"),
-    "cfg5": (7680, 4320, 16, 6, dict(blksize=32, overlap=16), dict(pel=2), 8, "8K YUV420P16 Degrain6 blksize=32 overlap=16 pel=2"),
+    "cfg1": (640, 360, 8, 1, dict(blksize=8), dict(pel=1), 504, "640x360 YUV420P8 Degrain1 blksize=8 pel=1"),
+    "cfg2": (1920, 1080, 8, 1, dict(blksize=8, overlap=4, search=4), dict(pel=2), 504, "1080p YUV420P8 Degrain1 blksize=8 overlap=4 pel=2 search=4"),
+    "cfg3": (3840, 2160, 16, 3, dict(blksize=16, overlap=8), dict(pel=2), 168, "4K YUV420P16 Degrain3 blksize=16 overlap=8 pel=2"),
+    "cfg5": (7680, 4320, 16, 6, dict(blksize=32, overlap=16), dict(pel=2), 84, "8K YUV420P16 Degrain6 blksize=32 overlap=16 pel=2"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
@@ -233,6 +233,14 @@ def main():
         bytes_chain, full = pipe.algorithmic_bytes_per_chain()
         chains = 2 * cfg[3] * B
         achieved = bytes_chain * chains / (avg_launch_ms * 1e-3) / 1e9
+        traffic = None  # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (same command)
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as f:
+                t = json.load(f)
+            if t.get("config") == "%s batch %d" % (args.config, B):
+                traffic = [v["hbm_bytes_per_dispatch_corrected"] for k, v in t["kernels"].items() if "analyse_kernel" in k][0]
+        except Exception:
+            traffic = None
         out = {
             "metric": "MDegrain%d %s fps (Super+Analyse+Degrain end-to-end)" % (cfg[3], args.config),
             "value": world * B * args.steps / dt, "unit": "fps", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -241,12 +249,12 @@ def main():
             "config": {"workload": cfg[7], "frames_per_step_per_gpu": B, "chains_per_step_per_gpu": 2 * cfg[3] * B,
                        "sharding": "frame ranges, no collective"},
             "roofline": {"bound": "hbm", "kernel": "analyse_kernel (one launch = %d chains)" % chains, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_chain * chains, "avg_launch_ms": avg_launch_ms,
                          "search_share_of_step": sum(search_ms) / (dt * 1e3)},
         }
         if not args.no_cpu and world == 1:
-            th = args.cpu_threads or min(os.cpu_count() or 1, 16)
+            th = args.cpu_threads or min(os.cpu_count() or 1, 32)
             out["cpu_baseline"] = cpu_baseline(cfg, th)
         print(json.dumps(out))
     if dist is not None:
