@@ -982,6 +982,57 @@ template <int BPS, typename GEO> struct Searcher {
         return (pl == 1 ? srcU : srcV) + (long long)(cvpad + (stepY >> logyr) * by + row) * pitchC + (long long)(chpad + (stepX >> logxr) * bx) * BPS + xb;
     }
 
+    // ---- specialised source-block staging (compile-time geometry): every lane owns the same NPF items of every block,
+    // so their row/column offsets are computed once per level; per block only the block origin is added.
+    static constexpr int G_BW = GEO::BW ? GEO::BW : 8, G_BH = GEO::BH ? GEO::BH : 8, G_XR = GEO::XR ? GEO::XR : 1, G_YR = GEO::YR ? GEO::YR : 1;
+    static constexpr int G_LROWB = G_BW * BPS, G_LCB = G_LROWB < 16 ? G_LROWB : 16, G_LC = G_LROWB / G_LCB, G_LT = G_BH * G_LC;
+    static constexpr int G_CROWB = (G_BW / G_XR) * BPS, G_CCB = G_CROWB < 16 ? G_CROWB : 16, G_CC = G_CROWB / G_CCB, G_CT = (G_BH / G_YR) * G_CC;
+    static constexpr int G_UOFF = G_BH * G_LROWB, G_VOFF = G_UOFF + (G_BH / G_YR) * G_CROWB;
+    static constexpr int G_NPF = (G_LT + 2 * G_CT + WAVE - 1) / WAVE;
+    static constexpr bool G_PF = GEO::BW != 0 && G_NPF <= PF_MAX;
+    int pfG[PF_MAX], pfL[PF_MAX], pfP[PF_MAX]; // per lane: global row/col offset, LDS offset, plane (0,1,2; -1 = no item)
+
+    __device__ __forceinline__ void pf_setup() {
+        const int l = lane_id();
+#pragma unroll
+        for (int k = 0; k < G_NPF; k++) {
+            const int t = l + k * WAVE;
+            const int TT_ = G_LT + (chroma ? 2 * G_CT : 0);
+            if (t < G_LT) {
+                const int row = t / G_LC, xb = (t % G_LC) * G_LCB;
+                pfP[k] = 0; pfG[k] = (int)(row * pitchY) + xb; pfL[k] = row * G_LROWB + xb;
+            } else if (t < TT_) {
+                int tt = t - G_LT;
+                const int pl = tt >= G_CT ? 2 : 1;
+                if (pl == 2) tt -= G_CT;
+                const int row = tt / G_CC, xb = (tt % G_CC) * G_CCB;
+                pfP[k] = pl; pfG[k] = (int)(row * pitchC) + xb; pfL[k] = (pl == 2 ? G_VOFF : G_UOFF) + row * G_CROWB + xb;
+            } else { pfP[k] = -1; pfG[k] = 0; pfL[k] = 0; }
+        }
+    }
+    __device__ __forceinline__ void pf_issue(int bx, int by, int stepX, int stepY, A4x32 *pf) const {
+        const long long offY = (long long)(vpad + stepY * by) * pitchY + (long long)(hpad + stepX * bx) * BPS;
+        const long long offC = (long long)(cvpad + (stepY >> logyr) * by) * pitchC + (long long)(chpad + (stepX >> logxr) * bx) * BPS;
+#pragma unroll
+        for (int k = 0; k < G_NPF; k++) {
+            const int pl = pfP[k];
+            if (pl < 0) continue;
+            gl_u8 *g = (pl == 0 ? srcY + offY : (pl == 1 ? srcU : srcV) + offC) + pfG[k];
+            if (G_LCB == G_CCB) pf[k] = ld_chunk_g(g, G_LCB);
+            else pf[k] = pl == 0 ? ld_chunk_g(g, G_LCB) : ld_chunk_g(g, G_CCB);
+        }
+    }
+    __device__ __forceinline__ void pf_store(const A4x32 *pf) const {
+#pragma unroll
+        for (int k = 0; k < G_NPF; k++) {
+            const int pl = pfP[k];
+            if (pl < 0) continue;
+            if (G_LCB == G_CCB) st_chunk_l(lds + pfL[k], pf[k], G_LCB);
+            else if (pl == 0) st_chunk_l(lds + pfL[k], pf[k], G_LCB);
+            else st_chunk_l(lds + pfL[k], pf[k], G_CCB);
+        }
+    }
+
     // GroupOfPlanes.c:69-125 + PlaneOfBlocks.cpp:971-1131 for one level
     __device__ __forceinline__ void search_level(int lvl, Vec *globalMV, GL_AS const GVec *coarse, int coarseBlkX, int coarseBlkY, int coarseLogPel) {
         const int l = lane_id();
@@ -1091,6 +1142,7 @@ template <int BPS, typename GEO> struct Searcher {
         // global loads are issued one block ahead and only consumed at the top of the next iteration.
         const bool usePF = TT <= PF_MAX * WAVE;
         A4x32 pf[PF_MAX];
+        if (G_PF) pf_setup();
         Vec nSelf, nBelow;
         int nextIb = 0, nextBy = 0; // scan position of the block being prefetched (:1037-1056), advanced without divisions
         auto prefetch = [&]() {
@@ -1103,7 +1155,8 @@ template <int BPS, typename GEO> struct Searcher {
             const bool aheadCol = (dir == 1 && bx < nBlkX - 1) || (dir == -1 && bx > 0);
             nBelow.x = 0; nBelow.y = 0; nBelow.sad = 0;
             if (by < nBlkY - 1 && aheadCol) nBelow = uni(ld_vec(&vectors[idx + nBlkX + dir]));
-            if (usePF) {
+            if (G_PF) pf_issue(bx, by, stepX, stepY, pf);
+            else if (usePF) {
 #pragma unroll
                 for (int k = 0; k < PF_MAX; k++) {
                     const int t = l + k * WAVE;
@@ -1126,7 +1179,8 @@ template <int BPS, typename GEO> struct Searcher {
 
             // consume the prefetched data: source block -> LDS (PlaneOfBlocks.cpp:1058-1079), predictors -> registers
             const Vec self = nSelf, below = nBelow;
-            if (usePF) {
+            if (G_PF) pf_store(pf);
+            else if (usePF) {
 #pragma unroll
                 for (int k = 0; k < PF_MAX; k++) {
                     const int t = l + k * WAVE;
