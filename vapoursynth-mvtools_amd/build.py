@@ -16,6 +16,8 @@ SOURCES = ["mvx_api.hip", "mvx_super.hip", "mvx_analyse.hip", "mvx_degrain.hip"]
 # not be fused into FMAs; no fast-math anywhere.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wall",
          "-Wno-unused-function"]
+if os.environ.get("MVX_NT_REF"):  # developer-only experiment: non-temporal reference loads
+    FLAGS.append("-DMVX_NT_REF")
 if os.environ.get("MVX_PROFILE"):  # developer-only: per-phase cycle counters inside the search kernel
     FLAGS.append("-DMVX_PROFILE")
 
