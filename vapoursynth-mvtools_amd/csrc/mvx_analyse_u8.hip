@@ -1,0 +1,11 @@
+// 8-bit search kernels specialised for the common 4:2:0 block geometries (Geo<BW, BH, XR, YR, scan step>)
+#include "mvx_analyse_kernel.h"
+int mvx_analyse_launch_u8(const AParams &P, const ALaunch &L) {
+    if (P.xr != 2 || P.yr != 2) return 1;
+    // The LDS search-window kernels (Geo<..., scan step>) are bit-exact but measured SLOWER than the plain ones in round 1
+    // (DESIGN.md 4.2): opt-in via MVX_WINDOW=1 until the window path is cheaper in instructions.
+    const int S = L.ldsWin >= 0 ? P.blkX - P.ovX : 0;
+    if (P.blkX == 8 && P.blkY == 8) return S == 4 ? launch_analyse_kernel<1, Geo<8, 8, 2, 2, 4>>(L) : launch_analyse_kernel<1, Geo<8, 8, 2, 2>>(L);
+    if (P.blkX == 16 && P.blkY == 16) return S == 8 ? launch_analyse_kernel<1, Geo<16, 16, 2, 2, 8>>(L) : launch_analyse_kernel<1, Geo<16, 16, 2, 2>>(L);
+    return 1;
+}
