@@ -52,7 +52,10 @@ def synth_clip_device(torch, width, height, bits, nframes, seed, device):
             base = tex if p == 0 else texc[p - 1]
             img = base[oy:oy + height:s, ox:ox + width:s].clone()
             h, w = img.shape
-            rx, ry = (width // 2 - 2 * f) // s, (height // 3 + 2 * f) // s
+            per = max(8, min(height * 5 // 24, width // 4) - 8)   # the rectangle bounces so that long clips keep it inside
+            fb = f % (2 * per)
+            fb = fb if fb < per else 2 * per - fb
+            rx, ry = (width // 2 - 2 * fb) // s, (height // 3 + 2 * fb) // s
             rw, rh = (width // 4) // s, (height // 4) // s
             img[ry:ry + rh, rx:rx + rw] = base[8:8 + rh * s:s, 8:8 + rw * s:s] * 0.8 + (35 if p == 0 else 10)
             img = img + torch.randint(-2, 3, img.shape, generator=g, device=device).float()

@@ -689,85 +689,91 @@ template <int BPS, typename GEO> struct Searcher {
     static constexpr int W_RS = W_RB + 16, W_RSC = W_RBC + 16;         // row stride: + 16-byte mirror of the ring start (reads never wrap)
     static constexpr int W_CBS = W_S * BPS < 16 ? W_S * BPS : 16, W_SCL = W_S * BPS / W_CBS;
     static constexpr int W_CBSC = W_SC * BPS < 16 ? W_SC * BPS : 16, W_SCC = W_SC * BPS / W_CBSC;
-#define WQ_MAX 4
+    // Strip items (one CBS-byte piece of one window row of one sub-pel plane) are dealt to per-plane slots: slots
+    // 0..WQY-1 hold luma items, slot WQY the U items, slot WQY+1 the V items (same geometry as U).  Within a slot every
+    // lane owns item min(lane + 64*q, last): surplus lanes duplicate the last item (same address, same data, same LDS
+    // target), which keeps the per-block code free of branches and per-lane predicates.
+#define WQY 2
+#define WQ_MAX (WQY + 2)
     int winOn, ldsWin, winCap;
     int wLdsC;                                         // LDS offset of the chroma windows (U planes then V planes)
-    int wQ;                                            // strip items per lane
+    int wQY;                                           // luma slots in use (1 or 2)
     int wcx, wcy, wccx, wccy;                          // expected motion of this block row (full-pel), luma / chroma
     int worg, worgC, wrow0, wrow0C;                    // ring origin columns, absolute row of window row 0
     int wgoodL, wgoodR, wgoodLC, wgoodRC;              // strip-aligned column range whose strips lie fully inside the plane
     int wvalL, wvalR, wvalLC, wvalRC;                  // columns valid for the current block
     int wPend;                                         // strip index pending in registers
     int gmvx0, gmvy0;                                  // the level's global motion predictor before the cumulative clipping
-    int wG[WQ_MAX], wL[WQ_MAX], wRow[WQ_MAX], wPl[WQ_MAX]; // per lane strip items: global offset, LDS offset, window row, plane (3 = none)
+    int wPP[WQY], wRowL[WQY], wChL[WQY], wLdsL[WQY];   // per lane luma items: sub-pel plane, window row, piece, LDS offset
+    int wPPC, wRowC, wChC, wLdsU;                      // per lane chroma item (U; V = + wVstep in LDS)
+    unsigned wOffL[WQY], wOffC;                        // per block row: byte offset of (plane, clamped row, piece) in the plane set
+    int wVstep;
 
     __device__ __forceinline__ void win_setup_level() {
         winOn = 0;
         if (!W_ON || ldsWin < 0 || P.ablate == 6) return;
         const int npp = pel * pel;
-        const int NIL = npp * W_WH * W_SCL, NIC = chroma ? 2 * npp * W_WHC * W_SCC : 0;
-        wQ = (NIL + NIC + WAVE - 1) / WAVE;
+        const int NIL = npp * W_WH * W_SCL, NIC = chroma ? npp * W_WHC * W_SCC : 0;
+        wQY = (NIL + WAVE - 1) / WAVE;
         const int lumaBytes = npp * W_WH * W_RS, chromaBytes = chroma ? 2 * npp * W_WHC * W_RSC : 0;
-        if (wQ > WQ_MAX || lumaBytes + chromaBytes > winCap) return;
+        if (wQY > WQY || NIC > WAVE || lumaBytes + chromaBytes > winCap) return;
+        if ((long long)npp * pstrideY >= 0x7fffffffLL) return; // 32-bit plane offsets
         wLdsC = ldsWin + lumaBytes;
+        wVstep = npp * W_WHC * W_RSC;
         const int l = lane_id();
 #pragma unroll
-        for (int q = 0; q < WQ_MAX; q++) {
-            const int i = l + q * WAVE;
-            wPl[q] = 3; wG[q] = 0; wL[q] = 0; wRow[q] = 0;
-            if (i < NIL) {
-                const int pp = i / (W_WH * W_SCL), rem = i - pp * (W_WH * W_SCL), row = rem / W_SCL, ch = rem % W_SCL;
-                wPl[q] = 0; wRow[q] = row;
-                wG[q] = (int)(pp * pstrideY) + ch * W_CBS;                 // + clamped row * pitch + column, per strip
-                wL[q] = ldsWin + (pp * W_WH + row) * W_RS + ch * W_CBS;
-            } else if (i < NIL + NIC) {
-                int i2 = i - NIL;
-                const int per = npp * W_WHC * W_SCC;
-                const int v = i2 >= per;
-                if (v) i2 -= per;
-                const int pp = i2 / (W_WHC * W_SCC), rem = i2 - pp * (W_WHC * W_SCC), row = rem / W_SCC, ch = rem % W_SCC;
-                wPl[q] = 1 + v; wRow[q] = row;
-                wG[q] = (int)(pp * pstrideC) + ch * W_CBSC;
-                wL[q] = wLdsC + ((v * npp + pp) * W_WHC + row) * W_RSC + ch * W_CBSC;
-            }
+        for (int q = 0; q < WQY; q++) {
+            const int i = min(l + q * WAVE, NIL - 1);
+            const int pp = i / (W_WH * W_SCL), rem = i - pp * (W_WH * W_SCL), row = rem / W_SCL, ch = rem % W_SCL;
+            wPP[q] = pp; wRowL[q] = row; wChL[q] = ch;
+            wLdsL[q] = ldsWin + (pp * W_WH + row) * W_RS + ch * W_CBS;
+        }
+        {
+            const int i = min(l, max(NIC - 1, 0));
+            const int pp = i / (W_WHC * W_SCC), rem = i - pp * (W_WHC * W_SCC), row = rem / W_SCC, ch = rem % W_SCC;
+            wPPC = pp; wRowC = row; wChC = ch;
+            wLdsU = wLdsC + (pp * W_WHC + row) * W_RSC + ch * W_CBSC;
         }
         winOn = 1;
+    }
+    // per block row: plane offsets of this lane's items with the window rows clamped into the plane
+    __device__ __forceinline__ void win_row_offsets() {
+#pragma unroll
+        for (int q = 0; q < WQY; q++) {
+            const int ar = min(max(wrow0 + wRowL[q], 0), ph - 1);
+            wOffL[q] = (unsigned)(wPP[q] * (int)pstrideY) + (unsigned)ar * (unsigned)pitchY + (unsigned)(wChL[q] * W_CBS);
+        }
+        const int arc = min(max(wrow0C + wRowC, 0), (ph >> logyr) - 1);
+        wOffC = (unsigned)(wPPC * (int)pstrideC) + (unsigned)arc * (unsigned)pitchC + (unsigned)(wChC * W_CBSC);
     }
 
     // request strip k (SX columns, k-th from the row origin in scan direction) into registers
     __device__ __forceinline__ void win_issue(int k, A4x32 *wpf) const {
         const int c0 = blkScanDir == 1 ? worg + k * W_S : worg - (k + 1) * W_S;
         const int c0c = blkScanDir == 1 ? worgC + k * W_SC : worgC - (k + 1) * W_SC;
-        const int cc = min(max(c0, 0), pw - W_S), ccc = min(max(c0c, 0), (pw >> logxr) - W_SC); // addresses stay inside the plane
-        const int hmaxC = (ph >> logyr) - 1;
-#pragma unroll
-        for (int q = 0; q < WQ_MAX; q++) {
-            if (q >= wQ) break;
-            const int pl = wPl[q];
-            if (pl == 3) continue;
-            if (pl == 0) {
-                const int ar = min(max(wrow0 + wRow[q], 0), ph - 1);
-                wpf[q] = ld_chunk_g(refY + wG[q] + (long long)ar * pitchY + cc * BPS, W_CBS);
-            } else {
-                const int ar = min(max(wrow0C + wRow[q], 0), hmaxC);
-                wpf[q] = ld_chunk_g((pl == 1 ? refU : refV) + wG[q] + (long long)ar * pitchC + ccc * BPS, W_CBSC);
-            }
+        const unsigned cb = (unsigned)(min(max(c0, 0), pw - W_S) * BPS), cbc = (unsigned)(min(max(c0c, 0), (pw >> logxr) - W_SC) * BPS); // inside the plane
+        wpf[0] = ld_chunk_g(refY + (wOffL[0] + cb), W_CBS);
+        if (wQY > 1) wpf[1] = ld_chunk_g(refY + (wOffL[1] + cb), W_CBS);
+        if (chroma) {
+            wpf[WQY] = ld_chunk_g(refU + (wOffC + cbc), W_CBSC);
+            wpf[WQY + 1] = ld_chunk_g(refV + (wOffC + cbc), W_CBSC);
         }
     }
     __device__ __forceinline__ void win_store(int k, const A4x32 *wpf) const {
         const int rc = ((blkScanDir == 1 ? k * W_S : -(k + 1) * W_S) & (W_WW - 1)) * BPS;
         const int rcc = ((blkScanDir == 1 ? k * W_SC : -(k + 1) * W_SC) & (W_WWC - 1)) * BPS;
-#pragma unroll
-        for (int q = 0; q < WQ_MAX; q++) {
-            if (q >= wQ) break;
-            const int pl = wPl[q];
-            if (pl == 3) continue;
-            if (pl == 0) {
-                st_chunk_l(lds + wL[q] + rc, wpf[q], W_CBS);
-                if (rc < 16) st_chunk_l(lds + wL[q] + rc + W_RB, wpf[q], W_CBS); // mirror of the ring start
-            } else {
-                st_chunk_l(lds + wL[q] + rcc, wpf[q], W_CBSC);
-                if (rcc < 16) st_chunk_l(lds + wL[q] + rcc + W_RBC, wpf[q], W_CBSC);
+        st_chunk_l(lds + wLdsL[0] + rc, wpf[0], W_CBS);
+        if (wQY > 1) st_chunk_l(lds + wLdsL[1] + rc, wpf[1], W_CBS);
+        if (rc < 16) { // mirror of the ring start
+            st_chunk_l(lds + wLdsL[0] + rc + W_RB, wpf[0], W_CBS);
+            if (wQY > 1) st_chunk_l(lds + wLdsL[1] + rc + W_RB, wpf[1], W_CBS);
+        }
+        if (chroma) {
+            st_chunk_l(lds + wLdsU + rcc, wpf[WQY], W_CBSC);
+            st_chunk_l(lds + wLdsU + wVstep + rcc, wpf[WQY + 1], W_CBSC);
+            if (rcc < 16) {
+                st_chunk_l(lds + wLdsU + rcc + W_RBC, wpf[WQY], W_CBSC);
+                st_chunk_l(lds + wLdsU + wVstep + rcc + W_RBC, wpf[WQY + 1], W_CBSC);
             }
         }
     }
@@ -791,16 +797,16 @@ template <int BPS, typename GEO> struct Searcher {
         const int pwc = pw >> logxr;
         wgoodLC = worgC + cdiv(-worgC, W_SC) * W_SC;
         wgoodRC = worgC + fdiv(pwc - worgC, W_SC) * W_SC;
+        win_row_offsets();
         for (int k = 0; k < W_NS; k++) { win_issue(k, wpf); win_store(k, wpf); }
         win_issue(W_NS, wpf);
         wPend = W_NS;
     }
-    // every later block of the row: the strip requested during the previous block goes to LDS, the next one is requested
-    __device__ __forceinline__ void win_advance(A4x32 *wpf) {
-        win_store(wPend, wpf);
-        wPend++;
-        win_issue(wPend, wpf);
-    }
+    // every later block of the row: the strip requested during the previous block goes to LDS (win_consume, BEFORE this
+    // block issues any new global load, so that its wait only covers loads that are a whole block old), then the next
+    // strip is requested (win_request)
+    __device__ __forceinline__ void win_consume(A4x32 *wpf) { win_store(wPend, wpf); wPend++; }
+    __device__ __forceinline__ void win_request(A4x32 *wpf) { win_issue(wPend, wpf); }
     __device__ __forceinline__ void win_block_range() {
         wvalL = max(x0 + wcx - W_MX, wgoodL); wvalR = min(x0 + wcx + G_BW + W_MX, wgoodR);
         wvalLC = max(cx0 + wccx - W_MXC, wgoodLC); wvalRC = min(cx0 + wccx + G_BW / G_XR + W_MXC, wgoodRC);
@@ -808,51 +814,39 @@ template <int BPS, typename GEO> struct Searcher {
 
     // SAD of this lane's items of one plane region against the LDS window; winRow = LDS offset of the window row holding
     // the candidate's first row, b0 = byte offset of its first column relative to the ring origin (any sign)
+    // unaligned LDS read of CB bytes (the gfx950 DS unit handles under-aligned b64/b128 reads natively) + SAD against the
+    // naturally aligned source chunk
+    template <int CB> __device__ __forceinline__ unsigned win_chunk(const lds_u8 *sp, const lds_u8 *rp, unsigned acc) const {
+        if (CB == 16) {
+            v4u a = *(const LDS_AS v4u *)sp; uv4 b = *(const LDS_AS uv4 *)rp;
+            acc = sad32<BPS>(a[0], b[0], acc); acc = sad32<BPS>(a[1], b[1], acc);
+            acc = sad32<BPS>(a[2], b[2], acc); acc = sad32<BPS>(a[3], b[3], acc);
+        } else if (CB == 8) {
+            v2u a = *(const LDS_AS v2u *)sp; uv2 b = *(const LDS_AS uv2 *)rp;
+            acc = sad32<BPS>(a[0], b[0], acc); acc = sad32<BPS>(a[1], b[1], acc);
+        } else if (CB == 4) acc = sad32<BPS>(*(const LDS_AS unsigned *)sp, *(const LDS_AS uv1 *)rp, acc);
+        else acc = sad32<BPS>(*(const LDS_AS unsigned short *)sp, *(const LDS_AS uh1 *)rp, acc);
+        return acc;
+    }
     template <int LOGG, int T, int LOGC, int CB, int ROWB, int RB, int RS>
     __device__ __forceinline__ unsigned win_region(int s, const lds_u8 *src, int winRow, int b0, unsigned acc) const {
         constexpr int G = 1 << LOGG, C = 1 << LOGC;
         constexpr int N = T >= G ? T / G : 1;
-        constexpr int ND = CB >= 4 ? CB / 4 : 1;
         if (T < G && s >= T) return acc;
         if (G >= C) { // chunk column fixed per lane; rows advance by G / C per item -> one base address, immediate offsets
             const int row0 = s >> LOGC, xb = (s & (C - 1)) * CB;
-            const int bo = (b0 + xb) & (RB - 1), sh = (bo & 3) * 8;
-            const lds_u8 *rp = lds + winRow + row0 * RS + (bo & ~3);
+            const int bo = (b0 + xb) & (RB - 1);
+            const lds_u8 *rp = lds + winRow + row0 * RS + bo;
             const lds_u8 *sp = src + row0 * ROWB + xb;
             constexpr int rstep = (G >> LOGC) * RS, sstep = (G >> LOGC) * ROWB;
 #pragma unroll
-            for (int k = 0; k < N; k++) {
-                unsigned d[ND + 1];
-#pragma unroll
-                for (int i = 0; i <= ND; i++) d[i] = *(const LDS_AS unsigned *)(rp + k * rstep + 4 * i);
-                if (CB == 16) {
-                    v4u a = *(const LDS_AS v4u *)(sp + k * sstep);
-#pragma unroll
-                    for (int i = 0; i < 4; i++) acc = sad32<BPS>(a[i], __builtin_amdgcn_alignbit(d[i + 1], d[i], sh), acc);
-                } else if (CB == 8) {
-                    v2u a = *(const LDS_AS v2u *)(sp + k * sstep);
-                    acc = sad32<BPS>(a[0], __builtin_amdgcn_alignbit(d[1], d[0], sh), acc);
-                    acc = sad32<BPS>(a[1], __builtin_amdgcn_alignbit(d[2], d[1], sh), acc);
-                } else if (CB == 4) acc = sad32<BPS>(*(const LDS_AS unsigned *)(sp + k * sstep), __builtin_amdgcn_alignbit(d[1], d[0], sh), acc);
-                else acc = sad32<BPS>(*(const LDS_AS unsigned short *)(sp + k * sstep), __builtin_amdgcn_alignbit(d[1], d[0], sh) & 0xffffu, acc);
-            }
+            for (int k = 0; k < N; k++) acc = win_chunk<CB>(sp + k * sstep, rp + k * rstep, acc);
         } else {
 #pragma unroll
             for (int k = 0; k < N; k++) {
                 const int t = s + k * G, row = t >> LOGC, xb = (t & (C - 1)) * CB;
-                const int bo = (b0 + xb) & (RB - 1), sh = (bo & 3) * 8;
-                const lds_u8 *rp = lds + winRow + row * RS + (bo & ~3);
-                const lds_u8 *sp = src + row * ROWB + xb;
-                unsigned d[ND + 1];
-#pragma unroll
-                for (int i = 0; i <= ND; i++) d[i] = *(const LDS_AS unsigned *)(rp + 4 * i);
-#pragma unroll
-                for (int i = 0; i < ND; i++) {
-                    unsigned a = CB >= 4 ? *(const LDS_AS unsigned *)(sp + 4 * i) : (unsigned)*(const LDS_AS unsigned short *)sp;
-                    unsigned r = __builtin_amdgcn_alignbit(d[i + 1], d[i], sh);
-                    if (CB < 4) r &= 0xffffu;
-                    acc = sad32<BPS>(a, r, acc);
-                }
+                const int bo = (b0 + xb) & (RB - 1);
+                acc = win_chunk<CB>(src + row * ROWB + xb, lds + winRow + row * RS + bo, acc);
             }
         }
         return acc;
@@ -925,10 +919,16 @@ template <int BPS, typename GEO> struct Searcher {
             ok = ok && vector_ok(vx, vy);
         }
         unsigned aL = 0, aC = 0;
+#ifdef MVX_PROFILE
+        bool wmiss = false;
+#endif
         const long long ft0 = PROF_T();
         if (ok) {
             bool done = false;
             if (W_ON) { if (winOn) done = eval_win<LOGG>(s, vx, vy, vyc, aL, aC); }
+#ifdef MVX_PROFILE
+            wmiss = !done;
+#endif
             if (!done) {
                 if (GEO::BW != 0) eval_fixed<LOGG>(s, vx, vy, vyc, aL, aC);
                 else eval_cand(s, LOGG, vx, vy, vyc, aL, aC);
@@ -936,6 +936,9 @@ template <int BPS, typename GEO> struct Searcher {
         }
         const long long ft1 = PROF_T();
         PROF_ADD(4, ft1 - ft0); PROF_ADD(8, 1);
+#ifdef MVX_PROFILE
+        if (__builtin_amdgcn_ballot_w64(wmiss)) prof[5] += 1; // passes with at least one candidate outside the LDS window
+#endif
         aL = group_sum_c<LOGG>(aL);
         aC = group_sum_c<LOGG>(aC);
         int w;
@@ -1478,13 +1481,19 @@ template <int BPS, typename GEO> struct Searcher {
                     st_chunk_l(lds + loff, a, cb);
                 }
             }
+            bool winRowStart = false;
+            if (W_ON) {
+                if (winOn) { // slide the LDS search window: the strip requested a block ago goes to LDS
+                    winRowStart = (blkScanDir == 1) ? blkx == 0 : blkx == nBlkX - 1;
+                    if (!winRowStart) win_consume(wpf);
+                }
+            }
             const long long btA = PROF_T();
             if (n + 1 < nBlk) prefetch();
             const long long btW = PROF_T();
             if (W_ON) {
-                if (winOn) { // slide the LDS search window
-                    const bool rowStart = (blkScanDir == 1) ? blkx == 0 : blkx == nBlkX - 1;
-                    if (rowStart) win_row_init(wpf); else win_advance(wpf);
+                if (winOn) {
+                    if (winRowStart) win_row_init(wpf); else win_request(wpf);
                     win_block_range();
                 }
             }
@@ -1584,8 +1593,11 @@ template <int BPS, typename GEO> struct Searcher {
     }
 };
 
+#ifndef MVX_WAVES_PER_EU
+#define MVX_WAVES_PER_EU 1 // two chains per SIMD were measured slower (r1): the CU's texture addresser / L1 is the shared bottleneck
+#endif
 template <int BPS, typename GEO>
-__global__ __launch_bounds__(64, 1) void analyse_kernel(const AParams *Pp, const AJob *jobs, int ldsRow, int ldsHist, int histBins, int ldsWin, int winCap) {
+__global__ __launch_bounds__(64, MVX_WAVES_PER_EU) void analyse_kernel(const AParams *Pp, const AJob *jobs, int ldsRow, int ldsHist, int histBins, int ldsWin, int winCap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const AParams &P = *Pp;
     const AJob &J = jobs[blockIdx.x];
