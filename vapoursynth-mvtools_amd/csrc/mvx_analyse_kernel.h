@@ -548,6 +548,70 @@ template <int BPS, typename GEO> struct Searcher {
         }
     }
 
+    static constexpr int G_BW = GEO::BW ? GEO::BW : 8, G_BH = GEO::BH ? GEO::BH : 8, G_XR = GEO::XR ? GEO::XR : 1, G_YR = GEO::YR ? GEO::YR : 1;
+    static constexpr int G_LROWB = G_BW * BPS, G_LCB = G_LROWB < 16 ? G_LROWB : 16, G_LC = G_LROWB / G_LCB, G_LT = G_BH * G_LC;
+    static constexpr int G_CROWB = (G_BW / G_XR) * BPS, G_CCB = G_CROWB < 16 ? G_CROWB : 16, G_CC = G_CROWB / G_CCB, G_CT = (G_BH / G_YR) * G_CC;
+    static constexpr int G_UOFF = G_BH * G_LROWB, G_VOFF = G_UOFF + (G_BH / G_YR) * G_CROWB;
+    // ---- two-phase form of eval_fixed<3> (eight lanes per candidate): the reference chunks are requested into registers
+    // early and compared against the source block later, so that the memory latency of the predictor round overlaps the
+    // rest of the block prologue.
+    static constexpr int P_LC = ilog2c(G_LC), P_CC = ilog2c(G_CC);
+    static constexpr int P_NL = G_LT >= 8 ? G_LT / 8 : 1, P_NC = G_CT >= 8 ? G_CT / 8 : 1;
+    struct PreA { int vx, vy, vyc; bool ok; v4u l[P_NL], u[P_NC], v[P_NC]; };
+    template <int CB> __device__ __forceinline__ static v4u ld_ref(gl_u8 *q) {
+        if (CB == 16) { uv4 t = LDREF((GL_AS const uv4 *)q); return v4u{t[0], t[1], t[2], t[3]}; }
+        else if (CB == 8) { uv2 t = LDREF((GL_AS const uv2 *)q); return v4u{t[0], t[1], 0, 0}; }
+        else if (CB == 4) return v4u{LDREF((GL_AS const uv1 *)q), 0, 0, 0};
+        else return v4u{LDREF((GL_AS const uh1 *)q), 0, 0, 0};
+    }
+    template <int CB> __device__ __forceinline__ static unsigned sad_ref(const lds_u8 *l, const v4u &r, unsigned acc) {
+        if (CB == 16) {
+            v4u a = *(const LDS_AS v4u *)l;
+            acc = sad32<BPS>(a[0], r[0], acc); acc = sad32<BPS>(a[1], r[1], acc);
+            acc = sad32<BPS>(a[2], r[2], acc); acc = sad32<BPS>(a[3], r[3], acc);
+        } else if (CB == 8) {
+            v2u a = *(const LDS_AS v2u *)l;
+            acc = sad32<BPS>(a[0], r[0], acc); acc = sad32<BPS>(a[1], r[1], acc);
+        } else if (CB == 4) acc = sad32<BPS>(*(const LDS_AS unsigned *)l, r[0], acc);
+        else acc = sad32<BPS>(*(const LDS_AS unsigned short *)l, r[0], acc);
+        return acc;
+    }
+    template <int T, int LOGC, int CB, int N> __device__ __forceinline__ void region_load8(int s, gl_u8 *ref, long long refPitch, v4u *r) const {
+        constexpr int C = 1 << LOGC;
+        static_assert(C <= 8, "chunks per row");
+        const int row0 = s >> LOGC, xb = (s & (C - 1)) * CB;
+        if (T < 8) { if (s < T) r[0] = ld_ref<CB>(ref + (long long)row0 * refPitch + xb); return; }
+        gl_u8 *p = ref + (long long)row0 * refPitch + xb;
+        const long long step = (long long)(8 >> LOGC) * refPitch;
+#pragma unroll
+        for (int k = 0; k < N; k++) r[k] = ld_ref<CB>(p + k * step);
+    }
+    template <int T, int LOGC, int CB, int ROWB, int N> __device__ __forceinline__ unsigned region_sad8(int s, const lds_u8 *src, const v4u *r, unsigned acc) const {
+        constexpr int C = 1 << LOGC;
+        const int row0 = s >> LOGC, xb = (s & (C - 1)) * CB;
+        const lds_u8 *sp = src + row0 * ROWB + xb;
+        if (T < 8) { if (s < T) acc = sad_ref<CB>(sp, r[0], acc); return acc; }
+        constexpr int lstep = (8 >> LOGC) * ROWB;
+#pragma unroll
+        for (int k = 0; k < N; k++) acc = sad_ref<CB>(sp + k * lstep, r[k], acc);
+        return acc;
+    }
+    __device__ __forceinline__ void pre_load(int s, PreA &A) const {
+        region_load8<G_LT, P_LC, G_LCB, P_NL>(s, ref_luma(A.vx, A.vy), pitchY, A.l);
+        if (chroma) {
+            const long long co = ref_chroma_off(A.vx, A.vyc);
+            region_load8<G_CT, P_CC, G_CCB, P_NC>(s, refU + co, pitchC, A.u);
+            region_load8<G_CT, P_CC, G_CCB, P_NC>(s, refV + co, pitchC, A.v);
+        }
+    }
+    __device__ __forceinline__ void pre_sad(int s, const PreA &A, unsigned &aL, unsigned &aC) const {
+        aL = region_sad8<G_LT, P_LC, G_LCB, G_LROWB, P_NL>(s, lds, A.l, aL);
+        if (chroma) {
+            aC = region_sad8<G_CT, P_CC, G_CCB, G_CROWB, P_NC>(s, lds + G_UOFF, A.u, aC);
+            aC = region_sad8<G_CT, P_CC, G_CCB, G_CROWB, P_NC>(s, lds + G_VOFF, A.v, aC);
+        }
+    }
+
     // partial SADs of this lane's share (items s, s+G, ...) of one candidate
     __device__ __forceinline__ void eval_cand(int s, int logG, int vx, int vy, int vyc, unsigned &aL, unsigned &aC) const {
         if (GEO::BW != 0) {
@@ -606,7 +670,7 @@ template <int BPS, typename GEO> struct Searcher {
             }
             unsigned aL = 0, aC = 0;
             const long long pt0 = PROF_T();
-            if (ok && P.ablate != 3) {
+            if (ok && ablate != 3) {
                 bool done = false;
                 if (W_ON) { // the general rounds use the window for the two common group sizes
                     if (winOn && logG == 3) done = eval_win<3>(s, vx, vy, vyc, aL, aC);
@@ -663,14 +727,13 @@ template <int BPS, typename GEO> struct Searcher {
         } else
             predictors[0] = predictors[1];
         if (smallestPlane) predictor = predictors[0];
+    }
+    // :456-462: lambda shrinks with the predictor's SAD
+    __device__ __forceinline__ void scale_lambda() {
         double scale = (double)LSAD / (double)(LSAD + (predictor.sad >> 1));
         nLambda = uni((long long)((double)nLambda * scale * scale));
     }
 
-    static constexpr int G_BW = GEO::BW ? GEO::BW : 8, G_BH = GEO::BH ? GEO::BH : 8, G_XR = GEO::XR ? GEO::XR : 1, G_YR = GEO::YR ? GEO::YR : 1;
-    static constexpr int G_LROWB = G_BW * BPS, G_LCB = G_LROWB < 16 ? G_LROWB : 16, G_LC = G_LROWB / G_LCB, G_LT = G_BH * G_LC;
-    static constexpr int G_CROWB = (G_BW / G_XR) * BPS, G_CCB = G_CROWB < 16 ? G_CROWB : 16, G_CC = G_CROWB / G_CCB, G_CT = (G_BH / G_YR) * G_CC;
-    static constexpr int G_UOFF = G_BH * G_LROWB, G_VOFF = G_UOFF + (G_BH / G_YR) * G_CROWB;
     // ---- LDS search window (specialised kernels with a compile-time scan step) -------------------------------------
     // Per chain, the reference rows around the expected motion-compensated position of the current block live in LDS:
     // for every sub-pel plane a band of BH + 2*MY rows and a ring of WW columns that slides with the scan.  One strip of
@@ -695,6 +758,7 @@ template <int BPS, typename GEO> struct Searcher {
     // target), which keeps the per-block code free of branches and per-lane predicates.
 #define WQY 2
 #define WQ_MAX (WQY + 2)
+    int ablate;                                        // developer switch (MVX_ABLATE), copied once: never re-read from memory inside the block loop
     int winOn, ldsWin, winCap;
     int wLdsC;                                         // LDS offset of the chroma windows (U planes then V planes)
     int wQY;                                           // luma slots in use (1 or 2)
@@ -711,7 +775,7 @@ template <int BPS, typename GEO> struct Searcher {
 
     __device__ __forceinline__ void win_setup_level() {
         winOn = 0;
-        if (!W_ON || ldsWin < 0 || P.ablate == 6) return;
+        if (!W_ON || ldsWin < 0 || ablate == 6) return;
         const int npp = pel * pel;
         const int NIL = npp * W_WH * W_SCL, NIC = chroma ? npp * W_WHC * W_SCC : 0;
         wQY = (NIL + WAVE - 1) / WAVE;
@@ -884,30 +948,53 @@ template <int BPS, typename GEO> struct Searcher {
     // The default search (predictor set, then Hex2 hexagon + square at level 0 or the 24-point exhaustive rings at the
     // coarse levels, no tryMany) as straight-line code with compile-time candidate tables; semantics identical to the
     // general state machine below, which still handles every other pattern and the bad-block rescue.
-    enum { FR_A, FR_HEX6, FR_SQUARE, FR_EXH2 };
+    // FR_HEXSQ: the hexagon round and, speculatively, the square refinement around the SAME centre in one pass (one memory
+    // latency instead of two).  The square results are only used when no hexagon point improved the cost -- then the
+    // reference's square refinement runs around the unchanged centre against the unchanged nMinCost, which is exactly
+    // what was evaluated; otherwise they are discarded and the square is redone around the moved centre.
+    enum { FR_A, FR_HEX6, FR_SQUARE, FR_EXH2, FR_HEXSQ };
     // block SADs bounded by 2^27 -> costs fit 32 bits once the (already int) motion distortion is added with saturation:
     // a saturated cost can never beat nMinCost, which is at most the zero candidate's cost.
     static constexpr bool COST32 = GEO::BW != 0 && GEO::BW * GEO::BH <= 1024;
 
-    template <int KIND> __device__ __forceinline__ int round_fast(int cx, int cy) {
-        constexpr int LOGG = KIND == FR_EXH2 ? 1 : 3;
-        constexpr int TOTAL = KIND == FR_A ? 7 : KIND == FR_HEX6 ? 6 : KIND == FR_SQUARE ? 8 : 24;
+    // the predictor set of pobPseudoEPZSearch (:832-915): zero, global, hierarchical predictor, median, left, up, ahead
+    __device__ __forceinline__ void cand_A(int g, int &vx, int &vy, int &vyc) const {
+        vx = 0; vy = zeroMVfieldShifted.y;
+        vx = g == 1 ? globalMVPredictor.x : vx; vy = g == 1 ? globalMVPredictor.y : vy;
+        vx = g == 2 ? predictor.x : vx; vy = g == 2 ? predictor.y : vy;
+        vx = g == 3 ? predictors[0].x : vx; vy = g == 3 ? predictors[0].y : vy;
+        vx = g == 4 ? predictors[1].x : vx; vy = g == 4 ? predictors[1].y : vy;
+        vx = g == 5 ? predictors[2].x : vx; vy = g == 5 ? predictors[2].y : vy;
+        vx = g == 6 ? predictors[3].x : vx; vy = g == 6 ? predictors[3].y : vy;
+        vyc = g == 0 ? 0 : vy; // chroma of the zero candidate ignores fieldShift (:836-839)
+    }
+    // early request of the predictor round's reference samples (consumed by round_fast<FR_A, true>)
+    __device__ __forceinline__ void pre_issue_A(PreA &A) const {
+        const int lane = lane_id();
+        const int g = lane >> 3, s = lane & 7;
+        cand_A(g, A.vx, A.vy, A.vyc);
+        A.ok = g < 7;
+        if (A.ok) pre_load(s, A);
+    }
+
+    template <int KIND, bool PRE = false> __device__ __forceinline__ int round_fast(int cx, int cy, const PreA *pre = nullptr) {
+        constexpr int LOGG = KIND == FR_EXH2 ? 1 : KIND == FR_HEXSQ ? 2 : 3;
+        constexpr int TOTAL = KIND == FR_A ? 7 : KIND == FR_HEX6 ? 6 : KIND == FR_SQUARE ? 8 : KIND == FR_HEXSQ ? 14 : 24;
         const int lane = lane_id();
         const int g = lane >> LOGG, s = lane & ((1 << LOGG) - 1);
         int vx, vy, vyc;
         bool ok = g < TOTAL;
         if (KIND == FR_A) {
-            vx = 0; vy = zeroMVfieldShifted.y;
-            vx = g == 1 ? globalMVPredictor.x : vx; vy = g == 1 ? globalMVPredictor.y : vy;
-            vx = g == 2 ? predictor.x : vx; vy = g == 2 ? predictor.y : vy;
-            vx = g == 3 ? predictors[0].x : vx; vy = g == 3 ? predictors[0].y : vy;
-            vx = g == 4 ? predictors[1].x : vx; vy = g == 4 ? predictors[1].y : vy;
-            vx = g == 5 ? predictors[2].x : vx; vy = g == 5 ? predictors[2].y : vy;
-            vx = g == 6 ? predictors[3].x : vx; vy = g == 6 ? predictors[3].y : vy;
-            vyc = g == 0 ? 0 : vy; // chroma of the zero candidate ignores fieldShift (:836-839)
+            if (PRE) { vx = pre->vx; vy = pre->vy; vyc = pre->vyc; }
+            else cand_A(g, vx, vy, vyc);
         } else {
             int dx, dy;
             if (KIND == FR_HEX6) { dx = tab8(HEX2X >> 8, g & 7); dy = tab8(HEX2Y >> 8, g & 7); }                  // hex2[g+1], :682-687
+            else if (KIND == FR_HEXSQ) {
+                const int k = (g + 2) & 7; // square index of groups 6..13
+                dx = g < 6 ? tab8(HEX2X >> 8, g & 7) : tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), k);
+                dy = g < 6 ? tab8(HEX2Y >> 8, g & 7) : tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), k);
+            }
             else if (KIND == FR_SQUARE) { dx = tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), g & 7); dy = tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), g & 7); } // :636-658 r=1
             else { // rings 1 and 2 (:786-791): 8 + 16 candidates in reference order
                 const int k = g < 8 ? g : g - 8;
@@ -923,7 +1010,9 @@ template <int BPS, typename GEO> struct Searcher {
         bool wmiss = false;
 #endif
         const long long ft0 = PROF_T();
-        if (ok) {
+        if (PRE) {
+            if (ok) pre_sad(s, *pre, aL, aC);
+        } else if (ok) {
             bool done = false;
             if (W_ON) { if (winOn) done = eval_win<LOGG>(s, vx, vy, vyc, aL, aC); }
 #ifdef MVX_PROFILE
@@ -956,13 +1045,18 @@ template <int BPS, typename GEO> struct Searcher {
                 cc = sat_add(motion_distortion(vx, vy), cc);
             }
             const int lim = nMinCost > 0x7fffffffLL ? 0x7fffffff : (int)nMinCost;
-            const int cost = (ok && cc < lim) ? cc : 0x7fffffff;
+            const bool first = KIND != FR_HEXSQ || g < 6; // FR_HEXSQ: hexagon points first
+            const int cost = (ok && first && cc < lim) ? cc : 0x7fffffff;
             int mc;
             w = wave_argmin_i32(cost, &mc);
             if (w >= 0) {
                 nMinCost = mc;
                 bestMV.sad = (long long)bcast_i(tot, w);
-                if (KIND != FR_HEX6) { bestMV.x = bcast_i(vx, w); bestMV.y = bcast_i(vy, w); }
+                if (KIND != FR_HEX6 && KIND != FR_HEXSQ) { bestMV.x = bcast_i(vx, w); bestMV.y = bcast_i(vy, w); }
+            } else if (KIND == FR_HEXSQ) { // no hexagon point improved: the speculative square results are the real ones
+                const int cost2 = (ok && !first && cc < lim) ? cc : 0x7fffffff;
+                const int w2 = wave_argmin_i32(cost2, &mc);
+                if (w2 >= 0) { nMinCost = mc; bestMV.sad = (long long)bcast_i(tot, w2); bestMV.x = bcast_i(vx, w2); bestMV.y = bcast_i(vy, w2); }
             }
         } else {
             const long long tot = (long long)aL + (chroma ? (long long)aC : 0);
@@ -974,13 +1068,18 @@ template <int BPS, typename GEO> struct Searcher {
                 cc = (long long)motion_distortion(vx, vy) + aL + ((penaltyNew * (long long)aL) >> 8);
                 if (chroma) cc += (long long)aC + ((penaltyNew * (long long)aC) >> 8);
             }
-            const long long cost = (ok && cc < nMinCost) ? cc : BIG64;
+            const bool first = KIND != FR_HEXSQ || g < 6;
+            const long long cost = (ok && first && cc < nMinCost) ? cc : BIG64;
             long long mc;
             w = wave_argmin_ll(cost, &mc);
             if (w >= 0) {
                 nMinCost = mc;
                 bestMV.sad = bcast_ll(tot, w);
-                if (KIND != FR_HEX6) { bestMV.x = bcast_i(vx, w); bestMV.y = bcast_i(vy, w); }
+                if (KIND != FR_HEX6 && KIND != FR_HEXSQ) { bestMV.x = bcast_i(vx, w); bestMV.y = bcast_i(vy, w); }
+            } else if (KIND == FR_HEXSQ) {
+                const long long cost2 = (ok && !first && cc < nMinCost) ? cc : BIG64;
+                const int w2 = wave_argmin_ll(cost2, &mc);
+                if (w2 >= 0) { nMinCost = mc; bestMV.sad = bcast_ll(tot, w2); bestMV.x = bcast_i(vx, w2); bestMV.y = bcast_i(vy, w2); }
             }
         }
         PROF_ADD(6, PROF_T() - ft1);
@@ -992,18 +1091,21 @@ template <int BPS, typename GEO> struct Searcher {
     }
 
     // returns true when the block is finished; false -> continue in the general state machine at the bad-block check
-    __device__ __forceinline__ bool search_block_fast() {
-        globalMVPredictor = clip_mv(globalMVPredictor); // cumulative clip (:859)
+    template <bool PRE> __device__ __forceinline__ bool search_block_fast(const PreA *pre) {
+        if (!PRE) globalMVPredictor = clip_mv(globalMVPredictor); // cumulative clip (:859); done before the early request otherwise
         nMinCost = BIG64;
-        round_fast<FR_A>(0, 0);
+        round_fast<FR_A, PRE>(0, 0, pre);
         if (searchType == SearchHex2) { // pobHex2Search :667-724 with i_me_range <= 3: no half-hexagon iterations
             int bmx = bestMV.x, bmy = bestMV.y;
             if (nSearchParam > 1) {
-                const int dir = round_fast<FR_HEX6>(bmx, bmy);
-                if (dir >= 0) { bmx += tab8(HEX2X, dir + 1); bmy += tab8(HEX2Y, dir + 1); }
-                bestMV.x = bmx; bestMV.y = bmy;
-            }
-            round_fast<FR_SQUARE>(bmx, bmy);
+                const int dir = round_fast<FR_HEXSQ>(bmx, bmy); // >= 0: a hexagon point won; < 0: the square around (bmx, bmy) is done too
+                if (dir >= 0) {
+                    bmx += tab8(HEX2X, dir + 1); bmy += tab8(HEX2Y, dir + 1);
+                    bestMV.x = bmx; bestMV.y = bmy;
+                    round_fast<FR_SQUARE>(bmx, bmy);
+                }
+            } else
+                round_fast<FR_SQUARE>(bmx, bmy);
         } else
             round_fast<FR_EXH2>(bestMV.x, bestMV.y);
         return !(blkIdx > 1 && bestMV.sad > (badSAD + badSAD * badcount / 16)); // :942
@@ -1174,7 +1276,7 @@ template <int BPS, typename GEO> struct Searcher {
             PROF_ADD(10, st1 - st0); PROF_ADD(11, st2 - st1);
 
             switch (post) {
-            case POST_ROUNDA: aCost = rCost; aTot = rTot; aVx = rVx; aVy = rVy; pc = tryMany ? PC_TRY_NEXT : PC_REFINE; if (P.ablate == 2) pc = PC_DONE; break;
+            case POST_ROUNDA: aCost = rCost; aTot = rTot; aVx = rVx; aVy = rVy; pc = tryMany ? PC_TRY_NEXT : PC_REFINE; if (ablate == 2) pc = PC_DONE; break;
             case POST_HEX6:
                 if (w >= 0) dir = w;
                 if (dir != -2) { bmx += tab8(HEX2X, dir + 1); bmy += tab8(HEX2Y, dir + 1); it = 1; pc = PC_HEX3; }
@@ -1231,7 +1333,6 @@ template <int BPS, typename GEO> struct Searcher {
     // so their row/column offsets are computed once per level; per block only the block origin is added.
     static constexpr int G_NPF = (G_LT + 2 * G_CT + WAVE - 1) / WAVE;
     static constexpr bool G_PF = GEO::BW != 0 && G_NPF <= PF_MAX;
-    unsigned pfSink;   // keeps the L2-prefetch loads alive (never stored unless an impossible condition holds)
     int pfG[PF_MAX], pfL[PF_MAX], pfP[PF_MAX]; // per lane: global row/col offset, LDS offset, plane (0,1,2; -1 = no item)
 
     __device__ __forceinline__ void pf_setup() {
@@ -1273,40 +1374,6 @@ template <int BPS, typename GEO> struct Searcher {
             else if (pl == 0) st_chunk_l(lds + pfL[k], pf[k], G_LCB);
             else st_chunk_l(lds + pfL[k], pf[k], G_CCB);
         }
-    }
-
-    // ---- L2 prefetch of the reference search window.  A chain walks a block row left-to-right (or back), every block
-    // re-reading the rows around the motion-compensated position shifted by one block step; a 128-byte line serves
-    // several consecutive blocks and then the next line is needed from HBM at full latency, in the middle of a search
-    // round.  Each block, every lane touches one row of the window (rotating over the rows) ~1.5 lines AHEAD of the scan
-    // so that the line is in L2 when the scan reaches it.  Pure performance hint: the loaded values are discarded.
-    __device__ __forceinline__ unsigned prefetch_window(int slotBase, int lW2L, int lW2C, int rowsL, int rowsC, int mvx, int mvy) const {
-        const int l = lane_id();
-        const int npp = pel * pel;
-        const int slot = slotBase + l;
-        const int lumaSlots = npp << lW2L;
-        gl_u8 *base; long long pit; int yy, xx, rowBytes, hmax;
-        if (slot < lumaSlots) {
-            const int pp = slot >> lW2L, rw = slot & ((1 << lW2L) - 1);
-            if (rw >= rowsL) return 0;
-            base = refY + pp * pstrideY; pit = pitchY; hmax = ph - 1; rowBytes = pw * BPS;
-            yy = y0 + (mvy >> logPel) - 4 + rw;
-            xx = (x0 + (mvx >> logPel)) * BPS;
-        } else {
-            int s2 = slot - lumaSlots;
-            if (!chroma || s2 >= ((2 * npp) << lW2C)) return 0;
-            const int v = s2 >= (npp << lW2C);
-            if (v) s2 -= npp << lW2C;
-            const int pp = s2 >> lW2C, rw = s2 & ((1 << lW2C) - 1);
-            if (rw >= rowsC) return 0;
-            base = (v ? refV : refU) + pp * pstrideC; pit = pitchC; hmax = ph / (1 << logyr) - 1; rowBytes = (pw >> logxr) * BPS;
-            yy = cy0 + (mvy >> (logPel + logyr)) - 3 + rw;
-            xx = (cx0 + (mvx >> (logPel + logxr))) * BPS;
-        }
-        xx += blkScanDir * 192;
-        xx = min(max(xx, 0), rowBytes - 4) & ~3;
-        yy = min(max(yy, 0), hmax);
-        return *(GL_AS const unsigned *)(base + (long long)yy * pit + xx);
     }
 
     // GroupOfPlanes.c:69-125 + PlaneOfBlocks.cpp:971-1131 for one level
@@ -1445,15 +1512,17 @@ template <int BPS, typename GEO> struct Searcher {
         int curIb = 0, curBy = 0;
         win_setup_level();
         A4x32 wpf[WQ_MAX];
-        // search-window prefetch geometry: rows padded to powers of two so that slot -> (sub-pel plane, row) is shifts only
-        const int pfRowsL = blkH + 8, pfRowsC = (blkH >> logyr) + 6;
-        int lW2L = 0, lW2C = 0;
-        while ((1 << lW2L) < pfRowsL) lW2L++;
-        while ((1 << lW2C) < pfRowsC) lW2C++;
-        const int pfSlots = ((pel * pel) << lW2L) + (chroma ? ((2 * pel * pel) << lW2C) : 0);
-        const int pfK = (pfSlots + WAVE - 1) / WAVE;
-        int pfPhase = 0;
-
+        const bool fast = !tryMany && ((searchType == SearchHex2 && nSearchParam <= 3) || (searchType == SearchExhaustive && nSearchParam == 2));
+        // early request of the predictor round (specialised kernels, reference samples from global memory)
+#ifdef MVX_NO_EARLY
+        constexpr bool EARLY_K = false;
+#else
+        // compile-time: one variant of the fast path per kernel.  Measured (r1, A/B in one session): +1.7 % on 1080p 8-bit,
+        // -11 % on 4K 16-bit at full load (more loads in flight per CU when the texture path is already the bottleneck)
+        constexpr bool EARLY_K = BPS == 1 && GEO::BW != 0 && G_PF && !W_ON;
+#endif
+        const bool early = EARLY_K && fast;
+        PreA preA;
         for (int n = 0; n < nBlk; n++) {
             const long long bt0 = PROF_T();
             blky = curBy;
@@ -1489,7 +1558,7 @@ template <int BPS, typename GEO> struct Searcher {
                 }
             }
             const long long btA = PROF_T();
-            if (n + 1 < nBlk) prefetch();
+            if (!early && n + 1 < nBlk) prefetch();
             const long long btW = PROF_T();
             if (W_ON) {
                 if (winOn) {
@@ -1517,16 +1586,17 @@ template <int BPS, typename GEO> struct Searcher {
             predictor = clip_mv(self);              // :1100
             const bool havePrev = (blkScanDir == 1 && blkx > 0) || (blkScanDir == -1 && blkx < nBlkX - 1);
             fetch_predictors(prev, havePrev, up, ahead, useBelow || useUpAhead);
-
-            // L2 prefetch for the coming blocks (rows rotate: pfK passes cover the whole window)
-            const unsigned pfv = P.ablate != 5 ? 0u : prefetch_window(pfPhase * WAVE, lW2L, lW2C, pfRowsL, pfRowsC, prev.x, prev.y); // measured slower (r1): off
-            if (++pfPhase == pfK) pfPhase = 0;
+            if (early) { // the predictor round's reference samples are requested now; the rest of the prologue hides their latency
+                globalMVPredictor = clip_mv(globalMVPredictor); // cumulative clip (:859)
+                pre_issue_A(preA);
+                if (n + 1 < nBlk) prefetch();
+            }
+            scale_lambda();
 
             __builtin_amdgcn_wave_barrier(); // single wave: DS ops are in order; keep the compiler from moving LDS reads above the staging writes
             const long long bt1 = PROF_T();
-            const bool fast = !tryMany && ((searchType == SearchHex2 && nSearchParam <= 3) || (searchType == SearchExhaustive && nSearchParam == 2));
-            if (P.ablate == 1) { bestMV = predictor; bestMV.sad = 0; }
-            else if (fast) { if (!search_block_fast()) search_block(true); }
+            if (ablate == 1) { bestMV = predictor; bestMV.sad = 0; }
+            else if (fast) { if (!search_block_fast<EARLY_K>(&preA)) search_block(true); }
             else search_block(false);
             const long long bt2 = PROF_T();
             __builtin_amdgcn_wave_barrier();
@@ -1534,7 +1604,6 @@ template <int BPS, typename GEO> struct Searcher {
             // results: vectors[blkIdx] (:967) == blob row (:1106); the row also stays in LDS for the next row's predictors
             if (l == 0) { st_vec(&vectors[blkIdx], bestMV); st_vec_lds(&rowbuf[blkx], bestMV); }
             prev = bestMV;
-            pfSink += pfv;
             const long long bt3 = PROF_T();
             PROF_ADD(0, bt1 - bt0); PROF_ADD(1, bt2 - bt1); PROF_ADD(2, bt3 - bt2); PROF_ADD(3, 1);
         }
@@ -1619,7 +1688,7 @@ __global__ __launch_bounds__(64, MVX_WAVES_PER_EU) void analyse_kernel(const APa
     Searcher<BPS, GEO> S(P, J);
     S.lds = (lds_u8 *)smem; S.ldsRow = ldsRow; S.ldsHist = ldsHist; S.histBins = histBins;
     S.ldsWin = ldsWin; S.winCap = winCap; S.winOn = 0;
-    S.pfSink = 0;
+    S.ablate = uni(P.ablate);
 #ifdef MVX_PROFILE
     for (int i = 0; i < 16; i++) S.prof[i] = 0;
     const long long kt0 = PROF_T();
@@ -1632,7 +1701,6 @@ __global__ __launch_bounds__(64, MVX_WAVES_PER_EU) void analyse_kernel(const APa
         S.search_level(lvl, &globalMV, coarse, cbx, cby, clp);
         coarse = S.vectors; cbx = P.lv[lvl].nBlkX; cby = P.lv[lvl].nBlkY; clp = P.lv[lvl].logPel;
     }
-    if (P.nLevels < 0 && S.pfSink == 0x9e3779b9u) hdr[1] = 2; // never true (nLevels >= 1): only keeps the prefetch loads from being optimised away
 #ifdef MVX_PROFILE
     S.prof[9] = PROF_T() - kt0;
     if (l == 0 && blockIdx.x == 0) for (int i = 0; i < 16; i++) g_prof[i] = (unsigned long long)S.prof[i];

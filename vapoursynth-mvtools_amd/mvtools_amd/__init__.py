@@ -17,7 +17,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIBPATH = os.path.join(os.path.dirname(_HERE), "libmvtools_amd.so")
+_LIBPATH = os.environ.get("MVX_LIB") or os.path.join(os.path.dirname(_HERE), "libmvtools_amd.so")  # MVX_LIB: developer override (A/B builds)
 UNSET = -2147483648
 ERRLEN = 256
 
