@@ -167,6 +167,8 @@ DEGRAIN_CASES = [
     (192, 112, 8, 2, {}, dict(blksize=16, overlap=8), {}),
     (192, 112, 16, 3, {}, dict(blksize=16, overlap=8), {}),           # cfg3 shape
     (256, 160, 16, 6, {}, dict(blksize=32, overlap=16), {}),          # cfg5 shape (tr=6)
+    (196, 116, 16, 1, {}, dict(blksize=16, overlap=8), {}),           # width not a multiple of the cell: partial cell rows
+    (196, 116, 8, 2, {}, dict(blksize=8, overlap=4), {}),
     (200, 120, 8, 1, {}, dict(blksize=8, overlap=0), {}),             # no overlap + uncovered strips
     (200, 120, 8, 1, dict(pel=1), dict(blksize=8, overlap=2), {}),
     (200, 120, 8, 1, dict(pel=4), dict(blksize=8, overlap=4), {}),

@@ -1,6 +1,2 @@
-r() { python bench.py --no-cpu "$@" 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d[\"value\"], \"fps\", d[\"roofline\"][\"avg_launch_ms\"], \"ms/launch\")"; }
-timeout 500 python -m pytest tests -m gpu -q --timeout 200 2>&1 | tail -2
-echo B168; r
-echo B168 lds33k; MVX_LDS_MIN=33000 r
-echo B21; r --batch 21
-echo cfg2; r --config cfg2
+r() { python bench.py --no-cpu "$@" 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d[\"value\"],1), \"fps\", round(d[\"roofline\"][\"avg_launch_ms\"],1), \"ms/launch\")"; }
+for D in 0 1 2 8 32 64 252 0; do echo -n "order D=$D: "; MVX_JOB_ORDER=$D r; done

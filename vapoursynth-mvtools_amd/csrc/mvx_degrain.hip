@@ -231,6 +231,153 @@ __global__ __launch_bounds__(256) void degrain_kernel(const DGParams *Pp, const 
     drow[x] = (T)out;
 }
 
+// ---- vectorised gather for overlapped blocks: one thread per row of an overlap cell.
+// A cell is stepX consecutive samples starting at a multiple of stepX: all of them are covered by the same <= 2 x 2
+// blocks, and inside one block they are contiguous, so every (block, reference) costs ONE unaligned vector load of
+// W = stepX samples instead of W scalar loads, and the plan record / window row are fetched once per W outputs.
+// Same arithmetic per sample as degrain_kernel (Degrain_C + overlaps_c + ToPixels + LimitChanges).
+typedef unsigned dg_uv4 __attribute__((ext_vector_type(4), aligned(1)));
+typedef unsigned dg_uv2 __attribute__((ext_vector_type(2), aligned(1)));
+typedef unsigned dg_uv1 __attribute__((aligned(1)));
+typedef unsigned short dg_uh1 __attribute__((aligned(1)));
+
+// W samples of type T from an arbitrarily aligned address, widened to int
+template <typename T, int W> __device__ __forceinline__ void dg_load(const unsigned char *p, int *o) {
+    constexpr int BYTES = W * (int)sizeof(T);
+    unsigned d[(BYTES + 3) / 4];
+    if (BYTES >= 16) {
+#pragma unroll
+        for (int k = 0; k < BYTES / 16; k++) { dg_uv4 t = *(const dg_uv4 *)(p + 16 * k); d[4 * k] = t[0]; d[4 * k + 1] = t[1]; d[4 * k + 2] = t[2]; d[4 * k + 3] = t[3]; }
+    } else if (BYTES == 8) { dg_uv2 t = *(const dg_uv2 *)p; d[0] = t[0]; d[1] = t[1]; }
+    else if (BYTES == 4) d[0] = *(const dg_uv1 *)p;
+    else d[0] = *(const dg_uh1 *)p;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        if (sizeof(T) == 2) o[i] = (int)((d[i >> 1] >> (16 * (i & 1))) & 0xffffu);
+        else o[i] = (int)((d[i >> 2] >> (8 * (i & 3))) & 0xffu);
+    }
+}
+template <typename T, int W> __device__ __forceinline__ void dg_store(unsigned char *p, const int *v) {
+    constexpr int BYTES = W * (int)sizeof(T);
+    unsigned d[(BYTES + 3) / 4];
+#pragma unroll
+    for (int k = 0; k < (BYTES + 3) / 4; k++) d[k] = 0;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        if (sizeof(T) == 2) d[i >> 1] |= (unsigned)v[i] << (16 * (i & 1));
+        else d[i >> 2] |= (unsigned)v[i] << (8 * (i & 3));
+    }
+    if (BYTES >= 16) {
+#pragma unroll
+        for (int k = 0; k < BYTES / 16; k++) { dg_uv4 t = { d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3] }; *(dg_uv4 *)(p + 16 * k) = t; }
+    } else if (BYTES == 8) { dg_uv2 t = { d[0], d[1] }; *(dg_uv2 *)p = t; }
+    else if (BYTES == 4) *(dg_uv1 *)p = d[0];
+    else *(dg_uh1 *)p = (unsigned short)d[0];
+}
+
+template <typename T, int NR, int W>
+__global__ __launch_bounds__(256) void degrain_cell_kernel(const DGParams *Pp, const DGJob *jobs, const PlanRec *plan, int planeFirst, int planesPerFrame) {
+    const DGParams &P = *Pp;
+    const int z = blockIdx.z, f = z / planesPerFrame, p = planeFirst + z % planesPerFrame;
+    const PlaneG &g = P.pl[p];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    const int x0 = c * W;
+    if (x0 >= g.W || y >= g.H) return;
+    const DGJob &J = jobs[f];
+    const unsigned char *srow = J.src[p] + (long long)y * g.srcPitch + (long long)x0 * sizeof(T);
+    unsigned char *drow = J.dst[p] + (long long)y * g.dstPitch + (long long)x0 * sizeof(T);
+    const bool fullW = x0 + W <= g.W;
+    int s[W];
+    if (fullW) dg_load<T, W>(srow, s);
+    else {
+#pragma unroll
+        for (int i = 0; i < W; i++) s[i] = x0 + i < g.W ? (int)((const T *)srow)[i] : 0;
+    }
+    int out[W];
+#pragma unroll
+    for (int i = 0; i < W; i++) out[i] = s[i];
+    if (g.process && x0 < g.WB && y < g.HB) { // MVDegrains.cpp:211-214,238-249,290-298: uncovered strips keep the source
+        const PlanRec *pl = plan + ((size_t)f * 2 + (p ? 1 : 0)) * P.nBlk;
+        int bx1 = c; if (bx1 > P.nBlkX - 1) bx1 = P.nBlkX - 1;
+        const int bx0 = x0 - g.blkW + 1 <= 0 ? 0 : (x0 - g.blkW + g.stepX) / g.stepX;
+        int by1 = y / g.stepY; if (by1 > P.nBlkY - 1) by1 = P.nBlkY - 1;
+        const int by0 = y - g.blkH + 1 <= 0 ? 0 : (y - g.blkH + g.stepY) / g.stepY;
+        unsigned acc[W];
+#pragma unroll
+        for (int i = 0; i < W; i++) acc[i] = 0;
+        const int16_t *win = P.win[p];
+        for (int by = by0; by <= by1; by++) {
+            const int py = y - by * g.stepY;
+            const int wby = by == 0 ? 0 : (by == P.nBlkY - 1 ? 6 : 3);
+            for (int bx = bx0; bx <= bx1; bx++) {
+                const int px = x0 - bx * g.stepX;   // >= 0; the block covers samples i < blkW - px of this cell
+                const int nv = g.blkW - px;
+                if (nv <= 0) continue;
+                const int wbx = bx == P.nBlkX - 1 ? 2 : (bx == 0 ? 0 : 1);
+                const PlanRec &R = pl[by * P.nBlkX + bx];
+                const int wsrc = R.wsrc;
+                int sum[W];
+#pragma unroll
+                for (int i = 0; i < W; i++) sum[i] = 128 + s[i] * wsrc;
+                const long long rowOff = (long long)py * g.supPitch + (long long)px * sizeof(T);
+                const int16_t *wrow = win + (wby + wbx) * g.blkW * g.blkH + py * g.blkW + px;
+                int wv[W];
+                if (nv >= W) { // whole cell inside the block: vector loads
+#pragma unroll
+                    for (int r = 0; r < NR; r++) {
+                        const int w = R.w[r];
+                        if (w) {
+                            int v[W];
+                            dg_load<T, W>(J.refs[r][p] + R.off[r] + rowOff, v);
+#pragma unroll
+                            for (int i = 0; i < W; i++) sum[i] += v[i] * w;
+                        }
+                    }
+                    dg_load<unsigned short, W>((const unsigned char *)wrow, wv);
+                } else { // partially covered (overlap != block/2): per-sample loads of the covered samples only
+#pragma unroll
+                    for (int r = 0; r < NR; r++) {
+                        const int w = R.w[r];
+                        if (w) {
+                            const T *q = (const T *)(J.refs[r][p] + R.off[r] + rowOff);
+#pragma unroll
+                            for (int i = 0; i < W; i++) if (i < nv) sum[i] += (int)q[i] * w;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < W; i++) wv[i] = i < nv ? (int)wrow[i] : 0;
+                }
+#pragma unroll
+                for (int i = 0; i < W; i++) {
+                    const int val = (T)(sum[i] >> 8);
+                    if (i < nv) acc[i] += (unsigned)((val * wv[i]) >> 6);
+                }
+            }
+        }
+        const int pm = (1 << P.bits) - 1;
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            if (x0 + i < g.WB) {
+                unsigned a0 = acc[i];
+                if (sizeof(T) == 1) a0 &= 0xffffu; // 16-bit accumulator of the 8-bit path (Overlap.cpp:254-256)
+                const int a = (int)((a0 + 16) >> 5); // Overlap.cpp:335-356
+                int o = a > pm ? pm : a;
+                if (g.limit < pm) { // MVDegrains.h:163-181
+                    const int lo = s[i] - g.limit, hi = s[i] + g.limit;
+                    o = o < lo ? lo : o;
+                    o = o > hi ? hi : o;
+                }
+                out[i] = o;
+            }
+        }
+    }
+    if (fullW) dg_store<T, W>(drow, out);
+    else {
+#pragma unroll
+        for (int i = 0; i < W; i++) if (x0 + i < g.W) ((T *)drow)[i] = (T)out[i];
+    }
+}
+
 // ---- compensate
 
 struct CPlanRec { unsigned off[2]; int fromRef; }; // off[0] luma, off[1] chroma
@@ -483,6 +630,20 @@ template <typename T> static void launch_degrain(int nr, dim3 grid, hipStream_t 
 #undef DG
 }
 
+template <typename T, int W> static void launch_degrain_cells_w(int nr, dim3 grid, hipStream_t st, const DGParams *dP, const DGJob *dJ, const PlanRec *plan, int p0, int npl) {
+#define DGC(N) hipLaunchKernelGGL((degrain_cell_kernel<T, N, W>), grid, dim3(256), 0, st, dP, dJ, plan, p0, npl)
+    switch (nr) { case 2: DGC(2); break; case 4: DGC(4); break; case 6: DGC(6); break; case 8: DGC(8); break; case 10: DGC(10); break; default: DGC(12); break; }
+#undef DGC
+}
+template <typename T> static void launch_degrain_cells(int nr, int W, dim3 grid, hipStream_t st, const DGParams *dP, const DGJob *dJ, const PlanRec *plan, int p0, int npl) {
+    switch (W) {
+    case 2: launch_degrain_cells_w<T, 2>(nr, grid, st, dP, dJ, plan, p0, npl); break;
+    case 4: launch_degrain_cells_w<T, 4>(nr, grid, st, dP, dJ, plan, p0, npl); break;
+    case 8: launch_degrain_cells_w<T, 8>(nr, grid, st, dP, dJ, plan, p0, npl); break;
+    default: launch_degrain_cells_w<T, 16>(nr, grid, st, dP, dJ, plan, p0, npl); break;
+    }
+}
+
 extern "C" __attribute__((visibility("default"))) int mvx_degrain_frames(mvx_degrain *d, int nframes, const mvx_degrain_job *jobs, void *stream) {
     if (nframes <= 0) return MVX_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -502,9 +663,22 @@ extern "C" __attribute__((visibility("default"))) int mvx_degrain_frames(mvx_deg
     HIP_CHECK(hipMemcpyAsync(d->dJobs, hj.data(), sizeof(DGJob) * nframes, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(usable_kernel, dim3(P.nRefs, nframes), dim3(256), 0, st, d->dP, d->dJobs, d->dUsable, 0);
     hipLaunchKernelGGL(degrain_plan_kernel, dim3((P.nBlk + 255) / 256, nframes), dim3(256), 0, st, d->dP, d->dJobs, d->dUsable, (PlanRec *)d->dPlan);
-    dim3 grid((P.pl[0].W + 63) / 64, (P.pl[0].H + 3) / 4, nframes * 3);
-    if (P.bps == 1) launch_degrain<uint8_t>(P.nRefs, grid, st, d->dP, d->dJobs, (const PlanRec *)d->dPlan);
-    else launch_degrain<uint16_t>(P.nRefs, grid, st, d->dP, d->dJobs, (const PlanRec *)d->dPlan);
+    // overlapped blocks with a power-of-two step: vectorised cell kernel, one launch per plane class; otherwise the
+    // per-sample gather
+    auto cellW = [&](int p) { const int w = P.pl[p].stepX; return (P.overlap && (w == 2 || w == 4 || w == 8 || w == 16)) ? w : 0; };
+    const bool cells = cellW(0) && (P.nplanes == 1 || (cellW(1) && P.pl[1].stepX == P.pl[2].stepX));
+    if (cells) {
+        for (int cls = 0; cls < (P.nplanes > 1 ? 2 : 1); cls++) {
+            const int p0 = cls, npl = cls ? 2 : 1, W = cellW(p0);
+            dim3 grid(((P.pl[p0].W + W - 1) / W + 31) / 32, (P.pl[p0].H + 7) / 8, nframes * npl);
+            if (P.bps == 1) launch_degrain_cells<uint8_t>(P.nRefs, W, grid, st, d->dP, d->dJobs, (const PlanRec *)d->dPlan, p0, npl);
+            else launch_degrain_cells<uint16_t>(P.nRefs, W, grid, st, d->dP, d->dJobs, (const PlanRec *)d->dPlan, p0, npl);
+        }
+    } else {
+        dim3 grid((P.pl[0].W + 63) / 64, (P.pl[0].H + 3) / 4, nframes * 3);
+        if (P.bps == 1) launch_degrain<uint8_t>(P.nRefs, grid, st, d->dP, d->dJobs, (const PlanRec *)d->dPlan);
+        else launch_degrain<uint16_t>(P.nRefs, grid, st, d->dP, d->dJobs, (const PlanRec *)d->dPlan);
+    }
     HIP_CHECK(hipGetLastError());
     return MVX_OK;
 }
