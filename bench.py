@@ -75,12 +75,15 @@ def synth_clip_device(torch, width, height, bits, nframes, seed, device):
 class Pipeline:
     """Super -> Analyse x 2tr -> DegrainN over a resident batch, all on the current HIP stream."""
 
-    def __init__(self, mv, torch, cfg, batch, device, seed):
+    def __init__(self, mv, torch, cfg, batch, device, seed, src=None):
         (self.w, self.h, self.bits, self.tr, akw, skw, _, self.label) = cfg
         self.mv, self.torch, self.B, self.device = mv, torch, batch, device
         tr = self.tr
         self.n = batch + 2 * tr
-        self.src = synth_clip_device(torch, self.w, self.h, self.bits, self.n, seed, device)
+        # `src` lets a second pipeline slot (own filter handles, own super / vector / output buffers, own stream) share
+        # the read-only input clip
+        self.src = src if src is not None else synth_clip_device(torch, self.w, self.h, self.bits, self.n, seed, device)
+        self.stream = torch.cuda.Stream(device=device)
         self.sup = mv.Super(self.w, self.h, self.bits, **skw)
         self.supers = self.sup.alloc(self.n, device=device)
         self.an = {}
@@ -94,6 +97,10 @@ class Pipeline:
         self.ev = []  # (start, end) events around the search launches
 
     def step(self, time_search=False):
+        with self.torch.cuda.stream(self.stream):
+            self._step(time_search)
+
+    def _step(self, time_search):
         torch, tr, B = self.torch, self.tr, self.B
         self.sup.build(self.src, out=self.supers)
         # all 2*tr vector clips share one parameter block (delta / isb only pick the reference frame), so every chain
@@ -189,6 +196,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--slots", type=int, default=1, help="batches in flight: slot i owns its buffers and HIP stream, so the Super / "
+                    "Degrain kernels of one batch run under the (latency-bound) search kernel of the other")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -210,6 +219,8 @@ def main():
     cfg = CONFIGS[args.config]
     B = args.batch or cfg[6]
     pipe = Pipeline(mv, torch, cfg, B, device, seed=1000 + rank)  # every rank owns a different frame range
+    pipes = [pipe] + [Pipeline(mv, torch, cfg, B, device, seed=1000 + rank, src=pipe.src) for _ in range(max(1, args.slots) - 1)]
+    torch.cuda.synchronize()
 
     def barrier():
         torch.cuda.synchronize()
@@ -217,12 +228,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        pipe.step()
+    for i in range(args.warmup):
+        pipes[i % len(pipes)].step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pipe.step(time_search=True)
+    for i in range(args.steps):  # exactly K steps = K batches, round-robin over the slots
+        pipes[i % len(pipes)].step(time_search=True)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -231,7 +242,7 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        search_ms = [a.elapsed_time(b) for a, b in pipe.ev]
+        search_ms = [a.elapsed_time(b) for pp in pipes for a, b in pp.ev]
         avg_launch_ms = sum(search_ms) / len(search_ms)
         bytes_chain, full = pipe.algorithmic_bytes_per_chain()
         chains = 2 * cfg[3] * B
@@ -250,7 +261,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16" if cfg[2] > 8 else "u8", "data": "synthetic",
             "config": {"workload": cfg[7], "frames_per_step_per_gpu": B, "chains_per_step_per_gpu": 2 * cfg[3] * B,
-                       "sharding": "frame ranges, no collective"},
+                       "sharding": "frame ranges, no collective", "batches_in_flight": len(pipes)},
             "roofline": {"bound": "hbm", "kernel": "analyse_kernel (one launch = %d chains)" % chains, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_chain * chains, "avg_launch_ms": avg_launch_ms,

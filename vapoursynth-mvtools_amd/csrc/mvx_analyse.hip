@@ -190,13 +190,13 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         if (((uintptr_t)jobs[i].blob) & 15) { mvx_set_error("mvx_analyse_frames: blob must be 16-byte aligned"); return MVX_E_ARG; }
     }
     HIP_CHECK(hipMemcpyAsync(a->dJobs, hj.data(), sizeof(AJob) * njobs, hipMemcpyHostToDevice, st));
-    // LDS: [source block (Y,U,V) | previous-row vectors | histogram]
+    // LDS: [source block (Y,U,V) | previous-row vectors | predictor rows (this, below) | histogram]
     int srcBytes = P.blkX * P.blkY * P.bps;
     if (P.chroma) srcBytes += 2 * (P.blkX / P.xr) * (P.blkY / P.yr) * P.bps;
     int ldsRow = (srcBytes + 15) & ~15;
     int maxBlkX = 0;
     for (int i = 0; i < P.nLevels; i++) if (P.lv[i].nBlkX > maxBlkX) maxBlkX = P.lv[i].nBlkX;
-    int ldsHist = ldsRow + maxBlkX * 16;
+    int ldsHist = ldsRow + maxBlkX * 48; // previous-row results + two rows of hierarchical predictors, 16 bytes per block each
     const int histBins = 1024;
     int ldsBytes = ldsHist + histBins * 4;
     if (ldsBytes > 160 * 1024) { mvx_set_error("mvx_analyse_frames: frame too wide for the LDS row buffer"); return MVX_E_ARG; }
