@@ -1,0 +1,38 @@
+#!/bin/bash
+# Collects the per-round evidence on the GPU box: default bench line, kernel-trace stats, HBM traffic PMC passes.
+# usage (on the MI355X box, from the repo root):  bash tools/profile_round.sh r1
+R=${1:-r1}
+export TMPDIR=/tmp
+out=$PWD/gpurun_out; mkdir -p $out
+python bench.py > $out/${R}_bench_default.json 2> $out/bench.err || tail -5 $out/bench.err
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python $OLDPWD/bench.py --no-cpu > /tmp/kt.log 2>&1)
+python3 - "$out/${R}_kernel_stats.csv" <<'PY'
+import glob, sys, shutil
+f = glob.glob('/tmp/kt/**/*kernel_stats.csv', recursive=True)
+if f: shutil.copy(f[0], sys.argv[1])
+else: print("no kernel_stats.csv found")
+PY
+for c in FETCH_SIZE WRITE_SIZE; do
+  (cd /tmp && rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $OLDPWD/bench.py --no-cpu --steps 1 --warmup 0 > /tmp/pmc_$c.log 2>&1)
+done
+python3 - "$out/${R}_pmc_traffic.json" <<'PY'
+import csv, glob, json, sys, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob('/tmp/pmc_%s/**/*counter_collection.csv' % c, recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r['Kernel_Name']
+            if r['Counter_Name'] != c: continue
+            acc[k][c] += float(r['Counter_Value']); n[(k, c)] += 1
+res = {"config": "cfg3 batch 168", "command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace -- python bench.py --no-cpu --steps 1 --warmup 0 (one pass per counter)",
+       "correction": "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (MI355X_MICROARCH.md: gfx950 FETCH_SIZE counts 64 B per 128-B request for 16 B/lane reads)", "kernels": {}}
+for k in acc:
+    if not any(t in k for t in ("analyse_kernel", "degrain", "super_")): continue
+    d = n[(k, "FETCH_SIZE")] or 1
+    fs = acc[k]["FETCH_SIZE"] / d; ws = acc[k]["WRITE_SIZE"] / (n[(k, "WRITE_SIZE")] or 1)
+    res["kernels"][k.split('(')[0]] = {"dispatches": d, "FETCH_SIZE_KB_per_dispatch": fs, "WRITE_SIZE_KB_per_dispatch": ws,
+                                      "hbm_bytes_per_dispatch_corrected": 2 * fs * 1024 + ws * 1024}
+json.dump(res, open(sys.argv[1], "w"), indent=1)
+print(json.dumps(res)[:600])
+PY
+head -c 1500 $out/${R}_bench_default.json; echo; head -8 $out/${R}_kernel_stats.csv
