@@ -101,6 +101,15 @@ ANALYSE_CASES = [
     (320, 192, 8, {}, dict(blksize=8, overlap=4, _noise=14)),               # heavy noise: many bad blocks, ties
     (320, 192, 16, {}, dict(blksize=16, overlap=8, _noise=14)),
     (320, 192, 8, dict(pel=4), dict(blksize=8, overlap=4, _noise=10, badrange=6)),
+    # SATD cost modes (PlaneOfBlocks.cpp:117-203); _lumaramp adds a brightness change so that dct 6-10 really mix SATD in
+    (256, 144, 8, {}, dict(blksize=8, overlap=4, dct=5)),
+    (256, 144, 16, {}, dict(blksize=16, overlap=8, dct=5)),
+    (256, 144, 8, {}, dict(blksize=8, overlap=4, dct=6, _lumaramp=40)),
+    (256, 144, 8, {}, dict(blksize=8, overlap=4, dct=7, _lumaramp=40)),
+    (256, 144, 8, {}, dict(blksize=16, overlap=8, dct=8, _lumaramp=40)),
+    (256, 144, 16, {}, dict(blksize=8, overlap=4, dct=9, _lumaramp=40)),
+    (256, 144, 8, {}, dict(blksize=4, overlap=2, dct=10, _lumaramp=40)),
+    (256, 144, 8, {}, dict(blksize=32, overlap=16, dct=5, chroma=0)),
 ]
 
 
@@ -109,7 +118,12 @@ def test_analyse_parity(oracle, mv, w, h, bits, skw, akw):
     import torch
     akw = dict(akw)
     noise = akw.pop("_noise", 3)
+    ramp = akw.pop("_lumaramp", 0)
     frames = pl.moving_clip(w, h, bits, 2, seed=11, noise=noise)
+    if ramp:  # brightness change between the two frames (8-bit scale), stronger to the right: the luma-gated SATD modes fire
+        f1 = frames[1]
+        y = f1[0].astype(np.int64) + (np.linspace(0, ramp, w)[None, :] * (1 << (bits - 8))).astype(np.int64)
+        f1[0][...] = np.clip(y, 0, (1 << bits) - 1).astype(f1[0].dtype)
     osup = oracle.Super(w, h, bits, **skw)
     gsup = mv.Super(w, h, bits, **skw)
     oan = oracle.Analyse(osup, **akw)

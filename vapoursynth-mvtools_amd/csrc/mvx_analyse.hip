@@ -63,7 +63,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_create(const m
     if (P.searchTypeCoarse < 0 || P.searchTypeCoarse > 7) AFAIL("Analyse: search_coarse must be between 0 and 7 (inclusive).");
     if (P.dctmode < 0 || P.dctmode > 10) AFAIL("Analyse: dct must be between 0 and 10 (inclusive).");
     if (P.dctmode >= 5 && ad.nBlkSizeX == 16 && ad.nBlkSizeY == 2) AFAIL("Analyse: dct 5..10 cannot work with 16x2 blocks.");
-    if (P.dctmode != 0) AFAIL("Analyse: dct modes other than 0 are not implemented on the GPU path yet.");
+    if (P.dctmode >= 1 && P.dctmode <= 4) AFAIL("Analyse: dct 1..4 (FFTW3 DCT cost) are not implemented on the GPU path.");
     if (divide < 0 || divide > 2) AFAIL("Analyse: divide must be between 0 and 2 (inclusive).");
     if (divide) AFAIL("Analyse: divide is not implemented on the GPU path yet.");
     {
@@ -222,7 +222,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         if (v > ldsBytes && v <= 160 * 1024) ldsBytes = v;
     }
     ALaunch L = { njobs, ldsBytes, ldsRow, ldsHist, histBins, ldsWin, winCap, st, a->dP, a->dJobs };
-    int rc = P.bps == 1 ? mvx_analyse_launch_u8(P, L) : mvx_analyse_launch_u16(P, L); // specialised 4:2:0 geometries
+    int rc = P.dctmode != 0 ? 1 : P.bps == 1 ? mvx_analyse_launch_u8(P, L) : mvx_analyse_launch_u16(P, L); // specialised 4:2:0 geometries (SAD cost only)
     if (rc == 1) rc = mvx_analyse_launch_any(P, L);                                     // everything else
     if (rc) return rc;
     HIP_CHECK(hipGetLastError());

@@ -1,5 +1,6 @@
 // generic search kernels (block geometry only known at run time)
 #include "mvx_analyse_kernel.h"
 int mvx_analyse_launch_any(const AParams &P, const ALaunch &L) {
+    if (P.dctmode != 0) return P.bps == 1 ? launch_analyse_kernel<1, GeoAnyDct>(L) : launch_analyse_kernel<2, GeoAnyDct>(L); // SATD cost modes
     return P.bps == 1 ? launch_analyse_kernel<1, GeoAny>(L) : launch_analyse_kernel<2, GeoAny>(L);
 }

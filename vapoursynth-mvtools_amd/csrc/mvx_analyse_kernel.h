@@ -308,8 +308,11 @@ __device__ unsigned long long g_prof[32];
 // Compile-time block geometry for the specialised kernels (BW == 0: geometry only known at run time -> generic loops).
 constexpr int pow2c(int v, int r = 1) { return r >= v ? r : pow2c(v, r * 2); }
 // SX = blkW - overlapX (the scan step) enables the LDS search window (0: no window).
-template <int BW_, int BH_, int XR_, int YR_, int SX_ = 0> struct Geo { static constexpr int BW = BW_, BH = BH_, XR = XR_, YR = YR_, SX = SX_; };
+// DCT: the SATD cost modes (dct 5..10) are compiled into their own generic kernel only -- their code costs the default
+// kernels 5-7 % through register allocation even when it never runs (measured)
+template <int BW_, int BH_, int XR_, int YR_, int SX_ = 0, bool DCT_ = false> struct Geo { static constexpr int BW = BW_, BH = BH_, XR = XR_, YR = YR_, SX = SX_; static constexpr bool DCT = DCT_; };
 typedef Geo<0, 0, 0, 0, 0> GeoAny;
+typedef Geo<0, 0, 0, 0, 0, true> GeoAnyDct;
 
 template <int BPS, typename GEO> struct Searcher {
     const AParams &P;
@@ -332,6 +335,7 @@ template <int BPS, typename GEO> struct Searcher {
 
     // plane-scan state (uniform)
     int searchType, nSearchParam;
+    int dctmode, dctweight16, srcLuma, sumLumaChange; // SATD cost modes (dct 5..10), PlaneOfBlocks.cpp:117-203
     long long nLambda, LSAD;
     int penaltyNew, penaltyZero, pglobal, badrange, badcount, tryMany;
     long long badSAD;
@@ -612,6 +616,88 @@ template <int BPS, typename GEO> struct Searcher {
         }
     }
 
+    // ---- SATD / luma sums for the dct = 5..10 cost modes (rare configurations: plain per-lane loops, any geometry) ----
+    // sum |H4 * D * H4^T| of one 4x4 block, SADFunctions.cpp:581-637 (the reference's packed form is an exact emulation
+    // of this plain one)
+    __device__ __forceinline__ unsigned had4x4(const lds_u8 *s, int sp, gl_u8 *r, long long rp) const {
+        int t[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int a[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int sv = BPS == 1 ? (int)*(const LDS_AS unsigned char *)(s + i * sp + k) : (int)*(const LDS_AS unsigned short *)(s + i * sp + 2 * k);
+                const int rv = BPS == 1 ? (int)*(GL_AS const unsigned char *)(r + i * rp + k) : (int)*(GL_AS const uh1 *)(r + i * rp + 2 * k);
+                a[k] = sv - rv;
+            }
+            const int t0 = a[0] + a[1], t1 = a[0] - a[1], t2 = a[2] + a[3], t3 = a[2] - a[3];
+            t[i][0] = t0 + t2; t[i][2] = t0 - t2; t[i][1] = t1 + t3; t[i][3] = t1 - t3;
+        }
+        unsigned sum = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int t0 = t[0][i] + t[1][i], t1 = t[0][i] - t[1][i], t2 = t[2][i] + t[3][i], t3 = t[2][i] - t[3][i];
+            sum += (unsigned)abs(t0 + t2) + (unsigned)abs(t1 + t3) + (unsigned)abs(t0 - t2) + (unsigned)abs(t1 - t3);
+        }
+        return sum;
+    }
+    // this lane's share of Satd_C (SADFunctions.cpp:686-710): one 4x4 block, otherwise 8x4 partitions, each (a + b) >> 1
+    __device__ __forceinline__ unsigned eval_satd(int s, int logG, int vx, int vy) const {
+        gl_u8 *ref = ref_luma(vx, vy);
+        const int G = 1 << logG;
+        if (blkW == 4 && blkH == 4) return s == 0 ? had4x4(lds, lumaRowB, ref, pitchY) >> 1 : 0u;
+        const int ppr = blkW >> 3, np = ppr * (blkH >> 2);
+        unsigned sum = 0;
+        for (int t = s; t < np; t += G) {
+            const int py = (t / ppr) * 4, px = (t % ppr) * 8;
+            const lds_u8 *sp = lds + py * lumaRowB + px * BPS;
+            gl_u8 *rp = ref + (long long)py * pitchY + px * BPS;
+            sum += (had4x4(sp, lumaRowB, rp, pitchY) + had4x4(sp + 4 * BPS, lumaRowB, rp + 4 * BPS, pitchY)) >> 1;
+        }
+        return sum;
+    }
+    // this lane's share of luma_c (Luma.cpp:14-25) of a reference block
+    __device__ __forceinline__ unsigned eval_luma_ref(int s, int logG, int vx, int vy) const {
+        gl_u8 *ref = ref_luma(vx, vy);
+        const int G = 1 << logG, n = blkW * blkH;
+        unsigned sum = 0;
+        for (int t = s; t < n; t += G) {
+            const int y = t / blkW, x = t - y * blkW;
+            sum += BPS == 1 ? (unsigned)*(GL_AS const unsigned char *)(ref + (long long)y * pitchY + x) : (unsigned)*(GL_AS const uh1 *)(ref + (long long)y * pitchY + 2 * x);
+        }
+        return sum;
+    }
+    // luma sum of the staged source block, whole wave (uniform result)
+    __device__ __forceinline__ int src_luma() const {
+        const int n = blkW * blkH;
+        int sum = 0;
+        for (int t = lane_id(); t < n; t += WAVE) {
+            const int y = t / blkW, x = t - y * blkW;
+            sum += BPS == 1 ? (int)*(const LDS_AS unsigned char *)(lds + y * lumaRowB + x) : (int)*(const LDS_AS unsigned short *)(lds + y * lumaRowB + 2 * x);
+        }
+        return uni(wave_sum_i32(sum));
+    }
+    // pobLumaSAD, PlaneOfBlocks.cpp:117-203 (dct 1-4 need FFTW: rejected at create time).  sad / satd / refLuma are the
+    // candidate's group totals.
+    __device__ __forceinline__ bool satd_wanted_always() const { return dctmode == 5 || (dctmode == 6 && dctweight16 > 0) || (dctmode == 9 && dctweight16 > 1); }
+    __device__ __forceinline__ bool satd_by_luma(int refLuma) const {
+        const int sh = dctmode == 10 ? 4 : 5;
+        return abs(srcLuma - refLuma) > ((srcLuma + refLuma) >> sh);
+    }
+    __device__ __forceinline__ unsigned luma_cost(unsigned sadU, unsigned satdU, bool lumaHit) const {
+        long long sad = sadU; const long long d = satdU;
+        switch (dctmode) {
+        case 5: return satdU;
+        case 6: if (dctweight16 > 0) sad = (sad * (16 - dctweight16) + d * dctweight16) / 16; break;
+        case 7: if (lumaHit) sad = sad / 2 + d / 2; break;
+        case 8: if (lumaHit) sad = sad / 4 + d / 2 + d / 4; break;
+        case 10: if (lumaHit) sad = sad / 2 + d / 4 + sad / 4; break;
+        case 9: if (dctweight16 > 1) { const int h = dctweight16 / 2; sad = (sad * (16 - h) + d * h) / 16; } break;
+        default: break;
+        }
+        return (unsigned)sad;
+    }
+
     // partial SADs of this lane's share (items s, s+G, ...) of one candidate
     __device__ __forceinline__ void eval_cand(int s, int logG, int vx, int vy, int vyc, unsigned &aL, unsigned &aC) const {
         if (GEO::BW != 0) {
@@ -681,6 +767,20 @@ template <int BPS, typename GEO> struct Searcher {
             const long long pt1 = PROF_T();
             aL = group_sum(aL, logG);
             aC = group_sum(aC, logG);
+            if (GEO::DCT && dctmode != 0) { // SATD cost modes: the luma term becomes a mix of SAD and SATD (:117-203)
+                bool hit = false, want = satd_wanted_always();
+                if (dctmode == 7 || dctmode == 8 || dctmode == 10) {
+                    unsigned rl = 0;
+                    if (ok) rl = eval_luma_ref(s, logG, vx, vy);
+                    rl = group_sum(rl, logG);
+                    hit = satd_by_luma((int)rl);
+                    want = hit;
+                }
+                unsigned sd = 0;
+                if (ok && want) sd = eval_satd(s, logG, vx, vy);
+                sd = group_sum(sd, logG);
+                aL = luma_cost(aL, sd, hit);
+            }
             const long long pt2 = PROF_T();
             PROF_ADD(4, pt1 - pt0); PROF_ADD(5, pt2 - pt1); PROF_ADD(8, 1);
             const long long tot = (long long)aL + (chroma ? (long long)aC : 0);
@@ -1382,7 +1482,7 @@ template <int BPS, typename GEO> struct Searcher {
     }
 
     // GroupOfPlanes.c:69-125 + PlaneOfBlocks.cpp:971-1131 for one level
-    __device__ __forceinline__ void search_level(int lvl, Vec *globalMV, GL_AS const GVec *coarse, int coarseBlkX, int coarseBlkY, int coarseLogPel) {
+    __device__ __forceinline__ void search_level(int lvl, Vec *globalMV, int *meanLumaChange, GL_AS const GVec *coarse, int coarseBlkX, int coarseBlkY, int coarseLogPel) {
         const int l = lane_id();
         const ALevel &L = P.lv[lvl];
         level = lvl; nBlkX = L.nBlkX; nBlkY = L.nBlkY; pel = L.pel; logPel = L.logPel;
@@ -1481,6 +1581,8 @@ template <int BPS, typename GEO> struct Searcher {
         else if (P.plevel == 2) nLambdaLevel = nLambdaLevel * nScale * nScale;
         penaltyZero = P.pzero; pglobal = P.global ? P.pglobal : P.pzero; badcount = 0;
         penaltyNew = P.pnew; LSAD = P.lsad;
+        dctmode = GEO::DCT ? P.dctmode : 0; sumLumaChange = 0; srcLuma = 0;
+        dctweight16 = min(16, abs(*meanLumaChange) / (blkW * blkH)); // PlaneOfBlocks.cpp:981
 
         LDS_AS Vec *rowbuf = (LDS_AS Vec *)(lds + ldsRow);
         const int stepX = P.blkX - P.ovX, stepY = P.blkY - P.ovY;
@@ -1541,7 +1643,7 @@ template <int BPS, typename GEO> struct Searcher {
         int curIb = 0, curBy = 0;
         win_setup_level();
         A4x32 wpf[WQ_MAX];
-        const bool fast = !tryMany && ((searchType == SearchHex2 && nSearchParam <= 3) || (searchType == SearchExhaustive && nSearchParam == 2));
+        const bool fast = !tryMany && dctmode == 0 && ((searchType == SearchHex2 && nSearchParam <= 3) || (searchType == SearchExhaustive && nSearchParam == 2));
         // early request of the predictor round (specialised kernels, reference samples from global memory)
 #ifdef MVX_NO_EARLY
         constexpr bool EARLY_K = false;
@@ -1632,6 +1734,7 @@ template <int BPS, typename GEO> struct Searcher {
             scale_lambda();
 
             __builtin_amdgcn_wave_barrier(); // single wave: DS ops are in order; keep the compiler from moving LDS reads above the staging writes
+            if (GEO::DCT && (dctmode == 7 || dctmode == 8 || dctmode == 10)) srcLuma = src_luma(); // :829-830 (only these modes read it)
             const long long bt1 = PROF_T();
             if (ablate == 1) { bestMV = predictor; bestMV.sad = 0; }
             else if (fast) { if (!search_block_fast<EARLY_K>(&preA)) search_block(true); }
@@ -1639,12 +1742,15 @@ template <int BPS, typename GEO> struct Searcher {
             const long long bt2 = PROF_T();
             __builtin_amdgcn_wave_barrier();
 
+            if (GEO::DCT && smallestPlane && (dctmode == 6 || dctmode == 9)) // :1109-1110 (feeds dctweight16 of the finer levels)
+                sumLumaChange += uni(wave_sum_i32((int)eval_luma_ref(l, 6, 0, 0))) - src_luma();
             // results: vectors[blkIdx] (:967) == blob row (:1106); the row also stays in LDS for the next row's predictors
             if (l == 0) { st_vec(&vectors[blkIdx], bestMV); st_vec_lds(&rowbuf[blkx], bestMV); }
             prev = bestMV;
             const long long bt3 = PROF_T();
             PROF_ADD(0, bt1 - bt0); PROF_ADD(1, bt2 - bt1); PROF_ADD(2, bt3 - bt2); PROF_ADD(3, 1);
         }
+        if (GEO::DCT && smallestPlane) *meanLumaChange = sumLumaChange / nBlk; // :1130
         // vectors[] of this level feed the next level's interpolation / global-MV estimate (other lanes read them)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1732,11 +1838,12 @@ __global__ __launch_bounds__(64, MVX_WAVES_PER_EU) void analyse_kernel(const APa
     const long long kt0 = PROF_T();
 #endif
     Vec globalMV; globalMV.x = 0; globalMV.y = 0; globalMV.sad = -1; // zeroMV, MVAnalysisData.h:79
+    int meanLumaChange = 0; // GroupOfPlanes.c:94: set by the smallest plane, weights SATD in dct modes 6 / 9
     GL_AS const GVec *coarse = nullptr;
     int cbx = 0, cby = 0, clp = 0;
     for (int lvl = P.nLevels - 1; lvl >= 0; lvl--) {
         if (coarse && P.global) S.estimate_global(coarse, cbx * cby, 8192 * P.lv[lvl + 1].pel, &globalMV);
-        S.search_level(lvl, &globalMV, coarse, cbx, cby, clp);
+        S.search_level(lvl, &globalMV, &meanLumaChange, coarse, cbx, cby, clp);
         coarse = S.vectors; cbx = P.lv[lvl].nBlkX; cby = P.lv[lvl].nBlkY; clp = P.lv[lvl].logPel;
     }
 #ifdef MVX_PROFILE
