@@ -43,6 +43,13 @@ def synth_clip_device(torch, width, height, bits, nframes, seed, device):
     tex = (40 * torch.sin(xx * 0.21 + yy * 0.07) + 30 * torch.sin(xx * 0.05 - yy * 0.13) + 20 * torch.sin(xx * 0.33 + 1.3) * torch.cos(yy * 0.27)
            + 25 * (((xx.long() // 8) + (yy.long() // 8)) & 1).float() + 120)
     texc = [20 * torch.sin(xx * 0.11 + yy * 0.05 + k) + 128 for k in (0.3, 1.7)]
+    import mvtools_amd as mv
+    shapes = []
+    for p in range(3):
+        s_ = 2 if p else 1
+        rowbytes = (width // s_) * (2 if bits > 8 else 1)
+        shapes.append((height // s_, (rowbytes + 255) // 256 * 256))
+    arena = mv.arena_frames(nframes, shapes, device)  # one allocation for the whole clip (see Super.alloc)
     frames = []
     for f in range(nframes):
         ox, oy = margin + 3 * f, margin - 1 * f
@@ -62,7 +69,8 @@ def synth_clip_device(torch, width, height, bits, nframes, seed, device):
             v = torch.clamp(torch.round(img * scale), 0, pm).to(torch.int32)
             rowbytes = w * (2 if bits > 8 else 1)
             pitch = (rowbytes + 255) // 256 * 256
-            t = torch.zeros((h, pitch), dtype=torch.uint8, device=device)
+            t = arena[f][p]
+            assert t.shape == (h, pitch)
             if bits > 8:
                 t[:, :rowbytes] = torch.stack([(v & 0xFF), (v >> 8)], dim=-1).to(torch.uint8).reshape(h, rowbytes)
             else:
@@ -93,7 +101,7 @@ class Pipeline:
         a0 = self.an[(1, 1)]
         self.blobs = {k: a.alloc_blobs(batch, device=device) for k, a in self.an.items()}
         self.dg = mv.Degrain(tr, self.sup, a0.ad, [p.stride(0) for p in self.src[0]])
-        self.out = [[torch.empty_like(p) for p in self.src[0]] for _ in range(batch)]
+        self.out = mv.arena_frames(batch, [tuple(p.shape) for p in self.src[0]], device, zero=False)
         self.ev = []  # (start, end) events around the search launches
 
     def step(self, time_search=False):
