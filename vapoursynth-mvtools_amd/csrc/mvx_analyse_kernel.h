@@ -1650,7 +1650,11 @@ template <int BPS, typename GEO> struct Searcher {
 #else
         // compile-time: one variant of the fast path per kernel.  Measured (r1, A/B in one session): +1.7 % on 1080p 8-bit,
         // -11 % on 4K 16-bit at full load (more loads in flight per CU when the texture path is already the bottleneck)
+#ifdef MVX_FORCE_EARLY
+        constexpr bool EARLY_K = GEO::BW != 0 && G_PF && !W_ON;
+#else
         constexpr bool EARLY_K = BPS == 1 && GEO::BW != 0 && G_PF && !W_ON;
+#endif
 #endif
         const bool early = EARLY_K && fast;
         PreA preA;
