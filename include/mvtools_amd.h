@@ -167,6 +167,9 @@ int mvx_compensate_frames(mvx_compensate *c, int nframes, const mvx_compensate_j
 
 /* ---- vector blob helpers (reader side: Fakery.c, MVAnalysisData.c:7-31) -------------------------- */
 void mvx_scale_thscd(int64_t *thscd1, int32_t *thscd2, const mvx_analysis_data *ad);
+/* bytes of the MVTools_vectors property of a vector clip with this analysis data (Fakery.c:110-121 level geometry,
+ * GroupOfPlanes.c:127-148 array layout) */
+int mvx_vectors_size(const mvx_analysis_data *ad);
 
 /* ---- small device-memory helpers so that a C host (e.g. the VapourSynth shell) needs no HIP headers */
 void *mvx_dev_alloc(size_t bytes);            /* zero-filled */

@@ -1,0 +1,195 @@
+"""The VapourSynth API-4 filter shell (vsplugin/mvtools_vs.c) driven through the in-repo mini host (vsplugin/minihost.c).
+
+CPU part: the plugin loads, registers the reference's plugin id / namespace / function names / argument strings
+(src/EntryPoint.c:28-33, src/MVSuper.c:279-291, src/MVAnalyse.c:639-671, src/MVDegrains.cpp:813-932,
+src/MVCompensate.c:579-592) and reports the reference's creation-time errors.  GPU part: whole filter graphs
+(Super -> Analyse x2 -> Degrain / Compensate) evaluated frame by frame through the shell equal the oracle.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import pipeline as pl
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "vapoursynth-mvtools_amd")
+HOST = os.path.join(PKG, "mvx_vs_host")
+PLUGIN = os.path.join(PKG, "libmvtools_vs.so")
+
+
+def host(*args, check=True):
+    if not (os.path.exists(HOST) and os.path.exists(PLUGIN)):
+        import sys
+        sys.path.insert(0, PKG)
+        import build
+        build.build()
+    r = subprocess.run([HOST, PLUGIN] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+    if check:
+        assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+DEGRAIN_TAIL = "thsad:int:opt;thsadc:int:opt;plane:int:opt;limit:int:opt;limitc:int:opt;thscd1:int:opt;thscd2:int:opt;opt:int:opt;"
+EXPECTED = {
+    "Super": "clip:vnode;hpad:int:opt;vpad:int:opt;pel:int:opt;levels:int:opt;chroma:int:opt;sharp:int:opt;rfilter:int:opt;pelclip:vnode:opt;opt:int:opt;",
+    "Analyse": "super:vnode;blksize:int:opt;blksizev:int:opt;levels:int:opt;search:int:opt;searchparam:int:opt;pelsearch:int:opt;isb:int:opt;lambda:int:opt;"
+               "chroma:int:opt;delta:int:opt;truemotion:int:opt;lsad:int:opt;plevel:int:opt;global:int:opt;pnew:int:opt;pzero:int:opt;pglobal:int:opt;"
+               "overlap:int:opt;overlapv:int:opt;divide:int:opt;badsad:int:opt;badrange:int:opt;opt:int:opt;meander:int:opt;trymany:int:opt;fields:int:opt;"
+               "tff:int:opt;search_coarse:int:opt;dct:int:opt;",
+    "Compensate": "clip:vnode;super:vnode;vectors:vnode;scbehavior:int:opt;thsad:int:opt;fields:int:opt;time:float:opt;thscd1:int:opt;thscd2:int:opt;opt:int:opt;tff:int:opt;",
+}
+_v = "clip:vnode;super:vnode;"
+for _r in range(1, 7):
+    _v += "mvbw%s:vnode;mvfw%s:vnode;" % (("", "") if _r == 1 else (_r, _r))
+    EXPECTED["Degrain%d" % _r] = _v + DEGRAIN_TAIL
+
+
+def test_plugin_registers_reference_interface():
+    out = host("list").splitlines()
+    assert out[0] == "id=com.nodame.mvtools ns=mv"
+    got = dict(line.split(" ", 1) for line in out[1:])
+    assert got == EXPECTED
+
+
+def test_plugin_exports_only_the_entry_point():
+    syms = subprocess.run(["nm", "-D", "--defined-only", PLUGIN], capture_output=True, text=True).stdout
+    names = [l.split()[-1] for l in syms.splitlines() if " T " in l]
+    assert names == ["VapourSynthPluginInit2"]  # src/EntryPoint.c:28, everything else hidden (meson.build:15)
+
+
+@pytest.mark.parametrize("args,msg", [
+    (("Super", 640, 360, 8, "f.pel=3"), "Super: pel must be 1, 2, or 4."),
+    (("Super", 640, 360, 8, "f.sharp=3"), "Super: sharp must be between 0 and 2 (inclusive)."),
+    (("Super", 640, 360, 8, "f.rfilter=9"), "Super: rfilter must be between 0 and 4 (inclusive)."),
+    (("Super", 640, 360, 8, "f.nosuch=1"), "Super: Function does not take argument(s) named nosuch"),
+    (("AnalyseOnClip", 640, 360, 8), "Analyse: required properties not found in first frame of super clip. Maybe clip didn't come from mv.Super? Was the first frame trimmed away?"),
+])
+def test_creation_errors_without_gpu(args, msg):
+    assert host("error", *args).strip() == "ERROR " + msg
+
+
+def test_super_create_reports_geometry_without_gpu():
+    assert host("error", "Super", 640, 360, 8, "f.pel=1").strip() == "OK 672x978 frames=4"
+
+
+def _write_clip(path, frames):
+    with open(path, "wb") as f:
+        for fr in frames:
+            for p in fr:
+                f.write(np.ascontiguousarray(p).tobytes())
+
+
+def _read_frames(path, w, h, bits, n):
+    dt = np.uint8 if bits == 8 else np.uint16
+    data = np.fromfile(path, dtype=dt)
+    per = w * h + 2 * (w // 2) * (h // 2)
+    assert data.size == per * n
+    out = []
+    for i in range(n):
+        d = data[i * per:(i + 1) * per]
+        out.append([d[:w * h].reshape(h, w), d[w * h:w * h + (w // 2) * (h // 2)].reshape(h // 2, w // 2), d[w * h + (w // 2) * (h // 2):].reshape(h // 2, w // 2)])
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [8, 16])
+def test_creation_errors_with_real_frames(bits):
+    # these need frame 0 of the super / vector clips, i.e. a GPU
+    assert host("error", "Analyse", 128, 96, bits, "f.blksize=7").strip().startswith("ERROR Analyse: the block size must be")
+    assert host("error", "Analyse", 128, 96, bits, "s.levels=1", "f.levels=3").strip() == "ERROR Analyse: super clip has 1 levels. Analyse needs 3 levels."
+    assert host("error", "Degrain1Swapped", 128, 96, bits).strip() == "ERROR Degrain1: mvfw must be generated with isb=False."
+    assert host("error", "Degrain1", 128, 96, bits, "f.plane=7").strip() == "ERROR Degrain1: plane must be between 0 and 4 (inclusive)."
+    assert host("error", "Degrain1", 128, 96, bits, "f.limit=%d" % (1 << bits)).strip() == "ERROR Degrain1: limit must be between 0 and %d (inclusive)." % ((1 << bits) - 1)
+    assert host("error", "Degrain1", 128, 96, bits).strip().startswith("OK 128x96")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,bits,nf,sargs,aargs", [(128, 96, 8, 4, {}, dict(blksize=8, overlap=4)), (192, 112, 16, 3, dict(pel=1), dict(blksize=16, overlap=8))])
+def test_shell_super_and_analyse_match_oracle(oracle, tmp_path, w, h, bits, nf, sargs, aargs):
+    frames = pl.moving_clip(w, h, bits, nf, seed=31, noise=3)
+    src = tmp_path / "in.raw"
+    _write_clip(src, frames)
+    osup = oracle.Super(w, h, bits, **sargs)
+    osf = [osup.frame(f) for f in frames]
+    cli = ["s.%s=%s" % kv for kv in sargs.items()] + ["a.%s=%s" % kv for kv in aargs.items()]
+    # Super: defined regions equal, Super_* props on frame 0
+    out = host("run", "super", src, w, h, bits, nf, tmp_path / "sup.raw", *cli)
+    info = osup.s
+    assert out.splitlines()[0] == "super %dx%d Super_height=%d Super_hpad=%d Super_vpad=%d Super_pel=%d Super_modeyuv=%d Super_levels=%d" % (
+        info.superWidth, info.superHeight, h, info.hpad, info.vpad, info.pel, info.modeYUV, info.levels)
+    dt = np.uint8 if bits == 8 else np.uint16
+    raw = np.fromfile(tmp_path / "sup.raw", dtype=dt)
+    sw, sh = info.superWidth, info.superHeight
+    per = sw * sh + 2 * (sw // 2) * (sh // 2)
+    assert raw.size == per * nf
+    for n in range(nf):
+        d = raw[n * per:(n + 1) * per]
+        got = [d[:sw * sh].reshape(sh, sw), d[sw * sh:sw * sh + (sw // 2) * (sh // 2)].reshape(sh // 2, sw // 2), d[sw * sh + (sw // 2) * (sh // 2):].reshape(sh // 2, sw // 2)]
+        assert not pl.defined_equal(osup, osf[n], got)
+    # Analyse: both props byte-identical (nMagicKey / nVersion / nCPUFlags are host dependent in the reference)
+    host("run", "analyse", src, w, h, bits, nf, tmp_path / "vec.raw", *cli)
+    blob = np.fromfile(tmp_path / "vec.raw", dtype=np.uint8)
+    off = 0
+    for n in range(nf):
+        for isb in (1, 0):
+            oan = oracle.Analyse(osup, num_frames=nf, isb=isb, delta=1, **aargs)
+            nref = n + 1 if isb else n - 1
+            want = oan.frame(osf[n], osf[nref] if 0 <= nref < nf else None)
+            ad = np.frombuffer(bytes(oan.ad), dtype=np.int32)
+            got_ad = blob[off:off + 84].view(np.int32)
+            keep = [i for i, (k, _) in enumerate(oracle.AnalysisData._fields_) if k not in ("nMagicKey", "nVersion", "nCPUFlags")]
+            assert np.array_equal(got_ad[keep], ad[keep])
+            off += 84
+            assert np.array_equal(blob[off:off + want.size], want), (n, isb)
+            off += want.size
+    assert off == blob.size
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,bits,radius,dargs", [(128, 96, 8, 1, {}), (192, 112, 16, 2, dict(thsad=300, limit=2000)), (128, 96, 8, 3, dict(plane=0))])
+def test_shell_degrain_matches_oracle(oracle, tmp_path, w, h, bits, radius, dargs):
+    nf = 2 * radius + 2
+    aargs = dict(blksize=8, overlap=4)
+    frames = pl.moving_clip(w, h, bits, nf, seed=33, noise=3)
+    src = tmp_path / "in.raw"
+    _write_clip(src, frames)
+    cli = ["a.%s=%s" % kv for kv in aargs.items()] + ["d.%s=%s" % kv for kv in dargs.items()]
+    host("run", "degrain%d" % radius, src, w, h, bits, nf, tmp_path / "out.raw", *cli)
+    got = _read_frames(tmp_path / "out.raw", w, h, bits, nf)
+    osup = oracle.Super(w, h, bits)
+    osf = [osup.frame(f) for f in frames]
+    ans = {(d, isb): oracle.Analyse(osup, num_frames=nf, isb=isb, delta=d, **aargs) for d in range(1, radius + 1) for isb in (1, 0)}
+    odg = oracle.Degrain(radius, osup, ans[(1, 1)].ad, **dargs)
+    for n in range(nf):
+        refs, blobs = [], []
+        for d in range(1, radius + 1):
+            for isb in (1, 0):
+                nref = n + d if isb else n - d
+                r = osf[nref] if 0 <= nref < nf else None
+                refs.append(r)
+                blobs.append(ans[(d, isb)].frame(osf[n], r))
+        want = odg.frame(frames[n], refs, blobs)
+        for p in range(3):
+            assert np.array_equal(got[n][p], want[p]), (n, p)
+
+
+@pytest.mark.gpu
+def test_shell_compensate_matches_oracle(oracle, tmp_path):
+    w, h, bits, nf = 128, 96, 8, 4
+    aargs = dict(blksize=8, overlap=4)
+    frames = pl.moving_clip(w, h, bits, nf, seed=35, noise=3)
+    src = tmp_path / "in.raw"
+    _write_clip(src, frames)
+    host("run", "compensate", src, w, h, bits, nf, tmp_path / "out.raw", *["a.%s=%s" % kv for kv in aargs.items()], "c.thsad=5000")
+    got = _read_frames(tmp_path / "out.raw", w, h, bits, nf)
+    osup = oracle.Super(w, h, bits)
+    osf = [osup.frame(f) for f in frames]
+    oan = oracle.Analyse(osup, num_frames=nf, isb=1, delta=1, **aargs)
+    ocp = oracle.Compensate(osup, oan.ad, thsad=5000)
+    for n in range(nf):
+        r = osf[n + 1] if n + 1 < nf else None
+        want = ocp.frame(osf[n], r, oan.frame(osf[n], r))
+        for p in range(3):
+            assert np.array_equal(got[n][p], want[p]), (n, p)

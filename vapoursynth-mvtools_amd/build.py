@@ -33,7 +33,34 @@ def _hipcc():
     return "hipcc"
 
 
+VSDIR = os.path.join(HERE, "vsplugin")
+VS_PLUGIN = os.path.join(HERE, "libmvtools_vs.so")
+VS_HOST = os.path.join(HERE, "mvx_vs_host")
+
+
+def build_vs(force=False, verbose=False):
+    """The VapourSynth API-4 filter shell (plain C, links libmvtools_amd.so) and the mini host used by the tests."""
+    srcs = [os.path.join(VSDIR, f) for f in os.listdir(VSDIR)] + [os.path.join(HERE, "..", "include", "mvtools_amd.h")]
+    if not force and all(os.path.exists(o) and all(os.path.getmtime(d) <= os.path.getmtime(o) for d in srcs) for o in (VS_PLUGIN, VS_HOST)):
+        return VS_PLUGIN, VS_HOST
+    cc = os.environ.get("CC", "gcc")
+    cmds = [[cc, "-std=gnu11", "-O2", "-Wall", "-Wextra", "-fPIC", "-shared", "-fvisibility=hidden", os.path.join(VSDIR, "mvtools_vs.c"), "-o", VS_PLUGIN,
+             "-L" + HERE, "-lmvtools_amd", "-Wl,-rpath,$ORIGIN", "-lpthread"],
+            [cc, "-std=gnu11", "-O2", "-Wall", "-Wextra", os.path.join(VSDIR, "minihost.c"), "-o", VS_HOST, "-ldl"]]
+    for cmd in cmds:
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return VS_PLUGIN, VS_HOST
+
+
 def build(force=False, verbose=False):
+    out = _build_lib(force, verbose)
+    build_vs(force, verbose)
+    return out
+
+
+def _build_lib(force=False, verbose=False):
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "mvtools_amd.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
         return OUT

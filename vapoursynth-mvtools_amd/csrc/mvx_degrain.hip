@@ -45,6 +45,18 @@ void mvx_over_windows(int16_t *win9, int nx, int ny, int ox, int oy) {
         }
 }
 
+extern "C" __attribute__((visibility("default"))) int mvx_vectors_size(const mvx_analysis_data *ad) { // Fakery.c:110-121, GroupOfPlanes.c:127-148
+    const int nWidth_B = (ad->nBlkSizeX - ad->nOverlapX) * ad->nBlkX + ad->nOverlapX;
+    const int nHeight_B = (ad->nBlkSizeY - ad->nOverlapY) * ad->nBlkY + ad->nOverlapY;
+    int size = 8;
+    for (int i = ad->nLvCount - 1; i >= 0; i--) {
+        const int bx = ((nWidth_B >> i) - ad->nOverlapX) / (ad->nBlkSizeX - ad->nOverlapX);
+        const int by = ((nHeight_B >> i) - ad->nOverlapY) / (ad->nBlkSizeY - ad->nOverlapY);
+        size += 4 + bx * by * 16;
+    }
+    return size;
+}
+
 extern "C" __attribute__((visibility("default"))) void mvx_scale_thscd(int64_t *thscd1, int32_t *thscd2, const mvx_analysis_data *ad) { // MVAnalysisData.c:7-31
     *thscd1 = *thscd1 * (ad->nBlkSizeX * ad->nBlkSizeY) / (8 * 8);
     if (ad->nMotionFlags & MOTION_USE_CHROMA_MOTION) *thscd1 += *thscd1 / (ad->xRatioUV * ad->yRatioUV) * 2;

@@ -1,0 +1,415 @@
+/*
+ * minihost.c -- a minimal, single-threaded VapourSynth-API-4-shaped host for testing libmvtools_vs.so without a
+ * VapourSynth installation (test infrastructure; shares vs4_api.h with the plugin, see the caveat there).
+ *
+ * It implements exactly the VSAPI / VSPLUGINAPI members the mvtools hot path uses: maps, frames, nodes, the two-phase
+ * getFrame protocol (arInitial -> requestFrameFilter ... -> arAllFramesReady) evaluated synchronously and recursively,
+ * and createVideoFilter.  Frames of every node are kept (no eviction): clips in the tests are a handful of frames.
+ *
+ *   mvx_vs_host <plugin.so> list
+ *   mvx_vs_host <plugin.so> error  <Filter> <w> <h> <bits> [f.key=value ...]       -> prints the creation error (or OK)
+ *   mvx_vs_host <plugin.so> run <pipeline> <in.raw> <w> <h> <bits> <nframes> <out.raw> [s.|a.|d.|c.key=value ...]
+ *       pipeline: super | analyse | degrainN | compensate
+ *       in.raw  : nframes x (Y, U, V planes, 4:2:0, tightly packed, little endian)
+ *       out.raw : super      -> every super frame (planes tightly packed) ; props of frame 0 on stdout
+ *                 analyse    -> per frame: 84-byte MVTools_MVAnalysisData + MVTools_vectors, backward (isb=1) then forward
+ *                 degrainN / compensate -> output frames, planes tightly packed
+ */
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "vs4_api.h"
+
+/* ---------------------------------------------------------------------------------------------------- maps */
+
+typedef struct Item { int64_t i; double f; char *data; int size; int hint; VSNode *node; } Item;
+typedef struct Entry { char *key; int type; int n; Item *v; struct Entry *next; } Entry;
+struct VSMap { Entry *head; char *error; };
+
+static VSNode *node_addref(VSNode *n);
+static void node_free(VSNode *n);
+
+static VSMap *VS_CC createMap(void) { return (VSMap *)calloc(1, sizeof(VSMap)); }
+static void VS_CC clearMap(VSMap *m) {
+    for (Entry *e = m->head; e;) {
+        Entry *nx = e->next;
+        for (int i = 0; i < e->n; i++) { free(e->v[i].data); if (e->v[i].node) node_free(e->v[i].node); }
+        free(e->v); free(e->key); free(e);
+        e = nx;
+    }
+    m->head = NULL;
+    free(m->error); m->error = NULL;
+}
+static void VS_CC freeMap(VSMap *m) { if (m) { clearMap(m); free(m); } }
+static Entry *find(const VSMap *m, const char *key) { for (Entry *e = m->head; e; e = e->next) if (!strcmp(e->key, key)) return e; return NULL; }
+static Item *put(VSMap *m, const char *key, int type, int append) {
+    Entry *e = find(m, key);
+    if (e && (append == maReplace || e->type != type)) {
+        for (int i = 0; i < e->n; i++) { free(e->v[i].data); if (e->v[i].node) node_free(e->v[i].node); }
+        e->n = 0; e->type = type;
+    }
+    if (!e) { e = (Entry *)calloc(1, sizeof(Entry)); e->key = strdup(key); e->type = type; e->next = m->head; m->head = e; }
+    e->v = (Item *)realloc(e->v, sizeof(Item) * (e->n + 1));
+    memset(&e->v[e->n], 0, sizeof(Item));
+    return &e->v[e->n++];
+}
+static const Item *get(const VSMap *m, const char *key, int index, int type, int *error) {
+    Entry *e = find(m, key);
+    int err = peSuccess;
+    if (!e) err = peUnset; else if (e->type != type) err = peType; else if (index < 0 || index >= e->n) err = peIndex;
+    if (error) *error = err;
+    else if (err) { fprintf(stderr, "minihost: fatal property access %s\n", key); abort(); }
+    return err ? NULL : &e->v[index];
+}
+static void VS_CC mapSetError(VSMap *m, const char *msg) { clearMap(m); m->error = strdup(msg ? msg : "Error: no error specified"); }
+static const char *VS_CC mapGetError(const VSMap *m) { return m->error; }
+static int VS_CC mapNumElements(const VSMap *m, const char *key) { Entry *e = find(m, key); return e ? e->n : -1; }
+static int64_t VS_CC mapGetInt(const VSMap *m, const char *k, int i, int *err) { const Item *it = get(m, k, i, ptInt, err); return it ? it->i : 0; }
+static int VS_CC mapGetIntSaturated(const VSMap *m, const char *k, int i, int *err) {
+    int64_t v = mapGetInt(m, k, i, err);
+    return v > 2147483647LL ? 2147483647 : v < -2147483647LL - 1 ? -2147483647 - 1 : (int)v;
+}
+static int VS_CC mapSetInt(VSMap *m, const char *k, int64_t v, int append) { put(m, k, ptInt, append)->i = v; return 0; }
+static double VS_CC mapGetFloat(const VSMap *m, const char *k, int i, int *err) { const Item *it = get(m, k, i, ptFloat, err); return it ? it->f : 0; }
+static int VS_CC mapSetFloat(VSMap *m, const char *k, double v, int append) { put(m, k, ptFloat, append)->f = v; return 0; }
+static const char *VS_CC mapGetData(const VSMap *m, const char *k, int i, int *err) { const Item *it = get(m, k, i, ptData, err); return it ? it->data : NULL; }
+static int VS_CC mapGetDataSize(const VSMap *m, const char *k, int i, int *err) { const Item *it = get(m, k, i, ptData, err); return it ? it->size : -1; }
+static int VS_CC mapSetData(VSMap *m, const char *k, const char *d, int size, int type, int append) {
+    if (size < 0) size = (int)strlen(d);
+    Item *it = put(m, k, ptData, append);
+    it->data = (char *)malloc((size_t)size + 1); memcpy(it->data, d, (size_t)size); it->data[size] = 0; it->size = size; it->hint = type;
+    return 0;
+}
+static VSNode *VS_CC mapGetNode(const VSMap *m, const char *k, int i, int *err) { const Item *it = get(m, k, i, ptVideoNode, err); return it ? node_addref(it->node) : NULL; }
+static int VS_CC mapSetNode(VSMap *m, const char *k, VSNode *n, int append) { put(m, k, ptVideoNode, append)->node = node_addref(n); return 0; }
+static void copy_map(VSMap *dst, const VSMap *src) {
+    for (Entry *e = src->head; e; e = e->next)
+        for (int i = 0; i < e->n; i++) {
+            if (e->type == ptInt) mapSetInt(dst, e->key, e->v[i].i, maAppend);
+            else if (e->type == ptFloat) mapSetFloat(dst, e->key, e->v[i].f, maAppend);
+            else if (e->type == ptData) mapSetData(dst, e->key, e->v[i].data, e->v[i].size, e->v[i].hint, maAppend);
+            else if (e->type == ptVideoNode) mapSetNode(dst, e->key, e->v[i].node, maAppend);
+        }
+}
+
+/* ---------------------------------------------------------------------------------------------------- frames */
+
+struct VSFrame { int refs; VSVideoFormat fmt; int w, h; uint8_t *data[3]; ptrdiff_t stride[3]; VSMap *props; };
+
+static int plane_w(const VSFrame *f, int p) { return p ? f->w >> f->fmt.subSamplingW : f->w; }
+static int plane_h(const VSFrame *f, int p) { return p ? f->h >> f->fmt.subSamplingH : f->h; }
+
+static VSFrame *VS_CC newVideoFrame(const VSVideoFormat *fmt, int w, int h, const VSFrame *propSrc, VSCore *core) {
+    (void)core;
+    VSFrame *f = (VSFrame *)calloc(1, sizeof(VSFrame));
+    f->refs = 1; f->fmt = *fmt; f->w = w; f->h = h; f->props = createMap();
+    for (int p = 0; p < fmt->numPlanes; p++) {
+        f->stride[p] = ((ptrdiff_t)plane_w(f, p) * fmt->bytesPerSample + 63) / 64 * 64;
+        if (posix_memalign((void **)&f->data[p], 64, (size_t)f->stride[p] * plane_h(f, p))) abort();
+        memset(f->data[p], 0xCD, (size_t)f->stride[p] * plane_h(f, p)); /* new frames are uninitialised in VapourSynth */
+    }
+    if (propSrc) copy_map(f->props, propSrc->props);
+    return f;
+}
+static void VS_CC freeFrame(const VSFrame *cf) {
+    VSFrame *f = (VSFrame *)cf;
+    if (!f || --f->refs) return;
+    for (int p = 0; p < 3; p++) free(f->data[p]);
+    freeMap(f->props); free(f);
+}
+static const VSFrame *frame_addref(const VSFrame *f) { ((VSFrame *)f)->refs++; return f; }
+static VSFrame *VS_CC copyFrame(const VSFrame *s, VSCore *core) {
+    VSFrame *f = newVideoFrame(&s->fmt, s->w, s->h, s, core);
+    for (int p = 0; p < s->fmt.numPlanes; p++) memcpy(f->data[p], s->data[p], (size_t)s->stride[p] * plane_h(s, p));
+    return f;
+}
+static const VSMap *VS_CC getFramePropertiesRO(const VSFrame *f) { return f->props; }
+static VSMap *VS_CC getFramePropertiesRW(VSFrame *f) { return f->props; }
+static ptrdiff_t VS_CC getStride(const VSFrame *f, int p) { return f->stride[p]; }
+static const uint8_t *VS_CC getReadPtr(const VSFrame *f, int p) { return f->data[p]; }
+static uint8_t *VS_CC getWritePtr(VSFrame *f, int p) { return f->data[p]; }
+static const VSVideoFormat *VS_CC getVideoFrameFormat(const VSFrame *f) { return &f->fmt; }
+static int VS_CC getFrameWidth(const VSFrame *f, int p) { return plane_w(f, p); }
+static int VS_CC getFrameHeight(const VSFrame *f, int p) { return plane_h(f, p); }
+
+/* ---------------------------------------------------------------------------------------------------- nodes */
+
+struct VSNode { int refs; VSVideoInfo vi; VSFilterGetFrame getFrame; VSFilterFree freeFn; void *inst; const VSFrame **cache; char name[32]; };
+struct VSFrameContext { int n; struct { int n; VSNode *node; const VSFrame *f; } req[64]; int nreq; char error[1024]; };
+
+static VSAPI g_api;
+static VSNode *node_addref(VSNode *n) { n->refs++; return n; }
+static void node_free(VSNode *n) {
+    if (!n || --n->refs) return;
+    for (int i = 0; i < n->vi.numFrames; i++) if (n->cache[i]) freeFrame(n->cache[i]);
+    if (n->freeFn) n->freeFn(n->inst, NULL, &g_api);
+    free(n->cache); free(n);
+}
+static void VS_CC freeNode(VSNode *n) { node_free(n); }
+static VSNode *VS_CC addNodeRef(VSNode *n) { return node_addref(n); }
+static const VSVideoInfo *VS_CC getVideoInfo(VSNode *n) { return &n->vi; }
+
+static const VSFrame *eval_frame(int n, VSNode *node, char *err, int errsz) {
+    if (n < 0) n = 0;
+    if (n >= node->vi.numFrames) n = node->vi.numFrames - 1;
+    if (node->cache[n]) return frame_addref(node->cache[n]);
+    if (!node->getFrame) { snprintf(err, (size_t)errsz, "source frame %d missing", n); return NULL; }
+    VSFrameContext ctx;
+    memset(&ctx, 0, sizeof(ctx));
+    ctx.n = n;
+    void *fd = NULL;
+    const VSFrame *out = node->getFrame(n, arInitial, node->inst, &fd, &ctx, NULL, &g_api);
+    if (!out && !ctx.error[0]) {
+        for (int i = 0; i < ctx.nreq; i++) {
+            ctx.req[i].f = eval_frame(ctx.req[i].n, ctx.req[i].node, ctx.error, sizeof(ctx.error));
+            if (!ctx.req[i].f) break;
+        }
+        if (!ctx.error[0]) out = node->getFrame(n, arAllFramesReady, node->inst, &fd, &ctx, NULL, &g_api);
+    }
+    for (int i = 0; i < ctx.nreq; i++) if (ctx.req[i].f) freeFrame(ctx.req[i].f);
+    if (!out) { snprintf(err, (size_t)errsz, "%s", ctx.error[0] ? ctx.error : "filter returned no frame"); return NULL; }
+    node->cache[n] = out;
+    return frame_addref(out);
+}
+static const VSFrame *VS_CC getFrame(int n, VSNode *node, char *err, int sz) { return eval_frame(n, node, err, sz); }
+static void VS_CC requestFrameFilter(int n, VSNode *node, VSFrameContext *ctx) {
+    for (int i = 0; i < ctx->nreq; i++) if (ctx->req[i].n == n && ctx->req[i].node == node) return;
+    if (ctx->nreq >= 64) { fprintf(stderr, "minihost: too many frame requests\n"); abort(); }
+    ctx->req[ctx->nreq].n = n; ctx->req[ctx->nreq].node = node; ctx->req[ctx->nreq].f = NULL; ctx->nreq++;
+}
+static const VSFrame *VS_CC getFrameFilter(int n, VSNode *node, VSFrameContext *ctx) {
+    for (int i = 0; i < ctx->nreq; i++) if (ctx->req[i].n == n && ctx->req[i].node == node && ctx->req[i].f) return frame_addref(ctx->req[i].f);
+    fprintf(stderr, "minihost: filter fetched frame %d it did not request\n", n);
+    return NULL;
+}
+static void VS_CC setFilterError(const char *msg, VSFrameContext *ctx) { snprintf(ctx->error, sizeof(ctx->error), "%s", msg ? msg : "unknown error"); }
+
+static void VS_CC createVideoFilter(VSMap *out, const char *name, const VSVideoInfo *vi, VSFilterGetFrame gf, VSFilterFree ff, int mode, const VSFilterDependency *deps, int ndeps, void *inst, VSCore *core) {
+    (void)mode; (void)deps; (void)ndeps; (void)core;
+    VSNode *n = (VSNode *)calloc(1, sizeof(VSNode));
+    n->refs = 1; n->vi = *vi; n->getFrame = gf; n->freeFn = ff; n->inst = inst;
+    n->cache = (const VSFrame **)calloc((size_t)vi->numFrames, sizeof(VSFrame *));
+    snprintf(n->name, sizeof(n->name), "%s", name);
+    mapSetNode(out, "clip", n, maAppend);
+    node_free(n); /* the map holds the reference */
+}
+static void VS_CC logMessage(int t, const char *msg, VSCore *core) { (void)t; (void)core; fprintf(stderr, "vs: %s\n", msg); }
+
+/* ---------------------------------------------------------------------------------------------------- plugin side */
+
+typedef struct Func { char name[32]; char *args; VSPublicFunction fn; void *user; } Func;
+static Func g_funcs[32];
+static int g_nfuncs;
+static char g_id[128], g_ns[32];
+
+static int VS_CC papiVersion(void) { return VAPOURSYNTH_API_VERSION; }
+static int VS_CC configPlugin(const char *id, const char *ns, const char *name, int pv, int av, int flags, VSPlugin *p) {
+    (void)name; (void)pv; (void)av; (void)flags; (void)p;
+    snprintf(g_id, sizeof(g_id), "%s", id); snprintf(g_ns, sizeof(g_ns), "%s", ns);
+    return 1;
+}
+static int VS_CC registerFunction(const char *name, const char *args, const char *ret, VSPublicFunction fn, void *user, VSPlugin *p) {
+    (void)ret; (void)p;
+    Func *f = &g_funcs[g_nfuncs++];
+    snprintf(f->name, sizeof(f->name), "%s", name); f->args = strdup(args); f->fn = fn; f->user = user;
+    return 1;
+}
+/* invoke with argument checking against the registered signature (unknown keys are errors, like the real core) */
+static VSNode *invoke(const char *name, VSMap *in, char *err, size_t errsz) {
+    for (int i = 0; i < g_nfuncs; i++)
+        if (!strcmp(g_funcs[i].name, name)) {
+            for (Entry *e = in->head; e; e = e->next) {
+                char pat[80];
+                snprintf(pat, sizeof(pat), "%s:", e->key);
+                const char *hit = strstr(g_funcs[i].args, pat);
+                if (!hit || (hit != g_funcs[i].args && hit[-1] != ';')) { snprintf(err, errsz, "%s: Function does not take argument(s) named %s", name, e->key); return NULL; }
+            }
+            VSMap *out = createMap();
+            g_funcs[i].fn(in, out, g_funcs[i].user, NULL, &g_api);
+            VSNode *n = NULL;
+            if (mapGetError(out)) snprintf(err, errsz, "%s", mapGetError(out));
+            else { int e = 0; n = mapGetNode(out, "clip", 0, &e); if (e) snprintf(err, errsz, "%s: no clip returned", name); }
+            freeMap(out);
+            return n;
+        }
+    snprintf(err, errsz, "no function %s", name);
+    return NULL;
+}
+
+static void init_api(void) {
+    memset(&g_api, 0, sizeof(g_api));
+    g_api.createVideoFilter = createVideoFilter; g_api.freeNode = freeNode; g_api.addNodeRef = addNodeRef; g_api.getVideoInfo = getVideoInfo;
+    g_api.newVideoFrame = newVideoFrame; g_api.freeFrame = freeFrame; g_api.copyFrame = copyFrame;
+    g_api.getFramePropertiesRO = getFramePropertiesRO; g_api.getFramePropertiesRW = getFramePropertiesRW;
+    g_api.getStride = getStride; g_api.getReadPtr = getReadPtr; g_api.getWritePtr = getWritePtr; g_api.getVideoFrameFormat = getVideoFrameFormat;
+    g_api.getFrameWidth = getFrameWidth; g_api.getFrameHeight = getFrameHeight;
+    g_api.getFrame = getFrame; g_api.getFrameFilter = getFrameFilter; g_api.requestFrameFilter = requestFrameFilter; g_api.setFilterError = setFilterError;
+    g_api.createMap = createMap; g_api.freeMap = freeMap; g_api.clearMap = clearMap; g_api.mapSetError = mapSetError; g_api.mapGetError = mapGetError;
+    g_api.mapNumElements = mapNumElements; g_api.mapGetInt = mapGetInt; g_api.mapGetIntSaturated = mapGetIntSaturated; g_api.mapSetInt = mapSetInt;
+    g_api.mapGetFloat = mapGetFloat; g_api.mapSetFloat = mapSetFloat; g_api.mapGetData = mapGetData; g_api.mapGetDataSize = mapGetDataSize; g_api.mapSetData = mapSetData;
+    g_api.mapGetNode = mapGetNode; g_api.mapSetNode = mapSetNode; g_api.logMessage = logMessage;
+}
+
+/* ---------------------------------------------------------------------------------------------------- driver */
+
+static VSNode *source_clip(const char *path, int w, int h, int bits, int nframes) {
+    VSNode *n = (VSNode *)calloc(1, sizeof(VSNode));
+    n->refs = 1;
+    n->vi.format.colorFamily = cfYUV; n->vi.format.sampleType = stInteger; n->vi.format.bitsPerSample = bits; n->vi.format.bytesPerSample = bits > 8 ? 2 : 1;
+    n->vi.format.subSamplingW = 1; n->vi.format.subSamplingH = 1; n->vi.format.numPlanes = 3;
+    n->vi.fpsNum = 24; n->vi.fpsDen = 1; n->vi.width = w; n->vi.height = h; n->vi.numFrames = nframes;
+    n->cache = (const VSFrame **)calloc((size_t)nframes, sizeof(VSFrame *));
+    FILE *fp = path ? fopen(path, "rb") : NULL;
+    if (path && !fp) { fprintf(stderr, "cannot open %s\n", path); exit(2); }
+    for (int f = 0; f < nframes; f++) {
+        VSFrame *fr = newVideoFrame(&n->vi.format, w, h, NULL, NULL);
+        for (int p = 0; p < 3; p++)
+            for (int y = 0; y < plane_h(fr, p); y++) {
+                uint8_t *row = fr->data[p] + (size_t)y * fr->stride[p];
+                const size_t rb = (size_t)plane_w(fr, p) * n->vi.format.bytesPerSample;
+                if (fp) { if (fread(row, 1, rb, fp) != rb) { fprintf(stderr, "short read\n"); exit(2); } }
+                else memset(row, 0, rb);
+            }
+        n->cache[f] = fr;
+    }
+    if (fp) fclose(fp);
+    return n;
+}
+
+/* key=value arguments with a one-letter filter prefix ("a.blksize=8") */
+static void add_args(VSMap *m, char prefix, int argc, char **argv) {
+    for (int i = 0; i < argc; i++) {
+        if (argv[i][0] != prefix || argv[i][1] != '.') continue;
+        char key[64];
+        const char *eq = strchr(argv[i], '=');
+        if (!eq) continue;
+        snprintf(key, sizeof(key), "%.*s", (int)(eq - argv[i] - 2), argv[i] + 2);
+        if (strchr(eq + 1, '.')) mapSetFloat(m, key, atof(eq + 1), maReplace);
+        else mapSetInt(m, key, atoll(eq + 1), maReplace);
+    }
+}
+static void dump_frame(FILE *fp, const VSFrame *f) {
+    for (int p = 0; p < f->fmt.numPlanes; p++)
+        for (int y = 0; y < plane_h(f, p); y++) fwrite(f->data[p] + (size_t)y * f->stride[p], 1, (size_t)plane_w(f, p) * f->fmt.bytesPerSample, fp);
+}
+static void die(const char *what, const char *err) { printf("ERROR %s: %s\n", what, err); exit(1); }
+
+int main(int argc, char **argv) {
+    if (argc < 3) { fprintf(stderr, "usage: see minihost.c\n"); return 2; }
+    init_api();
+    void *h = dlopen(argv[1], RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
+    VSInitPlugin init = (VSInitPlugin)dlsym(h, "VapourSynthPluginInit2");
+    if (!init) { fprintf(stderr, "VapourSynthPluginInit2 not exported\n"); return 2; }
+    VSPLUGINAPI papi = { papiVersion, configPlugin, registerFunction };
+    init(NULL, &papi);
+
+    char err[2048] = "";
+    if (!strcmp(argv[2], "list")) {
+        printf("id=%s ns=%s\n", g_id, g_ns);
+        for (int i = 0; i < g_nfuncs; i++) printf("%s %s\n", g_funcs[i].name, g_funcs[i].args);
+        return 0;
+    }
+    if (!strcmp(argv[2], "error")) { /* error <Filter> w h bits [f.key=value] : creation-time behaviour on a blank clip */
+        const char *filter = argv[3];
+        const int w = atoi(argv[4]), hh = atoi(argv[5]), bits = atoi(argv[6]);
+        VSNode *clip = source_clip(NULL, w, hh, bits, 4);
+        VSMap *m = createMap();
+        VSNode *out = NULL;
+        if (!strcmp(filter, "Super")) { mapSetNode(m, "clip", clip, maReplace); add_args(m, 'f', argc - 7, argv + 7); out = invoke("Super", m, err, sizeof(err)); }
+        else {
+            VSMap *sm = createMap(); mapSetNode(sm, "clip", clip, maReplace); add_args(sm, 's', argc - 7, argv + 7);
+            VSNode *sup = invoke("Super", sm, err, sizeof(err));
+            if (!sup) die("Super", err);
+            if (!strcmp(filter, "Analyse")) { mapSetNode(m, "super", sup, maReplace); add_args(m, 'f', argc - 7, argv + 7); out = invoke("Analyse", m, err, sizeof(err)); }
+            else if (!strcmp(filter, "AnalyseOnClip")) { mapSetNode(m, "super", clip, maReplace); out = invoke("Analyse", m, err, sizeof(err)); }
+            else { /* DegrainN / Compensate with deliberately swapped or plain vector clips: a.* args go to both analyses */
+                VSMap *a1 = createMap(), *a2 = createMap();
+                mapSetNode(a1, "super", sup, maReplace); mapSetNode(a2, "super", sup, maReplace);
+                add_args(a1, 'a', argc - 7, argv + 7); add_args(a2, 'a', argc - 7, argv + 7);
+                mapSetInt(a1, "isb", 1, maReplace); mapSetInt(a2, "isb", 0, maReplace);
+                VSNode *bw = invoke("Analyse", a1, err, sizeof(err)); if (!bw) die("Analyse", err);
+                VSNode *fw = invoke("Analyse", a2, err, sizeof(err)); if (!fw) die("Analyse", err);
+                mapSetNode(m, "clip", clip, maReplace); mapSetNode(m, "super", sup, maReplace);
+                add_args(m, 'f', argc - 7, argv + 7);
+                if (!strcmp(filter, "Compensate")) { mapSetNode(m, "vectors", bw, maReplace); out = invoke("Compensate", m, err, sizeof(err)); }
+                else if (!strcmp(filter, "Degrain1Swapped")) { mapSetNode(m, "mvbw", fw, maReplace); mapSetNode(m, "mvfw", bw, maReplace); out = invoke("Degrain1", m, err, sizeof(err)); }
+                else { mapSetNode(m, "mvbw", bw, maReplace); mapSetNode(m, "mvfw", fw, maReplace); out = invoke(filter, m, err, sizeof(err)); }
+            }
+        }
+        if (out) printf("OK %dx%d frames=%d\n", out->vi.width, out->vi.height, out->vi.numFrames);
+        else printf("ERROR %s\n", err);
+        return 0;
+    }
+    if (strcmp(argv[2], "run") || argc < 10) { fprintf(stderr, "bad command\n"); return 2; }
+    const char *pipeline = argv[3], *inPath = argv[4], *outPath = argv[9];
+    const int w = atoi(argv[5]), hh = atoi(argv[6]), bits = atoi(argv[7]), nframes = atoi(argv[8]);
+    char **extra = argv + 10; const int nextra = argc - 10;
+    VSNode *clip = source_clip(inPath, w, hh, bits, nframes);
+    FILE *fo = fopen(outPath, "wb");
+    if (!fo) { fprintf(stderr, "cannot write %s\n", outPath); return 2; }
+
+    VSMap *sm = createMap(); mapSetNode(sm, "clip", clip, maReplace); add_args(sm, 's', nextra, extra);
+    VSNode *sup = invoke("Super", sm, err, sizeof(err));
+    if (!sup) die("Super", err);
+    if (!strcmp(pipeline, "super")) {
+        for (int n = 0; n < nframes; n++) {
+            const VSFrame *f = eval_frame(n, sup, err, sizeof(err));
+            if (!f) die("Super frame", err);
+            if (n == 0) {
+                int e;
+                printf("super %dx%d", f->w, f->h);
+                const char *keys[] = { "Super_height", "Super_hpad", "Super_vpad", "Super_pel", "Super_modeyuv", "Super_levels" };
+                for (int k = 0; k < 6; k++) printf(" %s=%lld", keys[k], (long long)mapGetInt(f->props, keys[k], 0, &e));
+                printf("\n");
+            }
+            dump_frame(fo, f); freeFrame(f);
+        }
+        fclose(fo); printf("DONE\n"); return 0;
+    }
+    /* vector clips: delta 1..R, backward then forward */
+    int R = 1;
+    if (!strncmp(pipeline, "degrain", 7)) R = atoi(pipeline + 7);
+    VSNode *vec[12];
+    for (int r = 0; r < R; r++)
+        for (int isb = 1; isb >= 0; isb--) {
+            VSMap *am = createMap(); mapSetNode(am, "super", sup, maReplace); add_args(am, 'a', nextra, extra);
+            mapSetInt(am, "isb", isb, maReplace); mapSetInt(am, "delta", r + 1, maReplace);
+            vec[2 * r + (isb ? 0 : 1)] = invoke("Analyse", am, err, sizeof(err));
+            if (!vec[2 * r + (isb ? 0 : 1)]) die("Analyse", err);
+        }
+    if (!strcmp(pipeline, "analyse")) {
+        for (int n = 0; n < nframes; n++)
+            for (int k = 0; k < 2; k++) {
+                const VSFrame *f = eval_frame(n, vec[k], err, sizeof(err));
+                if (!f) die("Analyse frame", err);
+                int e;
+                fwrite(mapGetData(f->props, "MVTools_MVAnalysisData", 0, &e), 1, (size_t)mapGetDataSize(f->props, "MVTools_MVAnalysisData", 0, &e), fo);
+                fwrite(mapGetData(f->props, "MVTools_vectors", 0, &e), 1, (size_t)mapGetDataSize(f->props, "MVTools_vectors", 0, &e), fo);
+                freeFrame(f);
+            }
+        fclose(fo); printf("DONE\n"); return 0;
+    }
+    VSMap *m = createMap();
+    mapSetNode(m, "clip", clip, maReplace); mapSetNode(m, "super", sup, maReplace);
+    VSNode *out;
+    if (!strcmp(pipeline, "compensate")) { mapSetNode(m, "vectors", vec[0], maReplace); add_args(m, 'c', nextra, extra); out = invoke("Compensate", m, err, sizeof(err)); }
+    else {
+        static const char *vn[] = { "mvbw", "mvfw", "mvbw2", "mvfw2", "mvbw3", "mvfw3", "mvbw4", "mvfw4", "mvbw5", "mvfw5", "mvbw6", "mvfw6" };
+        for (int r = 0; r < 2 * R; r++) mapSetNode(m, vn[r], vec[r], maReplace);
+        add_args(m, 'd', nextra, extra);
+        char fn[16]; snprintf(fn, sizeof(fn), "Degrain%d", R);
+        out = invoke(fn, m, err, sizeof(err));
+    }
+    if (!out) die(pipeline, err);
+    for (int n = 0; n < nframes; n++) {
+        const VSFrame *f = eval_frame(n, out, err, sizeof(err));
+        if (!f) die("output frame", err);
+        dump_frame(fo, f); freeFrame(f);
+    }
+    fclose(fo);
+    printf("DONE\n");
+    return 0;
+}

@@ -1,0 +1,747 @@
+/*
+ * mvtools_vs.c -- VapourSynth API-4 filter shell over libmvtools_amd.so (the C ABI in include/mvtools_amd.h).
+ *
+ * Registers, under the reference's plugin id / namespace ("com.nodame.mvtools", "mv"), the filters of the hot path
+ * with the reference's exact argument strings:
+ *     Super       (src/MVSuper.c:279-291)        Analyse   (src/MVAnalyse.c:639-671)
+ *     Degrain1..6 (src/MVDegrains.cpp:813-932)   Compensate (src/MVCompensate.c:579-592)
+ * and keeps the reference's inter-filter data layout: super-frame geometry + Super_* props on frame 0
+ * (src/MVSuper.c:111-120), vector clips = copyFrame(super[n]) + binary props MVTools_MVAnalysisData / MVTools_vectors
+ * (src/MVAnalyse.c:224-239).  This file is the only code that touches VSAPI; all arithmetic happens on the GPU behind
+ * the C ABI, and every compute failure surfaces through setFilterError (there is no CPU path).
+ *
+ * Correctness-first form: one C-ABI call per requested frame.  Super frames produced here stay resident in a small
+ * device-side cache (keyed by a per-frame id prop) so that Analyse / Degrain / Compensate do not round-trip 131 MB
+ * pyramids through host memory; frames that did not come from this Super are uploaded on demand.  Batching the
+ * concurrently requested frames into one search launch (where the throughput is) is the next step and
+ * does not change this interface.
+ *
+ * Not supported (fail loudly at creation, like the C ABI): pelclip, divide, fields/tff, dct 1..4.
+ */
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "vs4_api.h"
+#include "../../include/mvtools_amd.h"
+
+#define PROP_ADATA "MVTools_MVAnalysisData"
+#define PROP_VECTORS "MVTools_vectors"
+#define PROP_SUPER_ID "_MVX_SuperId"
+
+/* ------------------------------------------------------------------------------------------------ device frame cache */
+
+typedef struct DevFrame { int64_t id; void *arena; void *plane[3]; size_t bytes; int pins; uint64_t stamp; } DevFrame;
+#define CACHE_MAX 64
+static DevFrame g_cache[CACHE_MAX];
+static int g_cache_cap = -1;
+static uint64_t g_stamp = 1;
+static int64_t g_next_instance = 1;
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static int cache_cap(void) {
+    if (g_cache_cap < 0) {
+        const char *e = getenv("MVX_VS_CACHE_FRAMES");
+        g_cache_cap = e ? atoi(e) : 16;
+        if (g_cache_cap > CACHE_MAX) g_cache_cap = CACHE_MAX;
+        if (g_cache_cap < 0) g_cache_cap = 0;
+    }
+    return g_cache_cap;
+}
+
+/* geometry of a super frame on the device: one arena per frame, planes at 256-byte pitches */
+typedef struct SuperGeo { mvx_super_info si; ptrdiff_t pitch[3]; size_t off[3]; size_t bytes; int bps; } SuperGeo;
+
+static void super_geo(SuperGeo *g, const mvx_super *s) {
+    mvx_super_get_info(s, &g->si);
+    g->bps = (g->si.bits + 7) / 8;
+    size_t o = 0;
+    for (int p = 0; p < 3; p++) {
+        g->pitch[p] = 0; g->off[p] = o;
+        if (p < g->si.num_planes) {
+            g->pitch[p] = ((ptrdiff_t)g->si.plane_width[p] * g->bps + 255) / 256 * 256;
+            o += (size_t)g->pitch[p] * g->si.plane_height[p];
+        }
+    }
+    g->bytes = o;
+}
+
+/* returns a pinned cache entry holding frame `id`, or NULL */
+static DevFrame *cache_find(int64_t id) {
+    DevFrame *r = NULL;
+    pthread_mutex_lock(&g_lock);
+    for (int i = 0; i < cache_cap(); i++)
+        if (g_cache[i].arena && g_cache[i].id == id) { r = &g_cache[i]; r->pins++; r->stamp = g_stamp++; break; }
+    pthread_mutex_unlock(&g_lock);
+    return r;
+}
+/* hands a freshly filled arena to the cache (pinned); returns NULL if the cache is full of pinned frames / disabled */
+static DevFrame *cache_insert(int64_t id, void *arena, const SuperGeo *g) {
+    DevFrame *slot = NULL;
+    void *victim = NULL;
+    pthread_mutex_lock(&g_lock);
+    for (int i = 0; i < cache_cap(); i++) {
+        DevFrame *e = &g_cache[i];
+        if (!e->arena) { slot = e; break; }
+        if (e->pins == 0 && (!slot || e->stamp < slot->stamp)) slot = e;
+    }
+    if (slot) {
+        victim = slot->arena;
+        slot->id = id; slot->arena = arena; slot->bytes = g->bytes; slot->pins = 1; slot->stamp = g_stamp++;
+        for (int p = 0; p < 3; p++) slot->plane[p] = p < g->si.num_planes ? (char *)arena + g->off[p] : NULL;
+    }
+    pthread_mutex_unlock(&g_lock);
+    if (victim) mvx_dev_free(victim);
+    return slot;
+}
+static void cache_unpin(DevFrame *e) {
+    if (!e) return;
+    pthread_mutex_lock(&g_lock);
+    e->pins--;
+    pthread_mutex_unlock(&g_lock);
+}
+
+/* a super frame on the device for the duration of one getFrame: from the cache or uploaded into a temporary arena */
+typedef struct DevRef { DevFrame *cached; void *temp; void *plane[3]; } DevRef;
+
+static int super_to_device(DevRef *r, const VSFrame *f, const SuperGeo *g, const VSAPI *vs) {
+    memset(r, 0, sizeof(*r));
+    int err = 0;
+    const int64_t id = vs->mapGetInt(vs->getFramePropertiesRO(f), PROP_SUPER_ID, 0, &err);
+    if (!err && (r->cached = cache_find(id)) != NULL) {
+        for (int p = 0; p < 3; p++) r->plane[p] = r->cached->plane[p];
+        return 0;
+    }
+    void *arena = mvx_dev_alloc(g->bytes);
+    if (!arena) return -1;
+    for (int p = 0; p < g->si.num_planes; p++) {
+        void *d = (char *)arena + g->off[p];
+        if (mvx_copy_to_device(d, g->pitch[p], vs->getReadPtr(f, p), vs->getStride(f, p), (size_t)g->si.plane_width[p] * g->bps,
+                               (size_t)g->si.plane_height[p], NULL)) { mvx_dev_free(arena); return -1; }
+        r->plane[p] = d;
+    }
+    if (!err && (r->cached = cache_insert(id, arena, g)) != NULL) return 0; /* keep it for the next consumer */
+    r->temp = arena;
+    return 0;
+}
+static void dev_release(DevRef *r) {
+    if (r->cached) cache_unpin(r->cached);
+    if (r->temp) mvx_dev_free(r->temp);
+    memset(r, 0, sizeof(*r));
+}
+
+/* ------------------------------------------------------------------------------------------------ small helpers */
+
+static int32_t opt_int(const VSMap *in, const char *key, const VSAPI *vs) {
+    int err = 0;
+    const int v = vs->mapGetIntSaturated(in, key, 0, &err);
+    return err ? MVX_UNSET : v;
+}
+static int64_t opt_int64(const VSMap *in, const char *key, const VSAPI *vs) {
+    int err = 0;
+    const int64_t v = vs->mapGetInt(in, key, 0, &err);
+    return err ? (int64_t)MVX_UNSET : v;
+}
+static int arg_given(const VSMap *in, const char *key, const VSAPI *vs) { return vs->mapNumElements(in, key) > 0; }
+
+/* Super_* props of frame 0 of a super clip -> a geometry-only mvx_super handle (consumers: src/MVAnalyse.c:519-553,
+ * src/MVDegrains.cpp:556-581, src/MVCompensate.c:470-500).  `filter` prefixes the reference's messages. */
+static mvx_super *super_from_props(VSNode *super, const char *filter, char *error, size_t esz, const VSAPI *vs) {
+    char msg[1024];
+    const VSFrame *f0 = vs->getFrame(0, super, msg, sizeof(msg));
+    if (!f0) { snprintf(error, esz, "%s: failed to retrieve first frame from super clip. Error message: %s", filter, msg); return NULL; }
+    const VSMap *props = vs->getFramePropertiesRO(f0);
+    int e[6];
+    const int height = vs->mapGetIntSaturated(props, "Super_height", 0, &e[0]);
+    const int hpad = vs->mapGetIntSaturated(props, "Super_hpad", 0, &e[1]);
+    const int vpad = vs->mapGetIntSaturated(props, "Super_vpad", 0, &e[2]);
+    const int pel = vs->mapGetIntSaturated(props, "Super_pel", 0, &e[3]);
+    const int modeyuv = vs->mapGetIntSaturated(props, "Super_modeyuv", 0, &e[4]);
+    const int levels = vs->mapGetIntSaturated(props, "Super_levels", 0, &e[5]);
+    vs->freeFrame(f0);
+    for (int i = 0; i < 6; i++)
+        if (e[i]) {
+            snprintf(error, esz, "%s: required properties not found in first frame of super clip. Maybe clip didn't come from mv.Super? Was the first frame trimmed away?", filter);
+            return NULL;
+        }
+    const VSVideoInfo *vi = vs->getVideoInfo(super);
+    if (height <= 0 || hpad < 0 || hpad >= vi->width / 2 || vpad < 0 || pel < 1 || pel > 4 || modeyuv < 0 || modeyuv > 7 || levels < 1) {
+        snprintf(error, esz, "%s: parameters from super clip appear to be wrong.", filter);
+        return NULL;
+    }
+    mvx_super_args a;
+    a.width = vi->width - 2 * hpad; a.height = height; a.bits = vi->format.bitsPerSample;
+    a.subsampling_w = vi->format.subSamplingW; a.subsampling_h = vi->format.subSamplingH; a.gray = vi->format.colorFamily == cfGray;
+    a.hpad = hpad; a.vpad = vpad; a.pel = pel; a.levels = levels; a.chroma = modeyuv != 1; a.sharp = MVX_UNSET; a.rfilter = MVX_UNSET;
+    mvx_super *s = NULL;
+    char err[MVX_ERRLEN];
+    if (mvx_super_create(&a, &s, err)) { snprintf(error, esz, "%s: parameters from super clip appear to be wrong.", filter); return NULL; }
+    return s;
+}
+
+/* src/MVAnalysisData.c:34-64 adataFromVectorClip */
+static int adata_from_clip(mvx_analysis_data *ad, VSNode *clip, const char *filter, const char *name, char *error, size_t esz, const VSAPI *vs) {
+    char msg[1024];
+    const VSFrame *f0 = vs->getFrame(0, clip, msg, sizeof(msg));
+    if (!f0) { snprintf(error, esz, "%s: Failed to retrieve first frame from %s. Error message: %s", filter, name, msg); return -1; }
+    const VSMap *props = vs->getFramePropertiesRO(f0);
+    int err = 0;
+    const char *data = vs->mapGetData(props, PROP_ADATA, 0, &err);
+    int rc = 0;
+    if (err) { snprintf(error, esz, "%s: Property '%s' not found in first frame of %s.", filter, PROP_ADATA, name); rc = -1; }
+    else {
+        const int size = vs->mapGetDataSize(props, PROP_ADATA, 0, NULL);
+        if (size != (int)sizeof(*ad)) { snprintf(error, esz, "%s: Property '%s' in first frame of %s has wrong size (%d instead of %d).", filter, PROP_ADATA, name, size, (int)sizeof(*ad)); rc = -1; }
+        else memcpy(ad, data, sizeof(*ad));
+    }
+    vs->freeFrame(f0);
+    return rc;
+}
+/* src/MVAnalysisData.c:67-99 adataCheckSimilarity */
+static int adata_similar(const mvx_analysis_data *a, const mvx_analysis_data *b, const char *filter, const char *n1, const char *n2, char *error, size_t esz) {
+    const char *what = NULL;
+    if (a->nWidth != b->nWidth) what = "widths";
+    if (a->nHeight != b->nHeight) what = "heights";
+    if (a->nBlkSizeX != b->nBlkSizeX || a->nBlkSizeY != b->nBlkSizeY) what = "block sizes";
+    if (a->nPel != b->nPel) what = "pel precision";
+    if (a->nOverlapX != b->nOverlapX || a->nOverlapY != b->nOverlapY) what = "overlap";
+    if (a->xRatioUV != b->xRatioUV) what = "horizontal subsampling";
+    if (a->yRatioUV != b->yRatioUV) what = "vertical subsampling";
+    if (a->bitsPerSample != b->bitsPerSample) what = "bit depths";
+    if (!what) return 0;
+    snprintf(error, esz, "%s: %s and %s have different %s.", filter, n1, n2, what);
+    return -1;
+}
+
+static void upload_plane_set(void *dst[3], void **arena, const VSFrame *f, const ptrdiff_t pitch[3], int nplanes, int bps, const VSAPI *vs) {
+    size_t off[3], total = 0;
+    for (int p = 0; p < nplanes; p++) { off[p] = total; total += (size_t)pitch[p] * vs->getFrameHeight(f, p); }
+    *arena = mvx_dev_alloc(total);
+    for (int p = 0; p < 3; p++) dst[p] = NULL;
+    if (!*arena) return;
+    for (int p = 0; p < nplanes; p++) {
+        dst[p] = (char *)*arena + off[p];
+        mvx_copy_to_device(dst[p], pitch[p], vs->getReadPtr(f, p), vs->getStride(f, p), (size_t)vs->getFrameWidth(f, p) * bps, (size_t)vs->getFrameHeight(f, p), NULL);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ mv.Super */
+
+typedef struct SuperData { VSNode *node; VSVideoInfo vi; mvx_super *sup; SuperGeo geo; ptrdiff_t srcPitch[3]; int64_t instance; } SuperData;
+
+static const VSFrame *VS_CC superGetFrame(int n, int reason, void *inst, void **fd, VSFrameContext *ctx, VSCore *core, const VSAPI *vs) {
+    (void)fd;
+    SuperData *d = (SuperData *)inst;
+    if (reason == arInitial) { vs->requestFrameFilter(n, d->node, ctx); return NULL; }
+    if (reason != arAllFramesReady) return NULL;
+    const VSFrame *src = vs->getFrameFilter(n, d->node, ctx);
+    const SuperGeo *g = &d->geo;
+    void *srcArena = NULL, *dsrc[3], *ddst[3] = { NULL, NULL, NULL };
+    upload_plane_set(dsrc, &srcArena, src, d->srcPitch, g->si.num_planes, g->bps, vs);
+    void *arena = mvx_dev_alloc(g->bytes); /* zero-filled: only the defined rectangles are written (MVSuper.c:73 memsets too) */
+    int rc = (!srcArena || !arena) ? MVX_E_NOMEM : 0;
+    if (!rc) {
+        for (int p = 0; p < g->si.num_planes; p++) ddst[p] = (char *)arena + g->off[p];
+        rc = mvx_super_frames(d->sup, 1, (const void *const *)dsrc, d->srcPitch, (void *const *)ddst, g->pitch, NULL);
+    }
+    VSFrame *dst = NULL;
+    if (!rc) {
+        dst = vs->newVideoFrame(&d->vi.format, d->vi.width, d->vi.height, src, core);
+        for (int p = 0; p < g->si.num_planes && !rc; p++)
+            rc = mvx_copy_to_host(vs->getWritePtr(dst, p), vs->getStride(dst, p), ddst[p], g->pitch[p], (size_t)g->si.plane_width[p] * g->bps, (size_t)g->si.plane_height[p], NULL);
+        if (!rc) rc = mvx_stream_sync(NULL);
+    }
+    if (srcArena) mvx_dev_free(srcArena);
+    vs->freeFrame(src);
+    if (rc) {
+        if (arena) mvx_dev_free(arena);
+        if (dst) vs->freeFrame(dst);
+        vs->setFilterError(mvx_last_error(), ctx);
+        return NULL;
+    }
+    VSMap *props = vs->getFramePropertiesRW(dst);
+    if (n == 0) { /* src/MVSuper.c:111-120 */
+        vs->mapSetInt(props, "Super_height", g->si.height, maReplace);
+        vs->mapSetInt(props, "Super_hpad", g->si.hpad, maReplace);
+        vs->mapSetInt(props, "Super_vpad", g->si.vpad, maReplace);
+        vs->mapSetInt(props, "Super_pel", g->si.pel, maReplace);
+        vs->mapSetInt(props, "Super_modeyuv", g->si.modeYUV, maReplace);
+        vs->mapSetInt(props, "Super_levels", g->si.levels, maReplace);
+    }
+    /* the device copy stays resident for the consumers (harmless extra prop; frames without it are uploaded) */
+    const int64_t id = (d->instance << 32) | (uint32_t)n;
+    vs->mapSetInt(props, PROP_SUPER_ID, id, maReplace);
+    DevFrame *e = cache_insert(id, arena, g);
+    if (e) cache_unpin(e); else mvx_dev_free(arena);
+    return dst;
+}
+
+static void VS_CC superFree(void *inst, VSCore *core, const VSAPI *vs) {
+    (void)core;
+    SuperData *d = (SuperData *)inst;
+    vs->freeNode(d->node);
+    mvx_super_destroy(d->sup);
+    free(d);
+}
+
+static void VS_CC superCreate(const VSMap *in, VSMap *out, void *user, VSCore *core, const VSAPI *vs) {
+    (void)user;
+    if (arg_given(in, "pelclip", vs)) { vs->mapSetError(out, "Super: pelclip is not supported by the MI355X build."); return; }
+    VSNode *node = vs->mapGetNode(in, "clip", 0, 0);
+    const VSVideoInfo *vi = vs->getVideoInfo(node);
+    if (!mvx_vsh_is_constant_video_format(vi) || vi->format.bitsPerSample > 16 || vi->format.sampleType != stInteger || vi->format.subSamplingW > 1 ||
+        vi->format.subSamplingH > 1 || (vi->format.colorFamily != cfYUV && vi->format.colorFamily != cfGray)) {
+        /* argument-value errors come first in the reference (MVSuper.c:177-192): let the library report them on a dummy format */
+        mvx_super_args t = { 64, 64, 8, 1, 1, 0, opt_int(in, "hpad", vs), opt_int(in, "vpad", vs), opt_int(in, "pel", vs), opt_int(in, "levels", vs), opt_int(in, "chroma", vs), opt_int(in, "sharp", vs), opt_int(in, "rfilter", vs) };
+        mvx_super *ts = NULL; char terr[MVX_ERRLEN];
+        if (mvx_super_create(&t, &ts, terr)) vs->mapSetError(out, terr);
+        else { mvx_super_destroy(ts); vs->mapSetError(out, "Super: input clip must be GRAY, 420, 422, 440, or 444, up to 16 bits, with constant dimensions."); }
+        vs->freeNode(node);
+        return;
+    }
+    mvx_super_args a = { vi->width, vi->height, vi->format.bitsPerSample, vi->format.subSamplingW, vi->format.subSamplingH, vi->format.colorFamily == cfGray,
+                         opt_int(in, "hpad", vs), opt_int(in, "vpad", vs), opt_int(in, "pel", vs), opt_int(in, "levels", vs), opt_int(in, "chroma", vs),
+                         opt_int(in, "sharp", vs), opt_int(in, "rfilter", vs) };
+    if (a.chroma != MVX_UNSET) a.chroma = !!a.chroma;
+    mvx_super *sup = NULL;
+    char err[MVX_ERRLEN];
+    if (mvx_super_create(&a, &sup, err)) { vs->mapSetError(out, err); vs->freeNode(node); return; }
+    SuperData *d = (SuperData *)calloc(1, sizeof(*d));
+    d->node = node; d->sup = sup; d->vi = *vi;
+    super_geo(&d->geo, sup);
+    d->vi.width = d->geo.si.super_width; d->vi.height = d->geo.si.super_height;
+    const int bps = d->geo.bps;
+    for (int p = 0; p < 3; p++) {
+        const int w = p ? vi->width >> vi->format.subSamplingW : vi->width;
+        d->srcPitch[p] = ((ptrdiff_t)w * bps + 255) / 256 * 256;
+    }
+    pthread_mutex_lock(&g_lock);
+    d->instance = g_next_instance++;
+    pthread_mutex_unlock(&g_lock);
+    VSFilterDependency deps[1] = { { node, rpStrictSpatial } };
+    vs->createVideoFilter(out, "Super", &d->vi, superGetFrame, superFree, fmParallel, deps, 1, d, core);
+}
+
+/* ------------------------------------------------------------------------------------------------ mv.Analyse */
+
+typedef struct AnalyseData { VSNode *node; const VSVideoInfo *vi; mvx_super *sup; SuperGeo geo; mvx_analyse *an; mvx_analysis_data ad; int blobSize; } AnalyseData;
+
+static int analyse_nref(const AnalyseData *d, int n) { /* src/MVAnalyse.c:84-104 */
+    if (d->ad.nDeltaFrame > 0) return n + (d->ad.isBackward ? d->ad.nDeltaFrame : -d->ad.nDeltaFrame);
+    return -d->ad.nDeltaFrame;
+}
+
+static const VSFrame *VS_CC analyseGetFrame(int n, int reason, void *inst, void **fd, VSFrameContext *ctx, VSCore *core, const VSAPI *vs) {
+    (void)fd;
+    AnalyseData *d = (AnalyseData *)inst;
+    const int nref = analyse_nref(d, n);
+    const int haveRef = nref >= 0 && nref < d->vi->numFrames;
+    if (reason == arInitial) {
+        if (haveRef && nref < n) vs->requestFrameFilter(nref, d->node, ctx);
+        vs->requestFrameFilter(n, d->node, ctx);
+        if (haveRef && nref >= n && nref != n) vs->requestFrameFilter(nref, d->node, ctx);
+        return NULL;
+    }
+    if (reason != arAllFramesReady) return NULL;
+    const VSFrame *src = vs->getFrameFilter(n, d->node, ctx);
+    const VSFrame *ref = haveRef ? vs->getFrameFilter(nref, d->node, ctx) : NULL;
+    DevRef ds, dr;
+    memset(&dr, 0, sizeof(dr));
+    int rc = super_to_device(&ds, src, &d->geo, vs);
+    if (!rc && ref) rc = super_to_device(&dr, ref, &d->geo, vs);
+    void *dblob = rc ? NULL : mvx_dev_alloc((size_t)d->blobSize);
+    char *blob = (char *)malloc((size_t)d->blobSize);
+    if (!rc && (!dblob || !blob)) rc = MVX_E_NOMEM;
+    if (!rc) {
+        mvx_analyse_job job;
+        memset(&job, 0, sizeof(job));
+        for (int p = 0; p < 3; p++) { job.src[p] = ds.plane[p]; job.ref[p] = ref ? dr.plane[p] : NULL; }
+        job.blob = dblob;
+        rc = mvx_analyse_frames(d->an, 1, &job, NULL);
+        if (!rc) rc = mvx_copy_to_host(blob, d->blobSize, dblob, d->blobSize, (size_t)d->blobSize, 1, NULL);
+        if (!rc) rc = mvx_stream_sync(NULL);
+    }
+    dev_release(&ds); dev_release(&dr);
+    if (dblob) mvx_dev_free(dblob);
+    if (ref) vs->freeFrame(ref);
+    VSFrame *dst = NULL;
+    if (!rc) { /* src/MVAnalyse.c:224-239 */
+        dst = vs->copyFrame(src, core);
+        VSMap *props = vs->getFramePropertiesRW(dst);
+        vs->mapSetData(props, PROP_ADATA, (const char *)&d->ad, sizeof(d->ad), dtBinary, maReplace);
+        vs->mapSetData(props, PROP_VECTORS, blob, d->blobSize, dtBinary, maReplace);
+    } else
+        vs->setFilterError(rc == MVX_E_NOMEM ? "Analyse: out of memory." : mvx_last_error(), ctx);
+    free(blob);
+    vs->freeFrame(src);
+    return dst;
+}
+
+static void VS_CC analyseFree(void *inst, VSCore *core, const VSAPI *vs) {
+    (void)core;
+    AnalyseData *d = (AnalyseData *)inst;
+    vs->freeNode(d->node);
+    mvx_analyse_destroy(d->an);
+    mvx_super_destroy(d->sup);
+    free(d);
+}
+
+static void VS_CC analyseCreate(const VSMap *in, VSMap *out, void *user, VSCore *core, const VSAPI *vs) {
+    (void)user;
+    static const char *keys[] = { "blksize", "blksizev", "levels", "search", "searchparam", "pelsearch", "isb", "lambda", "chroma", "delta", "truemotion",
+                                  "lsad", "plevel", "global", "pnew", "pzero", "pglobal", "overlap", "overlapv", "divide", "badsad", "badrange", "opt",
+                                  "meander", "trymany", "fields", "tff", "search_coarse", "dct" };
+    mvx_analyse_args a;
+    int32_t *av = (int32_t *)&a;
+    for (size_t i = 0; i < sizeof(keys) / sizeof(keys[0]); i++) av[i] = opt_int(in, keys[i], vs);
+    VSNode *node = vs->mapGetNode(in, "super", 0, 0);
+    const VSVideoInfo *vi = vs->getVideoInfo(node);
+    char err[1200];
+    if (!mvx_vsh_is_constant_video_format(vi) || vi->format.bitsPerSample > 16 || vi->format.sampleType != stInteger || vi->format.subSamplingW > 1 ||
+        vi->format.subSamplingH > 1 || (vi->format.colorFamily != cfYUV && vi->format.colorFamily != cfGray)) {
+        vs->mapSetError(out, "Analyse: super clip must be GRAY, 420, 422, 440, or 444, up to 16 bits, with constant dimensions.");
+        vs->freeNode(node);
+        return;
+    }
+    mvx_super *sup = super_from_props(node, "Analyse", err, sizeof(err), vs);
+    if (!sup) { vs->mapSetError(out, err); vs->freeNode(node); return; }
+    AnalyseData *d = (AnalyseData *)calloc(1, sizeof(*d));
+    d->node = node; d->vi = vi; d->sup = sup;
+    super_geo(&d->geo, sup);
+    char lerr[MVX_ERRLEN];
+    if (mvx_analyse_create(&a, sup, vi->numFrames, d->geo.pitch, &d->an, lerr)) {
+        vs->mapSetError(out, lerr);
+        mvx_super_destroy(sup); vs->freeNode(node); free(d);
+        return;
+    }
+    mvx_analyse_get_data(d->an, &d->ad);
+    d->blobSize = mvx_analyse_blob_size(d->an);
+    VSFilterDependency deps[1] = { { node, rpGeneral } };
+    vs->createVideoFilter(out, "Analyse", vi, analyseGetFrame, analyseFree, fmParallel, deps, 1, d, core);
+}
+
+/* ------------------------------------------------------------------------------------------------ mv.Degrain1..6 */
+
+typedef struct DegrainData {
+    VSNode *node, *super, *vectors[12];
+    const VSVideoInfo *vi;
+    int radius;
+    mvx_super *sup; SuperGeo geo;
+    mvx_degrain *dg;
+    mvx_analysis_data ad[12];
+    ptrdiff_t pitch[3]; /* device pitch of clip / output planes */
+    int blobSize;
+    char name[16];
+} DegrainData;
+
+static const VSFrame *VS_CC degrainGetFrame(int n, int reason, void *inst, void **fd, VSFrameContext *ctx, VSCore *core, const VSAPI *vs) {
+    (void)fd;
+    DegrainData *d = (DegrainData *)inst;
+    const int nr = 2 * d->radius;
+    if (reason == arInitial) { /* src/MVDegrains.cpp:92-109 */
+        for (int r = 0; r < nr; r += 2) {
+            vs->requestFrameFilter(n, d->vectors[r], ctx);
+            vs->requestFrameFilter(n, d->vectors[r + 1], ctx);
+            const int offB = d->ad[r].nDeltaFrame, offF = -d->ad[r + 1].nDeltaFrame;
+            if (n + offB < d->vi->numFrames) vs->requestFrameFilter(n + offB, d->super, ctx);
+            if (n + offF >= 0) vs->requestFrameFilter(n + offF, d->super, ctx);
+        }
+        vs->requestFrameFilter(n, d->node, ctx);
+        return NULL;
+    }
+    if (reason != arAllFramesReady) return NULL;
+    const VSFrame *src = vs->getFrameFilter(n, d->node, ctx);
+    const int np = d->vi->format.numPlanes, bps = d->vi->format.bytesPerSample;
+    mvx_degrain_job job;
+    memset(&job, 0, sizeof(job));
+    DevRef refs[12];
+    void *blobArena[12];
+    memset(refs, 0, sizeof(refs)); memset(blobArena, 0, sizeof(blobArena));
+    int rc = 0;
+    void *srcArena = NULL, *dsrc[3];
+    upload_plane_set(dsrc, &srcArena, src, d->pitch, np, bps, vs);
+    size_t dstOff[3], dstBytes = 0;
+    for (int p = 0; p < np; p++) { dstOff[p] = dstBytes; dstBytes += (size_t)d->pitch[p] * vs->getFrameHeight(src, p); }
+    void *dstArena = mvx_dev_alloc(dstBytes);
+    if (!srcArena || !dstArena) rc = MVX_E_NOMEM;
+    for (int p = 0; p < np && !rc; p++) { job.src[p] = dsrc[p]; job.dst[p] = (char *)dstArena + dstOff[p]; }
+    for (int r = 0; r < nr && !rc; r++) {
+        const VSFrame *vf = vs->getFrameFilter(n, d->vectors[r], ctx);
+        int e = 0;
+        const char *blob = vs->mapGetData(vs->getFramePropertiesRO(vf), PROP_VECTORS, 0, &e);
+        const int size = e ? 0 : vs->mapGetDataSize(vs->getFramePropertiesRO(vf), PROP_VECTORS, 0, NULL);
+        if (e || size != d->blobSize) { rc = MVX_E_ARG; vs->freeFrame(vf); break; }
+        blobArena[r] = mvx_dev_alloc((size_t)size);
+        if (!blobArena[r] || mvx_copy_to_device(blobArena[r], size, blob, size, (size_t)size, 1, NULL)) rc = MVX_E_NOMEM;
+        if (!rc) rc = mvx_stream_sync(NULL); /* the prop memory goes away with the frame */
+        job.blobs[r] = blobArena[r];
+        vs->freeFrame(vf);
+        const int nref = (r & 1) ? n - d->ad[r].nDeltaFrame : n + d->ad[r].nDeltaFrame;
+        if (!rc && nref >= 0 && nref < d->vi->numFrames) {
+            const VSFrame *sf = vs->getFrameFilter(nref, d->super, ctx);
+            rc = super_to_device(&refs[r], sf, &d->geo, vs);
+            vs->freeFrame(sf);
+            for (int p = 0; p < 3; p++) job.refs[r][p] = refs[r].plane[p];
+        }
+    }
+    if (!rc) rc = mvx_degrain_frames(d->dg, 1, &job, NULL);
+    VSFrame *dst = NULL;
+    if (!rc) {
+        dst = vs->newVideoFrame(&d->vi->format, d->vi->width, d->vi->height, src, core);
+        for (int p = 0; p < np && !rc; p++)
+            rc = mvx_copy_to_host(vs->getWritePtr(dst, p), vs->getStride(dst, p), job.dst[p], d->pitch[p], (size_t)vs->getFrameWidth(dst, p) * bps, (size_t)vs->getFrameHeight(dst, p), NULL);
+        if (!rc) rc = mvx_stream_sync(NULL);
+    }
+    for (int r = 0; r < nr; r++) { dev_release(&refs[r]); if (blobArena[r]) mvx_dev_free(blobArena[r]); }
+    if (srcArena) mvx_dev_free(srcArena);
+    if (dstArena) mvx_dev_free(dstArena);
+    vs->freeFrame(src);
+    if (rc) {
+        char msg[MVX_ERRLEN + 64];
+        snprintf(msg, sizeof(msg), "%s: %s", d->name, rc == MVX_E_ARG ? "vector clip frame without matching MVTools_vectors property." : rc == MVX_E_NOMEM ? "out of memory." : mvx_last_error());
+        if (dst) vs->freeFrame(dst);
+        vs->setFilterError(msg, ctx);
+        return NULL;
+    }
+    return dst;
+}
+
+static void VS_CC degrainFree(void *inst, VSCore *core, const VSAPI *vs) {
+    (void)core;
+    DegrainData *d = (DegrainData *)inst;
+    vs->freeNode(d->node); vs->freeNode(d->super);
+    for (int r = 0; r < 2 * d->radius; r++) vs->freeNode(d->vectors[r]);
+    mvx_degrain_destroy(d->dg);
+    mvx_super_destroy(d->sup);
+    free(d);
+}
+
+static void VS_CC degrainCreate(const VSMap *in, VSMap *out, void *user, VSCore *core, const VSAPI *vs) {
+    const int radius = (int)(intptr_t)user;
+    static const char *vnames[] = { "mvbw", "mvfw", "mvbw2", "mvfw2", "mvbw3", "mvfw3", "mvbw4", "mvfw4", "mvbw5", "mvfw5", "mvbw6", "mvfw6" };
+    DegrainData *d = (DegrainData *)calloc(1, sizeof(*d));
+    d->radius = radius;
+    snprintf(d->name, sizeof(d->name), "Degrain%d", radius);
+    char err[1400] = "";
+    mvx_degrain_args a;
+    a.radius = radius; a.thsad = opt_int64(in, "thsad", vs); a.thsadc = opt_int64(in, "thsadc", vs); a.plane = opt_int(in, "plane", vs);
+    a.limit = opt_int(in, "limit", vs); a.limitc = opt_int(in, "limitc", vs); a.thscd1 = opt_int64(in, "thscd1", vs); a.thscd2 = opt_int(in, "thscd2", vs);
+    if (a.plane != MVX_UNSET && (a.plane < 0 || a.plane > 4)) snprintf(err, sizeof(err), "%s: plane must be between 0 and 4 (inclusive).", d->name);
+    if (!err[0]) {
+        d->super = vs->mapGetNode(in, "super", 0, NULL);
+        d->sup = super_from_props(d->super, d->name, err, sizeof(err), vs);
+    }
+    const int nr = 2 * radius;
+    for (int r = 0; r < nr && !err[0]; r++) {
+        d->vectors[r] = vs->mapGetNode(in, vnames[r], 0, NULL);
+        adata_from_clip(&d->ad[r], d->vectors[r], d->name, vnames[r], err, sizeof(err), vs);
+    }
+    for (int r = 1; r < nr && !err[0]; r++) adata_similar(&d->ad[0], &d->ad[r], d->name, vnames[0], vnames[r], err, sizeof(err));
+    if (!err[0]) { /* src/MVDegrains.cpp:606-640 */
+        const char *m = NULL;
+        for (int r = 0; r < nr; r++) if (d->ad[r].nDeltaFrame <= 0) m = "cannot use motion vectors with absolute frame references.";
+        if (!d->ad[0].isBackward) m = "mvbw must be generated with isb=True.";
+        if (d->ad[1].isBackward) m = "mvfw must be generated with isb=False.";
+        for (int k = 1; k < radius; k++) {
+            if (!d->ad[2 * k].isBackward) m = "mvbw must be generated with isb=True.";
+            if (d->ad[2 * k + 1].isBackward) m = "mvfw must be generated with isb=False.";
+            if (d->ad[2 * k].nDeltaFrame <= d->ad[2 * k - 2].nDeltaFrame) m = "mvbwN must have greater delta than mvbwP.";
+            if (d->ad[2 * k + 1].nDeltaFrame <= d->ad[2 * k - 1].nDeltaFrame) m = "mvfwN must have greater delta than mvfwP.";
+        }
+        if (m) snprintf(err, sizeof(err), "%s: %s", d->name, m);
+    }
+    if (!err[0]) {
+        d->node = vs->mapGetNode(in, "clip", 0, NULL);
+        d->vi = vs->getVideoInfo(d->node);
+        const VSVideoInfo *svi = vs->getVideoInfo(d->super);
+        super_geo(&d->geo, d->sup);
+        if (!mvx_vsh_is_constant_video_format(d->vi) || d->vi->format.bitsPerSample > 16 || d->vi->format.sampleType != stInteger || d->vi->format.subSamplingW > 1 ||
+            d->vi->format.subSamplingH > 1 || (d->vi->format.colorFamily != cfYUV && d->vi->format.colorFamily != cfGray))
+            snprintf(err, sizeof(err), "%s: input clip must be GRAY, 420, 422, 440, or 444, up to 16 bits, with constant dimensions.", d->name);
+        else if (d->geo.si.height != d->vi->height || d->geo.si.super_width != svi->width || d->geo.si.super_height != svi->height || d->geo.si.width != d->vi->width ||
+                 d->vi->format.bitsPerSample != svi->format.bitsPerSample || d->vi->format.subSamplingW != svi->format.subSamplingW || d->vi->format.subSamplingH != svi->format.subSamplingH)
+            snprintf(err, sizeof(err), "%s: wrong source or super clip frame size.", d->name);
+    }
+    if (!err[0]) {
+        const int bps = d->vi->format.bytesPerSample;
+        for (int p = 0; p < 3; p++) {
+            const int w = p ? d->vi->width >> d->vi->format.subSamplingW : d->vi->width;
+            d->pitch[p] = ((ptrdiff_t)w * bps + 255) / 256 * 256;
+        }
+        char lerr[MVX_ERRLEN];
+        if (mvx_degrain_create(&a, &d->ad[0], d->sup, d->pitch, d->geo.pitch, d->pitch, &d->dg, lerr)) snprintf(err, sizeof(err), "%s", lerr);
+    }
+    if (!err[0]) d->blobSize = mvx_vectors_size(&d->ad[0]);
+    if (err[0]) {
+        vs->mapSetError(out, err);
+        if (d->node) vs->freeNode(d->node);
+        if (d->super) vs->freeNode(d->super);
+        for (int r = 0; r < nr; r++) if (d->vectors[r]) vs->freeNode(d->vectors[r]);
+        if (d->dg) mvx_degrain_destroy(d->dg);
+        if (d->sup) mvx_super_destroy(d->sup);
+        free(d);
+        return;
+    }
+    VSFilterDependency deps[14];
+    deps[0].source = d->node; deps[0].requestPattern = rpStrictSpatial;
+    deps[1].source = d->super; deps[1].requestPattern = rpGeneral;
+    for (int r = 0; r < nr; r++) { deps[2 + r].source = d->vectors[r]; deps[2 + r].requestPattern = rpStrictSpatial; }
+    vs->createVideoFilter(out, d->name, d->vi, degrainGetFrame, degrainFree, fmParallel, deps, 2 + nr, d, core);
+}
+
+/* ------------------------------------------------------------------------------------------------ mv.Compensate */
+
+typedef struct CompData { VSNode *node, *super, *vectors; const VSVideoInfo *vi; mvx_super *sup; SuperGeo geo; mvx_compensate *cp; mvx_analysis_data ad; ptrdiff_t pitch[3]; int blobSize; } CompData;
+
+static int comp_nref(const CompData *d, int n) { /* src/MVCompensate.c:84-92 */
+    if (d->ad.nDeltaFrame > 0) return n + (d->ad.isBackward ? d->ad.nDeltaFrame : -d->ad.nDeltaFrame);
+    return -d->ad.nDeltaFrame;
+}
+
+static const VSFrame *VS_CC compGetFrame(int n, int reason, void *inst, void **fd, VSFrameContext *ctx, VSCore *core, const VSAPI *vs) {
+    (void)fd;
+    CompData *d = (CompData *)inst;
+    const int nref = comp_nref(d, n);
+    const int haveRef = nref >= 0 && nref < d->vi->numFrames;
+    if (reason == arInitial) {
+        vs->requestFrameFilter(n, d->vectors, ctx);
+        if (haveRef && nref < n) vs->requestFrameFilter(nref, d->super, ctx);
+        vs->requestFrameFilter(n, d->super, ctx);
+        if (haveRef && nref > n) vs->requestFrameFilter(nref, d->super, ctx);
+        vs->requestFrameFilter(n, d->node, ctx);
+        return NULL;
+    }
+    if (reason != arAllFramesReady) return NULL;
+    const VSFrame *src = vs->getFrameFilter(n, d->node, ctx);
+    const VSFrame *ssup = vs->getFrameFilter(n, d->super, ctx);
+    const VSFrame *rsup = haveRef ? vs->getFrameFilter(nref, d->super, ctx) : NULL;
+    const VSFrame *vf = vs->getFrameFilter(n, d->vectors, ctx);
+    const int np = d->vi->format.numPlanes, bps = d->vi->format.bytesPerSample;
+    DevRef ds, dr;
+    memset(&dr, 0, sizeof(dr));
+    int rc = super_to_device(&ds, ssup, &d->geo, vs);
+    if (!rc && rsup) rc = super_to_device(&dr, rsup, &d->geo, vs);
+    int e = 0;
+    const char *blob = vs->mapGetData(vs->getFramePropertiesRO(vf), PROP_VECTORS, 0, &e);
+    const int size = e ? 0 : vs->mapGetDataSize(vs->getFramePropertiesRO(vf), PROP_VECTORS, 0, NULL);
+    if (!rc && (e || size != d->blobSize)) rc = MVX_E_ARG;
+    void *dblob = rc ? NULL : mvx_dev_alloc((size_t)d->blobSize);
+    size_t dstOff[3], dstBytes = 0;
+    for (int p = 0; p < np; p++) { dstOff[p] = dstBytes; dstBytes += (size_t)d->pitch[p] * vs->getFrameHeight(src, p); }
+    void *dstArena = rc ? NULL : mvx_dev_alloc(dstBytes);
+    if (!rc && (!dblob || !dstArena)) rc = MVX_E_NOMEM;
+    mvx_compensate_job job;
+    memset(&job, 0, sizeof(job));
+    if (!rc) {
+        rc = mvx_copy_to_device(dblob, size, blob, size, (size_t)size, 1, NULL);
+        for (int p = 0; p < 3; p++) { job.src_super[p] = ds.plane[p]; job.ref_super[p] = rsup ? dr.plane[p] : NULL; }
+        for (int p = 0; p < np; p++) job.dst[p] = (char *)dstArena + dstOff[p];
+        job.blob = dblob;
+        if (!rc) rc = mvx_compensate_frames(d->cp, 1, &job, NULL);
+    }
+    VSFrame *dst = NULL;
+    if (!rc) {
+        dst = vs->newVideoFrame(&d->vi->format, d->vi->width, d->vi->height, src, core);
+        for (int p = 0; p < np && !rc; p++)
+            rc = mvx_copy_to_host(vs->getWritePtr(dst, p), vs->getStride(dst, p), job.dst[p], d->pitch[p], (size_t)vs->getFrameWidth(dst, p) * bps, (size_t)vs->getFrameHeight(dst, p), NULL);
+        if (!rc) rc = mvx_stream_sync(NULL);
+    }
+    dev_release(&ds); dev_release(&dr);
+    if (dblob) mvx_dev_free(dblob);
+    if (dstArena) mvx_dev_free(dstArena);
+    vs->freeFrame(vf); vs->freeFrame(ssup); if (rsup) vs->freeFrame(rsup);
+    vs->freeFrame(src);
+    if (rc) {
+        if (dst) vs->freeFrame(dst);
+        vs->setFilterError(rc == MVX_E_ARG ? "Compensate: vector clip frame without matching MVTools_vectors property." : rc == MVX_E_NOMEM ? "Compensate: out of memory." : mvx_last_error(), ctx);
+        return NULL;
+    }
+    return dst;
+}
+
+static void VS_CC compFree(void *inst, VSCore *core, const VSAPI *vs) {
+    (void)core;
+    CompData *d = (CompData *)inst;
+    vs->freeNode(d->node); vs->freeNode(d->super); vs->freeNode(d->vectors);
+    mvx_compensate_destroy(d->cp);
+    mvx_super_destroy(d->sup);
+    free(d);
+}
+
+static void VS_CC compCreate(const VSMap *in, VSMap *out, void *user, VSCore *core, const VSAPI *vs) {
+    (void)user;
+    CompData *d = (CompData *)calloc(1, sizeof(*d));
+    char err[1400] = "";
+    mvx_compensate_args a;
+    a.scbehavior = opt_int(in, "scbehavior", vs); a.thsad = opt_int64(in, "thsad", vs); a.thscd1 = opt_int64(in, "thscd1", vs); a.thscd2 = opt_int(in, "thscd2", vs);
+    int e = 0;
+    a.time = vs->mapGetFloat(in, "time", 0, &e);
+    if (e) a.time = 100.0;
+    if (opt_int(in, "fields", vs) != MVX_UNSET && opt_int(in, "fields", vs) != 0) snprintf(err, sizeof(err), "Compensate: fields=True is not supported by the MI355X build.");
+    if (!err[0]) {
+        d->super = vs->mapGetNode(in, "super", 0, NULL);
+        d->sup = super_from_props(d->super, "Compensate", err, sizeof(err), vs);
+    }
+    if (!err[0]) {
+        d->vectors = vs->mapGetNode(in, "vectors", 0, NULL);
+        adata_from_clip(&d->ad, d->vectors, "Compensate", "vectors", err, sizeof(err), vs);
+    }
+    if (!err[0]) {
+        d->node = vs->mapGetNode(in, "clip", 0, NULL);
+        d->vi = vs->getVideoInfo(d->node);
+        super_geo(&d->geo, d->sup);
+        const VSVideoInfo *svi = vs->getVideoInfo(d->super);
+        if (d->geo.si.height != d->vi->height || d->geo.si.width != d->vi->width || d->geo.si.super_width != svi->width || d->geo.si.super_height != svi->height)
+            snprintf(err, sizeof(err), "Compensate: wrong source or super clip frame size.");
+    }
+    if (!err[0]) {
+        const int bps = d->vi->format.bytesPerSample;
+        for (int p = 0; p < 3; p++) {
+            const int w = p ? d->vi->width >> d->vi->format.subSamplingW : d->vi->width;
+            d->pitch[p] = ((ptrdiff_t)w * bps + 255) / 256 * 256;
+        }
+        char lerr[MVX_ERRLEN];
+        if (mvx_compensate_create(&a, &d->ad, d->sup, d->geo.pitch, d->pitch, &d->cp, lerr)) snprintf(err, sizeof(err), "%s", lerr);
+    }
+    if (!err[0]) d->blobSize = mvx_vectors_size(&d->ad);
+    if (err[0]) {
+        vs->mapSetError(out, err);
+        if (d->node) vs->freeNode(d->node);
+        if (d->super) vs->freeNode(d->super);
+        if (d->vectors) vs->freeNode(d->vectors);
+        if (d->cp) mvx_compensate_destroy(d->cp);
+        if (d->sup) mvx_super_destroy(d->sup);
+        free(d);
+        return;
+    }
+    VSFilterDependency deps[3] = { { d->node, rpStrictSpatial }, { d->super, rpGeneral }, { d->vectors, rpStrictSpatial } };
+    vs->createVideoFilter(out, "Compensate", d->vi, compGetFrame, compFree, fmParallel, deps, 3, d, core);
+}
+
+/* ------------------------------------------------------------------------------------------------ entry point */
+
+#define DEGRAIN_TAIL "thsad:int:opt;thsadc:int:opt;plane:int:opt;limit:int:opt;limitc:int:opt;thscd1:int:opt;thscd2:int:opt;opt:int:opt;"
+
+/* replaces src/EntryPoint.c:28-52 for the filters of the hot path */
+VS_EXTERNAL_API(void) VapourSynthPluginInit2(VSPlugin *plugin, const VSPLUGINAPI *vspapi) {
+    vspapi->configPlugin("com.nodame.mvtools", "mv", "MVTools v24", VS_MAKE_VERSION(24, 0), VS_MAKE_VERSION(VAPOURSYNTH_API_MAJOR, VAPOURSYNTH_API_MINOR), 0, plugin);
+    vspapi->registerFunction("Super",
+                             "clip:vnode;hpad:int:opt;vpad:int:opt;pel:int:opt;levels:int:opt;chroma:int:opt;sharp:int:opt;rfilter:int:opt;pelclip:vnode:opt;opt:int:opt;",
+                             "clip:vnode;", superCreate, NULL, plugin);
+    vspapi->registerFunction("Analyse",
+                             "super:vnode;blksize:int:opt;blksizev:int:opt;levels:int:opt;search:int:opt;searchparam:int:opt;pelsearch:int:opt;isb:int:opt;lambda:int:opt;"
+                             "chroma:int:opt;delta:int:opt;truemotion:int:opt;lsad:int:opt;plevel:int:opt;global:int:opt;pnew:int:opt;pzero:int:opt;pglobal:int:opt;"
+                             "overlap:int:opt;overlapv:int:opt;divide:int:opt;badsad:int:opt;badrange:int:opt;opt:int:opt;meander:int:opt;trymany:int:opt;fields:int:opt;"
+                             "tff:int:opt;search_coarse:int:opt;dct:int:opt;",
+                             "clip:vnode;", analyseCreate, NULL, plugin);
+    vspapi->registerFunction("Degrain1", "clip:vnode;super:vnode;mvbw:vnode;mvfw:vnode;" DEGRAIN_TAIL, "clip:vnode;", degrainCreate, (void *)(intptr_t)1, plugin);
+    vspapi->registerFunction("Degrain2", "clip:vnode;super:vnode;mvbw:vnode;mvfw:vnode;mvbw2:vnode;mvfw2:vnode;" DEGRAIN_TAIL, "clip:vnode;", degrainCreate, (void *)(intptr_t)2, plugin);
+    vspapi->registerFunction("Degrain3", "clip:vnode;super:vnode;mvbw:vnode;mvfw:vnode;mvbw2:vnode;mvfw2:vnode;mvbw3:vnode;mvfw3:vnode;" DEGRAIN_TAIL, "clip:vnode;", degrainCreate, (void *)(intptr_t)3, plugin);
+    vspapi->registerFunction("Degrain4", "clip:vnode;super:vnode;mvbw:vnode;mvfw:vnode;mvbw2:vnode;mvfw2:vnode;mvbw3:vnode;mvfw3:vnode;mvbw4:vnode;mvfw4:vnode;" DEGRAIN_TAIL, "clip:vnode;", degrainCreate, (void *)(intptr_t)4, plugin);
+    vspapi->registerFunction("Degrain5", "clip:vnode;super:vnode;mvbw:vnode;mvfw:vnode;mvbw2:vnode;mvfw2:vnode;mvbw3:vnode;mvfw3:vnode;mvbw4:vnode;mvfw4:vnode;mvbw5:vnode;mvfw5:vnode;" DEGRAIN_TAIL, "clip:vnode;", degrainCreate, (void *)(intptr_t)5, plugin);
+    vspapi->registerFunction("Degrain6", "clip:vnode;super:vnode;mvbw:vnode;mvfw:vnode;mvbw2:vnode;mvfw2:vnode;mvbw3:vnode;mvfw3:vnode;mvbw4:vnode;mvfw4:vnode;mvbw5:vnode;mvfw5:vnode;mvbw6:vnode;mvfw6:vnode;" DEGRAIN_TAIL, "clip:vnode;", degrainCreate, (void *)(intptr_t)6, plugin);
+    vspapi->registerFunction("Compensate",
+                             "clip:vnode;super:vnode;vectors:vnode;scbehavior:int:opt;thsad:int:opt;fields:int:opt;time:float:opt;thscd1:int:opt;thscd2:int:opt;opt:int:opt;tff:int:opt;",
+                             "clip:vnode;", compCreate, NULL, plugin);
+}
