@@ -1,5 +1,7 @@
 """GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
 Bit-exact: integer samples, motion vectors and SADs (no tolerance anywhere)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -322,3 +324,63 @@ def test_full_size_properties_cfg2(mv):
     out = mv.Degrain(1, sup, an.ad, [p.stride(0) for p in src[0]]).run([(src[0], [sf[1], sf[1]], [b_same, b_same])])[0]
     for p in range(3):
         assert torch.equal(out[p][:, :f0[p].shape[1]], src[0][p][:, :f0[p].shape[1]])
+
+
+def _fullsize_props(mv, w, h, bits, blk, ov, tr, label):
+    """Size-independent properties at a BASELINE size: (1) identical frames -> all-zero vectors, Degrain == input;
+    (2) an integer translation is recovered by the interior blocks; (3) batch invariance: a chain gives the same blob
+    alone and inside a multi-chain launch, forward / backward and with a missing reference; (4) blob header and size."""
+    import torch
+    scale = 1 << (bits - 8)
+    rng = np.random.default_rng(12)
+    yy, xx = np.mgrid[0:h + 16, 0:w + 16].astype(np.float32)
+    tex = (40 * np.sin(xx * 0.21 + yy * 0.07) + 30 * np.sin(xx * 0.05 - yy * 0.13) + 25 * (((xx.astype(np.int32) // 8) + (yy.astype(np.int32) // 8)) & 1) + 120)
+    tex = (tex + rng.integers(-2, 3, tex.shape)).clip(0, 255)
+    dt = np.uint8 if bits == 8 else np.uint16
+    big = [(tex * scale).astype(dt), (tex[::2, ::2] * 0.5 * scale + 64 * scale).astype(dt), (tex[::2, ::2] * 0.25 * scale + 96 * scale).astype(dt)]
+    f0 = [big[0][8:8 + h, 8:8 + w], big[1][4:4 + h // 2, 4:4 + w // 2], big[2][4:4 + h // 2, 4:4 + w // 2]]
+    f1 = [big[0][8:8 + h, 6:6 + w], big[1][4:4 + h // 2, 3:3 + w // 2], big[2][4:4 + h // 2, 3:3 + w // 2]]  # content moves +2 px
+    sup = mv.Super(w, h, bits)
+    src = [mv.frame_to_device([np.ascontiguousarray(p) for p in f]) for f in (f0, f0, f1)]
+    sf = sup.build(src)
+    an = mv.Analyse(sup, blksize=blk, overlap=ov, isb=1)
+    jobs = [(sf[0], sf[1]), (sf[0], sf[2]), (sf[2], sf[0]), (sf[0], None)]
+    batch = an.run(jobs)
+    torch.cuda.synchronize()
+    singles = [an.run([j])[0] for j in jobs]
+    torch.cuda.synchronize()
+    for b, s in zip(batch, singles):
+        assert torch.equal(b, s), label + ": batch invariance"
+    bs = batch[0].cpu().numpy()
+    assert bs[:8].view(np.int32).tolist() == [an.blob_size, 1], label
+    assert an.blob_size == mv.lib().mvx_vectors_size(C.byref(an.ad))
+    x, y, sad = pl.blob_vectors(bs, an.ad, 0)
+    assert not x.any() and not y.any() and not sad.any(), label + ": identical frames"
+    x, y, sad = pl.blob_vectors(batch[1].cpu().numpy(), an.ad, 0)
+    inner = (slice(4, -4), slice(4, -4))
+    assert (x[inner] == 4).mean() > 0.99 and (y[inner] == 0).mean() > 0.99, label + ": +2 px == +4 half-pel"
+    x, y, sad = pl.blob_vectors(batch[2].cpu().numpy(), an.ad, 0)
+    assert (x[inner] == -4).mean() > 0.99 and (y[inner] == 0).mean() > 0.99, label + ": reverse direction"
+    assert batch[3].cpu().numpy()[:8].view(np.int32).tolist() == [an.blob_size, 0], label + ": missing reference -> invalid blob"
+    dg = mv.Degrain(tr, sup, an.ad, [p.stride(0) for p in src[0]])
+    out = dg.run([(src[0], [sf[1]] * (2 * tr), [batch[0]] * (2 * tr))])[0]
+    for p in range(3):
+        # every block blends to the source value v; the overlap sum is sum_k((v * win_k) >> 6) with integer windows whose
+        # taps add up to 2048 +- 1 (Overlap.cpp:40-125 rounds each tap), so the result is v +- a few v / 2048
+        a = out[p].cpu().numpy()
+        a = (a.view(np.uint16) if bits > 8 else a)[:, :f0[p].shape[1]].astype(np.int64)
+        d = f0[p].astype(np.int64) - a
+        assert (np.abs(d) <= (f0[p].astype(np.int64) >> 10) + 2).all(), label + ": Degrain of identical frames (%d..%d)" % (d.min(), d.max())
+        assert (d == 0).mean() > 0.5, label + ": %.3f exact" % (d == 0).mean()
+
+
+@pytest.mark.gpu
+def test_full_size_properties_cfg3(mv):
+    """BASELINE cfg3: 4K YUV420P16, blk 16, overlap 8, pel 2, Degrain3."""
+    _fullsize_props(mv, 3840, 2160, 16, 16, 8, 3, "cfg3")
+
+
+@pytest.mark.gpu
+def test_full_size_properties_cfg5(mv):
+    """BASELINE cfg5: 8K YUV420P16, blk 32, overlap 16, pel 2, Degrain6."""
+    _fullsize_props(mv, 7680, 4320, 16, 32, 16, 6, "cfg5")

@@ -113,6 +113,8 @@ def lib():
         L.mvx_compensate_destroy.argtypes = [C.c_void_p]
         L.mvx_compensate_frames.argtypes = [C.c_void_p, C.c_int, P(CompensateJob), C.c_void_p]
         L.mvx_scale_thscd.argtypes = [P(C.c_int64), P(C.c_int32), P(AnalysisData)]
+        L.mvx_vectors_size.argtypes = [P(AnalysisData)]
+        L.mvx_vectors_size.restype = C.c_int
         _lib = L
     return _lib
 
