@@ -165,6 +165,46 @@ typedef struct mvx_compensate_job {
 
 int mvx_compensate_frames(mvx_compensate *c, int nframes, const mvx_compensate_job *jobs, void *stream);
 
+/* ---- mv.BlockFPS ---------------------------------------------------------------------------------
+ * replaces mvblockfpsCreate / mvblockfpsGetFrame, MVBlockFPS.c:741-1014 / :229-676 (arg string :1017-1033);
+ * masks MaskFun.cpp:63-166, mask upsizer SimpleResize.cpp:27-121.                                     */
+
+typedef struct mvx_blockfps_args {
+    int64_t num, den;        /* MVX_UNSET -> 25 / 1; 0 -> double the input rate */
+    int32_t mode;            /* 0..8, MVX_UNSET -> 3 */
+    double ml;               /* pass 100.0 for the default */
+    int32_t blend;           /* MVX_UNSET -> 1 */
+    int64_t thscd1; int32_t thscd2;
+} mvx_blockfps_args;
+
+typedef struct mvx_blockfps_info { int32_t num_frames; int64_t fps_num, fps_den; } mvx_blockfps_info; /* of the output clip */
+
+typedef struct mvx_blockfps mvx_blockfps;
+
+/* fps_num / fps_den: frame rate of the input clip (the reference refuses clips without one) */
+int mvx_blockfps_create(const mvx_blockfps_args *args, const mvx_analysis_data *mvbw, const mvx_analysis_data *mvfw,
+                        const mvx_super *super_clip, int num_frames, int64_t fps_num, int64_t fps_den,
+                        const ptrdiff_t super_pitch[3], const ptrdiff_t clip_pitch[3], const ptrdiff_t dst_pitch[3],
+                        mvx_blockfps **out, char *err);
+void mvx_blockfps_destroy(mvx_blockfps *b);
+void mvx_blockfps_get_info(const mvx_blockfps *b, mvx_blockfps_info *info);
+/* output frame n -> the two input frames it lies between and its time position (MVBlockFPS.c:245-254,278-292) */
+void mvx_blockfps_map(const mvx_blockfps *b, int n, int *nleft, int *nright, int *time256);
+
+typedef struct mvx_blockfps_job {
+    int32_t time256;             /* from mvx_blockfps_map; 0 / 256 copy clip_left / clip_right */
+    int32_t reserved;
+    const void *src_super[3];    /* super frame nleft  } all four NULL when nleft or nright lies outside the clip */
+    const void *ref_super[3];    /* super frame nright }   (then, or when the vectors are unusable: blend / copy */
+    const void *blob_fw;         /* mvfw vectors at nright }   of clip_left and clip_right, MVBlockFPS.c:640-673) */
+    const void *blob_bw;         /* mvbw vectors at nleft  } */
+    const void *clip_left[3];    /* clip frame min(nleft, last)  */
+    const void *clip_right[3];   /* clip frame min(nright, last) */
+    void *dst[3];
+} mvx_blockfps_job;
+
+int mvx_blockfps_frames(mvx_blockfps *b, int nframes, const mvx_blockfps_job *jobs, void *stream);
+
 /* ---- vector blob helpers (reader side: Fakery.c, MVAnalysisData.c:7-31) -------------------------- */
 void mvx_scale_thscd(int64_t *thscd1, int32_t *thscd2, const mvx_analysis_data *ad);
 /* bytes of the MVTools_vectors property of a vector clip with this analysis data (Fakery.c:110-121 level geometry,

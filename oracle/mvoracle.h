@@ -131,6 +131,25 @@ void mvo_compensate_frame(const mvo_compensate *d, const uint8_t *const srcSuper
                           const uint8_t *const refSuper[3], const int refPitch[3], const uint8_t *blob,
                           uint8_t *const dst[3], const int dstPitch[3]);
 
+/* ---- mv.BlockFPS: MVBlockFPS.c, MaskFun.cpp, SimpleResize.cpp (parity UNPINNED: no reference TU of it builds here) ---- */
+typedef struct mvo_blockfps {
+    mvo_analysis_data bw, fw;
+    int mode, blend; double ml;
+    int64_t thscd1; int thscd2;
+    int64_t fa, fb, outFpsNum, outFpsDen;
+    int inFrames, outFrames;
+    int nSuperHPad, nSuperVPad, nSuperPel, nSuperModeYUV, nSuperLevels, bits;
+    int nBlkXP, nBlkYP, nWidthP, nHeightP, nWidthPUV, nHeightPUV, nPitchY, nPitchUV;
+} mvo_blockfps;
+
+int mvo_blockfps_init(mvo_blockfps *d, const mvo_analysis_data *bw, const mvo_analysis_data *fw, const mvo_super *s, int numFrames, int64_t fpsNum, int64_t fpsDen,
+                      int64_t num, int64_t den, int mode, double ml, int blend, int64_t thscd1, int thscd2, char *err);
+void mvo_blockfps_map(const mvo_blockfps *d, int n, int *nleft, int *nright, int *time256);
+int mvo_blockfps_frame(const mvo_blockfps *d, int time256, const uint8_t *const srcSuper[3], const int srcPitch[3], const uint8_t *const refSuper[3],
+                       const int refPitch[3], const uint8_t *blobF, const uint8_t *blobB, const uint8_t *const clipL[3], const int clipLPitch[3],
+                       const uint8_t *const clipR[3], const int clipRPitch[3], uint8_t *const dst[3], const int dstPitch[3]);
+void mvo_resize_tables(int *offsets, int *weights, int out, int in);
+
 /* ---- kernel-level entry points (for pinning against oracle/_ref) ---- */
 unsigned mvo_sad(int w, int h, int bits, const uint8_t *src, intptr_t srcPitch, const uint8_t *ref, intptr_t refPitch);
 unsigned mvo_satd(int w, int h, int bits, const uint8_t *src, intptr_t srcPitch, const uint8_t *ref, intptr_t refPitch);

@@ -69,6 +69,13 @@ class CompensateS(C.Structure):
                                "nSuperLevels", "bits", "numPlanes")]
 
 
+class BlockFPSS(C.Structure):
+    _fields_ = [("bw", AnalysisData), ("fw", AnalysisData), ("mode", C.c_int), ("blend", C.c_int), ("ml", C.c_double), ("thscd1", C.c_int64),
+                ("thscd2", C.c_int), ("fa", C.c_int64), ("fb", C.c_int64), ("outFpsNum", C.c_int64), ("outFpsDen", C.c_int64)] + [
+        (n, C.c_int) for n in ("inFrames", "outFrames", "nSuperHPad", "nSuperVPad", "nSuperPel", "nSuperModeYUV", "nSuperLevels", "bits",
+                               "nBlkXP", "nBlkYP", "nWidthP", "nHeightP", "nWidthPUV", "nHeightPUV", "nPitchY", "nPitchUV")]
+
+
 _lib = None
 
 
@@ -99,6 +106,12 @@ def lib():
                                           C.c_int, C.c_int, C.c_int64, C.c_int, C.c_char_p]
         _lib.mvo_compensate_init.argtypes = [P(CompensateS), P(AnalysisData), P(SuperS), C.c_int, C.c_int64, C.c_double,
                                              C.c_int64, C.c_int, C.c_char_p]
+        _lib.mvo_blockfps_init.argtypes = [P(BlockFPSS), P(AnalysisData), P(AnalysisData), P(SuperS), C.c_int, C.c_int64, C.c_int64, C.c_int64,
+                                           C.c_int64, C.c_int, C.c_double, C.c_int, C.c_int64, C.c_int, C.c_char_p]
+        _lib.mvo_blockfps_map.argtypes = [P(BlockFPSS), C.c_int, P(C.c_int), P(C.c_int), P(C.c_int)]
+        _lib.mvo_blockfps_frame.restype = C.c_int
+        _lib.mvo_blockfps_frame.argtypes = [P(BlockFPSS), C.c_int] + [C.c_void_p] * 12
+        _lib.mvo_resize_tables.argtypes = [u8p, u8p, C.c_int, C.c_int]
     return _lib
 
 
@@ -283,3 +296,48 @@ class Compensate:
             rp, rpitch = _planes(ref_super)
             lib().mvo_compensate_frame(C.byref(self.d), sp, spitch, rp, rpitch, C.c_void_p(b.ctypes.data), dp, dpitch)
         return dst
+
+
+class BlockFPS:
+    """mv.BlockFPS(clip, super, mvbw, mvfw, num, den, mode, ml, blend, thscd1, thscd2) -- MVBlockFPS.c:741-1014.
+    The clip's frame rate is fps_num / fps_den.  Parity of this filter is unpinned (see mvo_blockfps.c)."""
+
+    def __init__(self, sup, ad_bw, ad_fw, num_frames, fps_num=24, fps_den=1, num=None, den=None, mode=None, ml=100.0, blend=None, thscd1=None, thscd2=None):
+        self.d = BlockFPSS()
+        self.sup = sup
+        err = C.create_string_buffer(ERRLEN)
+        bw = AnalysisData.from_buffer_copy(bytes(ad_bw))
+        fw = AnalysisData.from_buffer_copy(bytes(ad_fw))
+        if lib().mvo_blockfps_init(C.byref(self.d), C.byref(bw), C.byref(fw), C.byref(sup.s), int(num_frames), int(fps_num), int(fps_den), _u(num), _u(den),
+                                   _u(mode), float(ml), _u(blend), _u(thscd1), _u(thscd2), err):
+            raise OracleError(err.value.decode())
+        self.num_frames = self.d.outFrames
+
+    def map(self, n):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        lib().mvo_blockfps_map(C.byref(self.d), n, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def frame(self, n, clip, supers, blobs_bw, blobs_fw):
+        """output frame n from the input clip (list of frames), its super frames and the two vector clips' blobs (per input frame)."""
+        nleft, nright, t = self.map(n)
+        last = self.d.inFrames - 1
+        if t == 0:
+            return [p.copy() for p in clip[min(nleft, last)]]
+        if t == 256:
+            return [p.copy() for p in clip[min(nright, last)]]
+        L, R = clip[min(nleft, last)], clip[min(nright, last)]
+        dst = _alloc_like(L)
+        dp, dpitch = _planes(dst)
+        lp, lpitch = _planes(L)
+        rp, rpitch = _planes(R)
+        good = nleft < self.d.inFrames and nright < self.d.inFrames
+        if good:
+            sp, spitch = _planes(supers[nleft])
+            fp, fpitch = _planes(supers[nright])
+            bF = np.ascontiguousarray(blobs_fw[nright])
+            bB = np.ascontiguousarray(blobs_bw[nleft])
+            rc = lib().mvo_blockfps_frame(C.byref(self.d), t, sp, spitch, fp, fpitch, C.c_void_p(bF.ctypes.data), C.c_void_p(bB.ctypes.data), lp, lpitch, rp, rpitch, dp, dpitch)
+        else:
+            rc = lib().mvo_blockfps_frame(C.byref(self.d), t, None, None, None, None, None, None, lp, lpitch, rp, rpitch, dp, dpitch)
+        return [p.copy() for p in L] if rc == 1 else dst

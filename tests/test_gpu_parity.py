@@ -384,3 +384,54 @@ def test_full_size_properties_cfg3(mv):
 def test_full_size_properties_cfg5(mv):
     """BASELINE cfg5: 8K YUV420P16, blk 32, overlap 16, pel 2, Degrain6."""
     _fullsize_props(mv, 7680, 4320, 16, 32, 16, 6, "cfg5")
+
+
+BLOCKFPS_CASES = [
+    # w, h, bits, analyse kwargs, blockfps kwargs (24 fps input)
+    (128, 96, 8, dict(blksize=8, overlap=4), dict(num=60, den=1)),                       # BASELINE cfg4: 24 -> 60
+    (128, 96, 8, dict(blksize=8, overlap=0), dict(num=60, den=1)),
+    (192, 112, 16, dict(blksize=16, overlap=8), dict(num=48, den=1, mode=0)),
+    (200, 120, 8, dict(blksize=8, overlap=4), dict(num=60, den=1, mode=1)),              # uncovered strips
+    (200, 120, 8, dict(blksize=8, overlap=0), dict(num=60, den=1, mode=2)),
+    (128, 96, 16, dict(blksize=8, overlap=4), dict(num=60, den=1, mode=4, ml=40.0)),
+    (128, 96, 8, dict(blksize=8, overlap=4), dict(num=60, den=1, mode=5, ml=20.0)),
+    (128, 96, 8, dict(blksize=16, overlap=8), dict(num=60, den=1, mode=6, ml=50.0)),
+    (128, 96, 16, dict(blksize=8, overlap=2), dict(num=60, den=1, mode=7, ml=50.0)),
+    (128, 96, 8, dict(blksize=8, overlap=4), dict(num=60, den=1, mode=8, ml=30.0)),
+    (128, 96, 8, dict(blksize=8, overlap=4), dict(num=0, den=0)),                        # default: double rate
+    (128, 96, 8, dict(blksize=8, overlap=4), dict(num=60, den=1, thscd1=20, thscd2=10)), # scene change -> blend fallback
+    (128, 96, 8, dict(blksize=8, overlap=4), dict(num=60, den=1, thscd1=20, thscd2=10, blend=0)),
+    (128, 96, 8, dict(blksize=8, overlap=4, delta=2), dict(num=36, den=1)),               # delta 2
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,bits,akw,bkw", BLOCKFPS_CASES)
+def test_blockfps_parity(oracle, mv, w, h, bits, akw, bkw):
+    import torch
+    nf = 6
+    akw = dict(akw)
+    delta = akw.pop("delta", 1)
+    frames, osup, gsup, osf, gsrc, gsf = _pipeline(oracle, mv, w, h, bits, 1, {}, akw, nframes=nf, seed=41)
+    oabw = oracle.Analyse(osup, num_frames=nf, isb=1, delta=delta, **akw)
+    oafw = oracle.Analyse(osup, num_frames=nf, isb=0, delta=delta, **akw)
+    obbw = [oabw.frame(osf[n], osf[n + delta] if n + delta < nf else None) for n in range(nf)]
+    obfw = [oafw.frame(osf[n], osf[n - delta] if n - delta >= 0 else None) for n in range(nf)]
+    gabw = mv.Analyse(gsup, num_frames=nf, isb=1, delta=delta, **akw)
+    gafw = mv.Analyse(gsup, num_frames=nf, isb=0, delta=delta, **akw)
+    gbbw = gabw.run([(gsf[n], gsf[n + delta] if n + delta < nf else None) for n in range(nf)])
+    gbfw = gafw.run([(gsf[n], gsf[n - delta] if n - delta >= 0 else None) for n in range(nf)])
+    ob = oracle.BlockFPS(osup, oabw.ad, oafw.ad, nf, 24, 1, **bkw)
+    gb = mv.BlockFPS(gsup, gabw.ad, gafw.ad, nf, [p.stride(0) for p in gsrc[0]], 24, 1, **bkw)
+    assert gb.num_frames == ob.num_frames and (gb.fps_num, gb.fps_den) == (ob.d.outFpsNum, ob.d.outFpsDen)
+    ns = list(range(gb.num_frames))
+    for n in ns:
+        assert gb.map(n) == ob.map(n)
+    out = gb.run(ns, gsrc, gsf, gbbw, gbfw)
+    torch.cuda.synchronize()
+    for n in ns:
+        want = ob.frame(n, frames, osf, obbw, obfw)
+        for p in range(3):
+            got = out[n][p].cpu().numpy()
+            got = (got.view(np.uint16) if bits > 8 else got)[:, :want[p].shape[1]]
+            assert np.array_equal(got, want[p]), (n, p, gb.map(n), int(np.count_nonzero(got != want[p])))

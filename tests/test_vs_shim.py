@@ -38,6 +38,7 @@ EXPECTED = {
                "chroma:int:opt;delta:int:opt;truemotion:int:opt;lsad:int:opt;plevel:int:opt;global:int:opt;pnew:int:opt;pzero:int:opt;pglobal:int:opt;"
                "overlap:int:opt;overlapv:int:opt;divide:int:opt;badsad:int:opt;badrange:int:opt;opt:int:opt;meander:int:opt;trymany:int:opt;fields:int:opt;"
                "tff:int:opt;search_coarse:int:opt;dct:int:opt;",
+    "BlockFPS": "clip:vnode;super:vnode;mvbw:vnode;mvfw:vnode;num:int:opt;den:int:opt;mode:int:opt;ml:float:opt;blend:int:opt;thscd1:int:opt;thscd2:int:opt;opt:int:opt;",
     "Compensate": "clip:vnode;super:vnode;vectors:vnode;scbehavior:int:opt;thsad:int:opt;fields:int:opt;time:float:opt;thscd1:int:opt;thscd2:int:opt;opt:int:opt;tff:int:opt;",
 }
 _v = "clip:vnode;super:vnode;"
@@ -193,3 +194,30 @@ def test_shell_compensate_matches_oracle(oracle, tmp_path):
         want = ocp.frame(osf[n], r, oan.frame(osf[n], r))
         for p in range(3):
             assert np.array_equal(got[n][p], want[p]), (n, p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits,bargs", [(8, dict(num=60, den=1)), (16, dict(num=60, den=1, mode=4, ml="40.0")), (8, dict(num=60, den=1, thscd1=20, thscd2=10))])
+def test_shell_blockfps_matches_oracle(oracle, tmp_path, bits, bargs):
+    w, h, nf = 128, 96, 5
+    aargs = dict(blksize=8, overlap=4)
+    frames = pl.moving_clip(w, h, bits, nf, seed=37, noise=3)
+    src = tmp_path / "in.raw"
+    _write_clip(src, frames)
+    out = host("run", "blockfps", src, w, h, bits, nf, tmp_path / "out.raw", *["a.%s=%s" % kv for kv in aargs.items()], *["b.%s=%s" % kv for kv in bargs.items()])
+    osup = oracle.Super(w, h, bits)
+    osf = [osup.frame(f) for f in frames]
+    abw = oracle.Analyse(osup, num_frames=nf, isb=1, delta=1, **aargs)
+    afw = oracle.Analyse(osup, num_frames=nf, isb=0, delta=1, **aargs)
+    bbw = [abw.frame(osf[n], osf[n + 1] if n + 1 < nf else None) for n in range(nf)]
+    bfw = [afw.frame(osf[n], osf[n - 1] if n >= 1 else None) for n in range(nf)]
+    kw = {k: (float(v) if k == "ml" else v) for k, v in bargs.items()}
+    ob = oracle.BlockFPS(osup, abw.ad, afw.ad, nf, 24, 1, **kw)  # the mini host's source clip runs at 24/1
+    lines = out.splitlines()
+    assert lines[0] == "blockfps frames=%d fps=%d/%d" % (ob.num_frames, ob.d.outFpsNum, ob.d.outFpsDen)
+    assert lines[1] == "frame1 _DurationNum=%d _DurationDen=%d" % (ob.d.outFpsDen, ob.d.outFpsNum)  # std.AssumeFPS ran (MVBlockFPS.c:989-1014)
+    got = _read_frames(tmp_path / "out.raw", w, h, bits, ob.num_frames)
+    for n in range(ob.num_frames):
+        want = ob.frame(n, frames, osf, bbw, bfw)
+        for p in range(3):
+            assert np.array_equal(got[n][p], want[p][:, :got[n][p].shape[1]]), (n, p, ob.map(n))

@@ -759,3 +759,399 @@ extern "C" __attribute__((visibility("default"))) int mvx_compensate_frames(mvx_
     HIP_CHECK(hipGetLastError());
     return MVX_OK;
 }
+
+// ================================================================================================ mv.BlockFPS
+// MVBlockFPS.c:229-676 (frame), :741-1014 (creation); MaskFun.cpp:63-166,349-371; SimpleResize.cpp:27-121.
+// One gather pass per output sample like Degrain / Compensate: the two motion-compensated fetches (backward vectors at
+// the left frame into the right super frame, forward vectors at the right frame into the left one, both scaled by the
+// time position), the per-mode blend, the overlap window sum and ToPixels.  The occlusion / SAD masks live at block
+// resolution (three small byte planes per frame pair) and are upsized bilinearly ON THE FLY per sample with the
+// reference's integer tables, so no full-size mask planes exist.
+
+struct BFParams {
+    int mode, blend, XP, YP;            // padded small-mask grid
+    int nWidthP[2], nHeightP[2];        // luma / chroma upsizer output sizes
+    double ml;
+    long long thscd1; int thscd2;
+    int supInterior[3];                 // byte offset of the un-padded level-0 sample (0,0) inside each super plane (:455-464)
+    const int *hOff[2], *hW[2], *vOff[2], *vW[2]; // SimpleResize tables, luma / chroma
+    long long clipPitch[3];
+};
+struct BFJob {
+    const unsigned char *srcSup[3], *refSup[3]; // super frame nleft / nright
+    const unsigned char *blobF, *blobB;         // mvfw vectors at nright, mvbw vectors at nleft
+    const unsigned char *clipL[3], *clipR[3];
+    unsigned char *dst[3];
+    int time256, good;
+};
+struct BFPlan { unsigned offB[2], offF[2]; };    // luma / chroma offsets of the two compensated blocks
+
+// per job: usable = both vector fields valid and no scene change (Fakery.c:144-146); 0 -> fallback
+__global__ __launch_bounds__(256) void bf_usable_kernel(const DGParams *Pp, const BFParams *Bp, const BFJob *jobs, int *usable) {
+    const DGParams &P = *Pp; const BFParams &B = *Bp;
+    const int f = blockIdx.x;
+    __shared__ int cnt[2];
+    if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const BFJob &J = jobs[f];
+    if (J.good) {
+        for (int d = 0; d < 2; d++) {
+            const GVecD *v = (const GVecD *)((d ? J.blobB : J.blobF) + P.lastLevelOff + 4);
+            int c = 0;
+            for (int i = threadIdx.x; i < P.nBlk; i += 256) c += v[i].sad > B.thscd1 ? 1 : 0;
+            atomicAdd(&cnt[d], c);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ok = J.good && J.time256 > 0 && J.time256 < 256;
+        if (ok) ok = ((const int *)J.blobF)[1] == 1 && ((const int *)J.blobB)[1] == 1 && !(cnt[0] > B.thscd2) && !(cnt[1] > B.thscd2);
+        usable[f] = ok;
+    }
+}
+
+// small masks, pass 1: scatter-max (occlusion, MaskFun.cpp:91-130) or direct (SAD mask, :139-166) into int planes
+// [job][F,B][YP*XP]; the scatter only ever takes maxima, so the order of the reference's loops does not matter.
+__global__ __launch_bounds__(256) void bf_mask_kernel(const DGParams *Pp, const BFParams *Bp, const BFJob *jobs, const int *usable, int *small) {
+    const DGParams &P = *Pp; const BFParams &B = *Bp;
+    const int f = blockIdx.z, dir = blockIdx.y; // dir 0 = forward mask, 1 = backward mask
+    if (!usable[f] || B.mode < 3) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.nBlk) return;
+    const BFJob &J = jobs[f];
+    const GVecD *vec = (const GVecD *)((dir ? J.blobB : J.blobF) + P.lastLevelOff + 4);
+    const int nBlkX = P.nBlkX, nBlkY = P.nBlkY, by = i / nBlkX, bx = i - by * nBlkX;
+    const int time256 = dir ? 256 - J.time256 : J.time256;
+    const int stepX = P.pl[0].stepX, stepY = P.pl[0].stepY, nPel = P.pel;
+    int *m = small + ((size_t)f * 2 + dir) * B.XP * B.YP;
+    if (B.mode <= 5) {
+        const int tX = time256 * 16 / (stepX * nPel), tY = time256 * 16 / (stepY * nPel);
+        const double nX = 80.0 / (B.ml * stepX * nPel), nY = 80.0 / (B.ml * stepY * nPel);
+        const int vx = vec[i].x, vy = vec[i].y;
+        if (bx < nBlkX - 1) {
+            const int vx1 = vec[i + 1].x;
+            if (vx1 < vx) {
+                const int o = vx - vx1;
+                const int minb = dir ? max(0, bx + 1 - o * tX / 4096) : bx;
+                const int maxb = dir ? bx + 1 : min(bx + 1 - o * tX / 4096, nBlkX - 1);
+                const int val = min((int)(255 * o * nX), 255);
+                for (int b = minb; b <= maxb; b++) atomicMax(&m[b + by * B.XP], val);
+            }
+        }
+        if (by < nBlkY - 1) {
+            const int vy1 = vec[i + nBlkX].y;
+            if (vy1 < vy) {
+                const int o = vy - vy1;
+                const int minb = dir ? max(0, by + 1 - o * tY / 4096) : by;
+                const int maxb = dir ? by + 1 : min(by + 1 - o * tY / 4096, nBlkY - 1);
+                const int val = min((int)(255 * o * nY), 255);
+                for (int b = minb; b <= maxb; b++) atomicMax(&m[bx + b * B.XP], val);
+            }
+        }
+    } else {
+        const int tX = (256 - time256) * 16 / (stepX * nPel), tY = (256 - time256) * 16 / (stepY * nPel);
+        int bxi = bx - vec[i].x * tX / 4096, byi = by - vec[i].y * tY / 4096;
+        if (bxi < 0 || bxi >= nBlkX || byi < 0 || byi >= nBlkY) { bxi = bx; byi = by; }
+        const long long sad = vec[bxi + byi * nBlkX].sad >> (P.bits - 8);
+        const double factor = 4.0 / (B.ml * P.pl[0].blkW * P.pl[0].blkH);
+        const double l = 255 * ((double)sad * factor); // pow(x, 1.0) == x
+        m[bx + by * B.XP] = (int)(unsigned char)((l > 255) ? 255 : l);
+    }
+}
+// pass 2: byte planes [job][F,B,O][YP*XP] with the right / bottom padding clones (MaskFun.cpp:63-80) and O = F*B/255 (:93-101)
+__global__ __launch_bounds__(256) void bf_mask_finish_kernel(const DGParams *Pp, const BFParams *Bp, const int *usable, const int *small, unsigned char *masks) {
+    const DGParams &P = *Pp; const BFParams &B = *Bp;
+    const int f = blockIdx.y;
+    if (!usable[f] || B.mode < 3) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B.XP * B.YP) return;
+    const int y = i / B.XP, x = i - y * B.XP;
+    const int sx = min(x, P.nBlkX - 1), sy = min(y, P.nBlkY - 1); // right clone first, then bottom clone of the padded row
+    const int *mF = small + ((size_t)f * 2 + 0) * B.XP * B.YP, *mB = small + ((size_t)f * 2 + 1) * B.XP * B.YP;
+    const int vF = mF[sx + sy * B.XP], vB = mB[sx + sy * B.XP];
+    unsigned char *o = masks + (size_t)f * 3 * B.XP * B.YP;
+    o[i] = (unsigned char)vF;
+    o[B.XP * B.YP + i] = (unsigned char)vB;
+    o[2 * B.XP * B.YP + i] = (unsigned char)((vF * vB) / 255);
+}
+
+__global__ __launch_bounds__(256) void bf_plan_kernel(const DGParams *Pp, const BFJob *jobs, const int *usable, BFPlan *plan) {
+    const DGParams &P = *Pp;
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.nBlk || !usable[f]) return;
+    const BFJob &J = jobs[f];
+    const int by = i / P.nBlkX, bx = i - by * P.nBlkX;
+    const GVecD *vB = (const GVecD *)(J.blobB + P.lastLevelOff + 4), *vF = (const GVecD *)(J.blobF + P.lastLevelOff + 4);
+    const int x = bx * P.pl[0].stepX, y = by * P.pl[0].stepY, t = J.time256; // FakeBlockData x / y, Fakery.c:31-32
+    const int bX = x * P.pel + ((vB[i].x * (256 - t)) >> 8), bY = y * P.pel + ((vB[i].y * (256 - t)) >> 8);
+    const int fX = x * P.pel + ((vF[i].x * t) >> 8), fY = y * P.pel + ((vF[i].y * t) >> 8);
+    BFPlan r;
+    for (int c = 0; c < 2; c++) { // the reference DIVIDES by the subsampling ratio here (:482-488), it does not shift
+        const PlaneG &g = P.pl[c];
+        const int xr = 1 << g.subX, yr = 1 << g.subY;
+        r.offB[c] = sup_offset(g, P.pel, P.logPel, P.bps, bX / xr, bY / yr);
+        r.offF[c] = sup_offset(g, P.pel, P.logPel, P.bps, fX / xr, fY / yr);
+    }
+    plan[(size_t)f * P.nBlk + i] = r;
+}
+
+// SimpleResize.cpp:62-121 at one output sample
+__device__ __forceinline__ int bf_upsize(const unsigned char *m, int XP, const int *hOff, const int *hW, const int *vOff, const int *vW, int x, int y) {
+    const int wb = vW[y], wt = 16384 - wb, o = hOff[x], wr = hW[x], wl = 16384 - wr;
+    const unsigned char *s1 = m + vOff[y] * XP, *s2 = s1 + XP;
+    const int a = (unsigned char)((s1[o] * wt + s2[o] * wb + 8192) >> 14), b = (unsigned char)((s1[o + 1] * wt + s2[o + 1] * wb + 8192) >> 14);
+    return (unsigned char)((a * wl + b * wr + 8192) >> 14);
+}
+__device__ __forceinline__ int bf_median(int a, int b, int c) { const int mn = min(a, b), mx = max(a, b); return max(mn, min(mx, c)); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void blockfps_kernel(const DGParams *Pp, const BFParams *Bp, const BFJob *jobs, const int *usable, const BFPlan *plan, const unsigned char *masks) {
+    const DGParams &P = *Pp; const BFParams &B = *Bp;
+    const int z = blockIdx.z, f = z / 3, p = z % 3;
+    if (p >= P.nplanes) return;
+    const PlaneG &g = P.pl[p];
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= g.W || y >= g.H) return;
+    const BFJob &J = jobs[f];
+    T *drow = (T *)(J.dst[p] + (long long)y * g.dstPitch);
+    const int t = J.time256;
+    if (!usable[f]) { // time256 0 / 256, vectors unusable or frames outside the clip (:285-288, :640-673)
+        const int l = ((const T *)(J.clipL[p] + (long long)y * B.clipPitch[p]))[x];
+        if (t <= 0 || (t < 256 && !B.blend)) { drow[x] = (T)l; return; }
+        const int r = ((const T *)(J.clipR[p] + (long long)y * B.clipPitch[p]))[x];
+        drow[x] = t >= 256 ? (T)r : (T)((l * (256 - t) + r * t) >> 8);
+        return;
+    }
+    const int sVal = ((const T *)(J.srcSup[p] + B.supInterior[p] + (long long)y * g.supPitch))[x];
+    const int rVal = ((const T *)(J.refSup[p] + B.supInterior[p] + (long long)y * g.supPitch))[x];
+    const int covW = P.overlap ? g.WB : g.blkW * P.nBlkX, covH = P.overlap ? g.HB : g.blkH * P.nBlkY;
+    if (x >= covW || y >= covH) { drow[x] = (T)((sVal * (256 - t) + rVal * t) >> 8); return; } // Blend of the uncovered strips
+    const int mode = B.mode, c = p ? 1 : 0;
+    int mF = 0, mB = 0, mO = 0;
+    if (mode >= 3) {
+        const unsigned char *m = masks + (size_t)f * 3 * B.XP * B.YP;
+        if (mode != 5 && mode != 8) {
+            mF = bf_upsize(m, B.XP, B.hOff[c], B.hW[c], B.vOff[c], B.vW[c], x, y);
+            mB = bf_upsize(m + B.XP * B.YP, B.XP, B.hOff[c], B.hW[c], B.vOff[c], B.vW[c], x, y);
+        }
+        if (mode == 4 || mode == 5 || mode == 7 || mode == 8) mO = bf_upsize(m + 2 * B.XP * B.YP, B.XP, B.hOff[c], B.hW[c], B.vOff[c], B.vW[c], x, y);
+    }
+    const BFPlan *pl = plan + (size_t)f * P.nBlk;
+    auto result = [&](const BFPlan &R, int px, int py) -> int { // RealResultBlock, MVBlockFPS.c:117-227
+        const int b = ((const T *)(J.refSup[p] + R.offB[c] + (long long)py * g.supPitch))[px];
+        const int fw = ((const T *)(J.srcSup[p] + R.offF[c] + (long long)py * g.supPitch))[px];
+        switch (mode) {
+        case 0: return (b * t + fw * (256 - t)) >> 8;
+        case 1: return bf_median(rVal, sVal, (int)(T)((b * t + fw * (256 - t)) >> 8));
+        case 2: return bf_median((int)(T)((rVal * t + sVal * (256 - t)) >> 8), b, fw);
+        case 3: case 6: return (((mB * fw + (255 - mB) * b + 255) >> 8) * t + ((mF * b + (255 - mF) * fw + 255) >> 8) * (256 - t)) >> 8;
+        case 4: case 7: {
+            const int ff = (mF * b + (255 - mF) * fw + 255) >> 8, bb = (mB * fw + (255 - mB) * b + 255) >> 8;
+            const int avg = (rVal * t + sVal * (256 - t) + 255) >> 8, m = (bb * t + ff * (256 - t)) >> 8;
+            return (avg * mO + m * (255 - mO) + 255) >> 8;
+        }
+        default: return mO << (P.bits - 8);
+        }
+    };
+    int out;
+    if (!P.overlap) {
+        const int bx = x / g.blkW, by = y / g.blkH;
+        out = (T)result(pl[by * P.nBlkX + bx], x - bx * g.blkW, y - by * g.blkH);
+    } else {
+        int bx1 = x / g.stepX; if (bx1 > P.nBlkX - 1) bx1 = P.nBlkX - 1;
+        const int bx0 = x - g.blkW + 1 <= 0 ? 0 : (x - g.blkW + g.stepX) / g.stepX;
+        int by1 = y / g.stepY; if (by1 > P.nBlkY - 1) by1 = P.nBlkY - 1;
+        const int by0 = y - g.blkH + 1 <= 0 ? 0 : (y - g.blkH + g.stepY) / g.stepY;
+        unsigned acc = 0;
+        const int16_t *win = P.win[p];
+        for (int by = by0; by <= by1; by++) {
+            const int py = y - by * g.stepY;
+            const int wby = by == 0 ? 0 : (by == P.nBlkY - 1 ? 6 : 3);
+            for (int bx = bx0; bx <= bx1; bx++) {
+                const int px = x - bx * g.stepX;
+                const int wbx = bx == P.nBlkX - 1 ? 2 : (bx == 0 ? 0 : 1);
+                const int val = (T)result(pl[by * P.nBlkX + bx], px, py);
+                acc += (unsigned)((val * (int)win[(wby + wbx) * g.blkW * g.blkH + py * g.blkW + px]) >> 6);
+            }
+        }
+        if (sizeof(T) == 1) acc &= 0xffffu;
+        const int a = (int)((acc + 16) >> 5);
+        const int pm = (1 << P.bits) - 1;
+        out = a > pm ? pm : a;
+    }
+    drow[x] = (T)out;
+}
+
+struct mvx_blockfps : DGCommon {
+    BFParams B;
+    BFParams *dB = nullptr;
+    BFJob *dBJobs = nullptr;
+    size_t bjobsCap = 0;
+    int *dSmall = nullptr; unsigned char *dMasks = nullptr; size_t maskCap = 0;
+    int *dTables = nullptr;
+    mvx_analysis_data bw, fw;
+    long long fa, fb, outNum, outDen;
+    int inFrames, outFrames;
+    ~mvx_blockfps() {
+        if (dB) (void)hipFree(dB);
+        if (dBJobs) (void)hipFree(dBJobs);
+        if (dSmall) (void)hipFree(dSmall);
+        if (dMasks) (void)hipFree(dMasks);
+        if (dTables) (void)hipFree(dTables);
+    }
+};
+
+// SimpleResize.cpp:27-57 InitTables (same float arithmetic)
+static void bf_tables(int *offsets, int *weights, int out, int in) {
+    const float leftmost = 0.5f, rightmost = in - 0.5f;
+    const int leftmost_idx = std::max((int)leftmost, 0), rightmost_idx = std::min((int)rightmost, in - 1);
+    for (int i = 0; i < out; i++) {
+        const float position = (i + 0.5f) * (float)in / (float)out;
+        float weight; int offset;
+        if (position <= leftmost) { offset = leftmost_idx; weight = 0.0f; }
+        else if (position >= rightmost) { offset = rightmost_idx - 1; weight = 1.0f; }
+        else { offset = (int)(position - leftmost); weight = position - leftmost - offset; }
+        offsets[i] = offset;
+        weights[i] = (int)(weight * 16384);
+    }
+}
+static long long bf_gcd(long long x, long long y) { while (y) { long long t = x % y; x = y; y = t; } return x; }
+
+extern "C" __attribute__((visibility("default"))) int mvx_blockfps_create(const mvx_blockfps_args *a, const mvx_analysis_data *bw, const mvx_analysis_data *fw,
+        const mvx_super *sup, int num_frames, int64_t fps_num, int64_t fps_den, const ptrdiff_t super_pitch[3], const ptrdiff_t clip_pitch[3],
+        const ptrdiff_t dst_pitch[3], mvx_blockfps **out, char *err) {
+    char dummy[MVX_ERRLEN];
+    if (!err) err = dummy;
+    err[0] = 0;
+    *out = nullptr;
+    const mvx_super_info &si = sup->info;
+    const long long num = a->num == MVX_UNSET ? 25 : a->num, den = a->den == MVX_UNSET ? 1 : a->den;
+    const int mode = a->mode == MVX_UNSET ? 3 : a->mode;
+    const int blend = a->blend == MVX_UNSET ? 1 : !!a->blend;
+    long long thscd1 = a->thscd1 == MVX_UNSET ? 400 : a->thscd1;
+    int thscd2 = a->thscd2 == MVX_UNSET ? 130 : a->thscd2;
+    if (mode < 0 || mode > 8) DFAIL("BlockFPS: mode must be between 0 and 8 (inclusive).");
+    if (thscd1 > 8 * 8 * 255) DFAIL("BlockFPS: thscd1 can be at most %d.", 8 * 8 * 255);
+    { int64_t s1 = thscd1; int32_t s2 = thscd2; mvx_scale_thscd(&s1, &s2, bw); thscd1 = s1; thscd2 = s2; }
+    if (bw->nWidth != fw->nWidth) DFAIL("BlockFPS: mvbw and mvfw have different widths.");
+    if (bw->nHeight != fw->nHeight) DFAIL("BlockFPS: mvbw and mvfw have different heights.");
+    if (bw->nBlkSizeX != fw->nBlkSizeX || bw->nBlkSizeY != fw->nBlkSizeY) DFAIL("BlockFPS: mvbw and mvfw have different block sizes.");
+    if (bw->nPel != fw->nPel) DFAIL("BlockFPS: mvbw and mvfw have different pel precision.");
+    if (bw->nOverlapX != fw->nOverlapX || bw->nOverlapY != fw->nOverlapY) DFAIL("BlockFPS: mvbw and mvfw have different overlap.");
+    if (bw->nDeltaFrame <= 0 || fw->nDeltaFrame <= 0) DFAIL("BlockFPS: cannot use motion vectors with absolute frame references.");
+    if (bw->nDeltaFrame != fw->nDeltaFrame) DFAIL("BlockFPS: mvbw and mvfw must be generated with the same delta.");
+    if (!bw->isBackward) DFAIL("BlockFPS: mvbw must be generated with isb=True.");
+    if (fw->isBackward) DFAIL("BlockFPS: mvfw must be generated with isb=False.");
+    if (fps_num == 0 || fps_den == 0) DFAIL("BlockFPS: The input clip must have a frame rate. Invoke AssumeFPS if necessary.");
+    long long numerator, denominator;
+    if (num != 0 && den != 0) { numerator = num; denominator = den; } else { numerator = fps_num * 2; denominator = fps_den; }
+    if (bw->nHeight != si.height || bw->nWidth != si.super_width - si.hpad * 2 || bw->nWidth != si.width || bw->nPel != si.pel)
+        DFAIL("BlockFPS: wrong source or super clip frame size.");
+    mvx_blockfps *h = new mvx_blockfps();
+    memset(&h->P, 0, sizeof(h->P));
+    memset(&h->B, 0, sizeof(h->B));
+    int rc = fill_common(h, bw, si, clip_pitch, super_pitch, dst_pitch, err);
+    if (rc) { delete h; return rc; }
+    DGParams &P = h->P;
+    if (!(si.modeYUV & 6)) P.nplanes = 1;
+    P.nRefs = 2; P.thscd1 = thscd1; P.thscd2 = thscd2;
+    h->bw = *bw; h->fw = *fw;
+    h->fa = denominator * fps_num; h->fb = numerator * fps_den;
+    const long long g = bf_gcd(h->fa, h->fb);
+    h->fa /= g; h->fb /= g;
+    if (numerator <= 0 || denominator <= 0) { h->outNum = 0; h->outDen = 1; }
+    else { const long long x = bf_gcd(numerator, denominator); h->outNum = numerator / x; h->outDen = denominator / x; }
+    h->inFrames = num_frames;
+    h->outFrames = (int)(1 + (num_frames - 1) * h->fb / h->fa);
+    BFParams &B = h->B;
+    B.mode = mode; B.blend = blend; B.ml = a->ml; B.thscd1 = thscd1; B.thscd2 = thscd2;
+    B.XP = bw->nBlkX; B.YP = bw->nBlkY;
+    while (B.XP * (bw->nBlkSizeX - bw->nOverlapX) + bw->nOverlapX < bw->nWidth) B.XP++;
+    while (B.YP * (bw->nBlkSizeY - bw->nOverlapY) + bw->nOverlapY < bw->nHeight) B.YP++;
+    B.nWidthP[0] = B.XP * (bw->nBlkSizeX - bw->nOverlapX) + bw->nOverlapX;
+    B.nHeightP[0] = B.YP * (bw->nBlkSizeY - bw->nOverlapY) + bw->nOverlapY;
+    B.nWidthP[1] = B.nWidthP[0] / bw->xRatioUV; B.nHeightP[1] = B.nHeightP[0] / bw->yRatioUV;
+    const int bps = P.bps;
+    B.supInterior[0] = si.hpad * bps + (int)super_pitch[0] * si.vpad;
+    for (int p = 1; p < 3; p++) B.supInterior[p] = (si.hpad >> 1) * bps + (int)super_pitch[p < si.num_planes ? p : 0] * (si.vpad >> 1); // the reference's ">> 1" (:459-463)
+    for (int p = 0; p < 3; p++) B.clipPitch[p] = clip_pitch[p < si.num_planes ? p : 0];
+    *out = h;
+    return MVX_OK;
+}
+extern "C" __attribute__((visibility("default"))) void mvx_blockfps_destroy(mvx_blockfps *b) { delete b; }
+extern "C" __attribute__((visibility("default"))) void mvx_blockfps_get_info(const mvx_blockfps *b, mvx_blockfps_info *info) {
+    info->num_frames = b->outFrames; info->fps_num = b->outNum; info->fps_den = b->outDen;
+}
+// MVBlockFPS.c:245-254,278-292
+extern "C" __attribute__((visibility("default"))) void mvx_blockfps_map(const mvx_blockfps *b, int n, int *nleft, int *nright, int *time256) {
+    const int off = b->bw.nDeltaFrame;
+    *nleft = (int)(n * b->fa / b->fb);
+    int t = (int)(((double)n * b->fa / b->fb - *nleft) * 256 + 0.5);
+    if (off > 1) t = t / off;
+    *nright = *nleft + off;
+    *time256 = t;
+}
+
+extern "C" __attribute__((visibility("default"))) int mvx_blockfps_frames(mvx_blockfps *b, int nframes, const mvx_blockfps_job *jobs, void *stream) {
+    if (nframes <= 0) return MVX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = finish_common(b);
+    if (rc) return rc;
+    const DGParams &P = b->P;
+    BFParams &B = b->B;
+    if (!b->dB) { // upsizer tables + parameter block
+        const int n = B.nWidthP[0] + B.nWidthP[1] + B.nHeightP[0] + B.nHeightP[1];
+        std::vector<int> t(2 * n);
+        int *o = t.data(), *w = t.data() + n, pos = 0;
+        HIP_CHECK(hipMalloc((void **)&b->dTables, sizeof(int) * 2 * n));
+        for (int c = 0; c < 2; c++) {
+            bf_tables(o + pos, w + pos, B.nWidthP[c], B.XP); B.hOff[c] = b->dTables + pos; B.hW[c] = b->dTables + n + pos; pos += B.nWidthP[c];
+            bf_tables(o + pos, w + pos, B.nHeightP[c], B.YP); B.vOff[c] = b->dTables + pos; B.vW[c] = b->dTables + n + pos; pos += B.nHeightP[c];
+        }
+        HIP_CHECK(hipMemcpy(b->dTables, t.data(), sizeof(int) * 2 * n, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMalloc((void **)&b->dB, sizeof(BFParams)));
+        HIP_CHECK(hipMemcpy(b->dB, &B, sizeof(BFParams), hipMemcpyHostToDevice));
+    }
+    if ((rc = ensure_jobs(b, nframes, sizeof(BFPlan) * (size_t)P.nBlk))) return rc;
+    if ((size_t)nframes > b->bjobsCap) {
+        if (b->dBJobs) (void)hipFree(b->dBJobs);
+        b->bjobsCap = (size_t)nframes * 2;
+        HIP_CHECK(hipMalloc((void **)&b->dBJobs, b->bjobsCap * sizeof(BFJob)));
+    }
+    const size_t cells = (size_t)B.XP * B.YP;
+    if ((size_t)nframes > b->maskCap) {
+        if (b->dSmall) (void)hipFree(b->dSmall);
+        if (b->dMasks) (void)hipFree(b->dMasks);
+        b->maskCap = (size_t)nframes * 2;
+        HIP_CHECK(hipMalloc((void **)&b->dSmall, b->maskCap * 2 * cells * sizeof(int)));
+        HIP_CHECK(hipMalloc((void **)&b->dMasks, b->maskCap * 3 * cells));
+    }
+    std::vector<BFJob> hj(nframes);
+    for (int f = 0; f < nframes; f++) {
+        BFJob &j = hj[f];
+        memset(&j, 0, sizeof(j));
+        for (int p = 0; p < 3; p++) {
+            j.srcSup[p] = (const unsigned char *)jobs[f].src_super[p]; j.refSup[p] = (const unsigned char *)jobs[f].ref_super[p];
+            j.clipL[p] = (const unsigned char *)jobs[f].clip_left[p]; j.clipR[p] = (const unsigned char *)jobs[f].clip_right[p];
+            j.dst[p] = (unsigned char *)jobs[f].dst[p];
+        }
+        j.blobF = (const unsigned char *)jobs[f].blob_fw; j.blobB = (const unsigned char *)jobs[f].blob_bw;
+        j.time256 = jobs[f].time256;
+        j.good = j.srcSup[0] && j.refSup[0] && j.blobF && j.blobB;
+        if (!j.clipL[0] || (j.time256 > 0 && !j.clipR[0])) { mvx_set_error("mvx_blockfps_frames: clip_left / clip_right are required"); return MVX_E_ARG; }
+    }
+    HIP_CHECK(hipMemcpyAsync(b->dBJobs, hj.data(), sizeof(BFJob) * nframes, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(bf_usable_kernel, dim3(nframes), dim3(256), 0, st, b->dP, b->dB, b->dBJobs, b->dUsable);
+    if (B.mode >= 3) {
+        HIP_CHECK(hipMemsetAsync(b->dSmall, 0, (size_t)nframes * 2 * cells * sizeof(int), st));
+        hipLaunchKernelGGL(bf_mask_kernel, dim3((P.nBlk + 255) / 256, 2, nframes), dim3(256), 0, st, b->dP, b->dB, b->dBJobs, b->dUsable, b->dSmall);
+        hipLaunchKernelGGL(bf_mask_finish_kernel, dim3((unsigned)((cells + 255) / 256), nframes), dim3(256), 0, st, b->dP, b->dB, b->dUsable, b->dSmall, b->dMasks);
+    }
+    hipLaunchKernelGGL(bf_plan_kernel, dim3((P.nBlk + 255) / 256, nframes), dim3(256), 0, st, b->dP, b->dBJobs, b->dUsable, (BFPlan *)b->dPlan);
+    dim3 grid((P.pl[0].W + 63) / 64, (P.pl[0].H + 3) / 4, nframes * 3);
+    if (P.bps == 1) hipLaunchKernelGGL(blockfps_kernel<uint8_t>, grid, dim3(256), 0, st, b->dP, b->dB, b->dBJobs, b->dUsable, (const BFPlan *)b->dPlan, b->dMasks);
+    else hipLaunchKernelGGL(blockfps_kernel<uint16_t>, grid, dim3(256), 0, st, b->dP, b->dB, b->dBJobs, b->dUsable, (const BFPlan *)b->dPlan, b->dMasks);
+    HIP_CHECK(hipGetLastError());
+    return MVX_OK;
+}

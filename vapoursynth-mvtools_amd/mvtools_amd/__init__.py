@@ -74,6 +74,19 @@ class CompensateJob(C.Structure):
     _fields_ = [("src_super", C.c_void_p * 3), ("ref_super", C.c_void_p * 3), ("blob", C.c_void_p), ("dst", C.c_void_p * 3)]
 
 
+class BlockFPSArgs(C.Structure):
+    _fields_ = [("num", C.c_int64), ("den", C.c_int64), ("mode", C.c_int32), ("ml", C.c_double), ("blend", C.c_int32), ("thscd1", C.c_int64), ("thscd2", C.c_int32)]
+
+
+class BlockFPSInfo(C.Structure):
+    _fields_ = [("num_frames", C.c_int32), ("fps_num", C.c_int64), ("fps_den", C.c_int64)]
+
+
+class BlockFPSJob(C.Structure):
+    _fields_ = [("time256", C.c_int32), ("reserved", C.c_int32), ("src_super", C.c_void_p * 3), ("ref_super", C.c_void_p * 3), ("blob_fw", C.c_void_p),
+                ("blob_bw", C.c_void_p), ("clip_left", C.c_void_p * 3), ("clip_right", C.c_void_p * 3), ("dst", C.c_void_p * 3)]
+
+
 _lib = None
 
 
@@ -112,6 +125,12 @@ def lib():
                                             P(C.c_void_p), C.c_char_p]
         L.mvx_compensate_destroy.argtypes = [C.c_void_p]
         L.mvx_compensate_frames.argtypes = [C.c_void_p, C.c_int, P(CompensateJob), C.c_void_p]
+        L.mvx_blockfps_create.argtypes = [P(BlockFPSArgs), P(AnalysisData), P(AnalysisData), C.c_void_p, C.c_int, C.c_int64, C.c_int64, P(C.c_ssize_t),
+                                          P(C.c_ssize_t), P(C.c_ssize_t), P(C.c_void_p), C.c_char_p]
+        L.mvx_blockfps_destroy.argtypes = [C.c_void_p]
+        L.mvx_blockfps_get_info.argtypes = [C.c_void_p, P(BlockFPSInfo)]
+        L.mvx_blockfps_map.argtypes = [C.c_void_p, C.c_int, P(C.c_int), P(C.c_int), P(C.c_int)]
+        L.mvx_blockfps_frames.argtypes = [C.c_void_p, C.c_int, P(BlockFPSJob), C.c_void_p]
         L.mvx_scale_thscd.argtypes = [P(C.c_int64), P(C.c_int32), P(AnalysisData)]
         L.mvx_vectors_size.argtypes = [P(AnalysisData)]
         L.mvx_vectors_size.restype = C.c_int
@@ -375,4 +394,65 @@ class Compensate:
                 arr[k].dst[p] = out[k][p].data_ptr()
             arr[k].blob = blob.data_ptr()
         _check(lib().mvx_compensate_frames(self.h, n, arr, _stream()))
+        return out
+
+
+class BlockFPS:
+    """mv.BlockFPS(clip, super, mvbw, mvfw, num, den, mode, ml, blend, thscd1, thscd2) -- MVBlockFPS.c:741-1014.
+    `fps_num / fps_den` is the input clip's frame rate; `clip_pitch` the row pitch of its device planes."""
+
+    def __init__(self, sup, ad_bw, ad_fw, num_frames, clip_pitch, fps_num=24, fps_den=1, num=None, den=None, mode=None, ml=100.0, blend=None, thscd1=None,
+                 thscd2=None):
+        self.sup = sup
+        a = BlockFPSArgs(_u(num), _u(den), _u(mode), float(ml), _u(blend), _u(thscd1), _u(thscd2))
+        bw = AnalysisData.from_buffer_copy(bytes(ad_bw))
+        fw = AnalysisData.from_buffer_copy(bytes(ad_fw))
+        pad = lambda l: (C.c_ssize_t * 3)(*(list(l) + [0] * (3 - len(l))))
+        self.h = C.c_void_p()
+        self.pitch = list(clip_pitch)
+        err = C.create_string_buffer(ERRLEN)
+        _check(lib().mvx_blockfps_create(C.byref(a), C.byref(bw), C.byref(fw), sup.h, int(num_frames), int(fps_num), int(fps_den), pad(sup.pitch), pad(clip_pitch),
+                                         pad(clip_pitch), C.byref(self.h), err), err)
+        self.in_frames = int(num_frames)
+        info = BlockFPSInfo()
+        lib().mvx_blockfps_get_info(self.h, C.byref(info))
+        self.num_frames, self.fps_num, self.fps_den = info.num_frames, info.fps_num, info.fps_den
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().mvx_blockfps_destroy(self.h)
+        except Exception:
+            pass
+
+    def map(self, n):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        lib().mvx_blockfps_map(self.h, n, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def run(self, frames_out, clip, supers, blobs_bw, blobs_fw, out=None):
+        """frames_out: output frame numbers; clip / supers: device frames of the input clip and its super clip; blobs_*: per
+        input frame device blobs of the two vector clips (mvbw at n, mvfw at n)."""
+        torch = _torch()
+        n = len(frames_out)
+        if out is None:
+            out = arena_frames(n, [tuple(p.shape) for p in clip[0]], clip[0][0].device, zero=False)
+        arr = (BlockFPSJob * n)()
+        last = self.in_frames - 1
+        for k, fo in enumerate(frames_out):
+            nl, nr, t = self.map(fo)
+            arr[k].time256 = t
+            good = nl < self.in_frames and nr < self.in_frames
+            L, R = clip[min(nl, last)], clip[min(nr, last)]
+            for p in range(self.sup.nplanes):
+                arr[k].clip_left[p] = L[p].data_ptr()
+                arr[k].clip_right[p] = R[p].data_ptr()
+                arr[k].dst[p] = out[k][p].data_ptr()
+                if good:
+                    arr[k].src_super[p] = supers[nl][p].data_ptr()
+                    arr[k].ref_super[p] = supers[nr][p].data_ptr()
+            if good:
+                arr[k].blob_fw = blobs_fw[nr].data_ptr()
+                arr[k].blob_bw = blobs_bw[nl].data_ptr()
+        _check(lib().mvx_blockfps_frames(self.h, n, arr, _stream()))
         return out

@@ -9,7 +9,7 @@
  *   mvx_vs_host <plugin.so> list
  *   mvx_vs_host <plugin.so> error  <Filter> <w> <h> <bits> [f.key=value ...]       -> prints the creation error (or OK)
  *   mvx_vs_host <plugin.so> run <pipeline> <in.raw> <w> <h> <bits> <nframes> <out.raw> [s.|a.|d.|c.key=value ...]
- *       pipeline: super | analyse | degrainN | compensate
+ *       pipeline: super | analyse | degrainN | compensate | blockfps (b.key=value arguments)
  *       in.raw  : nframes x (Y, U, V planes, 4:2:0, tightly packed, little endian)
  *       out.raw : super      -> every super frame (planes tightly packed) ; props of frame 0 on stdout
  *                 analyse    -> per frame: 84-byte MVTools_MVAnalysisData + MVTools_vectors, backward (isb=1) then forward
@@ -238,6 +238,36 @@ static VSNode *invoke(const char *name, VSMap *in, char *err, size_t errsz) {
     return NULL;
 }
 
+/* the one foreign function the path needs: std.AssumeFPS (sets the clip's frame rate and the per-frame duration props) */
+typedef struct AssumeData { VSNode *node; int64_t num, den; } AssumeData;
+static const VSFrame *VS_CC assumeGetFrame(int n, int reason, void *inst, void **fd, VSFrameContext *ctx, VSCore *core, const VSAPI *vs) {
+    (void)fd;
+    AssumeData *d = (AssumeData *)inst;
+    if (reason == arInitial) { vs->requestFrameFilter(n, d->node, ctx); return NULL; }
+    if (reason != arAllFramesReady) return NULL;
+    const VSFrame *src = vs->getFrameFilter(n, d->node, ctx);
+    VSFrame *dst = vs->copyFrame(src, core);
+    vs->freeFrame(src);
+    vs->mapSetInt(vs->getFramePropertiesRW(dst), "_DurationNum", d->den, maReplace);
+    vs->mapSetInt(vs->getFramePropertiesRW(dst), "_DurationDen", d->num, maReplace);
+    return dst;
+}
+static void VS_CC assumeFree(void *inst, VSCore *core, const VSAPI *vs) { (void)core; AssumeData *d = (AssumeData *)inst; vs->freeNode(d->node); free(d); }
+static struct VSPlugin { int dummy; } *g_std = (struct VSPlugin *)&g_nfuncs;
+static VSPlugin *VS_CC getPluginByID(const char *id, VSCore *core) { (void)core; return strcmp(id, "com.vapoursynth.std") ? NULL : g_std; }
+static VSMap *VS_CC apiInvoke(VSPlugin *plugin, const char *name, const VSMap *args) {
+    VSMap *out = createMap();
+    if (plugin != g_std || strcmp(name, "AssumeFPS")) { mapSetError(out, "minihost: only std.AssumeFPS exists"); return out; }
+    int e = 0;
+    AssumeData *d = (AssumeData *)calloc(1, sizeof(*d));
+    d->node = mapGetNode(args, "clip", 0, &e);
+    d->num = mapGetInt(args, "fpsnum", 0, &e); d->den = mapGetInt(args, "fpsden", 0, &e);
+    VSVideoInfo vi = d->node->vi;
+    vi.fpsNum = d->num; vi.fpsDen = d->den;
+    createVideoFilter(out, "AssumeFPS", &vi, assumeGetFrame, assumeFree, fmParallel, NULL, 0, d, NULL);
+    return out;
+}
+
 static void init_api(void) {
     memset(&g_api, 0, sizeof(g_api));
     g_api.createVideoFilter = createVideoFilter; g_api.freeNode = freeNode; g_api.addNodeRef = addNodeRef; g_api.getVideoInfo = getVideoInfo;
@@ -250,6 +280,7 @@ static void init_api(void) {
     g_api.mapNumElements = mapNumElements; g_api.mapGetInt = mapGetInt; g_api.mapGetIntSaturated = mapGetIntSaturated; g_api.mapSetInt = mapSetInt;
     g_api.mapGetFloat = mapGetFloat; g_api.mapSetFloat = mapSetFloat; g_api.mapGetData = mapGetData; g_api.mapGetDataSize = mapGetDataSize; g_api.mapSetData = mapSetData;
     g_api.mapGetNode = mapGetNode; g_api.mapSetNode = mapSetNode; g_api.logMessage = logMessage;
+    g_api.getPluginByID = getPluginByID; g_api.invoke = apiInvoke;
 }
 
 /* ---------------------------------------------------------------------------------------------------- driver */
@@ -395,6 +426,19 @@ int main(int argc, char **argv) {
     VSMap *m = createMap();
     mapSetNode(m, "clip", clip, maReplace); mapSetNode(m, "super", sup, maReplace);
     VSNode *out;
+    if (!strcmp(pipeline, "blockfps")) {
+        mapSetNode(m, "mvbw", vec[0], maReplace); mapSetNode(m, "mvfw", vec[1], maReplace); add_args(m, 'b', nextra, extra);
+        out = invoke("BlockFPS", m, err, sizeof(err));
+        if (!out) die(pipeline, err);
+        printf("blockfps frames=%d fps=%lld/%lld\n", out->vi.numFrames, (long long)out->vi.fpsNum, (long long)out->vi.fpsDen);
+        for (int n = 0; n < out->vi.numFrames; n++) {
+            const VSFrame *f = eval_frame(n, out, err, sizeof(err));
+            if (!f) die("output frame", err);
+            if (n == 1) { int e; printf("frame1 _DurationNum=%lld _DurationDen=%lld\n", (long long)mapGetInt(f->props, "_DurationNum", 0, &e), (long long)mapGetInt(f->props, "_DurationDen", 0, &e)); }
+            dump_frame(fo, f); freeFrame(f);
+        }
+        fclose(fo); printf("DONE\n"); return 0;
+    }
     if (!strcmp(pipeline, "compensate")) { mapSetNode(m, "vectors", vec[0], maReplace); add_args(m, 'c', nextra, extra); out = invoke("Compensate", m, err, sizeof(err)); }
     else {
         static const char *vn[] = { "mvbw", "mvfw", "mvbw2", "mvfw2", "mvbw3", "mvfw3", "mvbw4", "mvfw4", "mvbw5", "mvfw5", "mvbw6", "mvfw6" };

@@ -4,7 +4,7 @@
  * Registers, under the reference's plugin id / namespace ("com.nodame.mvtools", "mv"), the filters of the hot path
  * with the reference's exact argument strings:
  *     Super       (src/MVSuper.c:279-291)        Analyse   (src/MVAnalyse.c:639-671)
- *     Degrain1..6 (src/MVDegrains.cpp:813-932)   Compensate (src/MVCompensate.c:579-592)
+ *     Degrain1..6 (src/MVDegrains.cpp:813-932)   Compensate (src/MVCompensate.c:579-592)   BlockFPS (src/MVBlockFPS.c:1017-1033)
  * and keeps the reference's inter-filter data layout: super-frame geometry + Super_* props on frame 0
  * (src/MVSuper.c:111-120), vector clips = copyFrame(super[n]) + binary props MVTools_MVAnalysisData / MVTools_vectors
  * (src/MVAnalyse.c:224-239).  This file is the only code that touches VSAPI; all arithmetic happens on the GPU behind
@@ -719,6 +719,176 @@ static void VS_CC compCreate(const VSMap *in, VSMap *out, void *user, VSCore *co
     vs->createVideoFilter(out, "Compensate", d->vi, compGetFrame, compFree, fmParallel, deps, 3, d, core);
 }
 
+/* ------------------------------------------------------------------------------------------------ mv.BlockFPS */
+
+typedef struct FpsData { VSNode *node, *super, *mvbw, *mvfw; const VSVideoInfo *oldvi; VSVideoInfo vi; mvx_super *sup; SuperGeo geo; mvx_blockfps *bf;
+                         mvx_analysis_data bw, fw; ptrdiff_t pitch[3]; int blobSize; } FpsData;
+
+static int fps_min(int a, int b) { return a < b ? a : b; }
+
+static const VSFrame *VS_CC fpsGetFrame(int n, int reason, void *inst, void **fd, VSFrameContext *ctx, VSCore *core, const VSAPI *vs) {
+    (void)fd;
+    FpsData *d = (FpsData *)inst;
+    int nleft, nright, time256;
+    mvx_blockfps_map(d->bf, n, &nleft, &nright, &time256);
+    const int last = d->oldvi->numFrames - 1;
+    const int good = nleft < d->oldvi->numFrames && nright < d->oldvi->numFrames;
+    if (reason == arInitial) { /* src/MVBlockFPS.c:236-276 */
+        if (time256 == 0) { vs->requestFrameFilter(fps_min(nleft, last), d->node, ctx); return NULL; }
+        if (time256 == 256) { vs->requestFrameFilter(fps_min(nright, last), d->node, ctx); return NULL; }
+        if (good) {
+            vs->requestFrameFilter(nright, d->mvfw, ctx);
+            vs->requestFrameFilter(nleft, d->mvbw, ctx);
+            vs->requestFrameFilter(nleft, d->super, ctx);
+            vs->requestFrameFilter(nright, d->super, ctx);
+        }
+        vs->requestFrameFilter(fps_min(nleft, last), d->node, ctx);
+        vs->requestFrameFilter(fps_min(nright, last), d->node, ctx); /* the reference only asks for it when blend=1; harmless */
+        return NULL;
+    }
+    if (reason != arAllFramesReady) return NULL;
+    if (time256 == 0) return vs->getFrameFilter(fps_min(nleft, last), d->node, ctx);   /* simply left  (:285-286) */
+    if (time256 == 256) return vs->getFrameFilter(fps_min(nright, last), d->node, ctx); /* simply right (:287-288) */
+    const VSFrame *cl = vs->getFrameFilter(fps_min(nleft, last), d->node, ctx);
+    const VSFrame *cr = vs->getFrameFilter(fps_min(nright, last), d->node, ctx);
+    const int np = d->vi.format.numPlanes, bps = d->vi.format.bytesPerSample;
+    mvx_blockfps_job job;
+    memset(&job, 0, sizeof(job));
+    job.time256 = time256;
+    void *arenaL = NULL, *arenaR = NULL, *dl[3], *dr[3], *blobF = NULL, *blobB = NULL;
+    upload_plane_set(dl, &arenaL, cl, d->pitch, np, bps, vs);
+    upload_plane_set(dr, &arenaR, cr, d->pitch, np, bps, vs);
+    size_t dstOff[3], dstBytes = 0;
+    for (int p = 0; p < np; p++) { dstOff[p] = dstBytes; dstBytes += (size_t)d->pitch[p] * vs->getFrameHeight(cl, p); }
+    void *dstArena = mvx_dev_alloc(dstBytes);
+    int rc = (!arenaL || !arenaR || !dstArena) ? MVX_E_NOMEM : 0;
+    for (int p = 0; p < np && !rc; p++) { job.clip_left[p] = dl[p]; job.clip_right[p] = dr[p]; job.dst[p] = (char *)dstArena + dstOff[p]; }
+    DevRef ds, dr2;
+    memset(&ds, 0, sizeof(ds)); memset(&dr2, 0, sizeof(dr2));
+    if (!rc && good) {
+        const VSFrame *sl = vs->getFrameFilter(nleft, d->super, ctx), *sr = vs->getFrameFilter(nright, d->super, ctx);
+        const VSFrame *vf = vs->getFrameFilter(nright, d->mvfw, ctx), *vb = vs->getFrameFilter(nleft, d->mvbw, ctx);
+        rc = super_to_device(&ds, sl, &d->geo, vs);
+        if (!rc) rc = super_to_device(&dr2, sr, &d->geo, vs);
+        int e1 = 0, e2 = 0;
+        const char *bf = vs->mapGetData(vs->getFramePropertiesRO(vf), PROP_VECTORS, 0, &e1);
+        const char *bb = vs->mapGetData(vs->getFramePropertiesRO(vb), PROP_VECTORS, 0, &e2);
+        if (!rc && (e1 || e2 || vs->mapGetDataSize(vs->getFramePropertiesRO(vf), PROP_VECTORS, 0, NULL) != d->blobSize ||
+                    vs->mapGetDataSize(vs->getFramePropertiesRO(vb), PROP_VECTORS, 0, NULL) != d->blobSize)) rc = MVX_E_ARG;
+        if (!rc) {
+            blobF = mvx_dev_alloc((size_t)d->blobSize); blobB = mvx_dev_alloc((size_t)d->blobSize);
+            if (!blobF || !blobB) rc = MVX_E_NOMEM;
+        }
+        if (!rc) rc = mvx_copy_to_device(blobF, d->blobSize, bf, d->blobSize, (size_t)d->blobSize, 1, NULL);
+        if (!rc) rc = mvx_copy_to_device(blobB, d->blobSize, bb, d->blobSize, (size_t)d->blobSize, 1, NULL);
+        if (!rc) rc = mvx_stream_sync(NULL);
+        for (int p = 0; p < 3; p++) { job.src_super[p] = ds.plane[p]; job.ref_super[p] = dr2.plane[p]; }
+        job.blob_fw = blobF; job.blob_bw = blobB;
+        vs->freeFrame(sl); vs->freeFrame(sr); vs->freeFrame(vf); vs->freeFrame(vb);
+    }
+    if (!rc) rc = mvx_blockfps_frames(d->bf, 1, &job, NULL);
+    VSFrame *dst = NULL;
+    if (!rc) {
+        dst = vs->newVideoFrame(&d->vi.format, d->vi.width, d->vi.height, cl, core);
+        for (int p = 0; p < np && !rc; p++)
+            rc = mvx_copy_to_host(vs->getWritePtr(dst, p), vs->getStride(dst, p), job.dst[p], d->pitch[p], (size_t)vs->getFrameWidth(dst, p) * bps, (size_t)vs->getFrameHeight(dst, p), NULL);
+        if (!rc) rc = mvx_stream_sync(NULL);
+    }
+    dev_release(&ds); dev_release(&dr2);
+    if (blobF) mvx_dev_free(blobF);
+    if (blobB) mvx_dev_free(blobB);
+    if (arenaL) mvx_dev_free(arenaL);
+    if (arenaR) mvx_dev_free(arenaR);
+    if (dstArena) mvx_dev_free(dstArena);
+    vs->freeFrame(cl); vs->freeFrame(cr);
+    if (rc) {
+        if (dst) vs->freeFrame(dst);
+        vs->setFilterError(rc == MVX_E_ARG ? "BlockFPS: vector clip frame without matching MVTools_vectors property." : rc == MVX_E_NOMEM ? "BlockFPS: out of memory." : mvx_last_error(), ctx);
+        return NULL;
+    }
+    return dst;
+}
+
+static void VS_CC fpsFree(void *inst, VSCore *core, const VSAPI *vs) {
+    (void)core;
+    FpsData *d = (FpsData *)inst;
+    vs->freeNode(d->node); vs->freeNode(d->super); vs->freeNode(d->mvbw); vs->freeNode(d->mvfw);
+    mvx_blockfps_destroy(d->bf);
+    mvx_super_destroy(d->sup);
+    free(d);
+}
+
+static void VS_CC fpsCreate(const VSMap *in, VSMap *out, void *user, VSCore *core, const VSAPI *vs) {
+    (void)user;
+    FpsData *d = (FpsData *)calloc(1, sizeof(*d));
+    char err[1400] = "";
+    mvx_blockfps_args a;
+    a.num = opt_int64(in, "num", vs); a.den = opt_int64(in, "den", vs); a.mode = opt_int(in, "mode", vs); a.blend = opt_int(in, "blend", vs);
+    a.thscd1 = opt_int64(in, "thscd1", vs); a.thscd2 = opt_int(in, "thscd2", vs);
+    int e = 0;
+    a.ml = vs->mapGetFloat(in, "ml", 0, &e);
+    if (e) a.ml = 100.0;
+    if (a.mode != MVX_UNSET && (a.mode < 0 || a.mode > 8)) snprintf(err, sizeof(err), "BlockFPS: mode must be between 0 and 8 (inclusive).");
+    if (!err[0]) { d->super = vs->mapGetNode(in, "super", 0, NULL); d->sup = super_from_props(d->super, "BlockFPS", err, sizeof(err), vs); }
+    if (!err[0]) { d->mvbw = vs->mapGetNode(in, "mvbw", 0, NULL); adata_from_clip(&d->bw, d->mvbw, "BlockFPS", "mvbw", err, sizeof(err), vs); }
+    if (!err[0]) { d->mvfw = vs->mapGetNode(in, "mvfw", 0, NULL); adata_from_clip(&d->fw, d->mvfw, "BlockFPS", "mvfw", err, sizeof(err), vs); }
+    if (!err[0]) {
+        d->node = vs->mapGetNode(in, "clip", 0, NULL);
+        d->oldvi = vs->getVideoInfo(d->node);
+        d->vi = *d->oldvi;
+        super_geo(&d->geo, d->sup);
+        const int bps = d->vi.format.bytesPerSample;
+        for (int p = 0; p < 3; p++) {
+            const int w = p ? d->vi.width >> d->vi.format.subSamplingW : d->vi.width;
+            d->pitch[p] = ((ptrdiff_t)w * bps + 255) / 256 * 256;
+        }
+        char lerr[MVX_ERRLEN];
+        if (mvx_blockfps_create(&a, &d->bw, &d->fw, d->sup, d->oldvi->numFrames, d->oldvi->fpsNum, d->oldvi->fpsDen, d->geo.pitch, d->pitch, d->pitch, &d->bf, lerr))
+            snprintf(err, sizeof(err), "%s", lerr);
+        else if (!mvx_vsh_is_constant_video_format(&d->vi) || d->vi.format.bitsPerSample > 16 || d->vi.format.sampleType != stInteger || d->vi.format.subSamplingW > 1 ||
+                 d->vi.format.subSamplingH > 1 || (d->vi.format.colorFamily != cfYUV && d->vi.format.colorFamily != cfGray))
+            snprintf(err, sizeof(err), "BlockFPS: input clip must be GRAY, 420, 422, 440, or 444, up to 16 bits, with constant dimensions.");
+    }
+    if (err[0]) {
+        vs->mapSetError(out, err);
+        if (d->node) vs->freeNode(d->node);
+        if (d->super) vs->freeNode(d->super);
+        if (d->mvbw) vs->freeNode(d->mvbw);
+        if (d->mvfw) vs->freeNode(d->mvfw);
+        if (d->bf) mvx_blockfps_destroy(d->bf);
+        if (d->sup) mvx_super_destroy(d->sup);
+        free(d);
+        return;
+    }
+    mvx_blockfps_info info;
+    mvx_blockfps_get_info(d->bf, &info);
+    d->vi.numFrames = info.num_frames; d->vi.fpsNum = info.fps_num; d->vi.fpsDen = info.fps_den;
+    d->blobSize = mvx_vectors_size(&d->bw);
+    VSFilterDependency deps[4] = { { d->node, rpGeneral }, { d->super, rpGeneral }, { d->mvbw, rpGeneral }, { d->mvfw, rpGeneral } };
+    vs->createVideoFilter(out, "BlockFPS", &d->vi, fpsGetFrame, fpsFree, fmParallel, deps, 4, d, core);
+    /* AssumeFPS sets the _DurationNum / _DurationDen frame properties (src/MVBlockFPS.c:989-1014) */
+    VSNode *node = vs->mapGetNode(out, "clip", 0, NULL);
+    VSMap *args = vs->createMap();
+    vs->mapSetNode(args, "clip", node, maReplace);
+    vs->freeNode(node);
+    vs->mapSetInt(args, "fpsnum", info.fps_num, maReplace);
+    vs->mapSetInt(args, "fpsden", info.fps_den, maReplace);
+    VSPlugin *std = vs->getPluginByID("com.vapoursynth.std", core);
+    VSMap *ret = vs->invoke(std, "AssumeFPS", args);
+    vs->freeMap(args);
+    if (vs->mapGetError(ret)) {
+        char msg[600];
+        snprintf(msg, sizeof(msg), "BlockFPS: Failed to invoke AssumeFPS. Error message: %s", vs->mapGetError(ret));
+        vs->mapSetError(out, msg);
+        vs->freeMap(ret);
+        return;
+    }
+    node = vs->mapGetNode(ret, "clip", 0, NULL);
+    vs->freeMap(ret);
+    vs->mapSetNode(out, "clip", node, maReplace);
+    vs->freeNode(node);
+}
+
 /* ------------------------------------------------------------------------------------------------ entry point */
 
 #define DEGRAIN_TAIL "thsad:int:opt;thsadc:int:opt;plane:int:opt;limit:int:opt;limitc:int:opt;thscd1:int:opt;thscd2:int:opt;opt:int:opt;"
@@ -741,6 +911,9 @@ VS_EXTERNAL_API(void) VapourSynthPluginInit2(VSPlugin *plugin, const VSPLUGINAPI
     vspapi->registerFunction("Degrain4", "clip:vnode;super:vnode;mvbw:vnode;mvfw:vnode;mvbw2:vnode;mvfw2:vnode;mvbw3:vnode;mvfw3:vnode;mvbw4:vnode;mvfw4:vnode;" DEGRAIN_TAIL, "clip:vnode;", degrainCreate, (void *)(intptr_t)4, plugin);
     vspapi->registerFunction("Degrain5", "clip:vnode;super:vnode;mvbw:vnode;mvfw:vnode;mvbw2:vnode;mvfw2:vnode;mvbw3:vnode;mvfw3:vnode;mvbw4:vnode;mvfw4:vnode;mvbw5:vnode;mvfw5:vnode;" DEGRAIN_TAIL, "clip:vnode;", degrainCreate, (void *)(intptr_t)5, plugin);
     vspapi->registerFunction("Degrain6", "clip:vnode;super:vnode;mvbw:vnode;mvfw:vnode;mvbw2:vnode;mvfw2:vnode;mvbw3:vnode;mvfw3:vnode;mvbw4:vnode;mvfw4:vnode;mvbw5:vnode;mvfw5:vnode;mvbw6:vnode;mvfw6:vnode;" DEGRAIN_TAIL, "clip:vnode;", degrainCreate, (void *)(intptr_t)6, plugin);
+    vspapi->registerFunction("BlockFPS",
+                             "clip:vnode;super:vnode;mvbw:vnode;mvfw:vnode;num:int:opt;den:int:opt;mode:int:opt;ml:float:opt;blend:int:opt;thscd1:int:opt;thscd2:int:opt;opt:int:opt;",
+                             "clip:vnode;", fpsCreate, NULL, plugin);
     vspapi->registerFunction("Compensate",
                              "clip:vnode;super:vnode;vectors:vnode;scbehavior:int:opt;thsad:int:opt;fields:int:opt;time:float:opt;thscd1:int:opt;thscd2:int:opt;opt:int:opt;tff:int:opt;",
                              "clip:vnode;", compCreate, NULL, plugin);

@@ -162,9 +162,12 @@ struct VSAPI {
     mvx_vs_slot mapConsumeNode, mapGetFrame, mapSetFrame, mapConsumeFrame, mapGetFunction, mapSetFunction, mapConsumeFunction;
 
     /* plugins */
-    mvx_vs_slot registerFunction, getPluginByID, getPluginByNamespace, getNextPlugin, getPluginName, getPluginID, getPluginNamespace,
+    mvx_vs_slot registerFunction;
+    VSPlugin *(VS_CC *getPluginByID)(const char *identifier, VSCore *core);
+    mvx_vs_slot getPluginByNamespace, getNextPlugin, getPluginName, getPluginID, getPluginNamespace,
         getNextPluginFunction, getPluginFunctionByName, getPluginFunctionName, getPluginFunctionArguments, getPluginFunctionReturnType,
-        getPluginPath, getPluginVersion, invoke;
+        getPluginPath, getPluginVersion;
+    VSMap *(VS_CC *invoke)(VSPlugin *plugin, const char *name, const VSMap *args);
 
     /* core */
     mvx_vs_slot createCore, freeCore, setMaxCacheSize, setThreadCount, getCoreInfo, getAPIVersion;
