@@ -1,6 +1,6 @@
 /*
  * mvoracle.h -- CPU restatement (plain C99) of the mvtools hot path:
- *   mv.Super -> mv.Analyse -> mv.DegrainN / mv.Compensate.
+ *   mv.Super -> mv.Analyse -> mv.DegrainN / mv.Compensate, and mv.BlockFPS.
  *
  * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as the
@@ -17,6 +17,7 @@
  *   - MVFrame.cpp / PlaneOfBlocks.cpp / GroupOfPlanes.c / Fakery.c / MVDegrains.h cannot be compiled
  *     here without stand-ins for the absent VapourSynth headers, so beyond the two items above the
  *     pyramid, the search driver, Degrain weights and Compensate are "parity unpinned".
+ *   - mv.BlockFPS (MVBlockFPS.c, MaskFun.cpp, SimpleResize.cpp: same absent headers) is "parity unpinned" entirely.
  */
 #ifndef MVORACLE_H
 #define MVORACLE_H
