@@ -109,8 +109,38 @@ typedef struct mvx_analyse_job {
     int32_t reserved;
 } mvx_analyse_job;
 
-/* One chain (frame, direction) per job; all jobs run concurrently in one launch. `jobs` is a HOST array. */
+/* One chain (frame, direction) per job; all jobs run concurrently in one launch. `jobs` is a HOST array.
+ * With divide > 0 the blob carries the extra array of half-size blocks and mvx_analyse_get_data reports the divided
+ * geometry (MVAnalyse.c:229, :615-624), which is what readers of the vector clip must use. */
 int mvx_analyse_frames(mvx_analyse *a, int njobs, const mvx_analyse_job *jobs, void *stream);
+
+/* ---- mv.Recalculate ------------------------------------------------------------------------------
+ * replaces mvrecalculateCreate / mvrecalculateGetFrame, MVRecalculate.c:263-545 / :68-254 (arg string :549-572);
+ * the per-block refinement is PlaneOfBlocks.cpp:1158-1424, `divide` GroupOfPlanes.c:177-302.           */
+
+typedef struct mvx_recalculate_args { /* MVX_UNSET = not passed */
+    int64_t thsad, smooth, blksize, blksizev, search, searchparam, lambda, chroma, truemotion, pnew, overlap, overlapv,
+        divide, meander, fields, dct;
+} mvx_recalculate_args;
+
+typedef struct mvx_recalculate mvx_recalculate;
+
+/* `vectors_data`: MVTools_MVAnalysisData of the vector clip being refined */
+int mvx_recalculate_create(const mvx_recalculate_args *args, const mvx_super *super_clip, const mvx_analysis_data *vectors_data,
+                           const ptrdiff_t super_pitch[3], mvx_recalculate **out, char *err);
+void mvx_recalculate_destroy(mvx_recalculate *r);
+void mvx_recalculate_get_data(const mvx_recalculate *r, mvx_analysis_data *out); /* MVTools_MVAnalysisData of the result */
+int mvx_recalculate_blob_size(const mvx_recalculate *r);
+
+typedef struct mvx_recalculate_job {
+    const void *src[3];   /* super frame n */
+    const void *ref[3];   /* super frame n +/- delta; ref[0]==NULL -> the default (invalid) blob */
+    const void *old_blob; /* MVTools_vectors of the old vector clip at frame n (device, 16-byte aligned) */
+    void *blob;           /* out, mvx_recalculate_blob_size() bytes, 16-byte aligned */
+} mvx_recalculate_job;
+
+/* one workgroup per BLOCK: blocks of a Recalculate are independent (no spatial predictors) */
+int mvx_recalculate_frames(mvx_recalculate *r, int njobs, const mvx_recalculate_job *jobs, void *stream);
 
 /* ---- mv.Degrain1..6 ------------------------------------------------------------------------------
  * replaces mvdegrainCreate<r> / mvdegrainGetFrame<r>, MVDegrains.cpp:511-809 / :85-330 (arg strings :813-932) */

@@ -664,6 +664,113 @@ static int pob_write_default(const pob *p, uint8_t *array, int divide) { /* :152
     return pob_array_size(p, divide);
 }
 
+/* PlaneOfBlocks.cpp:1158-1424 doPobRecalculateMVs: every block is independent -- its predictor is interpolated from the OLD
+ * vector field, evaluated, and refined with the chosen pattern only when its SAD exceeds thSAD */
+static void pob_recalculate(pob *p, const mvo_analysis_data *oldAd, const mvo_vector *oldVec, const mvo_frame *srcF, const mvo_frame *refF, int st, int stp,
+                            int lambda, int pnew, uint8_t *out, int fieldShift, int64_t thSAD, int dctmode, int smooth, int meander) {
+    p->dctmode = dctmode;
+    p->dctweight16 = 8;
+    p->zeroMVfieldShifted.x = 0; p->zeroMVfieldShifted.y = fieldShift; p->zeroMVfieldShifted.sad = 0;
+    p->globalMVPredictor.x = 0; p->globalMVPredictor.y = fieldShift; p->globalMVPredictor.sad = 9999999;
+    int size = (int)sizeof(int) + p->nBlkCount * (int)sizeof(mvo_vector);
+    memcpy(out, &size, sizeof(size));
+    mvo_vector *pBlkData = (mvo_vector *)(out + sizeof(int));
+    p->pSrcFrame = srcF; p->pRefFrame = refF;
+    const mvo_plane *s0 = &srcF->pl[0];
+    const int bps = p->bytesPerSample;
+    p->nRefPitch[0] = refF->pl[0].pitch;
+    if (p->chroma) { p->nRefPitch[1] = refF->pl[1].pitch; p->nRefPitch[2] = refF->pl[2].pitch; }
+    p->searchType = st; p->nSearchParam = stp;
+    const int nLambdaLevel = lambda / ((1 << p->nLogPel) * (1 << p->nLogPel));
+    const int nBlkXold = oldAd->nBlkX, nBlkYold = oldAd->nBlkY, bsxOld = oldAd->nBlkSizeX, bsyOld = oldAd->nBlkSizeY;
+    const int stepXold = bsxOld - oldAd->nOverlapX, stepYold = bsyOld - oldAd->nOverlapY, logPelOld = mvo_ilog2(oldAd->nPel);
+    (void)meander; /* the scan order cannot matter: blocks are independent */
+    for (p->blky = 0; p->blky < p->nBlkY; p->blky++)
+        for (p->blkx = 0; p->blkx < p->nBlkX; p->blkx++) {
+            p->blkIdx = p->blky * p->nBlkX + p->blkx;
+            p->blkScanDir = 1;
+            p->x[0] = s0->hpad + (p->nBlkSizeX - p->nOverlapX) * p->blkx;
+            p->y[0] = s0->vpad + (p->nBlkSizeY - p->nOverlapY) * p->blky;
+            for (int c = 1; c < 3 && p->chroma; c++) {
+                p->x[c] = srcF->pl[c].hpad + ((p->nBlkSizeX - p->nOverlapX) >> p->nLogxRatioUV) * p->blkx;
+                p->y[c] = srcF->pl[c].vpad + ((p->nBlkSizeY - p->nOverlapY) >> p->nLogyRatioUV) * p->blky;
+            }
+            copy_block(p->pSrc_temp[0], p->nSrcPitch_temp[0], s0->p[0] + p->x[0] * bps + p->y[0] * s0->pitch, s0->pitch, p->nBlkSizeX * bps, p->nBlkSizeY);
+            p->pSrc[0] = p->pSrc_temp[0]; p->nSrcPitch[0] = p->nSrcPitch_temp[0];
+            for (int c = 1; c < 3 && p->chroma; c++) {
+                const mvo_plane *sc = &srcF->pl[c];
+                copy_block(p->pSrc_temp[c], p->nSrcPitch_temp[c], sc->p[0] + p->x[c] * bps + p->y[c] * sc->pitch, sc->pitch, p->nBlkSizeX / p->xRatioUV * bps, p->nBlkSizeY / p->yRatioUV);
+                p->pSrc[c] = p->pSrc_temp[c]; p->nSrcPitch[c] = p->nSrcPitch_temp[c];
+            }
+            p->nLambda = p->blky == 0 ? 0 : nLambdaLevel;
+            p->penaltyNew = pnew;
+            p->nDxMax = (s0->pw - p->x[0] - p->nBlkSizeX) << p->nLogPel; /* :1262-1265: no level padding terms here */
+            p->nDyMax = (s0->ph - p->y[0] - p->nBlkSizeY) << p->nLogPel;
+            p->nDxMin = -(p->x[0] << p->nLogPel);
+            p->nDyMin = -(p->y[0] << p->nLogPel);
+            /* old vectors around the new block's centre (:1268-1321) */
+            const int centerX = p->nBlkSizeX / 2 + (p->nBlkSizeX - p->nOverlapX) * p->blkx, blkxold = (centerX - bsxOld / 2) / stepXold;
+            const int centerY = p->nBlkSizeY / 2 + (p->nBlkSizeY - p->nOverlapY) * p->blky, blkyold = (centerY - bsyOld / 2) / stepYold;
+            const int deltaX = VMAX(0, centerX - (bsxOld / 2 + stepXold * blkxold)), deltaY = VMAX(0, centerY - (bsyOld / 2 + stepYold * blkyold));
+            const int x1 = VMIN(nBlkXold - 1, VMAX(0, blkxold)), x2 = VMIN(nBlkXold - 1, VMAX(0, blkxold + 1));
+            const int y1 = VMIN(nBlkYold - 1, VMAX(0, blkyold)), y2 = VMIN(nBlkYold - 1, VMAX(0, blkyold + 1));
+            mvo_vector vo;
+            if (smooth == 1) {
+                const mvo_vector v1 = oldVec[x1 + y1 * nBlkXold], v2 = oldVec[x2 + y1 * nBlkXold], v3 = oldVec[x1 + y2 * nBlkXold], v4 = oldVec[x2 + y2 * nBlkXold];
+                const int a_x = v1.x * stepXold + deltaX * (v2.x - v1.x), a_y = v1.y * stepXold + deltaX * (v2.y - v1.y);
+                const int64_t a_s = v1.sad * stepXold + deltaX * (v2.sad - v1.sad);
+                const int b_x = v3.x * stepXold + deltaX * (v4.x - v3.x), b_y = v3.y * stepXold + deltaX * (v4.y - v3.y);
+                const int64_t b_s = v3.sad * stepXold + deltaX * (v4.sad - v3.sad);
+                vo.x = (a_x + deltaY * (b_x - a_x) / stepYold) / stepXold;
+                vo.y = (a_y + deltaY * (b_y - a_y) / stepYold) / stepXold;
+                vo.sad = (a_s + deltaY * (b_s - a_s) / stepYold) / stepXold;
+            } else {
+                const int rx = deltaX * 2 >= stepXold, ry = deltaY * 2 >= stepYold;
+                vo = oldVec[(rx ? x2 : x1) + (ry ? y2 : y1) * nBlkXold];
+            }
+            vo.x = (vo.x << p->nLogPel) >> logPelOld;
+            vo.y = (vo.y << p->nLogPel) >> logPelOld;
+            p->predictor = clip_mv(p, vo);
+            p->predictor.sad = vo.sad * (p->nBlkSizeX * p->nBlkSizeY) / (bsxOld * bsyOld);
+            p->bestMV = p->predictor;
+            if (dctmode >= 3) p->srcLuma = blk_luma(p, p->pSrc[0], p->nSrcPitch[0]);
+            const int64_t sad = full_sad(p, p->predictor.x, p->predictor.y, p->predictor.x, p->predictor.y);
+            p->bestMV.sad = sad;
+            p->nMinCost = sad;
+            if (p->bestMV.sad > thSAD) Refine(p);
+            p->vectors[p->blkIdx] = p->bestMV;
+            pBlkData[p->blkIdx] = p->bestMV;
+        }
+}
+
+/* GroupOfPlanes.c:177-302 Median3, GetMedian, gopExtraDivide (divide = 1: copies, 2: medians for the interior blocks) */
+static int median3d(int a, int b, int c) {
+    if (((b <= a) && (a <= c)) || ((c <= a) && (a <= b))) return a;
+    else if (((a <= b) && (b <= c)) || ((c <= b) && (b <= a))) return b;
+    return c;
+}
+static void get_median(int *vx, int *vy, int vx1, int vy1, int vx2, int vy2, int vx3, int vy3) {
+    *vx = median3d(vx1, vx2, vx3); *vy = median3d(vy1, vy2, vy3);
+    if ((*vx == vx1 && *vy == vy1) || (*vx == vx2 && *vy == vy2) || (*vx == vx3 && *vy == vy3)) return;
+    *vx = vx1; *vy = vy1;
+}
+static void extra_divide(int divide, int nBlkX, int nBlkY, const mvo_vector *in, mvo_vector *outv) {
+    for (int by = 0; by < nBlkY; by++)
+        for (int bx = 0; bx < nBlkX; bx++) {
+            mvo_vector b = in[by * nBlkX + bx];
+            b.sad >>= 2;
+            mvo_vector *o = outv + (size_t)by * nBlkX * 4 + bx * 2;
+            o[0] = o[1] = o[nBlkX * 2] = o[nBlkX * 2 + 1] = b;
+            if (divide > 1 && by >= 1 && by < nBlkY - 1 && bx >= 1 && bx < nBlkX - 1) {
+                const mvo_vector *c = &in[by * nBlkX + bx];
+                get_median(&o[0].x, &o[0].y, c->x, c->y, c[-1].x, c[-1].y, c[-nBlkX].x, c[-nBlkX].y);
+                get_median(&o[1].x, &o[1].y, c->x, c->y, c[1].x, c[1].y, c[-nBlkX].x, c[-nBlkX].y);
+                get_median(&o[nBlkX * 2].x, &o[nBlkX * 2].y, c->x, c->y, c[-1].x, c[-1].y, c[nBlkX].x, c[nBlkX].y);
+                get_median(&o[nBlkX * 2 + 1].x, &o[nBlkX * 2 + 1].y, c->x, c->y, c[1].x, c[1].y, c[nBlkX].x, c[nBlkX].y);
+            }
+        }
+}
+
 /* ------------------------------------------------------------------ GroupOfPlanes.c */
 
 typedef struct gop {
@@ -737,6 +844,19 @@ static void gop_write_default(gop *g, uint8_t *array) {
     for (int i = g->nLevelCount - 1; i >= 0; i--) array += pob_write_default(&g->planes[i], array, g->divideExtra);
 }
 
+/* GroupOfPlanes.c:206-302: the divided array follows plane 0's; its size header is NOT written by the reference on this
+ * path (uninitialised malloc bytes there) -- the oracle writes the value pobWriteDefaultToArray would (:1543-1547) */
+static void gop_extra_divide(gop *g, uint8_t *out) {
+    out += 2 * sizeof(int);
+    for (int i = g->nLevelCount - 1; i >= 1; i--) out += pob_array_size(&g->planes[i], 0);
+    int size;
+    memcpy(&size, out, sizeof(size));
+    const pob *p0 = &g->planes[0];
+    int dsize = (int)sizeof(int) + p0->nBlkCount * (int)sizeof(mvo_vector) * 4;
+    memcpy(out + size, &dsize, sizeof(dsize));
+    extra_divide(g->divideExtra, p0->nBlkX, p0->nBlkY, (const mvo_vector *)(out + sizeof(int)), (mvo_vector *)(out + size + sizeof(int)));
+}
+
 /* ------------------------------------------------------------------ filter shell: MVAnalyse.c */
 
 void mvo_analyse_args_default(mvo_analyse_args *a) {
@@ -790,7 +910,6 @@ int mvo_analyse_init(mvo_analyse *d, const mvo_analyse_args *a, const mvo_super 
     if (d->dctmode >= 1 && d->dctmode <= 4) FAIL("Analyse: dct 1..4 need FFTW3 (out of scope for the oracle).");
     if (d->dctmode >= 5 && ad->nBlkSizeX == 16 && ad->nBlkSizeY == 2) FAIL("Analyse: dct 5..10 cannot work with 16x2 blocks.");
     if (d->divideExtra < 0 || d->divideExtra > 2) FAIL("Analyse: divide must be between 0 and 2 (inclusive).");
-    if (d->divideExtra) FAIL("Analyse: divide is out of scope for the oracle.");
     {
         static const int ok[12][2] = { { 4, 4 }, { 8, 4 }, { 8, 8 }, { 16, 2 }, { 16, 8 }, { 16, 16 }, { 32, 16 }, { 32, 32 }, { 64, 32 }, { 64, 64 }, { 128, 64 }, { 128, 128 } };
         int found = 0;
@@ -803,8 +922,11 @@ int mvo_analyse_init(mvo_analyse *d, const mvo_analyse_args *a, const mvo_super 
     if (d->pglobal < 0 || d->pglobal > 256) FAIL("Analyse: pglobal must be between 0 and 256 (inclusive).");
     if (ad->nOverlapX < 0 || ad->nOverlapX > ad->nBlkSizeX / 2 || ad->nOverlapY < 0 || ad->nOverlapY > ad->nBlkSizeY / 2)
         FAIL("Analyse: overlap must be at most half of blksize, overlapv must be at most half of blksizev, and they both need to be at least 0.");
+    if (d->divideExtra && (ad->nBlkSizeX < 8 || ad->nBlkSizeY < 8)) FAIL("Analyse: blksize and blksizev must be at least 8 when divide=True."); /* :447 */
     if (d->searchType == SearchNstep) d->nSearchParam = (searchparam < 0) ? 0 : searchparam;
     else d->nSearchParam = (searchparam < 1) ? 1 : searchparam;
+    if (d->divideExtra && (ad->nOverlapX % (2 * s->xRatioUV) || ad->nOverlapY % (2 * s->yRatioUV))) /* :503-505 */
+        FAIL("Analyse: overlap and overlapv must be multiples of 2 or 4 when divide=True, depending on the super clip's subsampling.");
 
     if (s->gray) d->chroma = 0;
     int nModeYUV = d->chroma ? MVO_YUVPLANES : MVO_YPLANE;
@@ -870,6 +992,118 @@ void mvo_analyse_frame(const mvo_analyse *d, const uint8_t *const src[3], const 
         mvo_gof_update(&sg, (uint8_t *const *)src, srcPitch, a->yRatioUV);
         mvo_gof_update(&rg, (uint8_t *const *)ref, refPitch, a->yRatioUV);
         gop_search(&g, &sg, &rg, d, blob, fieldShift);
+        if (d->divideExtra) gop_extra_divide(&g, blob);
+    } else
+        gop_write_default(&g, blob);
+    gop_deinit(&g);
+}
+
+
+/* the analysis data a reader sees: with divide the extra level of half-size blocks (MVAnalyse.c:615-624, MVRecalculate.c:533-543) */
+void mvo_analysis_data_divided(const mvo_analysis_data *in, mvo_analysis_data *out) {
+    *out = *in;
+    out->nBlkX = in->nBlkX * 2; out->nBlkY = in->nBlkY * 2;
+    out->nBlkSizeX = in->nBlkSizeX / 2; out->nBlkSizeY = in->nBlkSizeY / 2;
+    out->nOverlapX = in->nOverlapX / 2; out->nOverlapY = in->nOverlapY / 2;
+    out->nLvCount = in->nLvCount + 1;
+}
+
+/* ------------------------------------------------------------------ filter shell: MVRecalculate.c */
+
+void mvo_recalculate_args_default(mvo_recalculate_args *a) {
+    int64_t *f = (int64_t *)a;
+    for (size_t i = 0; i < sizeof(*a) / sizeof(int64_t); i++) f[i] = MVO_UNSET;
+}
+
+/* MVRecalculate.c:263-545 mvrecalculateCreate (fields / tff not supported) */
+int mvo_recalculate_init(mvo_recalculate *d, const mvo_recalculate_args *a, const mvo_super *s, const mvo_analysis_data *vectors, char *err) {
+    memset(d, 0, sizeof(*d));
+    if (err) err[0] = 0;
+    mvo_analyse *an = &d->an;
+    mvo_analysis_data *ad = &an->ad;
+    d->thSAD = ARG(a->thsad, 200);
+    d->smooth = (int)ARG(a->smooth, 1);
+    ad->nBlkSizeX = (int)ARG(a->blksize, 8);
+    ad->nBlkSizeY = (int)ARG(a->blksizev, ad->nBlkSizeX);
+    an->searchType = (int)ARG(a->search, SearchHex2);
+    const int searchparam = (int)ARG(a->searchparam, 2);
+    an->chroma = !!ARG(a->chroma, 1);
+    const int truemotion = !!ARG(a->truemotion, 1);
+    an->nLambda = (int)ARG(a->lambda, truemotion ? (1000 * ad->nBlkSizeX * ad->nBlkSizeY / 64) : 0);
+    an->pnew = (int)ARG(a->pnew, truemotion ? 50 : 0);
+    ad->nOverlapX = (int)ARG(a->overlap, 0);
+    ad->nOverlapY = (int)ARG(a->overlapv, ad->nOverlapX);
+    an->dctmode = (int)ARG(a->dct, 0);
+    an->divideExtra = (int)ARG(a->divide, 0);
+    an->opt = 1;
+    an->meander = !!ARG(a->meander, 1);
+    if (an->searchType < 0 || an->searchType > 7) FAIL("Recalculate: search must be between 0 and 7 (inclusive).");
+    if (an->dctmode < 0 || an->dctmode > 10) FAIL("Recalculate: dct must be between 0 and 10 (inclusive).");
+    if (an->dctmode >= 1 && an->dctmode <= 4) FAIL("Recalculate: dct 1..4 need FFTW3 (out of scope for the oracle).");
+    if (an->dctmode >= 5 && ad->nBlkSizeX == 16 && ad->nBlkSizeY == 2) FAIL("Recalculate: dct 5..10 cannot work with 16x2 blocks.");
+    if (an->divideExtra < 0 || an->divideExtra > 2) FAIL("Recalculate: divide must be between 0 and 2 (inclusive).");
+    {
+        static const int ok[12][2] = { { 4, 4 }, { 8, 4 }, { 8, 8 }, { 16, 2 }, { 16, 8 }, { 16, 16 }, { 32, 16 }, { 32, 32 }, { 64, 32 }, { 64, 64 }, { 128, 64 }, { 128, 128 } };
+        int found = 0;
+        for (int i = 0; i < 12; i++) if (ad->nBlkSizeX == ok[i][0] && ad->nBlkSizeY == ok[i][1]) found = 1;
+        if (!found) FAIL("Recalculate: the block size must be 4x4, 8x4, 8x8, 16x2, 16x8, 16x16, 32x16, 32x32, 64x32, 64x64, 128x64, or 128x128.");
+    }
+    if (an->pnew < 0 || an->pnew > 256) FAIL("Recalculate: pnew must be between 0 and 256 (inclusive).");
+    if (ad->nOverlapX < 0 || ad->nOverlapX > ad->nBlkSizeX / 2 || ad->nOverlapY < 0 || ad->nOverlapY > ad->nBlkSizeY / 2)
+        FAIL("Recalculate: overlap must be at most half of blksize, overlapv must be at most half of blksizev, and they both need to be at least 0.");
+    if (an->divideExtra && (ad->nBlkSizeX < 8 || ad->nBlkSizeY < 8)) FAIL("Recalculate: blksize and blksizev must be at least 8 when divide=True.");
+    if (an->searchType == SearchNstep) an->nSearchParam = (searchparam < 0) ? 0 : searchparam;
+    else an->nSearchParam = (searchparam < 1) ? 1 : searchparam;
+    if (ad->nOverlapX % s->xRatioUV || ad->nOverlapY % s->yRatioUV) FAIL("Recalculate: The requested overlap is incompatible with the super clip's subsampling.");
+    if (an->divideExtra && (ad->nOverlapX % (2 * s->xRatioUV) || ad->nOverlapY % (2 * s->yRatioUV)))
+        FAIL("Recalculate: overlap and overlapv must be multiples of 2 or 4 when divide=True, depending on the super clip's subsampling.");
+    if (s->gray) an->chroma = 0;
+    const int nModeYUV = an->chroma ? MVO_YUVPLANES : MVO_YPLANE;
+    if ((nModeYUV & s->modeYUV) != nModeYUV) FAIL("Recalculate: super clip does not contain needed colour data.");
+    d->old = *vectors;
+    ad->yRatioUV = vectors->yRatioUV; ad->xRatioUV = vectors->xRatioUV;
+    ad->nWidth = vectors->nWidth; ad->nHeight = vectors->nHeight;
+    ad->nDeltaFrame = vectors->nDeltaFrame; ad->isBackward = vectors->isBackward;
+    ad->bitsPerSample = s->bits;
+    const int pixelMax = (1 << s->bits) - 1;
+    d->thSAD = (int64_t)((double)d->thSAD * pixelMax / 255.0 + 0.5);
+    an->nLambda = (int)((double)an->nLambda * pixelMax / 255.0 + 0.5);
+    d->thSAD = d->thSAD * (ad->nBlkSizeX * ad->nBlkSizeY) / 64;
+    if (an->chroma) d->thSAD += d->thSAD / (ad->xRatioUV * ad->yRatioUV) * 2;
+    ad->nMotionFlags = MOTION_USE_SIMD | (ad->isBackward ? MOTION_IS_BACKWARD : 0) | (an->chroma ? MOTION_USE_CHROMA_MOTION : 0);
+    ad->nPel = s->pel;
+    if (s->height != ad->nHeight || s->superWidth - 2 * s->hpad != ad->nWidth) FAIL("Recalculate: wrong frame size.");
+    ad->nHPadding = s->hpad; ad->nVPadding = s->vpad;
+    ad->nBlkX = (ad->nWidth - ad->nOverlapX) / (ad->nBlkSizeX - ad->nOverlapX);
+    ad->nBlkY = (ad->nHeight - ad->nOverlapY) / (ad->nBlkSizeY - ad->nOverlapY);
+    ad->nLvCount = 1;
+    an->nSuperLevels = s->levels; an->nSuperHPad = s->hpad; an->nSuperVPad = s->vpad; an->nSuperPel = s->pel; an->nSuperModeYUV = s->modeYUV;
+    return 0;
+}
+
+int mvo_recalculate_blob_size(const mvo_recalculate *d) { return mvo_analyse_blob_size(&d->an); }
+
+/* MVRecalculate.c:104-228: oldBlob = the old vector clip's MVTools_vectors at frame n; ref == NULL or an invalid old blob
+ * give the default (invalid) array */
+void mvo_recalculate_frame(const mvo_recalculate *d, const uint8_t *const src[3], const int srcPitch[3], const uint8_t *const ref[3], const int refPitch[3],
+                           const uint8_t *oldBlob, uint8_t *blob) {
+    gop g;
+    gop_init(&g, &d->an);
+    int valid;
+    memcpy(&valid, oldBlob + sizeof(int), sizeof(valid));
+    if (ref && valid) {
+        const mvo_analysis_data *a = &d->an.ad;
+        mvo_gof sg, rg;
+        mvo_gof_init(&sg, d->an.nSuperLevels, a->nWidth, a->nHeight, d->an.nSuperPel, d->an.nSuperHPad, d->an.nSuperVPad, d->an.nSuperModeYUV, a->xRatioUV, a->yRatioUV, a->bitsPerSample);
+        mvo_gof_init(&rg, d->an.nSuperLevels, a->nWidth, a->nHeight, d->an.nSuperPel, d->an.nSuperHPad, d->an.nSuperVPad, d->an.nSuperModeYUV, a->xRatioUV, a->yRatioUV, a->bitsPerSample);
+        mvo_gof_update(&sg, (uint8_t *const *)src, srcPitch, a->yRatioUV);
+        mvo_gof_update(&rg, (uint8_t *const *)ref, refPitch, a->yRatioUV);
+        int size = gop_array_size(&g), one = 1; /* GroupOfPlanes.c:128-147 gopRecalculateMVs */
+        memcpy(blob, &size, sizeof(size));
+        memcpy(blob + sizeof(int), &one, sizeof(one));
+        pob_recalculate(&g.planes[0], &d->old, mvo_blob_level0(&d->old, oldBlob), &sg.fr[0], &rg.fr[0], d->an.searchType, d->an.nSearchParam, d->an.nLambda, d->an.pnew,
+                        blob + 2 * sizeof(int), 0, d->thSAD, d->an.dctmode, d->smooth, d->an.meander);
+        if (d->an.divideExtra) gop_extra_divide(&g, blob);
     } else
         gop_write_default(&g, blob);
     gop_deinit(&g);

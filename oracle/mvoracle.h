@@ -87,6 +87,19 @@ int mvo_analyse_blob_size(const mvo_analyse *d);
 void mvo_analyse_frame(const mvo_analyse *d, const uint8_t *const src[3], const int srcPitch[3],
                        const uint8_t *const ref[3], const int refPitch[3], int fieldShift, uint8_t *blob);
 
+void mvo_analysis_data_divided(const mvo_analysis_data *in, mvo_analysis_data *out); /* what readers see with divide > 0 */
+
+/* ---- mv.Recalculate: MVRecalculate.c, PlaneOfBlocks.cpp:1158-1424, GroupOfPlanes.c:127-148 ---- */
+typedef struct mvo_recalculate_args { /* MVO_UNSET = not passed */
+    int64_t thsad, smooth, blksize, blksizev, search, searchparam, lambda, chroma, truemotion, pnew, overlap, overlapv, divide, meander, dct;
+} mvo_recalculate_args;
+typedef struct mvo_recalculate { mvo_analyse an; mvo_analysis_data old; int64_t thSAD; int smooth; } mvo_recalculate;
+void mvo_recalculate_args_default(mvo_recalculate_args *a);
+int mvo_recalculate_init(mvo_recalculate *d, const mvo_recalculate_args *a, const mvo_super *s, const mvo_analysis_data *vectors, char *err);
+int mvo_recalculate_blob_size(const mvo_recalculate *d);
+void mvo_recalculate_frame(const mvo_recalculate *d, const uint8_t *const src[3], const int srcPitch[3], const uint8_t *const ref[3], const int refPitch[3],
+                           const uint8_t *oldBlob, uint8_t *blob);
+
 /* ---- vector blob reader: Fakery.c, MVAnalysisData.c:7-31 ---- */
 void mvo_scale_thscd(int64_t *thscd1, int *thscd2, const mvo_analysis_data *ad);
 int mvo_blob_is_usable(const mvo_analysis_data *ad, const uint8_t *blob, int64_t thscd1, int thscd2);

@@ -217,6 +217,11 @@ class Analyse:
 
     @property
     def ad(self):
+        """the analysis data readers see (the divided geometry when divide > 0)"""
+        if self.d.divideExtra:
+            out = AnalysisData()
+            lib().mvo_analysis_data_divided(C.byref(self.d.ad), C.byref(out))
+            return out
         return self.d.ad
 
     def frame(self, src_super, ref_super, field_shift=0):
@@ -341,3 +346,52 @@ class BlockFPS:
         else:
             rc = lib().mvo_blockfps_frame(C.byref(self.d), t, None, None, None, None, None, None, lp, lpitch, rp, rpitch, dp, dpitch)
         return [p.copy() for p in L] if rc == 1 else dst
+
+
+class RecalculateArgs(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("thsad", "smooth", "blksize", "blksizev", "search", "searchparam", "lambda_", "chroma", "truemotion", "pnew", "overlap",
+                                         "overlapv", "divide", "meander", "dct")]
+
+
+class RecalculateS(C.Structure):
+    _fields_ = [("an", AnalyseS), ("old", AnalysisData), ("thSAD", C.c_int64), ("smooth", C.c_int)]
+
+
+class Recalculate:
+    """mv.Recalculate(super, vectors, thsad, smooth, blksize, ...) -- MVRecalculate.c:263-545."""
+
+    def __init__(self, sup, vectors_ad, **kw):
+        self.sup = sup
+        a = RecalculateArgs()
+        lib().mvo_recalculate_args_default(C.byref(a))
+        for k, v in kw.items():
+            k2 = {"lambda": "lambda_"}.get(k, k)
+            if k2 not in [n for n, _ in RecalculateArgs._fields_]:
+                raise TypeError("Recalculate: unknown argument " + k)
+            if v is not None:
+                setattr(a, k2, int(v))
+        self.d = RecalculateS()
+        old = AnalysisData.from_buffer_copy(bytes(vectors_ad))
+        err = C.create_string_buffer(ERRLEN)
+        if lib().mvo_recalculate_init(C.byref(self.d), C.byref(a), C.byref(sup.s), C.byref(old), err):
+            raise OracleError(err.value.decode())
+        self.blob_size = lib().mvo_recalculate_blob_size(C.byref(self.d))
+
+    @property
+    def ad(self):
+        if self.d.an.divideExtra:
+            out = AnalysisData()
+            lib().mvo_analysis_data_divided(C.byref(self.d.an.ad), C.byref(out))
+            return out
+        return self.d.an.ad
+
+    def frame(self, src_super, ref_super, old_blob):
+        blob = np.zeros(self.blob_size, dtype=np.uint8)
+        sp, spitch = _planes(src_super)
+        ob = np.ascontiguousarray(old_blob)
+        if ref_super is None:
+            lib().mvo_recalculate_frame(C.byref(self.d), sp, spitch, None, None, C.c_void_p(ob.ctypes.data), C.c_void_p(blob.ctypes.data))
+        else:
+            rp, rpitch = _planes(ref_super)
+            lib().mvo_recalculate_frame(C.byref(self.d), sp, spitch, rp, rpitch, C.c_void_p(ob.ctypes.data), C.c_void_p(blob.ctypes.data))
+        return blob

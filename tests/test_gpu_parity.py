@@ -435,3 +435,80 @@ def test_blockfps_parity(oracle, mv, w, h, bits, akw, bkw):
             got = out[n][p].cpu().numpy()
             got = (got.view(np.uint16) if bits > 8 else got)[:, :want[p].shape[1]]
             assert np.array_equal(got, want[p]), (n, p, gb.map(n), int(np.count_nonzero(got != want[p])))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits,akw", [(8, dict(blksize=16, overlap=8, divide=1)), (8, dict(blksize=16, overlap=8, divide=2)), (16, dict(blksize=8, overlap=4, divide=2)),
+                                      (8, dict(blksize=16, overlap=0, divide=2))])
+def test_analyse_divide_parity_and_degrain_on_divided_vectors(oracle, mv, bits, akw):
+    """divide = 1 / 2 (GroupOfPlanes.c:206-302): blob with the extra array of half-size blocks, the divided analysis data, and a
+    Degrain that reads such a vector clip (readers find level 0 by walking the plane size headers)."""
+    import torch
+    w, h, nf = 192, 128, 3
+    frames, osup, gsup, osf, gsrc, gsf = _pipeline(oracle, mv, w, h, bits, 1, {}, {}, nframes=nf, seed=51)
+    oan = {isb: oracle.Analyse(osup, num_frames=nf, isb=isb, **akw) for isb in (1, 0)}
+    gan = {isb: mv.Analyse(gsup, num_frames=nf, isb=isb, **akw) for isb in (1, 0)}
+    for k, _ in oracle.AnalysisData._fields_:
+        if k not in ("nMagicKey", "nVersion", "nCPUFlags"):
+            assert getattr(gan[1].ad, k) == getattr(oan[1].ad, k), k
+    assert gan[1].blob_size == oan[1].blob_size
+    want = {1: oan[1].frame(osf[1], osf[2]), 0: oan[0].frame(osf[1], osf[0])}
+    got = {1: gan[1].run([(gsf[1], gsf[2])])[0], 0: gan[0].run([(gsf[1], gsf[0])])[0]}
+    inval_w, inval_g = oan[1].frame(osf[2], None), gan[1].run([(gsf[2], None)])[0]
+    torch.cuda.synchronize()
+    for isb in (1, 0):
+        assert np.array_equal(got[isb].cpu().numpy(), want[isb]), isb
+    assert np.array_equal(inval_g.cpu().numpy(), inval_w)
+    odg = oracle.Degrain(1, osup, oan[1].ad)
+    gdg = mv.Degrain(1, gsup, gan[1].ad, [p.stride(0) for p in gsrc[0]])
+    wout = odg.frame(frames[1], [osf[2], osf[0]], [want[1], want[0]])
+    gout = gdg.run([(gsrc[1], [gsf[2], gsf[0]], [got[1], got[0]])])[0]
+    for p in range(3):
+        g = gout[p].cpu().numpy()
+        g = (g.view(np.uint16) if bits > 8 else g)[:, :wout[p].shape[1]]
+        assert np.array_equal(g, wout[p]), p
+
+
+RECALC_CASES = [
+    # bits, old analyse kwargs, recalculate kwargs
+    (8, dict(blksize=16, overlap=8), dict(blksize=8, overlap=4, thsad=100)),
+    (16, dict(blksize=16, overlap=8), dict(blksize=8, overlap=4, thsad=100)),
+    (8, dict(blksize=16, overlap=8), dict(blksize=8, overlap=4, thsad=50, smooth=0)),
+    (8, dict(blksize=16, overlap=0), dict(blksize=8, overlap=2, thsad=0, search=3, searchparam=2)),
+    (8, dict(blksize=8, overlap=4), dict(blksize=16, overlap=8, thsad=80, search=5, searchparam=4)),
+    (8, dict(blksize=16, overlap=8), dict(blksize=8, overlap=4, thsad=60, search=0, searchparam=4)),
+    (8, dict(blksize=16, overlap=8), dict(blksize=8, overlap=4, thsad=60, search=1, searchparam=3)),
+    (8, dict(blksize=16, overlap=8), dict(blksize=8, overlap=4, thsad=60, search=2, searchparam=4)),
+    (8, dict(blksize=16, overlap=8), dict(blksize=8, overlap=4, thsad=60, search=6, searchparam=3)),
+    (8, dict(blksize=16, overlap=8), dict(blksize=8, overlap=4, thsad=60, search=7, searchparam=3)),
+    (8, dict(blksize=16, overlap=8), dict(blksize=8, overlap=4, thsad=100, chroma=0, truemotion=0)),
+    (8, dict(blksize=16, overlap=8), dict(blksize=8, overlap=4, thsad=100, divide=2)),
+    (8, dict(blksize=16, overlap=8), dict(blksize=8, overlap=4, thsad=100, dct=5)),
+    (16, dict(blksize=16, overlap=8), dict(blksize=8, overlap=4, thsad=100, dct=6)),
+    (8, dict(blksize=16, overlap=8), dict(blksize=8, overlap=4, thsad=100, dct=7)),
+    (8, dict(blksize=16, overlap=8, divide=2), dict(blksize=8, overlap=4, thsad=100)),   # refining a divided clip
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits,akw,rkw", RECALC_CASES)
+def test_recalculate_parity(oracle, mv, bits, akw, rkw):
+    import torch
+    w, h, nf = 192, 128, 3
+    frames, osup, gsup, osf, gsrc, gsf = _pipeline(oracle, mv, w, h, bits, 1, dict(pel=2), {}, nframes=nf, seed=53)
+    oan = oracle.Analyse(osup, num_frames=nf, isb=1, **akw)
+    gan = mv.Analyse(gsup, num_frames=nf, isb=1, **akw)
+    oold = [oan.frame(osf[n], osf[n + 1] if n + 1 < nf else None) for n in range(nf)]
+    gold = gan.run([(gsf[n], gsf[n + 1] if n + 1 < nf else None) for n in range(nf)])
+    orc = oracle.Recalculate(osup, oan.ad, **rkw)
+    grc = mv.Recalculate(gsup, gan.ad, **rkw)
+    assert grc.blob_size == orc.blob_size
+    for k, _ in oracle.AnalysisData._fields_:
+        if k not in ("nMagicKey", "nVersion", "nCPUFlags"):
+            assert getattr(grc.ad, k) == getattr(orc.ad, k), k
+    got = grc.run([(gsf[n], gsf[n + 1] if n + 1 < nf else None, gold[n]) for n in range(nf)])
+    torch.cuda.synchronize()
+    for n in range(nf):
+        want = orc.frame(osf[n], osf[n + 1] if n + 1 < nf else None, oold[n])
+        g = got[n].cpu().numpy()
+        assert np.array_equal(g, want), (n, int(np.count_nonzero(g != want)))

@@ -86,8 +86,9 @@ def test_unimplemented_modes_fail_loudly(mv):
     sup = mv.Super(640, 360, 8)
     with pytest.raises(mv.MvtoolsError):
         mv.Analyse(sup, dct=1)  # FFTW DCT cost modes 1..4
+    rc = mv.Recalculate
     with pytest.raises(mv.MvtoolsError):
-        mv.Analyse(sup, divide=1)
+        rc(sup, mv.Analyse(sup).ad, dct=3)
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(thsad=200, thsadc=100, plane=0), dict(limit=5, limitc=7), dict(thscd1=300, thscd2=90),

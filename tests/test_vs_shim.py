@@ -38,6 +38,9 @@ EXPECTED = {
                "chroma:int:opt;delta:int:opt;truemotion:int:opt;lsad:int:opt;plevel:int:opt;global:int:opt;pnew:int:opt;pzero:int:opt;pglobal:int:opt;"
                "overlap:int:opt;overlapv:int:opt;divide:int:opt;badsad:int:opt;badrange:int:opt;opt:int:opt;meander:int:opt;trymany:int:opt;fields:int:opt;"
                "tff:int:opt;search_coarse:int:opt;dct:int:opt;",
+    "Recalculate": "super:vnode;vectors:vnode;thsad:int:opt;smooth:int:opt;blksize:int:opt;blksizev:int:opt;search:int:opt;searchparam:int:opt;lambda:int:opt;"
+                   "chroma:int:opt;truemotion:int:opt;pnew:int:opt;overlap:int:opt;overlapv:int:opt;divide:int:opt;opt:int:opt;meander:int:opt;fields:int:opt;"
+                   "tff:int:opt;dct:int:opt;",
     "BlockFPS": "clip:vnode;super:vnode;mvbw:vnode;mvfw:vnode;num:int:opt;den:int:opt;mode:int:opt;ml:float:opt;blend:int:opt;thscd1:int:opt;thscd2:int:opt;opt:int:opt;",
     "Compensate": "clip:vnode;super:vnode;vectors:vnode;scbehavior:int:opt;thsad:int:opt;fields:int:opt;time:float:opt;thscd1:int:opt;thscd2:int:opt;opt:int:opt;tff:int:opt;",
 }
@@ -221,3 +224,32 @@ def test_shell_blockfps_matches_oracle(oracle, tmp_path, bits, bargs):
         want = ob.frame(n, frames, osf, bbw, bfw)
         for p in range(3):
             assert np.array_equal(got[n][p], want[p][:, :got[n][p].shape[1]]), (n, p, ob.map(n))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits,aargs,rargs,dargs", [(8, dict(blksize=16, overlap=8), dict(blksize=8, overlap=4, thsad=100), {}),
+                                                    (16, dict(blksize=16, overlap=8, divide=2), dict(blksize=8, overlap=4, thsad=60, divide=1), {})])
+def test_shell_recalculate_and_divide_match_oracle(oracle, tmp_path, bits, aargs, rargs, dargs):
+    w, h, nf = 192, 128, 3
+    frames = pl.moving_clip(w, h, bits, nf, seed=39, noise=3)
+    src = tmp_path / "in.raw"
+    _write_clip(src, frames)
+    host("run", "recalculate", src, w, h, bits, nf, tmp_path / "vec.raw", *["a.%s=%s" % kv for kv in aargs.items()], *["r.%s=%s" % kv for kv in rargs.items()])
+    blob = np.fromfile(tmp_path / "vec.raw", dtype=np.uint8)
+    osup = oracle.Super(w, h, bits)
+    osf = [osup.frame(f) for f in frames]
+    off = 0
+    keep = [i for i, (k, _) in enumerate(oracle.AnalysisData._fields_) if k not in ("nMagicKey", "nVersion", "nCPUFlags")]
+    for n in range(nf):
+        for isb in (1, 0):
+            oan = oracle.Analyse(osup, num_frames=nf, isb=isb, delta=1, **aargs)
+            nref = n + 1 if isb else n - 1
+            ref = osf[nref] if 0 <= nref < nf else None
+            orc = oracle.Recalculate(osup, oan.ad, **rargs)
+            want = orc.frame(osf[n], ref, oan.frame(osf[n], ref))
+            ad = np.frombuffer(bytes(orc.ad), dtype=np.int32)
+            assert np.array_equal(blob[off:off + 84].view(np.int32)[keep], ad[keep])
+            off += 84
+            assert np.array_equal(blob[off:off + want.size], want), (n, isb)
+            off += want.size
+    assert off == blob.size

@@ -20,6 +20,56 @@ extern "C" __attribute__((visibility("default"))) const char *mvx_last_error(voi
 static int A(int v, int d) { return v == MVX_UNSET ? d : v; }
 
 // MVAnalyse.c:267-635 mvanalyseCreate
+// MVAnalyse.c:615-624 / MVRecalculate.c:533-543: the geometry readers see when divide > 0
+void mvx_divided_data(const mvx_analysis_data *in, mvx_analysis_data *out) {
+    *out = *in;
+    out->nBlkX = in->nBlkX * 2; out->nBlkY = in->nBlkY * 2;
+    out->nBlkSizeX = in->nBlkSizeX / 2; out->nBlkSizeY = in->nBlkSizeY / 2;
+    out->nOverlapX = in->nOverlapX / 2; out->nOverlapY = in->nOverlapY / 2;
+    out->nLvCount = in->nLvCount + 1;
+}
+
+// GroupOfPlanes.c:177-302 Median3 / GetMedian / gopExtraDivide.  One thread per block of the finest estimated plane writes its
+// four sub-blocks; invalid blobs get the default vector (PlaneOfBlocks.cpp:1543-1553).  Also writes the divided array's size
+// header, which the reference leaves uninitialised on the search path.
+__device__ __forceinline__ int mvx_median3(int a, int b, int c) {
+    if (((b <= a) && (a <= c)) || ((c <= a) && (a <= b))) return a;
+    if (((a <= b) && (b <= c)) || ((c <= b) && (b <= a))) return b;
+    return c;
+}
+__device__ __forceinline__ void mvx_get_median(GVec &o, const GVec &v1, const GVec &v2, const GVec &v3) {
+    int vx = mvx_median3(v1.x, v2.x, v3.x), vy = mvx_median3(v1.y, v2.y, v3.y);
+    if (!((vx == v1.x && vy == v1.y) || (vx == v2.x && vy == v2.y) || (vx == v3.x && vy == v3.y))) { vx = v1.x; vy = v1.y; }
+    o.x = vx; o.y = vy;
+}
+__global__ __launch_bounds__(256) void analyse_divide_kernel(const AParams *Pp, const AJob *jobs) {
+    const AParams &P = *Pp;
+    unsigned char *blob = jobs[blockIdx.y].blob;
+    const int valid = ((const int *)blob)[1];
+    const int nBlkX = P.lv[0].nBlkX, nBlkY = P.lv[0].nBlkY, nBlk = nBlkX * nBlkY;
+    unsigned char *rec0 = blob + P.lv[0].blobOff;
+    const GVec *in = (const GVec *)(rec0 + 4);
+    unsigned char *hdr = rec0 + 4 + nBlk * 16;
+    GVec *out = (GVec *)(hdr + 4);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) *(int *)hdr = 4 + nBlk * 64;
+    if (i >= nBlk) return;
+    const int by = i / nBlkX, bx = i - by * nBlkX;
+    GVec b[4];
+    if (!valid) { for (int k = 0; k < 4; k++) { b[k].x = 0; b[k].y = 0; b[k].sad = P.verybigSAD; } }
+    else {
+        GVec c = in[i];
+        GVec s = c; s.sad >>= 2;
+        b[0] = b[1] = b[2] = b[3] = s;
+        if (P.divide > 1 && by >= 1 && by < nBlkY - 1 && bx >= 1 && bx < nBlkX - 1) {
+            const GVec l = in[i - 1], r = in[i + 1], u = in[i - nBlkX], d = in[i + nBlkX];
+            mvx_get_median(b[0], c, l, u); mvx_get_median(b[1], c, r, u); mvx_get_median(b[2], c, l, d); mvx_get_median(b[3], c, r, d);
+        }
+    }
+    GVec *o = out + (size_t)by * nBlkX * 4 + bx * 2;
+    o[0] = b[0]; o[1] = b[1]; o[nBlkX * 2] = b[2]; o[nBlkX * 2 + 1] = b[3];
+}
+
 extern "C" __attribute__((visibility("default"))) int mvx_analyse_create(const mvx_analyse_args *a, const mvx_super *sup, int num_frames, const ptrdiff_t super_pitch[3],
                                   mvx_analyse **out, char *err) {
     char dummy[MVX_ERRLEN];
@@ -65,7 +115,6 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_create(const m
     if (P.dctmode >= 5 && ad.nBlkSizeX == 16 && ad.nBlkSizeY == 2) AFAIL("Analyse: dct 5..10 cannot work with 16x2 blocks.");
     if (P.dctmode >= 1 && P.dctmode <= 4) AFAIL("Analyse: dct 1..4 (FFTW3 DCT cost) are not implemented on the GPU path.");
     if (divide < 0 || divide > 2) AFAIL("Analyse: divide must be between 0 and 2 (inclusive).");
-    if (divide) AFAIL("Analyse: divide is not implemented on the GPU path yet.");
     {
         static const int okb[12][2] = { { 4, 4 }, { 8, 4 }, { 8, 8 }, { 16, 2 }, { 16, 8 }, { 16, 16 }, { 32, 16 }, { 32, 32 }, { 64, 32 }, { 64, 64 }, { 128, 64 }, { 128, 128 } };
         bool found = false;
@@ -78,6 +127,9 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_create(const m
     if (P.pglobal < 0 || P.pglobal > 256) AFAIL("Analyse: pglobal must be between 0 and 256 (inclusive).");
     if (ad.nOverlapX < 0 || ad.nOverlapX > ad.nBlkSizeX / 2 || ad.nOverlapY < 0 || ad.nOverlapY > ad.nBlkSizeY / 2)
         AFAIL("Analyse: overlap must be at most half of blksize, overlapv must be at most half of blksizev, and they both need to be at least 0.");
+    if (divide && (ad.nBlkSizeX < 8 || ad.nBlkSizeY < 8)) AFAIL("Analyse: blksize and blksizev must be at least 8 when divide=True."); // :447
+    if (divide && (ad.nOverlapX % (2 * si.xRatioUV) || ad.nOverlapY % (2 * si.yRatioUV)))                                                    // :503-505
+        AFAIL("Analyse: overlap and overlapv must be multiples of 2 or 4 when divide=True, depending on the super clip's subsampling.");
     if (P.searchType == SearchNstep) P.nSearchParam = searchparam < 0 ? 0 : searchparam;
     else P.nSearchParam = searchparam < 1 ? 1 : searchparam;
 
@@ -149,10 +201,14 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_create(const m
         L.blobOff = blobOff;
         blobOff += 4 + L.nBlkX * L.nBlkY * 16;
     }
+    P.divide = divide;
+    if (divide) blobOff += 4 + P.lv[0].nBlkX * P.lv[0].nBlkY * 16 * 4; // PlaneOfBlocks.cpp:1517-1526
     P.blobSize = blobOff;
 
     mvx_analyse *h = new mvx_analyse();
     h->ad = ad;
+    h->adOut = ad;
+    if (divide) mvx_divided_data(&ad, &h->adOut);
     h->P = P;
     *out = h; // device state is created on first use so that argument validation works without a GPU
     return MVX_OK;
@@ -164,7 +220,7 @@ extern "C" __attribute__((visibility("default"))) void mvx_analyse_destroy(mvx_a
     if (a->dJobs) (void)hipFree(a->dJobs);
     delete a;
 }
-extern "C" __attribute__((visibility("default"))) void mvx_analyse_get_data(const mvx_analyse *a, mvx_analysis_data *out) { *out = a->ad; }
+extern "C" __attribute__((visibility("default"))) void mvx_analyse_get_data(const mvx_analyse *a, mvx_analysis_data *out) { *out = a->adOut; }
 extern "C" __attribute__((visibility("default"))) int mvx_analyse_blob_size(const mvx_analyse *a) { return a->P.blobSize; }
 
 extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_analyse *a, int njobs, const mvx_analyse_job *jobs, void *stream) {
@@ -225,6 +281,177 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
     int rc = P.dctmode != 0 ? 1 : P.bps == 1 ? mvx_analyse_launch_u8(P, L) : mvx_analyse_launch_u16(P, L); // specialised 4:2:0 geometries (SAD cost only)
     if (rc == 1) rc = mvx_analyse_launch_any(P, L);                                     // everything else
     if (rc) return rc;
+    if (P.divide) hipLaunchKernelGGL(analyse_divide_kernel, dim3((P.lv[0].nBlkX * P.lv[0].nBlkY + 255) / 256, njobs), dim3(256), 0, st, a->dP, a->dJobs);
+    HIP_CHECK(hipGetLastError());
+    return MVX_OK;
+}
+
+// ================================================================================================ mv.Recalculate
+// MVRecalculate.c:263-545 (creation), :104-228 (frame); GroupOfPlanes.c:127-148; PlaneOfBlocks.cpp:1158-1424
+
+struct mvx_recalculate {
+    mvx_analysis_data ad, adOut, old;
+    AParams P;
+    RParams R;
+    AParams *dP = nullptr;
+    RParams *dR = nullptr;
+    AJob *dJobs = nullptr;
+    size_t jobsCap = 0;
+};
+
+#define RFAIL(...) do { snprintf(err, MVX_ERRLEN, __VA_ARGS__); mvx_set_error("%s", err); return MVX_E_ARG; } while (0)
+
+extern "C" __attribute__((visibility("default"))) int mvx_recalculate_create(const mvx_recalculate_args *a, const mvx_super *sup, const mvx_analysis_data *vectors,
+                                                                             const ptrdiff_t super_pitch[3], mvx_recalculate **out, char *err) {
+    char dummy[MVX_ERRLEN];
+    if (!err) err = dummy;
+    err[0] = 0;
+    *out = nullptr;
+    const mvx_super_info &si = sup->info;
+    auto A64 = [](int64_t v, int64_t d) { return v == MVX_UNSET ? d : v; };
+    mvx_analysis_data ad;
+    memset(&ad, 0, sizeof(ad));
+    AParams P;
+    memset(&P, 0, sizeof(P));
+    long long thSAD = A64(a->thsad, 200);
+    const int smooth = (int)A64(a->smooth, 1);
+    ad.nBlkSizeX = (int)A64(a->blksize, 8);
+    ad.nBlkSizeY = (int)A64(a->blksizev, ad.nBlkSizeX);
+    P.searchType = (int)A64(a->search, SearchHex2);
+    const int searchparam = (int)A64(a->searchparam, 2);
+    int chroma = !!A64(a->chroma, 1);
+    const int truemotion = !!A64(a->truemotion, 1);
+    int nLambda = (int)A64(a->lambda, truemotion ? (1000 * ad.nBlkSizeX * ad.nBlkSizeY / 64) : 0);
+    P.pnew = (int)A64(a->pnew, truemotion ? 50 : 0);
+    ad.nOverlapX = (int)A64(a->overlap, 0);
+    ad.nOverlapY = (int)A64(a->overlapv, ad.nOverlapX);
+    P.dctmode = (int)A64(a->dct, 0);
+    const int divide = (int)A64(a->divide, 0);
+    P.meander = !!A64(a->meander, 1);
+    if (A64(a->fields, 0)) RFAIL("Recalculate: fields=True is not supported by the MI355X build.");
+    if (P.searchType < 0 || P.searchType > 7) RFAIL("Recalculate: search must be between 0 and 7 (inclusive).");
+    if (P.dctmode < 0 || P.dctmode > 10) RFAIL("Recalculate: dct must be between 0 and 10 (inclusive).");
+    if (P.dctmode >= 5 && ad.nBlkSizeX == 16 && ad.nBlkSizeY == 2) RFAIL("Recalculate: dct 5..10 cannot work with 16x2 blocks.");
+    if (P.dctmode >= 1 && P.dctmode <= 4) RFAIL("Recalculate: dct 1..4 (FFTW3 DCT cost) are not implemented on the GPU path.");
+    if (divide < 0 || divide > 2) RFAIL("Recalculate: divide must be between 0 and 2 (inclusive).");
+    {
+        static const int okb[12][2] = { { 4, 4 }, { 8, 4 }, { 8, 8 }, { 16, 2 }, { 16, 8 }, { 16, 16 }, { 32, 16 }, { 32, 32 }, { 64, 32 }, { 64, 64 }, { 128, 64 }, { 128, 128 } };
+        bool found = false;
+        for (auto &b : okb) found |= (ad.nBlkSizeX == b[0] && ad.nBlkSizeY == b[1]);
+        if (!found) RFAIL("Recalculate: the block size must be 4x4, 8x4, 8x8, 16x2, 16x8, 16x16, 32x16, 32x32, 64x32, 64x64, 128x64, or 128x128.");
+    }
+    if (P.pnew < 0 || P.pnew > 256) RFAIL("Recalculate: pnew must be between 0 and 256 (inclusive).");
+    if (ad.nOverlapX < 0 || ad.nOverlapX > ad.nBlkSizeX / 2 || ad.nOverlapY < 0 || ad.nOverlapY > ad.nBlkSizeY / 2)
+        RFAIL("Recalculate: overlap must be at most half of blksize, overlapv must be at most half of blksizev, and they both need to be at least 0.");
+    if (divide && (ad.nBlkSizeX < 8 || ad.nBlkSizeY < 8)) RFAIL("Recalculate: blksize and blksizev must be at least 8 when divide=True.");
+    if (P.searchType == SearchNstep) P.nSearchParam = searchparam < 0 ? 0 : searchparam;
+    else P.nSearchParam = searchparam < 1 ? 1 : searchparam;
+    if (ad.nOverlapX % si.xRatioUV || ad.nOverlapY % si.yRatioUV) RFAIL("Recalculate: The requested overlap is incompatible with the super clip's subsampling.");
+    if (divide && (ad.nOverlapX % (2 * si.xRatioUV) || ad.nOverlapY % (2 * si.yRatioUV)))
+        RFAIL("Recalculate: overlap and overlapv must be multiples of 2 or 4 when divide=True, depending on the super clip's subsampling.");
+    if (si.gray) chroma = 0;
+    const int nModeYUV = chroma ? 7 : 1;
+    if ((nModeYUV & si.modeYUV) != nModeYUV) RFAIL("Recalculate: super clip does not contain needed colour data.");
+    ad.yRatioUV = vectors->yRatioUV; ad.xRatioUV = vectors->xRatioUV;
+    ad.nWidth = vectors->nWidth; ad.nHeight = vectors->nHeight;
+    ad.nDeltaFrame = vectors->nDeltaFrame; ad.isBackward = vectors->isBackward;
+    ad.bitsPerSample = si.bits;
+    const int pixelMax = (1 << si.bits) - 1;
+    thSAD = (long long)((double)thSAD * pixelMax / 255.0 + 0.5);
+    nLambda = (int)((double)nLambda * pixelMax / 255.0 + 0.5);
+    thSAD = thSAD * (ad.nBlkSizeX * ad.nBlkSizeY) / 64;
+    if (chroma) thSAD += thSAD / (ad.xRatioUV * ad.yRatioUV) * 2;
+    ad.nMotionFlags = MOTION_USE_SIMD | (ad.isBackward ? MOTION_IS_BACKWARD : 0) | (chroma ? MOTION_USE_CHROMA_MOTION : 0);
+    ad.nPel = si.pel;
+    if (si.height != ad.nHeight || si.super_width - 2 * si.hpad != ad.nWidth) RFAIL("Recalculate: wrong frame size.");
+    if (ad.xRatioUV != si.xRatioUV || ad.yRatioUV != si.yRatioUV) RFAIL("Recalculate: wrong frame size.");
+    ad.nHPadding = si.hpad; ad.nVPadding = si.vpad;
+    ad.nBlkX = (ad.nWidth - ad.nOverlapX) / (ad.nBlkSizeX - ad.nOverlapX);
+    ad.nBlkY = (ad.nHeight - ad.nOverlapY) / (ad.nBlkSizeY - ad.nOverlapY);
+    ad.nLvCount = 1;
+
+    P.nLevels = 1;
+    P.blkX = ad.nBlkSizeX; P.blkY = ad.nBlkSizeY; P.ovX = ad.nOverlapX; P.ovY = ad.nOverlapY;
+    P.xr = si.xRatioUV; P.yr = si.yRatioUV; P.logxr = mvx_ilog2(P.xr); P.logyr = mvx_ilog2(P.yr);
+    P.bits = si.bits; P.bps = (si.bits + 7) / 8; P.chroma = chroma;
+    P.lambda = nLambda;
+    P.verybigSAD = (long long)P.blkX * P.blkY * (1 << si.bits);
+    P.superHPad = si.hpad; P.superVPad = si.vpad;
+    for (int p = 0; p < 3; p++) P.pitch[p] = p < si.num_planes ? super_pitch[p] : 0;
+    if (si.num_planes > 1 && super_pitch[1] != super_pitch[2]) RFAIL("Recalculate: the U and V planes of the super clip must share one pitch.");
+    {
+        ALevel &L = P.lv[0];
+        L.nBlkX = ad.nBlkX; L.nBlkY = ad.nBlkY; L.pel = ad.nPel; L.logPel = mvx_ilog2(L.pel);
+        LevelPlane y, c;
+        mvx_level_plane(si, 0, 0, P.pitch[0], &y);
+        L.pw = y.pw; L.ph = y.ph; L.hpad = y.hpad; L.vpad = y.vpad;
+        L.off[0] = y.off; L.pstride[0] = P.pitch[0] * y.ph;
+        if (si.num_planes > 1) {
+            mvx_level_plane(si, 0, 1, P.pitch[1], &c);
+            L.cpw = c.pw; L.cph = c.ph; L.chpad = c.hpad; L.cvpad = c.vpad;
+            L.off[1] = c.off; L.pstride[1] = P.pitch[1] * c.ph;
+            mvx_level_plane(si, 0, 2, P.pitch[2], &c);
+            L.off[2] = c.off; L.pstride[2] = P.pitch[2] * c.ph;
+        }
+        L.blobOff = 8;
+    }
+    P.divide = divide;
+    P.blobSize = 8 + 4 + ad.nBlkX * ad.nBlkY * 16 + (divide ? 4 + ad.nBlkX * ad.nBlkY * 64 : 0);
+    mvx_recalculate *h = new mvx_recalculate();
+    h->ad = ad; h->adOut = ad; h->old = *vectors; h->P = P;
+    if (divide) mvx_divided_data(&ad, &h->adOut);
+    RParams &R = h->R;
+    R.nBlkX = vectors->nBlkX; R.nBlkY = vectors->nBlkY; R.blkX = vectors->nBlkSizeX; R.blkY = vectors->nBlkSizeY;
+    R.stepX = vectors->nBlkSizeX - vectors->nOverlapX; R.stepY = vectors->nBlkSizeY - vectors->nOverlapY;
+    R.logPel = mvx_ilog2(vectors->nPel); R.nLvCount = vectors->nLvCount;
+    R.thSAD = thSAD; R.smooth = smooth;
+    *out = h;
+    return MVX_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) void mvx_recalculate_destroy(mvx_recalculate *r) {
+    if (!r) return;
+    if (r->dP) (void)hipFree(r->dP);
+    if (r->dR) (void)hipFree(r->dR);
+    if (r->dJobs) (void)hipFree(r->dJobs);
+    delete r;
+}
+extern "C" __attribute__((visibility("default"))) void mvx_recalculate_get_data(const mvx_recalculate *r, mvx_analysis_data *out) { *out = r->adOut; }
+extern "C" __attribute__((visibility("default"))) int mvx_recalculate_blob_size(const mvx_recalculate *r) { return r->P.blobSize; }
+
+extern "C" __attribute__((visibility("default"))) int mvx_recalculate_frames(mvx_recalculate *r, int njobs, const mvx_recalculate_job *jobs, void *stream) {
+    if (njobs <= 0) return MVX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const AParams &P = r->P;
+    if (!r->dP) {
+        HIP_CHECK(hipMalloc((void **)&r->dP, sizeof(AParams)));
+        HIP_CHECK(hipMemcpy(r->dP, &P, sizeof(AParams), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMalloc((void **)&r->dR, sizeof(RParams)));
+        HIP_CHECK(hipMemcpy(r->dR, &r->R, sizeof(RParams), hipMemcpyHostToDevice));
+    }
+    if ((size_t)njobs > r->jobsCap) {
+        if (r->dJobs) (void)hipFree(r->dJobs);
+        r->jobsCap = (size_t)njobs * 2;
+        HIP_CHECK(hipMalloc((void **)&r->dJobs, r->jobsCap * sizeof(AJob)));
+    }
+    std::vector<AJob> hj(njobs);
+    for (int i = 0; i < njobs; i++) {
+        for (int p = 0; p < 3; p++) { hj[i].src[p] = (const unsigned char *)jobs[i].src[p]; hj[i].ref[p] = (const unsigned char *)jobs[i].ref[p]; }
+        hj[i].blob = (unsigned char *)jobs[i].blob;
+        hj[i].oldBlob = (const unsigned char *)jobs[i].old_blob;
+        hj[i].fieldShift = 0;
+        hj[i].valid = jobs[i].ref[0] != nullptr;
+        if (!hj[i].oldBlob) { mvx_set_error("mvx_recalculate_frames: old_blob is required"); return MVX_E_ARG; }
+        if ((((uintptr_t)jobs[i].blob) & 15) || (((uintptr_t)jobs[i].old_blob) & 15)) { mvx_set_error("mvx_recalculate_frames: blobs must be 16-byte aligned"); return MVX_E_ARG; }
+    }
+    HIP_CHECK(hipMemcpyAsync(r->dJobs, hj.data(), sizeof(AJob) * njobs, hipMemcpyHostToDevice, st));
+    int srcBytes = P.blkX * P.blkY * P.bps;
+    if (P.chroma) srcBytes += 2 * (P.blkX / P.xr) * (P.blkY / P.yr) * P.bps;
+    const int ldsRow = (srcBytes + 15) & ~15; // only the source block lives in LDS here
+    RLaunch L = { njobs, P.lv[0].nBlkX * P.lv[0].nBlkY, ldsRow + 64, ldsRow, ldsRow, 0, st, r->dP, r->dR, r->dJobs };
+    int rc = mvx_recalc_launch(P, L);
+    if (rc) return rc;
+    if (P.divide) hipLaunchKernelGGL(analyse_divide_kernel, dim3((L.nBlk + 255) / 256, njobs), dim3(256), 0, st, r->dP, r->dJobs);
     HIP_CHECK(hipGetLastError());
     return MVX_OK;
 }

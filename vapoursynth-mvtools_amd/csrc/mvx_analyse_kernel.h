@@ -42,6 +42,7 @@ struct AParams {
     int blkX, blkY, ovX, ovY, xr, yr, logxr, logyr, bps, bits, chroma;
     int searchType, searchTypeCoarse, nSearchParam, nPelSearch, lambda, lsad, pnew, plevel, global, pglobal, pzero;
     int badrange, meander, tryMany, dctmode;
+    int divide; // 0, or 1 / 2: an extra array of half-size blocks follows the finest plane (GroupOfPlanes.c:206-302)
     long long badSAD;
     long long verybigSAD;
     long long pitch[3];
@@ -56,9 +57,18 @@ struct AJob {
     const unsigned char *ref[3];
     unsigned char *blob;
     int fieldShift, valid;
+    const unsigned char *oldBlob; // mv.Recalculate only: MVTools_vectors of the clip being refined, at the same frame
+};
+
+// mv.Recalculate: geometry of the OLD vector field and the refinement threshold (MVRecalculate.c, PlaneOfBlocks.cpp:1158-1424)
+struct RParams {
+    int nBlkX, nBlkY, blkX, blkY, stepX, stepY, logPel, nLvCount;
+    long long thSAD;
+    int smooth;
 };
 
 struct mvx_analyse {
+    mvx_analysis_data adOut; // what mvx_analyse_get_data reports: the divided geometry when divide > 0 (MVAnalyse.c:229, :615-624)
     mvx_analysis_data ad;
     AParams P;
     AParams *dP = nullptr;
@@ -698,6 +708,22 @@ template <int BPS, typename GEO> struct Searcher {
         return (unsigned)sad;
     }
 
+    // SATD cost modes: the luma term of a candidate (group total aL) becomes a mix of SAD and SATD (:117-203)
+    __device__ __forceinline__ unsigned apply_dct(bool ok, int s, int logG, int vx, int vy, unsigned aL) const {
+        bool hit = false, want = satd_wanted_always();
+        if (dctmode == 7 || dctmode == 8 || dctmode == 10) {
+            unsigned rl = 0;
+            if (ok) rl = eval_luma_ref(s, logG, vx, vy);
+            rl = group_sum(rl, logG);
+            hit = satd_by_luma((int)rl);
+            want = hit;
+        }
+        unsigned sd = 0;
+        if (ok && want) sd = eval_satd(s, logG, vx, vy);
+        sd = group_sum(sd, logG);
+        return luma_cost(aL, sd, hit);
+    }
+
     // partial SADs of this lane's share (items s, s+G, ...) of one candidate
     __device__ __forceinline__ void eval_cand(int s, int logG, int vx, int vy, int vyc, unsigned &aL, unsigned &aC) const {
         if (GEO::BW != 0) {
@@ -767,20 +793,7 @@ template <int BPS, typename GEO> struct Searcher {
             const long long pt1 = PROF_T();
             aL = group_sum(aL, logG);
             aC = group_sum(aC, logG);
-            if (GEO::DCT && dctmode != 0) { // SATD cost modes: the luma term becomes a mix of SAD and SATD (:117-203)
-                bool hit = false, want = satd_wanted_always();
-                if (dctmode == 7 || dctmode == 8 || dctmode == 10) {
-                    unsigned rl = 0;
-                    if (ok) rl = eval_luma_ref(s, logG, vx, vy);
-                    rl = group_sum(rl, logG);
-                    hit = satd_by_luma((int)rl);
-                    want = hit;
-                }
-                unsigned sd = 0;
-                if (ok && want) sd = eval_satd(s, logG, vx, vy);
-                sd = group_sum(sd, logG);
-                aL = luma_cost(aL, sd, hit);
-            }
+            if (GEO::DCT && dctmode != 0) aL = apply_dct(ok, s, logG, vx, vy, aL);
             const long long pt2 = PROF_T();
             PROF_ADD(4, pt1 - pt0); PROF_ADD(5, pt2 - pt1); PROF_ADD(8, 1);
             const long long tot = (long long)aL + (chroma ? (long long)aC : 0);
@@ -1214,7 +1227,9 @@ template <int BPS, typename GEO> struct Searcher {
     // pobPseudoEPZSearch (PlaneOfBlocks.cpp:819-968) with pobRefine (:773-816) and every search pattern (:466-769)
     // flattened into one state machine around a SINGLE round() call site, so that the whole block state stays in
     // registers (a pattern-per-function structure would force it into scratch memory).
-    __device__ __forceinline__ void search_block(bool fromBadCheck) {
+    // entry: 0 = whole block (false), 1 = resume at the bad-block check after the fast path (true), 2 = pobRefine only (Recalculate)
+    __device__ __forceinline__ void search_block(int entry) {
+        const bool fromBadCheck = entry != 0;
         enum { PC_ROUNDA, PC_TRY_NEXT, PC_REFINE, PC_EXH, PC_LINE, PC_NSTEP, PC_UMH, PC_UMH_HEX4, PC_HEX, PC_HEX3, PC_SQUARE,
                PC_OT_BEGIN, PC_OT_H0, PC_OT_HLOOP, PC_OT_V0, PC_OT_VLOOP, PC_DM_BEGIN, PC_DM_LOOP, PC_DM_SECOND, PC_DM_DIAG,
                PC_REFINE_END, PC_BADCHECK, PC_BADEXP, PC_FINAL, PC_FINAL_EXP, PC_DONE };
@@ -1239,7 +1254,7 @@ template <int BPS, typename GEO> struct Searcher {
         int tryIdx = 0; Vec bestAll; bestAll.x = 0; bestAll.y = 0; bestAll.sad = 0; long long costAll = verybig + 1;
         long long foundSAD = 0; int expI = 0, mvx = 0, mvy = 0;
 
-        pc = fromBadCheck ? PC_BADCHECK : PC_ROUNDA;
+        pc = entry == 2 ? PC_REFINE : fromBadCheck ? PC_BADCHECK : PC_ROUNDA;
         while (pc != PC_DONE) {
             const long long st0 = PROF_T();
             int total = 0; bool upd = true;
@@ -1346,7 +1361,8 @@ template <int BPS, typename GEO> struct Searcher {
                 gen = { G_LIST, dx, dy, len, 0, lx, ly }; post = POST_DM_DIAG; break;
             }
             case PC_REFINE_END:
-                if (tryMany) { if (nMinCost < costAll) { bestAll = bestMV; costAll = nMinCost; } tryIdx++; pc = PC_TRY_NEXT; }
+                if (entry == 2) pc = PC_DONE;
+                else if (tryMany) { if (nMinCost < costAll) { bestAll = bestMV; costAll = nMinCost; } tryIdx++; pc = PC_TRY_NEXT; }
                 else pc = PC_BADCHECK;
                 continue;
             case PC_BADCHECK: // :938-963
@@ -1481,9 +1497,8 @@ template <int BPS, typename GEO> struct Searcher {
         }
     }
 
-    // GroupOfPlanes.c:69-125 + PlaneOfBlocks.cpp:971-1131 for one level
-    __device__ __forceinline__ void search_level(int lvl, Vec *globalMV, int *meanLumaChange, GL_AS const GVec *coarse, int coarseBlkX, int coarseBlkY, int coarseLogPel) {
-        const int l = lane_id();
+    // plane geometry, pointers and block staging layout of one level
+    __device__ __forceinline__ void setup_geometry(int lvl) {
         const ALevel &L = P.lv[lvl];
         level = lvl; nBlkX = L.nBlkX; nBlkY = L.nBlkY; pel = L.pel; logPel = L.logPel;
         chroma = P.chroma; logxr = P.logxr; logyr = P.logyr; blkW = P.blkX; blkH = P.blkY; meander = P.meander; verybig = P.verybigSAD;
@@ -1501,9 +1516,15 @@ template <int BPS, typename GEO> struct Searcher {
         uoff = P.blkY * lumaRowB; voff = uoff + cBlkY * chromaRowB;
         unsigned char *rec = J.blob + L.blobOff;
         vectors = (GL_AS GVec *)(rec + 4);
-        const int nBlk = nBlkX * nBlkY;
-        if (l == 0) *(int *)rec = 4 + nBlk * 16; // pobWriteHeaderToArray :413-416
+        if (lane_id() == 0) *(int *)rec = 4 + nBlkX * nBlkY * 16; // pobWriteHeaderToArray :413-416
 
+    }
+
+    // GroupOfPlanes.c:69-125 + PlaneOfBlocks.cpp:971-1131 for one level
+    __device__ __forceinline__ void search_level(int lvl, Vec *globalMV, int *meanLumaChange, GL_AS const GVec *coarse, int coarseBlkX, int coarseBlkY, int coarseLogPel) {
+        const int l = lane_id();
+        setup_geometry(lvl);
+        const int nBlk = nBlkX * nBlkY;
         smallestPlane = lvl == P.nLevels - 1;
         // ---- hierarchical predictors into vectors[] (pobInterpolatePrediction :1447-1514) or zero (pobInit :355)
         if (!coarse) {
@@ -1741,8 +1762,8 @@ template <int BPS, typename GEO> struct Searcher {
             if (GEO::DCT && (dctmode == 7 || dctmode == 8 || dctmode == 10)) srcLuma = src_luma(); // :829-830 (only these modes read it)
             const long long bt1 = PROF_T();
             if (ablate == 1) { bestMV = predictor; bestMV.sad = 0; }
-            else if (fast) { if (!search_block_fast<EARLY_K>(&preA)) search_block(true); }
-            else search_block(false);
+            else if (fast) { if (!search_block_fast<EARLY_K>(&preA)) search_block(1); }
+            else search_block(0);
             const long long bt2 = PROF_T();
             __builtin_amdgcn_wave_barrier();
 
@@ -1866,6 +1887,96 @@ extern "C" __attribute__((visibility("default"))) int mvx_debug_prof(unsigned lo
 
 // ---- launch helper shared by the kernel translation units (each instantiates a few geometries so that hipcc can build
 // them in parallel)
+// ---- mv.Recalculate: PlaneOfBlocks.cpp:1158-1424.  Every block is independent (its predictor comes from the OLD vector
+// field, there are no spatial predictors, no bad-block counter), so one workgroup = one wavefront = one BLOCK and the grid
+// is blocks x frames; the candidate evaluation and pattern searches are the Searcher's (entry 2 = pobRefine only).
+template <int BPS>
+__global__ __launch_bounds__(64, 1) void recalc_kernel(const AParams *Pp, const RParams *Rp, const AJob *jobs, int ldsRow, int ldsHist, int histBins) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const AParams &P = *Pp;
+    const RParams &R = *Rp;
+    const AJob &J = jobs[blockIdx.y];
+    typedef Searcher<BPS, GeoAnyDct> S_t;
+    S_t S(P, J);
+    S.lds = (lds_u8 *)smem; S.ldsRow = ldsRow; S.ldsHist = ldsHist; S.histBins = histBins;
+    S.ldsWin = -1; S.winCap = 0; S.winOn = 0; S.ablate = 0;
+    for (int i = 0; i < 16; i++) S.prof[i] = 0;
+    const int l = lane_id();
+    S.setup_geometry(0);
+    const int nBlk = S.nBlkX * S.nBlkY, b = blockIdx.x;
+    const int valid = J.valid && ((const int *)J.oldBlob)[1] == 1; // MVRecalculate.c:152 fgopIsValid && reference frame inside the clip
+    if (b == 0 && l == 0) { int *hdr = (int *)J.blob; hdr[0] = P.blobSize; hdr[1] = valid; }
+    if (!valid) { // gopWriteDefaultToArray
+        if (l == 0) { Vec d; d.x = 0; d.y = 0; d.sad = P.verybigSAD; S_t::st_vec(&S.vectors[b], d); }
+        return;
+    }
+    S.smallestPlane = 0;
+    S.blky = b / S.nBlkX; S.blkx = b - S.blky * S.nBlkX; S.blkIdx = b; S.blkScanDir = 1;
+    const int stepX = P.blkX - P.ovX, stepY = P.blkY - P.ovY;
+    S.x0 = S.hpad + stepX * S.blkx; S.y0 = S.vpad + stepY * S.blky;
+    S.cx0 = S.chpad + (stepX >> S.logxr) * S.blkx; S.cy0 = S.cvpad + (stepY >> S.logyr) * S.blky;
+    for (int t = l; t < S.TT; t += WAVE) { // source block -> LDS
+        int loff, cb;
+        gl_u8 *g = S.src_item_ptr(t, S.blkx, S.blky, stepX, stepY, loff, cb);
+        A4x32 a = ld_chunk_g(g, cb);
+        st_chunk_l(S.lds + loff, a, cb);
+    }
+    __builtin_amdgcn_wave_barrier();
+    S.searchType = P.searchType; S.nSearchParam = P.nSearchParam; S.tryMany = 0;
+    S.penaltyNew = P.pnew; S.penaltyZero = 0; S.pglobal = 0; S.badcount = 0; S.badrange = 0; S.badSAD = 0; S.LSAD = 0;
+    S.dctmode = P.dctmode; S.dctweight16 = 8; S.sumLumaChange = 0; S.srcLuma = 0; // :1167
+    S.zeroMVfieldShifted.x = 0; S.zeroMVfieldShifted.y = 0; S.zeroMVfieldShifted.sad = 0;
+    S.globalMVPredictor.x = 0; S.globalMVPredictor.y = 0; S.globalMVPredictor.sad = 9999999;
+    const int nLambdaLevel = P.lambda / (S.pel * S.pel);
+    S.nLambda = S.blky == 0 ? 0 : nLambdaLevel;
+    S.nDxMax = (S.pw - S.x0 - S.blkW) << S.logPel; // :1262-1265
+    S.nDyMax = (S.ph - S.y0 - S.blkH) << S.logPel;
+    S.nDxMin = -(S.x0 << S.logPel);
+    S.nDyMin = -(S.y0 << S.logPel);
+    // old vectors around the new block's centre (:1268-1321); plane headers walked like fgopUpdate
+    const unsigned char *po = J.oldBlob + 8;
+    for (int i = R.nLvCount - 1; i >= 1; i--) po += *(const int *)po;
+    GL_AS const GVec *ov = (GL_AS const GVec *)(po + 4);
+    const int centerX = P.blkX / 2 + stepX * S.blkx, blkxold = (centerX - R.blkX / 2) / R.stepX;
+    const int centerY = P.blkY / 2 + stepY * S.blky, blkyold = (centerY - R.blkY / 2) / R.stepY;
+    const int deltaX = max(0, centerX - (R.blkX / 2 + R.stepX * blkxold)), deltaY = max(0, centerY - (R.blkY / 2 + R.stepY * blkyold));
+    const int x1 = min(R.nBlkX - 1, max(0, blkxold)), x2 = min(R.nBlkX - 1, max(0, blkxold + 1));
+    const int y1 = min(R.nBlkY - 1, max(0, blkyold)), y2 = min(R.nBlkY - 1, max(0, blkyold + 1));
+    Vec vo;
+    if (R.smooth == 1) {
+        const Vec v1 = S_t::ld_vec(&ov[x1 + y1 * R.nBlkX]), v2 = S_t::ld_vec(&ov[x2 + y1 * R.nBlkX]), v3 = S_t::ld_vec(&ov[x1 + y2 * R.nBlkX]), v4 = S_t::ld_vec(&ov[x2 + y2 * R.nBlkX]);
+        const int ax = v1.x * R.stepX + deltaX * (v2.x - v1.x), ay = v1.y * R.stepX + deltaX * (v2.y - v1.y);
+        const long long as = v1.sad * R.stepX + deltaX * (v2.sad - v1.sad);
+        const int bx = v3.x * R.stepX + deltaX * (v4.x - v3.x), by = v3.y * R.stepX + deltaX * (v4.y - v3.y);
+        const long long bs = v3.sad * R.stepX + deltaX * (v4.sad - v3.sad);
+        vo.x = (ax + deltaY * (bx - ax) / R.stepY) / R.stepX;
+        vo.y = (ay + deltaY * (by - ay) / R.stepY) / R.stepX;
+        vo.sad = (as + deltaY * (bs - as) / R.stepY) / R.stepX;
+    } else {
+        const bool rx = deltaX * 2 >= R.stepX, ry = deltaY * 2 >= R.stepY;
+        vo = S_t::ld_vec(&ov[(rx ? x2 : x1) + (ry ? y2 : y1) * R.nBlkX]);
+    }
+    vo = uni(vo);
+    vo.x = (vo.x << S.logPel) >> R.logPel;
+    vo.y = (vo.y << S.logPel) >> R.logPel;
+    S.predictor = S.clip_mv(vo);
+    S.predictor.sad = vo.sad * (P.blkX * P.blkY) / (R.blkX * R.blkY);
+    S.bestMV = S.predictor;
+    if (S.dctmode == 7 || S.dctmode == 8 || S.dctmode == 10) S.srcLuma = S.src_luma();
+    unsigned aL = 0, aC = 0;
+    S.eval_cand(l, 6, S.predictor.x, S.predictor.y, S.predictor.y, aL, aC);
+    aL = group_sum(aL, 6); aC = group_sum(aC, 6);
+    if (S.dctmode != 0) aL = S.apply_dct(true, l, 6, S.predictor.x, S.predictor.y, aL);
+    const long long sad = uni((long long)aL + (S.chroma ? (long long)aC : 0));
+    S.bestMV.sad = sad;
+    S.nMinCost = sad;
+    if (sad > R.thSAD) S.search_block(2);
+    if (l == 0) S_t::st_vec(&S.vectors[b], S.bestMV);
+}
+
+struct RLaunch { int njobs, nBlk, ldsBytes, ldsRow, ldsHist, histBins; hipStream_t st; const AParams *dP; const RParams *dR; const AJob *dJobs; };
+int mvx_recalc_launch(const AParams &P, const RLaunch &L);
+
 struct ALaunch {
     int njobs, ldsBytes, ldsRow, ldsHist, histBins, ldsWin, winCap;
     hipStream_t st;

@@ -12,6 +12,7 @@
 #define MVX_MAX_LEVELS 24
 
 void mvx_set_error(const char *fmt, ...);
+void mvx_divided_data(const mvx_analysis_data *in, mvx_analysis_data *out);
 
 #define HIP_CHECK(expr)                                                                           \
     do {                                                                                          \

@@ -14,6 +14,15 @@
 
 struct __attribute__((packed, aligned(4))) GVecD { int x, y; long long sad; };
 
+// level-0 vectors of a MVTools_vectors blob: skip size + validity, then every coarser plane by ITS OWN size header -- the
+// reference's reader does exactly this, which is what makes clips produced with divide (an extra array of half-size
+// blocks after the finest estimated plane, whose geometry the level formula does not describe) readable
+__device__ __forceinline__ const GVecD *mvx_level0(const unsigned char *blob, int nLvCount) {
+    const unsigned char *p = blob + 8;
+    for (int i = nLvCount - 1; i >= 1; i--) p += *(const int *)p;
+    return (const GVecD *)(p + 4);
+}
+
 // ------------------------------------------------------------------------------------------------ host helpers
 
 // Overlap.cpp:40-125 overInit.  M_PI is the double constant; the cosf argument is formed in double.
@@ -80,7 +89,7 @@ struct PlaneG { // one plane of the clip / of level 0 of the super frame
 
 struct DGParams {
     int nRefs, nBlkX, nBlkY, nBlk, pel, logPel, bits, bps, nplanes, overlap;
-    int lastLevelOff;        // byte offset of the level-0 record inside a blob
+    int nLvCount;            // levels in a blob; the level-0 record is found by walking the per-plane size headers like fgopUpdate (Fakery.c:112-123)
     long long thSAD[2];
     long long thscd1; int thscd2;
     PlaneG pl[3];
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(256) void usable_kernel(const DGParams *Pp, const D
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
     int c = 0;
-    const GVecD *v = (const GVecD *)(blob + P.lastLevelOff + 4);
+    const GVecD *v = mvx_level0(blob, P.nLvCount);
     for (int i = threadIdx.x; i < P.nBlk; i += 256) c += v[i].sad > P.thscd1 ? 1 : 0;
     atomicAdd(&cnt, c);
     __syncthreads();
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(256) void degrain_plan_kernel(const DGParams *Pp, c
     for (int r = 0; r < n; r++) {
         us[r] = usable[f * 12 + r];
         if (us[r]) {
-            const GVecD *v = (const GVecD *)(J.blobs[r] + P.lastLevelOff + 4);
+            const GVecD *v = mvx_level0(J.blobs[r], P.nLvCount);
             vx[r] = v[i].x; vy[r] = v[i].y; sad[r] = v[i].sad;
         }
     }
@@ -400,7 +409,7 @@ __global__ __launch_bounds__(256) void compensate_plan_kernel(const DGParams *Pp
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P.nBlk || !usable[f * 12]) return;
     const int by = i / P.nBlkX, bx = i - by * P.nBlkX;
-    const GVecD *v = (const GVecD *)(jobs[f].blobs[0] + P.lastLevelOff + 4);
+    const GVecD *v = mvx_level0(jobs[f].blobs[0], P.nLvCount);
     const GVecD b = v[i];
     int blx, bly;
     CPlanRec rec;
@@ -508,18 +517,7 @@ static int fill_common(DGCommon *h, const mvx_analysis_data *ad, const mvx_super
     P.bits = si.bits; P.bps = (si.bits + 7) / 8; P.nplanes = si.num_planes;
     P.overlap = ad->nOverlapX > 0 || ad->nOverlapY > 0;
     if (P.overlap && (ad->nBlkX < 3 || ad->nBlkY < 3)) DFAIL("overlap needs at least 3x3 blocks (window selection divides by nBlk-2).");
-    // level-0 record is the last one in the blob (Fakery.c:110-121)
-    {
-        const int nWidth_B = (ad->nBlkSizeX - ad->nOverlapX) * ad->nBlkX + ad->nOverlapX;
-        const int nHeight_B = (ad->nBlkSizeY - ad->nOverlapY) * ad->nBlkY + ad->nOverlapY;
-        int off = 8;
-        for (int i = ad->nLvCount - 1; i > 0; i--) {
-            int bx = ((nWidth_B >> i) - ad->nOverlapX) / (ad->nBlkSizeX - ad->nOverlapX);
-            int by = ((nHeight_B >> i) - ad->nOverlapY) / (ad->nBlkSizeY - ad->nOverlapY);
-            off += 4 + bx * by * 16;
-        }
-        P.lastLevelOff = off;
-    }
+    P.nLvCount = ad->nLvCount;
     const int xSub = mvx_ilog2(si.xRatioUV), ySub = mvx_ilog2(si.yRatioUV);
     for (int p = 0; p < 3; p++) {
         PlaneG &g = P.pl[p];
@@ -796,7 +794,7 @@ __global__ __launch_bounds__(256) void bf_usable_kernel(const DGParams *Pp, cons
     const BFJob &J = jobs[f];
     if (J.good) {
         for (int d = 0; d < 2; d++) {
-            const GVecD *v = (const GVecD *)((d ? J.blobB : J.blobF) + P.lastLevelOff + 4);
+            const GVecD *v = mvx_level0((d ? J.blobB : J.blobF), P.nLvCount);
             int c = 0;
             for (int i = threadIdx.x; i < P.nBlk; i += 256) c += v[i].sad > B.thscd1 ? 1 : 0;
             atomicAdd(&cnt[d], c);
@@ -819,7 +817,7 @@ __global__ __launch_bounds__(256) void bf_mask_kernel(const DGParams *Pp, const 
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P.nBlk) return;
     const BFJob &J = jobs[f];
-    const GVecD *vec = (const GVecD *)((dir ? J.blobB : J.blobF) + P.lastLevelOff + 4);
+    const GVecD *vec = mvx_level0((dir ? J.blobB : J.blobF), P.nLvCount);
     const int nBlkX = P.nBlkX, nBlkY = P.nBlkY, by = i / nBlkX, bx = i - by * nBlkX;
     const int time256 = dir ? 256 - J.time256 : J.time256;
     const int stepX = P.pl[0].stepX, stepY = P.pl[0].stepY, nPel = P.pel;
@@ -882,7 +880,7 @@ __global__ __launch_bounds__(256) void bf_plan_kernel(const DGParams *Pp, const 
     if (i >= P.nBlk || !usable[f]) return;
     const BFJob &J = jobs[f];
     const int by = i / P.nBlkX, bx = i - by * P.nBlkX;
-    const GVecD *vB = (const GVecD *)(J.blobB + P.lastLevelOff + 4), *vF = (const GVecD *)(J.blobF + P.lastLevelOff + 4);
+    const GVecD *vB = mvx_level0(J.blobB, P.nLvCount), *vF = mvx_level0(J.blobF, P.nLvCount);
     const int x = bx * P.pl[0].stepX, y = by * P.pl[0].stepY, t = J.time256; // FakeBlockData x / y, Fakery.c:31-32
     const int bX = x * P.pel + ((vB[i].x * (256 - t)) >> 8), bY = y * P.pel + ((vB[i].y * (256 - t)) >> 8);
     const int fX = x * P.pel + ((vF[i].x * t) >> 8), fY = y * P.pel + ((vF[i].y * t) >> 8);

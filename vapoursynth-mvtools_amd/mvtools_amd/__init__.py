@@ -74,6 +74,18 @@ class CompensateJob(C.Structure):
     _fields_ = [("src_super", C.c_void_p * 3), ("ref_super", C.c_void_p * 3), ("blob", C.c_void_p), ("dst", C.c_void_p * 3)]
 
 
+RECALC_ARGS = ("thsad", "smooth", "blksize", "blksizev", "search", "searchparam", "lambda_", "chroma", "truemotion", "pnew", "overlap", "overlapv", "divide",
+               "meander", "fields", "dct")
+
+
+class RecalculateArgs(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in RECALC_ARGS]
+
+
+class RecalculateJob(C.Structure):
+    _fields_ = [("src", C.c_void_p * 3), ("ref", C.c_void_p * 3), ("old_blob", C.c_void_p), ("blob", C.c_void_p)]
+
+
 class BlockFPSArgs(C.Structure):
     _fields_ = [("num", C.c_int64), ("den", C.c_int64), ("mode", C.c_int32), ("ml", C.c_double), ("blend", C.c_int32), ("thscd1", C.c_int64), ("thscd2", C.c_int32)]
 
@@ -125,6 +137,11 @@ def lib():
                                             P(C.c_void_p), C.c_char_p]
         L.mvx_compensate_destroy.argtypes = [C.c_void_p]
         L.mvx_compensate_frames.argtypes = [C.c_void_p, C.c_int, P(CompensateJob), C.c_void_p]
+        L.mvx_recalculate_create.argtypes = [P(RecalculateArgs), C.c_void_p, P(AnalysisData), P(C.c_ssize_t), P(C.c_void_p), C.c_char_p]
+        L.mvx_recalculate_destroy.argtypes = [C.c_void_p]
+        L.mvx_recalculate_get_data.argtypes = [C.c_void_p, P(AnalysisData)]
+        L.mvx_recalculate_blob_size.argtypes = [C.c_void_p]
+        L.mvx_recalculate_frames.argtypes = [C.c_void_p, C.c_int, P(RecalculateJob), C.c_void_p]
         L.mvx_blockfps_create.argtypes = [P(BlockFPSArgs), P(AnalysisData), P(AnalysisData), C.c_void_p, C.c_int, C.c_int64, C.c_int64, P(C.c_ssize_t),
                                           P(C.c_ssize_t), P(C.c_ssize_t), P(C.c_void_p), C.c_char_p]
         L.mvx_blockfps_destroy.argtypes = [C.c_void_p]
@@ -456,3 +473,50 @@ class BlockFPS:
                 arr[k].blob_bw = blobs_bw[nl].data_ptr()
         _check(lib().mvx_blockfps_frames(self.h, n, arr, _stream()))
         return out
+
+
+class Recalculate:
+    """mv.Recalculate(super, vectors, thsad, smooth, blksize, ...) -- MVRecalculate.c:263-545."""
+
+    def __init__(self, sup, vectors_ad, **kw):
+        self.sup = sup
+        a = RecalculateArgs(*([UNSET] * len(RECALC_ARGS)))
+        for k, v in kw.items():
+            k2 = {"lambda": "lambda_"}.get(k, k)
+            if k2 not in RECALC_ARGS:
+                raise TypeError("Recalculate: unknown argument " + k)
+            if v is not None:
+                setattr(a, k2, int(v))
+        old = AnalysisData.from_buffer_copy(bytes(vectors_ad))
+        pad = lambda l: (C.c_ssize_t * 3)(*(list(l) + [0] * (3 - len(l))))
+        self.h = C.c_void_p()
+        err = C.create_string_buffer(ERRLEN)
+        _check(lib().mvx_recalculate_create(C.byref(a), sup.h, C.byref(old), pad(sup.pitch), C.byref(self.h), err), err)
+        self.ad = AnalysisData()
+        lib().mvx_recalculate_get_data(self.h, C.byref(self.ad))
+        self.blob_size = lib().mvx_recalculate_blob_size(self.h)
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().mvx_recalculate_destroy(self.h)
+        except Exception:
+            pass
+
+    def run(self, jobs, blobs=None):
+        """jobs: list of (src_super, ref_super_or_None, old_blob) -> list of device blobs."""
+        torch = _torch()
+        n = len(jobs)
+        if blobs is None:
+            stride = (self.blob_size + 255) // 256 * 256
+            buf = torch.zeros((n, stride), dtype=torch.uint8, device=jobs[0][0][0].device)
+            blobs = [buf[i, :self.blob_size] for i in range(n)]
+        arr = (RecalculateJob * n)()
+        for i, (s, r, ob) in enumerate(jobs):
+            for p in range(self.sup.nplanes):
+                arr[i].src[p] = s[p].data_ptr()
+                arr[i].ref[p] = r[p].data_ptr() if r is not None else None
+            arr[i].old_blob = ob.data_ptr()
+            arr[i].blob = blobs[i].data_ptr()
+        _check(lib().mvx_recalculate_frames(self.h, n, arr, _stream()))
+        return blobs

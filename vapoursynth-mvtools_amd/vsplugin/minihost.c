@@ -9,7 +9,7 @@
  *   mvx_vs_host <plugin.so> list
  *   mvx_vs_host <plugin.so> error  <Filter> <w> <h> <bits> [f.key=value ...]       -> prints the creation error (or OK)
  *   mvx_vs_host <plugin.so> run <pipeline> <in.raw> <w> <h> <bits> <nframes> <out.raw> [s.|a.|d.|c.key=value ...]
- *       pipeline: super | analyse | degrainN | compensate | blockfps (b.key=value arguments)
+ *       pipeline: super | analyse | recalculate (r.*) | degrainN | compensate | blockfps (b.*)
  *       in.raw  : nframes x (Y, U, V planes, 4:2:0, tightly packed, little endian)
  *       out.raw : super      -> every super frame (planes tightly packed) ; props of frame 0 on stdout
  *                 analyse    -> per frame: 84-byte MVTools_MVAnalysisData + MVTools_vectors, backward (isb=1) then forward
@@ -426,6 +426,24 @@ int main(int argc, char **argv) {
     VSMap *m = createMap();
     mapSetNode(m, "clip", clip, maReplace); mapSetNode(m, "super", sup, maReplace);
     VSNode *out;
+    if (!strcmp(pipeline, "recalculate")) { /* analyse (a.*) -> recalculate (r.*), backward then forward; dumps both props per frame */
+        for (int k = 0; k < 2; k++) {
+            VSMap *rm = createMap(); mapSetNode(rm, "super", sup, maReplace); mapSetNode(rm, "vectors", vec[k], maReplace); add_args(rm, 'r', nextra, extra);
+            VSNode *rc = invoke("Recalculate", rm, err, sizeof(err));
+            if (!rc) die("Recalculate", err);
+            vec[2 + k] = rc;
+        }
+        for (int n = 0; n < nframes; n++)
+            for (int k = 0; k < 2; k++) {
+                const VSFrame *f = eval_frame(n, vec[2 + k], err, sizeof(err));
+                if (!f) die("Recalculate frame", err);
+                int e;
+                fwrite(mapGetData(f->props, "MVTools_MVAnalysisData", 0, &e), 1, (size_t)mapGetDataSize(f->props, "MVTools_MVAnalysisData", 0, &e), fo);
+                fwrite(mapGetData(f->props, "MVTools_vectors", 0, &e), 1, (size_t)mapGetDataSize(f->props, "MVTools_vectors", 0, &e), fo);
+                freeFrame(f);
+            }
+        fclose(fo); printf("DONE\n"); return 0;
+    }
     if (!strcmp(pipeline, "blockfps")) {
         mapSetNode(m, "mvbw", vec[0], maReplace); mapSetNode(m, "mvfw", vec[1], maReplace); add_args(m, 'b', nextra, extra);
         out = invoke("BlockFPS", m, err, sizeof(err));

@@ -5,6 +5,7 @@
  * with the reference's exact argument strings:
  *     Super       (src/MVSuper.c:279-291)        Analyse   (src/MVAnalyse.c:639-671)
  *     Degrain1..6 (src/MVDegrains.cpp:813-932)   Compensate (src/MVCompensate.c:579-592)   BlockFPS (src/MVBlockFPS.c:1017-1033)
+ *     Recalculate (src/MVRecalculate.c:549-572)
  * and keeps the reference's inter-filter data layout: super-frame geometry + Super_* props on frame 0
  * (src/MVSuper.c:111-120), vector clips = copyFrame(super[n]) + binary props MVTools_MVAnalysisData / MVTools_vectors
  * (src/MVAnalyse.c:224-239).  This file is the only code that touches VSAPI; all arithmetic happens on the GPU behind
@@ -16,7 +17,7 @@
  * concurrently requested frames into one search launch (where the throughput is) is the next step and
  * does not change this interface.
  *
- * Not supported (fail loudly at creation, like the C ABI): pelclip, divide, fields/tff, dct 1..4.
+ * Not supported (fail loudly at creation, like the C ABI): pelclip, fields/tff, dct 1..4.
  */
 #include <pthread.h>
 #include <stdio.h>
@@ -212,6 +213,25 @@ static int adata_similar(const mvx_analysis_data *a, const mvx_analysis_data *b,
     if (!what) return 0;
     snprintf(error, esz, "%s: %s and %s have different %s.", filter, n1, n2, what);
     return -1;
+}
+
+/* MVTools_vectors of a vector-clip frame -> device.  The array states its own size in its first int (gopGetArraySize,
+ * GroupOfPlanes.c:167-174); clips made with divide carry an extra array the level formula does not describe. */
+static int blob_to_device(void **dblob, int *size, const VSFrame *vf, const VSAPI *vs) {
+    int e = 0;
+    const VSMap *props = vs->getFramePropertiesRO(vf);
+    const char *blob = vs->mapGetData(props, PROP_VECTORS, 0, &e);
+    *dblob = NULL;
+    if (e) return MVX_E_ARG;
+    const int n = vs->mapGetDataSize(props, PROP_VECTORS, 0, NULL);
+    int stated = 0;
+    if (n >= 8) memcpy(&stated, blob, sizeof(stated));
+    if (n < 8 || stated != n) return MVX_E_ARG;
+    *dblob = mvx_dev_alloc((size_t)n);
+    if (!*dblob) return MVX_E_NOMEM;
+    if (mvx_copy_to_device(*dblob, n, blob, n, (size_t)n, 1, NULL) || mvx_stream_sync(NULL)) return MVX_E_DEVICE; /* the prop memory goes away with the frame */
+    if (size) *size = n;
+    return 0;
 }
 
 static void upload_plane_set(void *dst[3], void **arena, const VSFrame *f, const ptrdiff_t pitch[3], int nplanes, int bps, const VSAPI *vs) {
@@ -421,6 +441,109 @@ static void VS_CC analyseCreate(const VSMap *in, VSMap *out, void *user, VSCore 
     vs->createVideoFilter(out, "Analyse", vi, analyseGetFrame, analyseFree, fmParallel, deps, 1, d, core);
 }
 
+/* ------------------------------------------------------------------------------------------------ mv.Recalculate */
+
+typedef struct RecalcData { VSNode *node, *vectors; const VSVideoInfo *vi; mvx_super *sup; SuperGeo geo; mvx_recalculate *rc; mvx_analysis_data ad, old; int blobSize; } RecalcData;
+
+static int recalc_nref(const RecalcData *d, int n) { /* src/MVRecalculate.c:78-85 */
+    const int off = d->ad.nDeltaFrame;
+    if (off > 0) return d->ad.isBackward ? n + off : n - off;
+    return -off;
+}
+
+static const VSFrame *VS_CC recalcGetFrame(int n, int reason, void *inst, void **fd, VSFrameContext *ctx, VSCore *core, const VSAPI *vs) {
+    (void)fd;
+    RecalcData *d = (RecalcData *)inst;
+    const int nref = recalc_nref(d, n);
+    const int haveRef = nref >= 0 && nref < d->vi->numFrames;
+    if (reason == arInitial) {
+        vs->requestFrameFilter(n, d->vectors, ctx);
+        if (haveRef && nref < n) vs->requestFrameFilter(nref, d->node, ctx);
+        vs->requestFrameFilter(n, d->node, ctx);
+        if (haveRef && nref > n) vs->requestFrameFilter(nref, d->node, ctx);
+        return NULL;
+    }
+    if (reason != arAllFramesReady) return NULL;
+    const VSFrame *src = vs->getFrameFilter(n, d->node, ctx);
+    const VSFrame *ref = haveRef ? vs->getFrameFilter(nref, d->node, ctx) : NULL;
+    const VSFrame *mvn = vs->getFrameFilter(n, d->vectors, ctx);
+    DevRef ds, dr;
+    memset(&dr, 0, sizeof(dr));
+    void *oldBlob = NULL;
+    int rc = blob_to_device(&oldBlob, NULL, mvn, vs);
+    vs->freeFrame(mvn);
+    if (!rc) rc = super_to_device(&ds, src, &d->geo, vs); else memset(&ds, 0, sizeof(ds));
+    if (!rc && ref) rc = super_to_device(&dr, ref, &d->geo, vs);
+    void *dblob = rc ? NULL : mvx_dev_alloc((size_t)d->blobSize);
+    char *blob = (char *)malloc((size_t)d->blobSize);
+    if (!rc && (!dblob || !blob)) rc = MVX_E_NOMEM;
+    if (!rc) {
+        mvx_recalculate_job job;
+        memset(&job, 0, sizeof(job));
+        for (int p = 0; p < 3; p++) { job.src[p] = ds.plane[p]; job.ref[p] = ref ? dr.plane[p] : NULL; }
+        job.old_blob = oldBlob; job.blob = dblob;
+        rc = mvx_recalculate_frames(d->rc, 1, &job, NULL);
+        if (!rc) rc = mvx_copy_to_host(blob, d->blobSize, dblob, d->blobSize, (size_t)d->blobSize, 1, NULL);
+        if (!rc) rc = mvx_stream_sync(NULL);
+    }
+    dev_release(&ds); dev_release(&dr);
+    if (dblob) mvx_dev_free(dblob);
+    if (oldBlob) mvx_dev_free(oldBlob);
+    if (ref) vs->freeFrame(ref);
+    VSFrame *dst = NULL;
+    if (!rc) { /* src/MVRecalculate.c:218-235 */
+        dst = vs->copyFrame(src, core);
+        VSMap *props = vs->getFramePropertiesRW(dst);
+        vs->mapSetData(props, PROP_ADATA, (const char *)&d->ad, sizeof(d->ad), dtBinary, maReplace);
+        vs->mapSetData(props, PROP_VECTORS, blob, d->blobSize, dtBinary, maReplace);
+    } else
+        vs->setFilterError(rc == MVX_E_ARG ? "Recalculate: vector clip frame without a valid MVTools_vectors property." : rc == MVX_E_NOMEM ? "Recalculate: out of memory." : mvx_last_error(), ctx);
+    free(blob);
+    vs->freeFrame(src);
+    return dst;
+}
+
+static void VS_CC recalcFree(void *inst, VSCore *core, const VSAPI *vs) {
+    (void)core;
+    RecalcData *d = (RecalcData *)inst;
+    vs->freeNode(d->node); vs->freeNode(d->vectors);
+    mvx_recalculate_destroy(d->rc);
+    mvx_super_destroy(d->sup);
+    free(d);
+}
+
+static void VS_CC recalcCreate(const VSMap *in, VSMap *out, void *user, VSCore *core, const VSAPI *vs) {
+    (void)user;
+    static const char *keys[] = { "thsad", "smooth", "blksize", "blksizev", "search", "searchparam", "lambda", "chroma", "truemotion", "pnew", "overlap", "overlapv",
+                                  "divide", "meander", "fields", "dct" };
+    mvx_recalculate_args a;
+    int64_t *av = (int64_t *)&a;
+    for (size_t i = 0; i < sizeof(keys) / sizeof(keys[0]); i++) av[i] = opt_int64(in, keys[i], vs);
+    RecalcData *d = (RecalcData *)calloc(1, sizeof(*d));
+    char err[1400] = "";
+    d->node = vs->mapGetNode(in, "super", 0, 0);
+    d->vi = vs->getVideoInfo(d->node);
+    d->sup = super_from_props(d->node, "Recalculate", err, sizeof(err), vs);
+    if (!err[0]) { d->vectors = vs->mapGetNode(in, "vectors", 0, NULL); adata_from_clip(&d->old, d->vectors, "Recalculate", "vectors", err, sizeof(err), vs); }
+    if (!err[0]) {
+        super_geo(&d->geo, d->sup);
+        char lerr[MVX_ERRLEN];
+        if (mvx_recalculate_create(&a, d->sup, &d->old, d->geo.pitch, &d->rc, lerr)) snprintf(err, sizeof(err), "%s", lerr);
+    }
+    if (err[0]) {
+        vs->mapSetError(out, err);
+        if (d->node) vs->freeNode(d->node);
+        if (d->vectors) vs->freeNode(d->vectors);
+        if (d->sup) mvx_super_destroy(d->sup);
+        free(d);
+        return;
+    }
+    mvx_recalculate_get_data(d->rc, &d->ad);
+    d->blobSize = mvx_recalculate_blob_size(d->rc);
+    VSFilterDependency deps[2] = { { d->node, rpGeneral }, { d->vectors, rpStrictSpatial } };
+    vs->createVideoFilter(out, "Recalculate", d->vi, recalcGetFrame, recalcFree, fmParallel, deps, 2, d, core);
+}
+
 /* ------------------------------------------------------------------------------------------------ mv.Degrain1..6 */
 
 typedef struct DegrainData {
@@ -468,13 +591,7 @@ static const VSFrame *VS_CC degrainGetFrame(int n, int reason, void *inst, void 
     for (int p = 0; p < np && !rc; p++) { job.src[p] = dsrc[p]; job.dst[p] = (char *)dstArena + dstOff[p]; }
     for (int r = 0; r < nr && !rc; r++) {
         const VSFrame *vf = vs->getFrameFilter(n, d->vectors[r], ctx);
-        int e = 0;
-        const char *blob = vs->mapGetData(vs->getFramePropertiesRO(vf), PROP_VECTORS, 0, &e);
-        const int size = e ? 0 : vs->mapGetDataSize(vs->getFramePropertiesRO(vf), PROP_VECTORS, 0, NULL);
-        if (e || size != d->blobSize) { rc = MVX_E_ARG; vs->freeFrame(vf); break; }
-        blobArena[r] = mvx_dev_alloc((size_t)size);
-        if (!blobArena[r] || mvx_copy_to_device(blobArena[r], size, blob, size, (size_t)size, 1, NULL)) rc = MVX_E_NOMEM;
-        if (!rc) rc = mvx_stream_sync(NULL); /* the prop memory goes away with the frame */
+        rc = blob_to_device(&blobArena[r], NULL, vf, vs);
         job.blobs[r] = blobArena[r];
         vs->freeFrame(vf);
         const int nref = (r & 1) ? n - d->ad[r].nDeltaFrame : n + d->ad[r].nDeltaFrame;
@@ -622,19 +739,15 @@ static const VSFrame *VS_CC compGetFrame(int n, int reason, void *inst, void **f
     memset(&dr, 0, sizeof(dr));
     int rc = super_to_device(&ds, ssup, &d->geo, vs);
     if (!rc && rsup) rc = super_to_device(&dr, rsup, &d->geo, vs);
-    int e = 0;
-    const char *blob = vs->mapGetData(vs->getFramePropertiesRO(vf), PROP_VECTORS, 0, &e);
-    const int size = e ? 0 : vs->mapGetDataSize(vs->getFramePropertiesRO(vf), PROP_VECTORS, 0, NULL);
-    if (!rc && (e || size != d->blobSize)) rc = MVX_E_ARG;
-    void *dblob = rc ? NULL : mvx_dev_alloc((size_t)d->blobSize);
+    void *dblob = NULL;
+    if (!rc) rc = blob_to_device(&dblob, NULL, vf, vs);
     size_t dstOff[3], dstBytes = 0;
     for (int p = 0; p < np; p++) { dstOff[p] = dstBytes; dstBytes += (size_t)d->pitch[p] * vs->getFrameHeight(src, p); }
     void *dstArena = rc ? NULL : mvx_dev_alloc(dstBytes);
-    if (!rc && (!dblob || !dstArena)) rc = MVX_E_NOMEM;
+    if (!rc && !dstArena) rc = MVX_E_NOMEM;
     mvx_compensate_job job;
     memset(&job, 0, sizeof(job));
     if (!rc) {
-        rc = mvx_copy_to_device(dblob, size, blob, size, (size_t)size, 1, NULL);
         for (int p = 0; p < 3; p++) { job.src_super[p] = ds.plane[p]; job.ref_super[p] = rsup ? dr.plane[p] : NULL; }
         for (int p = 0; p < np; p++) job.dst[p] = (char *)dstArena + dstOff[p];
         job.blob = dblob;
@@ -770,18 +883,8 @@ static const VSFrame *VS_CC fpsGetFrame(int n, int reason, void *inst, void **fd
         const VSFrame *vf = vs->getFrameFilter(nright, d->mvfw, ctx), *vb = vs->getFrameFilter(nleft, d->mvbw, ctx);
         rc = super_to_device(&ds, sl, &d->geo, vs);
         if (!rc) rc = super_to_device(&dr2, sr, &d->geo, vs);
-        int e1 = 0, e2 = 0;
-        const char *bf = vs->mapGetData(vs->getFramePropertiesRO(vf), PROP_VECTORS, 0, &e1);
-        const char *bb = vs->mapGetData(vs->getFramePropertiesRO(vb), PROP_VECTORS, 0, &e2);
-        if (!rc && (e1 || e2 || vs->mapGetDataSize(vs->getFramePropertiesRO(vf), PROP_VECTORS, 0, NULL) != d->blobSize ||
-                    vs->mapGetDataSize(vs->getFramePropertiesRO(vb), PROP_VECTORS, 0, NULL) != d->blobSize)) rc = MVX_E_ARG;
-        if (!rc) {
-            blobF = mvx_dev_alloc((size_t)d->blobSize); blobB = mvx_dev_alloc((size_t)d->blobSize);
-            if (!blobF || !blobB) rc = MVX_E_NOMEM;
-        }
-        if (!rc) rc = mvx_copy_to_device(blobF, d->blobSize, bf, d->blobSize, (size_t)d->blobSize, 1, NULL);
-        if (!rc) rc = mvx_copy_to_device(blobB, d->blobSize, bb, d->blobSize, (size_t)d->blobSize, 1, NULL);
-        if (!rc) rc = mvx_stream_sync(NULL);
+        if (!rc) rc = blob_to_device(&blobF, NULL, vf, vs);
+        if (!rc) rc = blob_to_device(&blobB, NULL, vb, vs);
         for (int p = 0; p < 3; p++) { job.src_super[p] = ds.plane[p]; job.ref_super[p] = dr2.plane[p]; }
         job.blob_fw = blobF; job.blob_bw = blobB;
         vs->freeFrame(sl); vs->freeFrame(sr); vs->freeFrame(vf); vs->freeFrame(vb);
@@ -905,6 +1008,11 @@ VS_EXTERNAL_API(void) VapourSynthPluginInit2(VSPlugin *plugin, const VSPLUGINAPI
                              "overlap:int:opt;overlapv:int:opt;divide:int:opt;badsad:int:opt;badrange:int:opt;opt:int:opt;meander:int:opt;trymany:int:opt;fields:int:opt;"
                              "tff:int:opt;search_coarse:int:opt;dct:int:opt;",
                              "clip:vnode;", analyseCreate, NULL, plugin);
+    vspapi->registerFunction("Recalculate",
+                             "super:vnode;vectors:vnode;thsad:int:opt;smooth:int:opt;blksize:int:opt;blksizev:int:opt;search:int:opt;searchparam:int:opt;lambda:int:opt;"
+                             "chroma:int:opt;truemotion:int:opt;pnew:int:opt;overlap:int:opt;overlapv:int:opt;divide:int:opt;opt:int:opt;meander:int:opt;fields:int:opt;"
+                             "tff:int:opt;dct:int:opt;",
+                             "clip:vnode;", recalcCreate, NULL, plugin);
     vspapi->registerFunction("Degrain1", "clip:vnode;super:vnode;mvbw:vnode;mvfw:vnode;" DEGRAIN_TAIL, "clip:vnode;", degrainCreate, (void *)(intptr_t)1, plugin);
     vspapi->registerFunction("Degrain2", "clip:vnode;super:vnode;mvbw:vnode;mvfw:vnode;mvbw2:vnode;mvfw2:vnode;" DEGRAIN_TAIL, "clip:vnode;", degrainCreate, (void *)(intptr_t)2, plugin);
     vspapi->registerFunction("Degrain3", "clip:vnode;super:vnode;mvbw:vnode;mvfw:vnode;mvbw2:vnode;mvfw2:vnode;mvbw3:vnode;mvfw3:vnode;" DEGRAIN_TAIL, "clip:vnode;", degrainCreate, (void *)(intptr_t)3, plugin);
