@@ -1837,6 +1837,13 @@ template <int BPS, typename GEO> struct Searcher {
 template <int BPS, typename GEO>
 __global__ __launch_bounds__(64, MVX_WAVES_PER_EU) void analyse_kernel(const AParams *Pp, const AJob *jobs, int ldsRow, int ldsHist, int histBins, int ldsWin, int winCap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // One chain per SIMD is the measured optimum.  The host's LDS request limits a CU to four chains, but a
+    // kernel that fits 256 VGPRs would let the dispatcher stack two of them on one SIMD while another SIMD idles (measured:
+    // -12 % on the 8-bit 8x8 kernel when an unrelated refactoring moved it from 262 to 256 registers).  Touching the last
+    // accumulator register pushes the wave's register allocation above 256, i.e. at most one wave per SIMD, for every variant.
+    // (Four chains per 256-thread workgroup, one workgroup per CU, was also tried: deterministic too, but 5 % slower at 4K16 --
+    // the four chains of a CU then run in lockstep and hit the texture path in the same phases.)
+    asm volatile("" ::: "a255");
     const AParams &P = *Pp;
     const AJob &J = jobs[blockIdx.x];
     const int l = threadIdx.x;
