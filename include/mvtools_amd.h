@@ -82,6 +82,14 @@ void mvx_super_get_info(const mvx_super *s, mvx_super_info *info);
 int mvx_super_frames(mvx_super *s, int nframes, const void *const *src, const ptrdiff_t src_pitch[3],
                      void *const *dst, const ptrdiff_t dst_pitch[3], void *stream);
 
+/* ---- mv.Finest -----------------------------------------------------------------------------------
+ * replaces mvfinestGetFrame, MVFinest.c:48-140 (arg string :213-218): the pel^2 sub-pel planes of level 0 of a super frame
+ * interleaved into one plane of (width + 2 hpad) * pel x (height + 2 vpad) * pel samples (chroma planes subsampled like
+ * the clip).  Planes the super clip does not carry (chroma=0) are not written. */
+void mvx_finest_size(const mvx_super *s, int32_t *width, int32_t *height);
+int mvx_finest_frames(const mvx_super *s, int nframes, const void *const *super_frames /* [f*3+p] */, const ptrdiff_t super_pitch[3],
+                      void *const *dst /* [f*3+p] */, const ptrdiff_t dst_pitch[3], void *stream);
+
 /* ---- mv.Analyse ----------------------------------------------------------------------------------
  * replaces mvanalyseCreate / mvanalyseGetFrame, MVAnalyse.c:267-635 / :76-254 (argument string :639-671);
  * the search itself is GroupOfPlanes.c:69-125 + PlaneOfBlocks.cpp:419-1131,1447-1636.                */
@@ -234,6 +242,13 @@ typedef struct mvx_blockfps_job {
 } mvx_blockfps_job;
 
 int mvx_blockfps_frames(mvx_blockfps *b, int nframes, const mvx_blockfps_job *jobs, void *stream);
+
+/* ---- mv.SCDetection -------------------------------------------------------------------------------
+ * replaces the decision of mvscdetectionGetFrame, MVSCDetection.c:43-73 (arg string :137-145): scene_change[i] (HOST array) =
+ * !usable(blobs[i]) for n device blobs of one vector clip, i.e. the value of _SceneChangePrev (forward vectors) or
+ * _SceneChangeNext (backward vectors); thscd1 / thscd2 as passed by the user (MVX_UNSET -> 400 / 130). Synchronous. */
+int mvx_scdetect(const mvx_analysis_data *vectors_data, int64_t thscd1, int32_t thscd2, int n, const void *const *blobs,
+                 int32_t *scene_change, void *stream, char *err);
 
 /* ---- vector blob helpers (reader side: Fakery.c, MVAnalysisData.c:7-31) -------------------------- */
 void mvx_scale_thscd(int64_t *thscd1, int32_t *thscd2, const mvx_analysis_data *ad);

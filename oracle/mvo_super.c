@@ -433,3 +433,24 @@ uint32_t mvo_fnv1a(const uint8_t *p, size_t n) {
     for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 16777619u; }
     return h;
 }
+
+/* ---- mv.Finest: MVFinest.c:48-140 + Merge4PlanesToBig / Merge16PlanesToBig (MaskFun.cpp:206-330): the pel^2 sub-pel planes of
+ * level 0 interleaved into one (padded width * pel) x (padded height * pel) plane; pel 1 copies the padded level-0 plane (the
+ * reference copies luma-sized rectangles for every plane there, overrunning the chroma planes: restated per plane).
+ * Planes the super clip does not carry (chroma=0) are left untouched.  Parity unpinned. */
+void mvo_finest_size(const mvo_super *s, int *w, int *h) { *w = (s->width + 2 * s->hpad) * s->pel; *h = (s->height + 2 * s->vpad) * s->pel; }
+void mvo_finest_frame(const mvo_super *s, const uint8_t *const sup[3], const int supPitch[3], uint8_t *const dst[3], const int dstPitch[3]) {
+    mvo_gof g;
+    mvo_gof_init(&g, s->levels, s->width, s->height, s->pel, s->hpad, s->vpad, s->modeYUV, s->xRatioUV, s->yRatioUV, s->bits);
+    mvo_gof_update(&g, (uint8_t *const *)sup, supPitch, s->yRatioUV);
+    const int bps = (s->bits + 7) / 8, pel = s->pel, np = s->gray ? 1 : 3;
+    for (int p = 0; p < np; p++) {
+        if (!(s->modeYUV & (1 << p))) continue;
+        const mvo_plane *m = &g.fr[0].pl[p];
+        for (int y = 0; y < m->ph * pel; y++)
+            for (int x = 0; x < m->pw * pel; x++) {
+                const uint8_t *q = m->p[(x % pel) | ((y % pel) * pel)] + (size_t)(y / pel) * m->pitch + (size_t)(x / pel) * bps;
+                memcpy(dst[p] + (size_t)y * dstPitch[p] + (size_t)x * bps, q, bps);
+            }
+    }
+}

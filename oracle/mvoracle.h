@@ -64,6 +64,10 @@ int mvo_super_init(mvo_super *s, int width, int height, int bits, int subW, int 
 void mvo_super_frame(const mvo_super *s, const uint8_t *const src[3], const int srcPitch[3],
                      uint8_t *const dst[3], const int dstPitch[3]);
 
+/* ---- mv.Finest: MVFinest.c (parity unpinned) ---- */
+void mvo_finest_size(const mvo_super *s, int *w, int *h);
+void mvo_finest_frame(const mvo_super *s, const uint8_t *const sup[3], const int supPitch[3], uint8_t *const dst[3], const int dstPitch[3]);
+
 /* ---- mv.Analyse: MVAnalyse.c, GroupOfPlanes.c, PlaneOfBlocks.cpp ---- */
 typedef struct mvo_analyse_args { /* every field may be MVO_UNSET */
     int blksize, blksizev, levels, search, searchparam, pelsearch, isb, lambda, chroma, delta, truemotion,

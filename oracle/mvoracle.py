@@ -169,6 +169,18 @@ class Super:
             out.append(buf[:, :w] if False else buf)  # keep full pitch so row stride == pitch
         return out
 
+    def finest(self, super_frame):
+        """mv.Finest(super) -- MVFinest.c: the interleaved sub-pel planes of level 0."""
+        w, h = C.c_int(), C.c_int()
+        lib().mvo_finest_size(C.byref(self.s), C.byref(w), C.byref(h))
+        dst = [np.zeros((h.value, w.value), dtype=self.dtype)]
+        if self.nplanes == 3:
+            dst += [np.zeros((h.value // self.s.yRatioUV, w.value // self.s.xRatioUV), dtype=self.dtype) for _ in range(2)]
+        sp, spitch = _planes(super_frame)
+        dp, dpitch = _planes(dst)
+        lib().mvo_finest_frame(C.byref(self.s), sp, spitch, dp, dpitch)
+        return dst
+
     def frame(self, src):
         dst = self.alloc()
         sp, spitch = _planes(src)

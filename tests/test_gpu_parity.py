@@ -512,3 +512,51 @@ def test_recalculate_parity(oracle, mv, bits, akw, rkw):
         want = orc.frame(osf[n], osf[n + 1] if n + 1 < nf else None, oold[n])
         g = got[n].cpu().numpy()
         assert np.array_equal(g, want), (n, int(np.count_nonzero(g != want)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,bits,skw", [(128, 96, 8, {}), (200, 120, 16, dict(pel=4)), (128, 96, 8, dict(pel=1)), (128, 96, 16, dict(chroma=0)), (132, 100, 8, dict(hpad=8, vpad=4))])
+def test_finest_parity(oracle, mv, w, h, bits, skw):
+    import torch
+    frames = pl.moving_clip(w, h, bits, 2, seed=61, noise=3)
+    osup = oracle.Super(w, h, bits, **skw)
+    gsup = mv.Super(w, h, bits, **skw)
+    gsf = gsup.build([mv.frame_to_device(f) for f in frames])
+    out = gsup.finest(gsf)
+    torch.cuda.synchronize()
+    for n in range(2):
+        want = osup.finest(osup.frame(frames[n]))
+        for p in range(3):
+            if skw.get("chroma", 1) == 0 and p:
+                continue  # not written (MVFinest.c:87)
+            g = out[n][p].cpu().numpy()
+            g = (g.view(np.uint16) if bits > 8 else g)[:, :want[p].shape[1]]
+            assert np.array_equal(g, want[p]), (n, p)
+
+
+@pytest.mark.gpu
+def test_scdetect_matches_oracle(oracle, mv):
+    import torch
+    w, h, bits, nf = 128, 96, 8, 4
+    frames, osup, gsup, osf, gsrc, gsf = _pipeline(oracle, mv, w, h, bits, 1, {}, {}, nframes=nf, seed=63)
+    frames2 = pl.moving_clip(w, h, bits, 1, seed=999, noise=30)  # an unrelated frame = a scene change
+    gcut = gsup.build([mv.frame_to_device(frames2[0])])[0]
+    ocut = osup.frame(frames2[0])
+    akw = dict(blksize=8, overlap=4)
+    oan = oracle.Analyse(osup, num_frames=nf, isb=1, **akw)
+    gan = mv.Analyse(gsup, num_frames=nf, isb=1, **akw)
+    gjobs = [(gsf[0], gsf[1]), (gsf[1], gcut), (gsf[2], None)]
+    ojobs = [(osf[0], osf[1]), (osf[1], ocut), (osf[2], None)]
+    gb = gan.run(gjobs)
+    for th in (dict(), dict(thscd1=100, thscd2=40), dict(thscd1=10, thscd2=5)):
+        got = mv.scdetect(gan.ad, gb, **th)
+        t1, t2 = C.c_int64(th.get("thscd1", 400)), C.c_int(th.get("thscd2", 130))
+        oracle.lib().mvo_scale_thscd(C.byref(t1), C.byref(t2), C.byref(oan.d.ad))
+        want = []
+        for s, r in ojobs:
+            b = oan.frame(s, r)
+            want.append(int(not oracle.lib().mvo_blob_is_usable(C.byref(oan.d.ad), C.c_void_p(b.ctypes.data), t1.value, t2.value)))
+        assert got == want, (th, got, want)
+    assert mv.scdetect(gan.ad, gb)[2] == 1  # invalid vectors count as a scene change
+    with pytest.raises(mv.MvtoolsError):
+        mv.scdetect(gan.ad, gb, thscd1=8 * 8 * 255 + 1)

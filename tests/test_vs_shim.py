@@ -38,6 +38,8 @@ EXPECTED = {
                "chroma:int:opt;delta:int:opt;truemotion:int:opt;lsad:int:opt;plevel:int:opt;global:int:opt;pnew:int:opt;pzero:int:opt;pglobal:int:opt;"
                "overlap:int:opt;overlapv:int:opt;divide:int:opt;badsad:int:opt;badrange:int:opt;opt:int:opt;meander:int:opt;trymany:int:opt;fields:int:opt;"
                "tff:int:opt;search_coarse:int:opt;dct:int:opt;",
+    "Finest": "super:vnode;opt:int:opt;",
+    "SCDetection": "clip:vnode;vectors:vnode;thscd1:int:opt;thscd2:int:opt;",
     "Recalculate": "super:vnode;vectors:vnode;thsad:int:opt;smooth:int:opt;blksize:int:opt;blksizev:int:opt;search:int:opt;searchparam:int:opt;lambda:int:opt;"
                    "chroma:int:opt;truemotion:int:opt;pnew:int:opt;overlap:int:opt;overlapv:int:opt;divide:int:opt;opt:int:opt;meander:int:opt;fields:int:opt;"
                    "tff:int:opt;dct:int:opt;",
@@ -253,3 +255,29 @@ def test_shell_recalculate_and_divide_match_oracle(oracle, tmp_path, bits, aargs
             assert np.array_equal(blob[off:off + want.size], want), (n, isb)
             off += want.size
     assert off == blob.size
+
+
+@pytest.mark.gpu
+def test_shell_finest_and_scdetection(oracle, tmp_path):
+    w, h, bits, nf = 128, 96, 8, 3
+    frames = pl.moving_clip(w, h, bits, nf, seed=43, noise=3)
+    src = tmp_path / "in.raw"
+    _write_clip(src, frames)
+    osup = oracle.Super(w, h, bits)
+    out = host("run", "finest", src, w, h, bits, nf, tmp_path / "fin.raw")
+    fw, fh = (w + 32) * 2, (h + 32) * 2
+    assert out.splitlines()[0] == "finest %dx%d" % (fw, fh)
+    got = _read_frames(tmp_path / "fin.raw", fw, fh, bits, nf)
+    for n in range(nf):
+        want = osup.finest(osup.frame(frames[n]))
+        for p in range(3):
+            assert np.array_equal(got[n][p], want[p]), (n, p)
+    # SCDetection: the clip passes through, the prop is _SceneChangeNext for backward vectors and _SceneChangePrev for forward ones;
+    # frames whose reference lies outside the clip carry invalid vectors = scene change (MVSCDetection.c:62-64, Fakery.c:144-146)
+    out = host("run", "scdetection", src, w, h, bits, nf, tmp_path / "sc.raw", "a.blksize=8", "a.overlap=4").splitlines()
+    assert out[:nf] == ["bw frame %d next=%d prev=-1" % (n, 1 if n == nf - 1 else 0) for n in range(nf)]
+    assert out[nf:2 * nf] == ["fw frame %d next=-1 prev=%d" % (n, 1 if n == 0 else 0) for n in range(nf)]
+    passthrough = _read_frames(tmp_path / "sc.raw", w, h, bits, nf)
+    for n in range(nf):
+        for p in range(3):
+            assert np.array_equal(passthrough[n][p], frames[n][p])

@@ -1153,3 +1153,43 @@ extern "C" __attribute__((visibility("default"))) int mvx_blockfps_frames(mvx_bl
     HIP_CHECK(hipGetLastError());
     return MVX_OK;
 }
+
+// ================================================================================================ mv.SCDetection
+// MVSCDetection.c:43-73: _SceneChangePrev / _SceneChangeNext = !fgopIsUsable(vectors at n) (Fakery.c:52-58,144-146)
+__global__ __launch_bounds__(256) void scdetect_kernel(const unsigned char *const *blobs, int nLvCount, int nBlk, long long thscd1, int thscd2, int *out) {
+    const unsigned char *blob = blobs[blockIdx.x];
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const GVecD *v = mvx_level0(blob, nLvCount);
+    int c = 0;
+    for (int i = threadIdx.x; i < nBlk; i += 256) c += v[i].sad > thscd1 ? 1 : 0;
+    atomicAdd(&cnt, c);
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = !(((const int *)blob)[1] == 1 && !(cnt > thscd2));
+}
+
+extern "C" __attribute__((visibility("default"))) int mvx_scdetect(const mvx_analysis_data *ad, int64_t thscd1, int32_t thscd2, int n, const void *const *blobs,
+                                                                   int32_t *scene_change, void *stream, char *err) {
+    char dummy[MVX_ERRLEN];
+    if (!err) err = dummy;
+    err[0] = 0;
+    if (n <= 0) return MVX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int64_t s1 = thscd1 == MVX_UNSET ? 400 : thscd1;
+    int32_t s2 = thscd2 == MVX_UNSET ? 130 : thscd2;
+    if (s1 > 8 * 8 * 255) DFAIL("SCDetection: thscd1 can be at most %d.", 8 * 8 * 255); // MVAnalysisData.c:11-14
+    mvx_scale_thscd(&s1, &s2, ad);
+    const unsigned char **dB = nullptr; int *dOut = nullptr;
+    HIP_CHECK(hipMalloc((void **)&dB, sizeof(void *) * n));
+    if (hipMalloc((void **)&dOut, sizeof(int) * n) != hipSuccess) { (void)hipFree(dB); mvx_set_error("mvx_scdetect: out of device memory"); return MVX_E_NOMEM; }
+    hipError_t e = hipMemcpyAsync(dB, blobs, sizeof(void *) * n, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(scdetect_kernel, dim3(n), dim3(256), 0, st, dB, ad->nLvCount, ad->nBlkX * ad->nBlkY, (long long)s1, (int)s2, dOut);
+        e = hipMemcpyAsync(scene_change, dOut, sizeof(int) * n, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(dB); (void)hipFree(dOut);
+    if (e != hipSuccess) { mvx_set_error("mvx_scdetect: %s", hipGetErrorString(e)); return MVX_E_DEVICE; }
+    return MVX_OK;
+}

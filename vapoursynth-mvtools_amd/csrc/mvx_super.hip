@@ -420,3 +420,40 @@ extern "C" __attribute__((visibility("default"))) int mvx_super_frames(mvx_super
     HIP_CHECK(hipGetLastError());
     return MVX_OK;
 }
+
+// ================================================================================================ mv.Finest
+// MVFinest.c:48-140, Merge4PlanesToBig / Merge16PlanesToBig MaskFun.cpp:206-330: interleave the pel^2 sub-pel planes of level 0.
+struct FinestArgs { const unsigned char *src; unsigned char *dst; long long srcPitch, dstPitch, planeStride; int pw, ph, pel, logPel; };
+
+template <typename T> __global__ __launch_bounds__(256) void finest_kernel(FinestArgs A) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= A.pw * A.pel || y >= A.ph * A.pel) return;
+    const int m = A.pel - 1, idx = (x & m) | ((y & m) << A.logPel);
+    const T v = ((const T *)(A.src + idx * A.planeStride + (long long)(y >> A.logPel) * A.srcPitch))[x >> A.logPel];
+    ((T *)(A.dst + (long long)y * A.dstPitch))[x] = v;
+}
+
+extern "C" __attribute__((visibility("default"))) void mvx_finest_size(const mvx_super *s, int32_t *width, int32_t *height) {
+    *width = (s->info.width + 2 * s->info.hpad) * s->info.pel;
+    *height = (s->info.height + 2 * s->info.vpad) * s->info.pel;
+}
+
+extern "C" __attribute__((visibility("default"))) int mvx_finest_frames(const mvx_super *s, int nframes, const void *const *super_frames, const ptrdiff_t super_pitch[3],
+                                                                        void *const *dst, const ptrdiff_t dst_pitch[3], void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const mvx_super_info &si = s->info;
+    const int logPel = si.pel == 4 ? 2 : si.pel == 2 ? 1 : 0;
+    for (int f = 0; f < nframes; f++)
+        for (int p = 0; p < si.num_planes; p++) {
+            if (!(si.modeYUV & (1 << p))) continue; // planes the super clip does not carry stay untouched (MVFinest.c:87 pPlanes[i] == NULL)
+            LevelPlane lp;
+            mvx_level_plane(si, 0, p, super_pitch[p], &lp);
+            FinestArgs A = { (const unsigned char *)super_frames[f * 3 + p] + lp.off, (unsigned char *)dst[f * 3 + p], (long long)super_pitch[p], (long long)dst_pitch[p],
+                             (long long)super_pitch[p] * lp.ph, lp.pw, lp.ph, si.pel, logPel };
+            dim3 grid((lp.pw * si.pel + 63) / 64, (lp.ph * si.pel + 3) / 4);
+            if (si.bits <= 8) hipLaunchKernelGGL(finest_kernel<uint8_t>, grid, dim3(256), 0, st, A);
+            else hipLaunchKernelGGL(finest_kernel<uint16_t>, grid, dim3(256), 0, st, A);
+        }
+    HIP_CHECK(hipGetLastError());
+    return MVX_OK;
+}

@@ -137,6 +137,9 @@ def lib():
                                             P(C.c_void_p), C.c_char_p]
         L.mvx_compensate_destroy.argtypes = [C.c_void_p]
         L.mvx_compensate_frames.argtypes = [C.c_void_p, C.c_int, P(CompensateJob), C.c_void_p]
+        L.mvx_finest_size.argtypes = [C.c_void_p, P(C.c_int32), P(C.c_int32)]
+        L.mvx_finest_frames.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p), P(C.c_ssize_t), P(C.c_void_p), P(C.c_ssize_t), C.c_void_p]
+        L.mvx_scdetect.argtypes = [P(AnalysisData), C.c_int64, C.c_int32, C.c_int, P(C.c_void_p), P(C.c_int32), C.c_void_p, C.c_char_p]
         L.mvx_recalculate_create.argtypes = [P(RecalculateArgs), C.c_void_p, P(AnalysisData), P(C.c_ssize_t), P(C.c_void_p), C.c_char_p]
         L.mvx_recalculate_destroy.argtypes = [C.c_void_p]
         L.mvx_recalculate_get_data.argtypes = [C.c_void_p, P(AnalysisData)]
@@ -259,6 +262,27 @@ class Super:
             return [[torch.zeros((self.info.plane_height[p], self.pitch[p]), dtype=torch.uint8, device=device) for p in range(self.nplanes)]
                     for _ in range(n)]
         return arena_frames(n, [(self.info.plane_height[p], self.pitch[p]) for p in range(self.nplanes)], device)
+
+    def finest(self, super_frames, out=None):
+        """mv.Finest(super) -- MVFinest.c: interleaved sub-pel planes of level 0, one output frame per super frame."""
+        torch = _torch()
+        n = len(super_frames)
+        w, h = C.c_int32(), C.c_int32()
+        lib().mvx_finest_size(self.h, C.byref(w), C.byref(h))
+        i = self.info
+        dims = [(h.value, w.value)] + [(h.value // i.yRatioUV, w.value // i.xRatioUV)] * 2
+        pitch = [((dims[p][1] * self.bps + 255) // 256) * 256 for p in range(self.nplanes)]
+        if out is None:
+            out = arena_frames(n, [(dims[p][0], pitch[p]) for p in range(self.nplanes)], super_frames[0][0].device)
+        src = (C.c_void_p * (3 * n))()
+        dst = (C.c_void_p * (3 * n))()
+        for f in range(n):
+            for p in range(self.nplanes):
+                src[f * 3 + p] = super_frames[f][p].data_ptr()
+                dst[f * 3 + p] = out[f][p].data_ptr()
+        pad = lambda l: (C.c_ssize_t * 3)(*(list(l) + [0] * (3 - len(l))))
+        _check(lib().mvx_finest_frames(self.h, n, src, pad(self.pitch), dst, pad(pitch), _stream()))
+        return out
 
     def build(self, frames, out=None):
         """frames: list of device frames (list of plane tensors sharing pitches) -> list of super frames."""
@@ -520,3 +544,14 @@ class Recalculate:
             arr[i].blob = blobs[i].data_ptr()
         _check(lib().mvx_recalculate_frames(self.h, n, arr, _stream()))
         return blobs
+
+
+def scdetect(analysis_data, blobs, thscd1=None, thscd2=None):
+    """mv.SCDetection's decision per frame (MVSCDetection.c:43-73): list of 0/1 = value of _SceneChangePrev/_SceneChangeNext."""
+    n = len(blobs)
+    ad = AnalysisData.from_buffer_copy(bytes(analysis_data))
+    ptrs = (C.c_void_p * n)(*[b.data_ptr() for b in blobs])
+    out = (C.c_int32 * n)()
+    err = C.create_string_buffer(ERRLEN)
+    _check(lib().mvx_scdetect(C.byref(ad), _u(thscd1), _u(thscd2), n, ptrs, out, _stream(), err), err)
+    return list(out)

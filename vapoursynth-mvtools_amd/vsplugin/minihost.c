@@ -9,7 +9,7 @@
  *   mvx_vs_host <plugin.so> list
  *   mvx_vs_host <plugin.so> error  <Filter> <w> <h> <bits> [f.key=value ...]       -> prints the creation error (or OK)
  *   mvx_vs_host <plugin.so> run <pipeline> <in.raw> <w> <h> <bits> <nframes> <out.raw> [s.|a.|d.|c.key=value ...]
- *       pipeline: super | analyse | recalculate (r.*) | degrainN | compensate | blockfps (b.*)
+ *       pipeline: super | finest | analyse | scdetection (d.*) | recalculate (r.*) | degrainN | compensate | blockfps (b.*)
  *       in.raw  : nframes x (Y, U, V planes, 4:2:0, tightly packed, little endian)
  *       out.raw : super      -> every super frame (planes tightly packed) ; props of frame 0 on stdout
  *                 analyse    -> per frame: 84-byte MVTools_MVAnalysisData + MVTools_vectors, backward (isb=1) then forward
@@ -426,6 +426,31 @@ int main(int argc, char **argv) {
     VSMap *m = createMap();
     mapSetNode(m, "clip", clip, maReplace); mapSetNode(m, "super", sup, maReplace);
     VSNode *out;
+    if (!strcmp(pipeline, "finest")) {
+        VSMap *fm = createMap(); mapSetNode(fm, "super", sup, maReplace);
+        VSNode *fin = invoke("Finest", fm, err, sizeof(err));
+        if (!fin) die("Finest", err);
+        printf("finest %dx%d\n", fin->vi.width, fin->vi.height);
+        for (int n = 0; n < nframes; n++) { const VSFrame *f = eval_frame(n, fin, err, sizeof(err)); if (!f) die("Finest frame", err); dump_frame(fo, f); freeFrame(f); }
+        fclose(fo); printf("DONE\n"); return 0;
+    }
+    if (!strcmp(pipeline, "scdetection")) { /* prints the scene-change props per frame for the backward and the forward vectors */
+        for (int k = 0; k < 2; k++) {
+            VSMap *sm2 = createMap(); mapSetNode(sm2, "clip", clip, maReplace); mapSetNode(sm2, "vectors", vec[k], maReplace); add_args(sm2, 'd', nextra, extra);
+            VSNode *sc = invoke("SCDetection", sm2, err, sizeof(err));
+            if (!sc) die("SCDetection", err);
+            for (int n = 0; n < nframes; n++) {
+                const VSFrame *f = eval_frame(n, sc, err, sizeof(err));
+                if (!f) die("SCDetection frame", err);
+                int e1, e2;
+                const long long nx = (long long)mapGetInt(f->props, "_SceneChangeNext", 0, &e1), pv = (long long)mapGetInt(f->props, "_SceneChangePrev", 0, &e2);
+                printf("%s frame %d next=%lld prev=%lld\n", k ? "fw" : "bw", n, e1 ? -1 : nx, e2 ? -1 : pv);
+                if (k == 1) dump_frame(fo, f);
+                freeFrame(f);
+            }
+        }
+        fclose(fo); printf("DONE\n"); return 0;
+    }
     if (!strcmp(pipeline, "recalculate")) { /* analyse (a.*) -> recalculate (r.*), backward then forward; dumps both props per frame */
         for (int k = 0; k < 2; k++) {
             VSMap *rm = createMap(); mapSetNode(rm, "super", sup, maReplace); mapSetNode(rm, "vectors", vec[k], maReplace); add_args(rm, 'r', nextra, extra);

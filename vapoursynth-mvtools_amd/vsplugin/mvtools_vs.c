@@ -5,7 +5,7 @@
  * with the reference's exact argument strings:
  *     Super       (src/MVSuper.c:279-291)        Analyse   (src/MVAnalyse.c:639-671)
  *     Degrain1..6 (src/MVDegrains.cpp:813-932)   Compensate (src/MVCompensate.c:579-592)   BlockFPS (src/MVBlockFPS.c:1017-1033)
- *     Recalculate (src/MVRecalculate.c:549-572)
+ *     Recalculate (src/MVRecalculate.c:549-572)   Finest (src/MVFinest.c:213-218)   SCDetection (src/MVSCDetection.c:137-145)
  * and keeps the reference's inter-filter data layout: super-frame geometry + Super_* props on frame 0
  * (src/MVSuper.c:111-120), vector clips = copyFrame(super[n]) + binary props MVTools_MVAnalysisData / MVTools_vectors
  * (src/MVAnalyse.c:224-239).  This file is the only code that touches VSAPI; all arithmetic happens on the GPU behind
@@ -439,6 +439,114 @@ static void VS_CC analyseCreate(const VSMap *in, VSMap *out, void *user, VSCore 
     d->blobSize = mvx_analyse_blob_size(d->an);
     VSFilterDependency deps[1] = { { node, rpGeneral } };
     vs->createVideoFilter(out, "Analyse", vi, analyseGetFrame, analyseFree, fmParallel, deps, 1, d, core);
+}
+
+/* ------------------------------------------------------------------------------------------------ mv.Finest */
+
+typedef struct FinestData { VSNode *super; VSVideoInfo vi; mvx_super *sup; SuperGeo geo; ptrdiff_t pitch[3]; } FinestData;
+
+static const VSFrame *VS_CC finestGetFrame(int n, int reason, void *inst, void **fd, VSFrameContext *ctx, VSCore *core, const VSAPI *vs) {
+    (void)fd;
+    FinestData *d = (FinestData *)inst;
+    if (reason == arInitial) { vs->requestFrameFilter(n, d->super, ctx); return NULL; }
+    if (reason != arAllFramesReady) return NULL;
+    const VSFrame *ref = vs->getFrameFilter(n, d->super, ctx);
+    VSFrame *dst = vs->newVideoFrame(&d->vi.format, d->vi.width, d->vi.height, ref, core);
+    const int np = d->vi.format.numPlanes, bps = d->vi.format.bytesPerSample;
+    DevRef ds;
+    int rc = super_to_device(&ds, ref, &d->geo, vs);
+    size_t off[3], total = 0;
+    for (int p = 0; p < np; p++) { off[p] = total; total += (size_t)d->pitch[p] * vs->getFrameHeight(dst, p); }
+    void *arena = rc ? NULL : mvx_dev_alloc(total);
+    if (!rc && !arena) rc = MVX_E_NOMEM;
+    if (!rc) {
+        const void *src3[3]; void *dst3[3];
+        for (int p = 0; p < 3; p++) { src3[p] = ds.plane[p]; dst3[p] = p < np ? (char *)arena + off[p] : NULL; }
+        rc = mvx_finest_frames(d->sup, 1, src3, d->geo.pitch, dst3, d->pitch, NULL);
+        for (int p = 0; p < np && !rc; p++)
+            rc = mvx_copy_to_host(vs->getWritePtr(dst, p), vs->getStride(dst, p), dst3[p], d->pitch[p], (size_t)vs->getFrameWidth(dst, p) * bps, (size_t)vs->getFrameHeight(dst, p), NULL);
+        if (!rc) rc = mvx_stream_sync(NULL);
+    }
+    dev_release(&ds);
+    if (arena) mvx_dev_free(arena);
+    vs->freeFrame(ref);
+    if (rc) { vs->freeFrame(dst); vs->setFilterError(rc == MVX_E_NOMEM ? "Finest: out of memory." : mvx_last_error(), ctx); return NULL; }
+    return dst;
+}
+static void VS_CC finestFree(void *inst, VSCore *core, const VSAPI *vs) {
+    (void)core;
+    FinestData *d = (FinestData *)inst;
+    vs->freeNode(d->super); mvx_super_destroy(d->sup); free(d);
+}
+static void VS_CC finestCreate(const VSMap *in, VSMap *out, void *user, VSCore *core, const VSAPI *vs) {
+    (void)user;
+    VSNode *super = vs->mapGetNode(in, "super", 0, 0);
+    const VSVideoInfo *vi = vs->getVideoInfo(super);
+    if (!mvx_vsh_is_constant_video_format(vi) || vi->format.bitsPerSample > 16 || vi->format.sampleType != stInteger || vi->format.subSamplingW > 1 ||
+        vi->format.subSamplingH > 1 || (vi->format.colorFamily != cfYUV && vi->format.colorFamily != cfGray)) {
+        vs->mapSetError(out, "Finest: input clip must be GRAY, 420, 422, 440, or 444, up to 16 bits, with constant dimensions.");
+        vs->freeNode(super);
+        return;
+    }
+    char err[1400] = "";
+    mvx_super *sup = super_from_props(super, "Finest", err, sizeof(err), vs);
+    if (!sup) { vs->mapSetError(out, err); vs->freeNode(super); return; }
+    FinestData *d = (FinestData *)calloc(1, sizeof(*d));
+    d->super = super; d->sup = sup; d->vi = *vi;
+    super_geo(&d->geo, sup);
+    int32_t w, h;
+    mvx_finest_size(sup, &w, &h);
+    d->vi.width = w; d->vi.height = h;
+    for (int p = 0; p < 3; p++) {
+        const int pw = p ? w >> vi->format.subSamplingW : w;
+        d->pitch[p] = ((ptrdiff_t)pw * vi->format.bytesPerSample + 255) / 256 * 256;
+    }
+    VSFilterDependency deps[1] = { { super, rpStrictSpatial } };
+    vs->createVideoFilter(out, "Finest", &d->vi, finestGetFrame, finestFree, fmParallel, deps, 1, d, core);
+}
+
+/* ------------------------------------------------------------------------------------------------ mv.SCDetection */
+
+typedef struct ScdData { VSNode *node, *vectors; const VSVideoInfo *vi; mvx_analysis_data ad; int64_t thscd1; int32_t thscd2; } ScdData;
+
+static const VSFrame *VS_CC scdGetFrame(int n, int reason, void *inst, void **fd, VSFrameContext *ctx, VSCore *core, const VSAPI *vs) {
+    (void)fd;
+    ScdData *d = (ScdData *)inst;
+    if (reason == arInitial) { vs->requestFrameFilter(n, d->vectors, ctx); vs->requestFrameFilter(n, d->node, ctx); return NULL; }
+    if (reason != arAllFramesReady) return NULL;
+    const VSFrame *src = vs->getFrameFilter(n, d->node, ctx);
+    VSFrame *dst = vs->copyFrame(src, core);
+    vs->freeFrame(src);
+    const VSFrame *mvn = vs->getFrameFilter(n, d->vectors, ctx);
+    void *dblob = NULL;
+    int rc = blob_to_device(&dblob, NULL, mvn, vs);
+    vs->freeFrame(mvn);
+    int32_t sc = 0;
+    char lerr[MVX_ERRLEN];
+    if (!rc) { const void *b1[1] = { dblob }; rc = mvx_scdetect(&d->ad, d->thscd1, d->thscd2, 1, b1, &sc, NULL, lerr); }
+    if (dblob) mvx_dev_free(dblob);
+    if (rc) { vs->freeFrame(dst); vs->setFilterError(rc == MVX_E_ARG ? "SCDetection: vector clip frame without a valid MVTools_vectors property." : mvx_last_error(), ctx); return NULL; }
+    vs->mapSetInt(vs->getFramePropertiesRW(dst), d->ad.isBackward ? "_SceneChangeNext" : "_SceneChangePrev", sc, maReplace); /* :62-64 */
+    return dst;
+}
+static void VS_CC scdFree(void *inst, VSCore *core, const VSAPI *vs) {
+    (void)core;
+    ScdData *d = (ScdData *)inst;
+    vs->freeNode(d->node); vs->freeNode(d->vectors); free(d);
+}
+static void VS_CC scdCreate(const VSMap *in, VSMap *out, void *user, VSCore *core, const VSAPI *vs) {
+    (void)user;
+    ScdData *d = (ScdData *)calloc(1, sizeof(*d));
+    char err[1400] = "";
+    d->thscd1 = opt_int64(in, "thscd1", vs); d->thscd2 = opt_int(in, "thscd2", vs);
+    d->vectors = vs->mapGetNode(in, "vectors", 0, NULL);
+    adata_from_clip(&d->ad, d->vectors, "SCDetection", "vectors", err, sizeof(err), vs);
+    if (!err[0] && (d->thscd1 == (int64_t)MVX_UNSET ? 400 : d->thscd1) > 8 * 8 * 255) snprintf(err, sizeof(err), "SCDetection: thscd1 can be at most %d.", 8 * 8 * 255);
+    if (err[0]) { vs->mapSetError(out, err); vs->freeNode(d->vectors); free(d); return; }
+    d->node = vs->mapGetNode(in, "clip", 0, NULL);
+    d->vi = vs->getVideoInfo(d->node);
+    VSFilterDependency deps[2] = { { d->node, rpStrictSpatial }, { d->vectors, rpStrictSpatial } };
+    vs->createVideoFilter(out, "SCDetection", d->vi, scdGetFrame, scdFree, fmParallel, deps, 2, d, core);
 }
 
 /* ------------------------------------------------------------------------------------------------ mv.Recalculate */
@@ -1008,6 +1116,8 @@ VS_EXTERNAL_API(void) VapourSynthPluginInit2(VSPlugin *plugin, const VSPLUGINAPI
                              "overlap:int:opt;overlapv:int:opt;divide:int:opt;badsad:int:opt;badrange:int:opt;opt:int:opt;meander:int:opt;trymany:int:opt;fields:int:opt;"
                              "tff:int:opt;search_coarse:int:opt;dct:int:opt;",
                              "clip:vnode;", analyseCreate, NULL, plugin);
+    vspapi->registerFunction("Finest", "super:vnode;opt:int:opt;", "clip:vnode;", finestCreate, NULL, plugin);
+    vspapi->registerFunction("SCDetection", "clip:vnode;vectors:vnode;thscd1:int:opt;thscd2:int:opt;", "clip:vnode;", scdCreate, NULL, plugin);
     vspapi->registerFunction("Recalculate",
                              "super:vnode;vectors:vnode;thsad:int:opt;smooth:int:opt;blksize:int:opt;blksizev:int:opt;search:int:opt;searchparam:int:opt;lambda:int:opt;"
                              "chroma:int:opt;truemotion:int:opt;pnew:int:opt;overlap:int:opt;overlapv:int:opt;divide:int:opt;opt:int:opt;meander:int:opt;fields:int:opt;"
