@@ -53,6 +53,19 @@ def run_case(oracle, c):
     cp = oracle.Compensate(sup, an.ad)
     o = cp.frame(sf[radius], refs[0], blobs[0])
     out["compensate_fnv"] = ["%08x" % oracle.fnv1a(p) for p in o]
+    # round-1 additions: Finest, Recalculate (+ divide), BlockFPS on the first two frames' vector fields
+    out["finest_fnv"] = ["%08x" % oracle.fnv1a(np.ascontiguousarray(p)) for p in sup.finest(sf[radius])]
+    abw = oracle.Analyse(sup, isb=1, delta=1, **c["akw"])
+    afw = oracle.Analyse(sup, isb=0, delta=1, **c["akw"])
+    nf = len(frames)
+    bbw = [abw.frame(sf[n], sf[n + 1] if n + 1 < nf else None) for n in range(nf)]
+    bfw = [afw.frame(sf[n], sf[n - 1] if n >= 1 else None) for n in range(nf)]
+    rc = oracle.Recalculate(sup, abw.ad, blksize=8, overlap=4, thsad=100, divide=2)
+    out["recalculate_divide_fnv"] = "%08x" % oracle.fnv1a(rc.frame(sf[0], sf[1], bbw[0]))
+    for mode in (3, 7):
+        bf = oracle.BlockFPS(sup, abw.ad, afw.ad, nf, 24, 1, num=60, den=1, mode=mode, ml=60.0)
+        o = bf.frame(1, frames, sf, bbw, bfw)
+        out["blockfps_mode%d_fnv" % mode] = ["%08x" % oracle.fnv1a(np.ascontiguousarray(p)) for p in o]
     return out
 
 

@@ -297,6 +297,23 @@ def test_gpu_against_golden_fixtures(oracle, mv, case):
     out = mv.Compensate(gsup, gan.ad).run([(gsf[radius], refs[0], blobs[0])])[0]
     got = ["%08x" % oracle.fnv1a(mv.plane_to_numpy(out[p], widths[p], gsup.dtype)) for p in range(3)]
     assert got == case["expect"]["compensate_fnv"]
+    # Finest, Recalculate + divide, BlockFPS
+    i = gsup.info
+    fw_, fh_ = (w + 2 * i.hpad) * i.pel, (h + 2 * i.vpad) * i.pel
+    fin = gsup.finest([gsf[radius]])[0]
+    fwid = [fw_, fw_ // 2, fw_ // 2]
+    assert ["%08x" % oracle.fnv1a(mv.plane_to_numpy(fin[p], fwid[p], gsup.dtype)) for p in range(3)] == case["expect"]["finest_fnv"]
+    nf = len(frames)
+    gabw = mv.Analyse(gsup, isb=1, delta=1, **c["akw"])
+    gafw = mv.Analyse(gsup, isb=0, delta=1, **c["akw"])
+    gbbw = gabw.run([(gsf[n], gsf[n + 1] if n + 1 < nf else None) for n in range(nf)])
+    gbfw = gafw.run([(gsf[n], gsf[n - 1] if n >= 1 else None) for n in range(nf)])
+    grc = mv.Recalculate(gsup, gabw.ad, blksize=8, overlap=4, thsad=100, divide=2)
+    assert "%08x" % oracle.fnv1a(grc.run([(gsf[0], gsf[1], gbbw[0])])[0].cpu().numpy()) == case["expect"]["recalculate_divide_fnv"]
+    for mode in (3, 7):
+        gbf = mv.BlockFPS(gsup, gabw.ad, gafw.ad, nf, [p.stride(0) for p in gsrc[0]], 24, 1, num=60, den=1, mode=mode, ml=60.0)
+        o = gbf.run([1], gsrc, gsf, gbbw, gbfw)[0]
+        assert ["%08x" % oracle.fnv1a(mv.plane_to_numpy(o[p], widths[p], gsup.dtype)) for p in range(3)] == case["expect"]["blockfps_mode%d_fnv" % mode]
 
 
 def test_full_size_properties_cfg2(mv):
