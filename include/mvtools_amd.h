@@ -82,6 +82,16 @@ void mvx_super_get_info(const mvx_super *s, mvx_super_info *info);
 int mvx_super_frames(mvx_super *s, int nframes, const void *const *src, const ptrdiff_t src_pitch[3],
                      void *const *dst, const ptrdiff_t dst_pitch[3], void *stream);
 
+/* mv.Super(pelclip=...): the sub-pel planes of level 0 are taken from the user's upsized clip instead of being interpolated.
+ * replaces MVSuper.c:229-256 (mvx_super_pelclip_mode: 0 = ignored because pel is 1, 1 = pelclip is pel x the clip size,
+ * 2 = pel x the padded size; other sizes -> MVX_E_ARG with the reference's message) and MVSuper.c:91-102 +
+ * mvpRefineExt MVFrame.cpp:1529-1631 (mvx_super_frames_pelclip).  pelclip: [nframes*3] device planes of the clip's format,
+ * rows aligned to pel samples.  mode 0 behaves like mvx_super_frames. */
+int mvx_super_pelclip_mode(const mvx_super *s, int pelclip_width, int pelclip_height, int32_t *mode, char *err);
+int mvx_super_frames_pelclip(mvx_super *s, int nframes, const void *const *src, const ptrdiff_t src_pitch[3],
+                             const void *const *pelclip, const ptrdiff_t pelclip_pitch[3], int pelclip_mode,
+                             void *const *dst, const ptrdiff_t dst_pitch[3], void *stream);
+
 /* ---- mv.Finest -----------------------------------------------------------------------------------
  * replaces mvfinestGetFrame, MVFinest.c:48-140 (arg string :213-218): the pel^2 sub-pel planes of level 0 of a super frame
  * interleaved into one plane of (width + 2 hpad) * pel x (height + 2 vpad) * pel samples (chroma planes subsampled like
@@ -185,6 +195,7 @@ typedef struct mvx_compensate_args {
     int64_t thsad;       /* MVX_UNSET -> 10000 */
     double time;         /* 0..100, pass 100.0 for the default */
     int64_t thscd1; int32_t thscd2;
+    int32_t fields;      /* MVX_UNSET/0 -> off; 1 needs pel > 1 (MVCompensate.c:514-517) */
 } mvx_compensate_args;
 
 typedef struct mvx_compensate mvx_compensate;
@@ -199,6 +210,8 @@ typedef struct mvx_compensate_job {
     const void *ref_super[3]; /* super frame nref; [0]==NULL if outside the clip */
     const void *blob;         /* MVTools_vectors at frame n */
     void *dst[3];
+    int32_t field_shift;      /* MVCompensate.c:188-225: +-pel/2 when fields=1, pel>1, (nref-n) odd and the field parities differ; else 0 */
+    int32_t reserved;
 } mvx_compensate_job;
 
 int mvx_compensate_frames(mvx_compensate *c, int nframes, const mvx_compensate_job *jobs, void *stream);

@@ -1015,7 +1015,7 @@ void mvo_recalculate_args_default(mvo_recalculate_args *a) {
     for (size_t i = 0; i < sizeof(*a) / sizeof(int64_t); i++) f[i] = MVO_UNSET;
 }
 
-/* MVRecalculate.c:263-545 mvrecalculateCreate (fields / tff not supported) */
+/* MVRecalculate.c:263-545 mvrecalculateCreate (fields: its fieldShift never reaches a result, PlaneOfBlocks.cpp:1167-1171) */
 int mvo_recalculate_init(mvo_recalculate *d, const mvo_recalculate_args *a, const mvo_super *s, const mvo_analysis_data *vectors, char *err) {
     memset(d, 0, sizeof(*d));
     if (err) err[0] = 0;

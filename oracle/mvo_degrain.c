@@ -336,10 +336,10 @@ int mvo_compensate_init(mvo_compensate *d, const mvo_analysis_data *ad, const mv
     return 0;
 }
 
-/* MVCompensate.c:73-374 mvcompensateGetFrame (fields=0) */
+/* MVCompensate.c:73-374 mvcompensateGetFrame; fieldShift is what :188-225 derives from the _Field props / tff */
 void mvo_compensate_frame(const mvo_compensate *d, const uint8_t *const srcSuper[3], const int srcPitch[3],
                           const uint8_t *const refSuper[3], const int refPitch[3], const uint8_t *blob,
-                          uint8_t *const dst[3], const int dstPitch[3]) {
+                          uint8_t *const dst[3], const int dstPitch[3], int fieldShift) {
     const mvo_analysis_data *ad = &d->ad;
     const int bps = (d->bits + 7) / 8;
     const int xSubUV = ad->xRatioUV == 2, ySubUV = ad->yRatioUV == 2;
@@ -357,7 +357,6 @@ void mvo_compensate_frame(const mvo_compensate *d, const uint8_t *const srcSuper
     const int dstTempPitch[3] = { ((ad->nWidth + 15) / 16) * 16 * bps * 2, (((ad->nWidth / ad->xRatioUV) + 15) / 16) * 16 * bps * 2,
                                   (((ad->nWidth / ad->xRatioUV) + 15) / 16) * 16 * bps * 2 };
     int num_planes = (d->nSuperModeYUV & (MVO_UPLANE | MVO_VPLANE)) ? 3 : 1;
-    const int fieldShift = 0;
 
     if (refSuper && mvo_blob_is_usable(ad, blob, d->nSCD1, d->nSCD2)) {
         const mvo_vector *vec = mvo_blob_level0(ad, blob);
@@ -439,4 +438,14 @@ void mvo_compensate_frame(const mvo_compensate *d, const uint8_t *const srcSuper
         for (int p = 0; p < num_planes; p++)
             bitblt(dst[p], dstPitch[p], s[p] + nHPadding[p] * bps + (size_t)nVPadding[p] * sp[p], sp[p], nWidth[p] * bps, nHeight[p]);
     }
+}
+
+/* MVCompensate.c:188-225 (Analyse: MVAnalyse.c:135-176, same arithmetic with nDeltaFrame % 2 for the parity test) */
+int mvo_field_shift(int fields, int pel, int n, int nref, int src_field, int ref_field, int tff, int *missing) {
+    *missing = 0;
+    if (!(fields && pel > 1 && ((nref - n) % 2 != 0))) return 0;
+    int src_top = src_field > 0, ref_top = ref_field > 0;
+    if ((src_field < 0 || ref_field < 0) && tff < 0) { *missing = 1; return 0; }
+    if (tff >= 0) { src_top = tff ^ (n % 2); ref_top = tff ^ (nref % 2); }
+    return (src_top && !ref_top) ? pel / 2 : ((ref_top && !src_top) ? -(pel / 2) : 0);
 }

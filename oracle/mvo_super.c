@@ -397,9 +397,54 @@ int mvo_super_init(mvo_super *s, int width, int height, int bits, int subW, int 
     return 0;
 }
 
+/* MVSuper.c:229-256: how a pelclip of the given size is used.  0 = ignored (pel 1), 1 = plain, 2 = already padded, -1 = error */
+int mvo_super_pelclip_mode(const mvo_super *s, int pelWidth, int pelHeight, char *err) {
+    if (err) err[0] = 0;
+    if (s->pel < 2) return 0;
+    if (pelWidth == s->width * s->pel && pelHeight == s->height * s->pel) return 1;
+    if (pelWidth == (s->width + s->hpad * 2) * s->pel && pelHeight == (s->height + s->vpad * 2) * s->pel) return 2;
+    if (err) snprintf(err, MVO_ERR, "Super: pelclip's dimensions must be multiples of the input clip's dimensions.");
+    return -1;
+}
+
+/* MVFrame.cpp:1529-1631 mvpRefineExt: sub-pel plane i takes every pel-th sample of the user's upsized clip at phase
+ * (i / pel, i % pel).  A plain pelclip fills the interior and the planes are then edge-padded; a padded one is read
+ * from ITS origin into the plane's origin over only w x h samples (the reference does not widen the loop to the padded
+ * size), the rest of those planes stays as the frame memset left it. */
+static void plane_refine_ext(mvo_plane *m, const uint8_t *pel8, int pelPitch, int padded) {
+    const int n = m->pel * m->pel;
+    for (int i = 1; i < n; i++) {
+        uint8_t *d = m->p[i] + (padded ? 0 : m->offpad);
+        const int ry = i / m->pel, rx = i % m->pel;
+        for (int y = 0; y < m->h; y++)
+            for (int x = 0; x < m->w; x++) {
+                const uint8_t *sp = pel8 + (size_t)(y * m->pel + ry) * pelPitch + (size_t)(x * m->pel + rx) * m->bps;
+                memcpy(d + (size_t)y * m->pitch + (size_t)x * m->bps, sp, m->bps);
+            }
+        if (!padded) {
+            if (m->bps == 1) pad_u8(m->p[i], m->pitch, m->hpad, m->vpad, m->w, m->h);
+            else pad_u16(m->p[i], m->pitch, m->hpad, m->vpad, m->w, m->h);
+        }
+    }
+}
+
+static void super_frame_impl(const mvo_super *s, const uint8_t *const src[3], const int srcPitch[3], const uint8_t *const pelclip[3],
+                             const int pelPitch[3], int pelMode, uint8_t *const dst[3], const int dstPitch[3]);
+
 /* MVSuper.c:43-126 mvsuperGetFrame (no pelclip) */
 void mvo_super_frame(const mvo_super *s, const uint8_t *const src[3], const int srcPitch[3],
                      uint8_t *const dst[3], const int dstPitch[3]) {
+    super_frame_impl(s, src, srcPitch, NULL, NULL, 0, dst, dstPitch);
+}
+
+/* MVSuper.c:43-126 with pelclip (:91-102); pelMode from mvo_super_pelclip_mode */
+void mvo_super_frame_pelclip(const mvo_super *s, const uint8_t *const src[3], const int srcPitch[3], const uint8_t *const pelclip[3],
+                             const int pelPitch[3], int pelMode, uint8_t *const dst[3], const int dstPitch[3]) {
+    super_frame_impl(s, src, srcPitch, pelclip, pelPitch, pelMode, dst, dstPitch);
+}
+
+static void super_frame_impl(const mvo_super *s, const uint8_t *const src[3], const int srcPitch[3], const uint8_t *const pelclip[3],
+                             const int pelPitch[3], int pelMode, uint8_t *const dst[3], const int dstPitch[3]) {
     int nplanes = s->gray ? 1 : 3;
     int bps = (s->bits + 7) / 8;
     for (int p = 0; p < nplanes; p++) { /* :75 */
@@ -424,8 +469,11 @@ void mvo_super_frame(const mvo_super *s, const uint8_t *const src[3], const int 
     }
     for (int p = 0; p < 3; p++) /* :89 mvgofPad */
         if (g.fr[0].pl[p].p[0] && (s->modeYUV & (1 << p))) plane_pad(&g.fr[0].pl[p]);
-    for (int p = 0; p < 3; p++) /* :103 mvgofRefine */
-        if (g.fr[0].pl[p].p[0] && (s->modeYUV & (1 << p))) plane_refine(&g.fr[0].pl[p], s->sharp);
+    for (int p = 0; p < 3; p++) { /* :91-103 mvpRefineExt / mvgofRefine */
+        if (!(g.fr[0].pl[p].p[0] && (s->modeYUV & (1 << p)))) continue;
+        if (pelMode > 0) plane_refine_ext(&g.fr[0].pl[p], pelclip[p], pelPitch[p], pelMode == 2);
+        else plane_refine(&g.fr[0].pl[p], s->sharp);
+    }
 }
 
 uint32_t mvo_fnv1a(const uint8_t *p, size_t n) {

@@ -63,6 +63,10 @@ int mvo_super_init(mvo_super *s, int width, int height, int bits, int subW, int 
 /* dst planes: pitch[p] * (superHeight >> (p?subH:0)) bytes each; zero-filled inside (MVSuper.c:75) */
 void mvo_super_frame(const mvo_super *s, const uint8_t *const src[3], const int srcPitch[3],
                      uint8_t *const dst[3], const int dstPitch[3]);
+/* pelclip (MVSuper.c:229-256, :91-102; MVFrame.cpp:1529-1631).  mode: 0 ignored, 1 plain, 2 padded, -1 error */
+int mvo_super_pelclip_mode(const mvo_super *s, int pelWidth, int pelHeight, char *err);
+void mvo_super_frame_pelclip(const mvo_super *s, const uint8_t *const src[3], const int srcPitch[3], const uint8_t *const pelclip[3],
+                             const int pelPitch[3], int pelMode, uint8_t *const dst[3], const int dstPitch[3]);
 
 /* ---- mv.Finest: MVFinest.c (parity unpinned) ---- */
 void mvo_finest_size(const mvo_super *s, int *w, int *h);
@@ -147,7 +151,11 @@ int mvo_compensate_init(mvo_compensate *d, const mvo_analysis_data *ad, const mv
 /* srcSuper = super frame n, refSuper = super frame nref (NULL if out of range), blob = vectors at n */
 void mvo_compensate_frame(const mvo_compensate *d, const uint8_t *const srcSuper[3], const int srcPitch[3],
                           const uint8_t *const refSuper[3], const int refPitch[3], const uint8_t *blob,
-                          uint8_t *const dst[3], const int dstPitch[3]);
+                          uint8_t *const dst[3], const int dstPitch[3], int fieldShift);
+/* MVAnalyse.c:135-176 / MVCompensate.c:188-225: the vertical shift between fields of opposite parity.
+ * src_field / ref_field = the frames' _Field props (-1 = absent); tff = -1 when the argument was not passed.
+ * Returns 0 and sets *missing when a needed _Field is absent and tff was not passed. */
+int mvo_field_shift(int fields, int pel, int n, int nref, int src_field, int ref_field, int tff, int *missing);
 
 /* ---- mv.BlockFPS: MVBlockFPS.c, MaskFun.cpp, SimpleResize.cpp (parity UNPINNED: no reference TU of it builds here) ---- */
 typedef struct mvo_blockfps {

@@ -119,6 +119,13 @@ class OracleError(Exception):
     pass
 
 
+def field_shift(fields, pel, n, nref, src_field=-1, ref_field=-1, tff=-1):
+    """MVAnalyse.c:135-176 / MVCompensate.c:188-225.  Returns (shift, missing)."""
+    miss = C.c_int(0)
+    v = lib().mvo_field_shift(int(fields), int(pel), int(n), int(nref), int(src_field), int(ref_field), int(tff), C.byref(miss))
+    return v, bool(miss.value)
+
+
 def _u(v):
     return UNSET if v is None else int(v)
 
@@ -186,6 +193,24 @@ class Super:
         sp, spitch = _planes(src)
         dp, dpitch = _planes(dst)
         lib().mvo_super_frame(C.byref(self.s), sp, spitch, dp, dpitch)
+        return dst
+
+    def pelclip_mode(self, pel_width, pel_height):
+        """MVSuper.c:229-256: 0 = pelclip ignored, 1 = plain, 2 = padded; raises on other sizes."""
+        err = C.create_string_buffer(ERRLEN)
+        m = lib().mvo_super_pelclip_mode(C.byref(self.s), int(pel_width), int(pel_height), err)
+        if m < 0:
+            raise OracleError(err.value.decode())
+        return m
+
+    def frame_pelclip(self, src, pelclip):
+        """mv.Super(clip, pelclip=...) for one frame (MVSuper.c:91-102, MVFrame.cpp:1529-1631)."""
+        mode = self.pelclip_mode(pelclip[0].shape[1], pelclip[0].shape[0])
+        dst = self.alloc()
+        sp, spitch = _planes(src)
+        pp, ppitch = _planes(pelclip)
+        dp, dpitch = _planes(dst)
+        lib().mvo_super_frame_pelclip(C.byref(self.s), sp, spitch, pp, ppitch, mode, dp, dpitch)
         return dst
 
     def defined_regions(self):
@@ -299,7 +324,7 @@ class Compensate:
                                      _u(thscd1), _u(thscd2), err):
             raise OracleError(err.value.decode())
 
-    def frame(self, src_super, ref_super, blob):
+    def frame(self, src_super, ref_super, blob, field_shift=0):
         s = self.sup.s
         dst = [np.zeros((s.height, s.width), dtype=self.sup.dtype)]
         if self.sup.nplanes == 3:
@@ -308,10 +333,10 @@ class Compensate:
         dp, dpitch = _planes(dst)
         b = np.ascontiguousarray(blob)
         if ref_super is None:
-            lib().mvo_compensate_frame(C.byref(self.d), sp, spitch, None, None, C.c_void_p(b.ctypes.data), dp, dpitch)
+            lib().mvo_compensate_frame(C.byref(self.d), sp, spitch, None, None, C.c_void_p(b.ctypes.data), dp, dpitch, int(field_shift))
         else:
             rp, rpitch = _planes(ref_super)
-            lib().mvo_compensate_frame(C.byref(self.d), sp, spitch, rp, rpitch, C.c_void_p(b.ctypes.data), dp, dpitch)
+            lib().mvo_compensate_frame(C.byref(self.d), sp, spitch, rp, rpitch, C.c_void_p(b.ctypes.data), dp, dpitch, int(field_shift))
         return dst
 
 

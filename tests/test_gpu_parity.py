@@ -59,6 +59,52 @@ def test_super_parity(oracle, mv, w, h, bits, sub, kw):
         assert not bad, "super frame %d differs in defined regions (plane, level, pelplane, count, y, x, oracle, gpu): %s" % (f, bad[:6])
 
 
+@pytest.mark.parametrize("w,h,bits,sub,pel,padded,kw", [
+    (128, 96, 8, (1, 1), 2, False, {}),
+    (128, 96, 16, (1, 1), 2, False, {}),
+    (136, 72, 8, (1, 1), 4, False, {}),
+    (136, 72, 16, (1, 1), 4, False, dict(hpad=16, vpad=8)),
+    (128, 96, 8, (1, 1), 2, True, {}),
+    (136, 72, 16, (1, 1), 4, True, {}),
+    (128, 96, 8, (0, 0), 2, False, {}),
+    (128, 96, 8, (1, 1), 2, False, dict(chroma=0)),
+])
+def test_super_pelclip_parity(oracle, mv, w, h, bits, sub, pel, padded, kw):
+    """mv.Super(pelclip=...) (MVSuper.c:229-256,:91-102; mvpRefineExt MVFrame.cpp:1529-1631): plain and pre-padded upsized clips,
+    then a search on the resulting super clip (its sub-pel planes are whatever the user supplied)"""
+    import torch
+    frames = pl.moving_clip(w, h, bits, 2, seed=8, sub=sub, noise=3)
+    osup = oracle.Super(w, h, bits, subsampling=sub, pel=pel, **kw)
+    gsup = mv.Super(w, h, bits, subsampling=sub, pel=pel, **kw)
+    pw, ph = ((w + 2 * osup.s.hpad) * pel, (h + 2 * osup.s.vpad) * pel) if padded else (w * pel, h * pel)
+    assert osup.pelclip_mode(pw, ph) == gsup.pelclip_mode(pw, ph) == (2 if padded else 1)
+    rng = np.random.default_rng(4)
+    dt = np.uint8 if bits == 8 else np.uint16
+    pelframes = [[rng.integers(0, 1 << bits, (ph >> (sub[1] if p else 0), pw >> (sub[0] if p else 0)), dtype=dt) for p in range(3)] for _ in frames]
+    gsrc = [mv.frame_to_device(f) for f in frames]
+    gpel = [mv.frame_to_device(f) for f in pelframes]
+    gout = gsup.build(gsrc, pelclip=gpel, pelclip_size=(pw, ph))
+    torch.cuda.synchronize()
+    osf = []
+    for f in range(2):
+        of = osup.frame_pelclip(frames[f], pelframes[f])
+        osf.append(of)
+        bad = pl.defined_equal(osup, of, _sup_to_numpy(mv, gsup, gout[f]))
+        assert not bad, "pelclip super frame %d differs (plane, level, pelplane, count, y, x, oracle, gpu): %s" % (f, bad[:6])
+        assert pl.defined_equal(osup, of, osup.frame(frames[f])), "the pelclip must change the sub-pel planes"
+    akw = dict(blksize=8, overlap=4, chroma=kw.get("chroma", 1))
+    ob = oracle.Analyse(osup, isb=1, **akw).frame(osf[0], osf[1])
+    gb = mv.Analyse(gsup, isb=1, **akw).run([(gout[0], gout[1])])[0]
+    assert np.array_equal(gb.cpu().numpy(), ob)
+
+
+def test_super_pelclip_errors(mv):
+    gsup = mv.Super(128, 96, 8, pel=2)
+    with pytest.raises(mv.MvtoolsError, match="Super: pelclip's dimensions must be multiples of the input clip's dimensions."):
+        gsup.pelclip_mode(128, 96)
+    assert mv.Super(128, 96, 8, pel=1).pelclip_mode(77, 33) == 0  # pel 1: the pelclip is ignored (MVSuper.c:240)
+
+
 def test_super_gray(oracle, mv):
     frames = [[p[0]] for p in pl.moving_clip(128, 96, 8, 1, seed=5)]
     osup = oracle.Super(128, 96, 8, gray=True)
@@ -259,6 +305,38 @@ def test_compensate_parity(oracle, mv, w, h, bits, skw, akw, ckw):
         for p in range(3):
             g = mv.plane_to_numpy(got[p], want[p].shape[1], want[p].dtype)
             assert np.array_equal(g, want[p]), "compensate plane %d differs (%d samples)" % (p, int((g != want[p]).sum()))
+
+
+@pytest.mark.parametrize("w,h,bits,pel,akw,shift", [
+    (128, 96, 8, 2, dict(blksize=8, overlap=4), 1),
+    (128, 96, 8, 2, dict(blksize=8, overlap=0), -1),
+    (192, 112, 16, 4, dict(blksize=16, overlap=8), 2),
+    (192, 112, 16, 4, dict(blksize=16, overlap=8), -2),
+    (128, 96, 8, 2, dict(blksize=8, overlap=4, thsad=60), 1),
+])
+def test_fields_shift_parity(oracle, mv, w, h, bits, pel, akw, shift):
+    """fields=True (MVAnalyse.c:172-176, MVCompensate.c:188-225): the +-pel/2 vertical shift between fields of opposite
+    parity, in the search (zero / global predictors) and in Compensate's block fetch (both the vector and the fallback)"""
+    import torch
+    ckw = {}
+    akw = dict(akw)
+    if "thsad" in akw:
+        ckw["thsad"] = akw.pop("thsad")
+    frames, osup, gsup, osf, gsrc, gsf = _pipeline(oracle, mv, w, h, bits, 1, dict(pel=pel), akw, nframes=2)
+    oan = oracle.Analyse(osup, isb=1, fields=1, **akw)
+    gan = mv.Analyse(gsup, isb=1, fields=1, **akw)
+    ob = oan.frame(osf[0], osf[1], field_shift=shift)
+    gb = gan.run([(gsf[0], gsf[1])], field_shift=shift)[0]
+    assert np.array_equal(gb.cpu().numpy(), ob)
+    oc = oracle.Compensate(osup, oan.ad, **ckw)
+    gc = mv.Compensate(gsup, gan.ad, fields=1, **ckw)
+    want = oc.frame(osf[0], osf[1], ob, field_shift=shift)
+    got = gc.run([(gsf[0], gsf[1], gb, shift)])[0]
+    torch.cuda.synchronize()
+    for p in range(3):
+        g = mv.plane_to_numpy(got[p], want[p].shape[1], want[p].dtype)
+        assert np.array_equal(g, want[p]), "compensate plane %d differs (%d samples)" % (p, int((g != want[p]).sum()))
+    assert not all(np.array_equal(a, b) for a, b in zip(want, oc.frame(osf[0], osf[1], ob)))
 
 
 def _golden_cases():

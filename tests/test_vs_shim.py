@@ -70,6 +70,8 @@ def test_plugin_exports_only_the_entry_point():
     (("Super", 640, 360, 8, "f.sharp=3"), "Super: sharp must be between 0 and 2 (inclusive)."),
     (("Super", 640, 360, 8, "f.rfilter=9"), "Super: rfilter must be between 0 and 4 (inclusive)."),
     (("Super", 640, 360, 8, "f.nosuch=1"), "Super: Function does not take argument(s) named nosuch"),
+    (("Super", 640, 360, 8, "f.pel=2", "x.pelw=1000", "x.pelh=720"), "Super: pelclip's dimensions must be multiples of the input clip's dimensions."),
+    (("Super", 640, 360, 8, "f.pel=2", "x.pelw=1280", "x.pelh=720", "x.pelbits=16"), "Super: pelclip must have the same format as the input clip, and it must have constant dimensions."),
     (("AnalyseOnClip", 640, 360, 8), "Analyse: required properties not found in first frame of super clip. Maybe clip didn't come from mv.Super? Was the first frame trimmed away?"),
 ])
 def test_creation_errors_without_gpu(args, msg):
@@ -78,6 +80,10 @@ def test_creation_errors_without_gpu(args, msg):
 
 def test_super_create_reports_geometry_without_gpu():
     assert host("error", "Super", 640, 360, 8, "f.pel=1").strip() == "OK 672x978 frames=4"
+    # a pelclip of either accepted size, or any size with pel=1 (ignored, src/MVSuper.c:240), creates fine
+    assert host("error", "Super", 640, 360, 8, "f.pel=2", "x.pelw=1280", "x.pelh=720").strip().startswith("OK ")
+    assert host("error", "Super", 640, 360, 8, "f.pel=2", "x.pelw=%d" % ((640 + 32) * 2), "x.pelh=%d" % ((360 + 32) * 2)).strip().startswith("OK ")
+    assert host("error", "Super", 640, 360, 8, "f.pel=1", "x.pelw=100", "x.pelh=100").strip() == "OK 672x978 frames=4"
 
 
 def _write_clip(path, frames):
@@ -199,6 +205,93 @@ def test_shell_compensate_matches_oracle(oracle, tmp_path):
         want = ocp.frame(osf[n], r, oan.frame(osf[n], r))
         for p in range(3):
             assert np.array_equal(got[n][p], want[p]), (n, p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits,pel,padded", [(8, 2, False), (16, 4, False), (8, 2, True)])
+def test_shell_super_pelclip_matches_oracle(oracle, tmp_path, bits, pel, padded):
+    w, h, nf = 128, 96, 2
+    frames = pl.moving_clip(w, h, bits, nf, seed=38, noise=3)
+    osup = oracle.Super(w, h, bits, pel=pel)
+    pw, ph = ((w + 2 * osup.s.hpad) * pel, (h + 2 * osup.s.vpad) * pel) if padded else (w * pel, h * pel)
+    rng = np.random.default_rng(5)
+    dt = np.uint8 if bits == 8 else np.uint16
+    pelframes = [[rng.integers(0, 1 << bits, (ph >> (1 if p else 0), pw >> (1 if p else 0)), dtype=dt) for p in range(3)] for _ in frames]
+    _write_clip(tmp_path / "in.raw", frames)
+    _write_clip(tmp_path / "pel.raw", pelframes)
+    host("run", "super", tmp_path / "in.raw", w, h, bits, nf, tmp_path / "sup.raw", "s.pel=%d" % pel, "x.pelclip=%s" % (tmp_path / "pel.raw"), "x.pelw=%d" % pw, "x.pelh=%d" % ph)
+    raw = np.fromfile(tmp_path / "sup.raw", dtype=dt)
+    sw, sh = osup.s.superWidth, osup.s.superHeight
+    per = sw * sh + 2 * (sw // 2) * (sh // 2)
+    assert raw.size == per * nf
+    for n in range(nf):
+        d = raw[n * per:(n + 1) * per]
+        got = [d[:sw * sh].reshape(sh, sw), d[sw * sh:sw * sh + (sw // 2) * (sh // 2)].reshape(sh // 2, sw // 2), d[sw * sh + (sw // 2) * (sh // 2):].reshape(sh // 2, sw // 2)]
+        assert not pl.defined_equal(osup, osup.frame_pelclip(frames[n], pelframes[n]), got)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("how", ["tff1", "tff0", "props1", "props0"])
+def test_shell_fields_match_oracle(oracle, tmp_path, how):
+    """fields=True through the shell: parity from tff (overrides) or from the frames' _Field props (src/MVAnalyse.c:135-179,
+    src/MVCompensate.c:188-225); Analyse and Compensate both apply the +-pel/2 shift"""
+    w, h, bits, nf, pel = 128, 96, 8, 4, 2
+    aargs = dict(blksize=8, overlap=4)
+    frames = pl.moving_clip(w, h, bits, nf, seed=36, noise=3)
+    src = tmp_path / "in.raw"
+    _write_clip(src, frames)
+    order = int(how[-1])
+    extra = ["a.tff=%d" % order, "c.tff=%d" % order] if how.startswith("tff") else ["x.fieldorder=%d" % order]
+    cli = ["a.%s=%s" % kv for kv in aargs.items()] + ["a.fields=1", "c.fields=1", "c.thsad=5000"] + extra
+    host("run", "analyse", src, w, h, bits, nf, tmp_path / "vec.raw", *cli)
+    host("run", "compensate", src, w, h, bits, nf, tmp_path / "out.raw", *cli)
+    got = _read_frames(tmp_path / "out.raw", w, h, bits, nf)
+    blob = np.fromfile(tmp_path / "vec.raw", dtype=np.uint8)
+    osup = oracle.Super(w, h, bits)
+    assert osup.s.pel == pel
+    osf = [osup.frame(f) for f in frames]
+    ans = {isb: oracle.Analyse(osup, num_frames=nf, isb=isb, delta=1, fields=1, **aargs) for isb in (1, 0)}
+    ocp = oracle.Compensate(osup, ans[1].ad, thsad=5000)
+    off, shifts = 0, set()
+    for n in range(nf):
+        for isb in (1, 0):
+            nref = n + 1 if isb else n - 1
+            r = osf[nref] if 0 <= nref < nf else None
+            if how.startswith("tff"):
+                fs, miss = oracle.field_shift(1, pel, n, nref, tff=order)
+            else:
+                fs, miss = oracle.field_shift(1, pel, n, nref, src_field=order ^ (n % 2), ref_field=order ^ (nref % 2))
+            assert not miss
+            if r is not None:
+                shifts.add(fs)
+            want = ans[isb].frame(osf[n], r, field_shift=fs if r is not None else 0)
+            off += 84
+            assert np.array_equal(blob[off:off + want.size], want), (n, isb)
+            off += want.size
+            if isb:
+                wantc = ocp.frame(osf[n], r, want, field_shift=fs if r is not None else 0)
+                for p in range(3):
+                    assert np.array_equal(got[n][p], wantc[p]), (n, p)
+    assert shifts == {1, -1}
+
+
+@pytest.mark.gpu
+def test_shell_fields_need_parity_information():
+    # no _Field prop on the frames and no tff: a frame-time error in the reference's words
+    msg = "_Field property not found in input frame. Therefore, you must pass tff argument."
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        frames = pl.moving_clip(128, 96, 8, 3, seed=37, noise=3)
+        _write_clip(os.path.join(d, "in.raw"), frames)
+        out = host("run", "analyse", os.path.join(d, "in.raw"), 128, 96, 8, 3, os.path.join(d, "o.raw"), "a.fields=1", check=False)
+        assert "Analyse: " + msg in out
+        out = host("run", "compensate", os.path.join(d, "in.raw"), 128, 96, 8, 3, os.path.join(d, "o.raw"), "c.fields=1", check=False)
+        assert "Compensate: " + msg in out
+        out = host("run", "recalculate", os.path.join(d, "in.raw"), 128, 96, 8, 3, os.path.join(d, "o.raw"), "r.fields=1", check=False)
+        assert "Recalculate: " + msg in out
+        out = host("run", "recalculate", os.path.join(d, "in.raw"), 128, 96, 8, 3, os.path.join(d, "o.raw"), "r.fields=1", "r.tff=1")
+        assert "DONE" in out
+    assert host("error", "Compensate", 128, 96, 8, "s.pel=1", "f.fields=1").strip() == "ERROR Compensate: fields option requires pel > 1."
 
 
 @pytest.mark.gpu

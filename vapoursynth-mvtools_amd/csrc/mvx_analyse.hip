@@ -328,7 +328,8 @@ extern "C" __attribute__((visibility("default"))) int mvx_recalculate_create(con
     P.dctmode = (int)A64(a->dct, 0);
     const int divide = (int)A64(a->divide, 0);
     P.meander = !!A64(a->meander, 1);
-    if (A64(a->fields, 0)) RFAIL("Recalculate: fields=True is not supported by the MI355X build.");
+    // fields: the shift MVRecalculate.c:171-175 derives only feeds zeroMVfieldShifted / globalMVPredictor (PlaneOfBlocks.cpp:1167-1171),
+    // which the recalculation never reads (ONLY_CHECK_NONDEFAULT_MV is not defined, PlaneOfBlocks.h:37): accepted, no effect on the blob.
     if (P.searchType < 0 || P.searchType > 7) RFAIL("Recalculate: search must be between 0 and 7 (inclusive).");
     if (P.dctmode < 0 || P.dctmode > 10) RFAIL("Recalculate: dct must be between 0 and 10 (inclusive).");
     if (P.dctmode >= 5 && ad.nBlkSizeX == 16 && ad.nBlkSizeY == 2) RFAIL("Recalculate: dct 5..10 cannot work with 16x2 blocks.");

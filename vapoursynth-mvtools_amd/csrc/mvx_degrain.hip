@@ -103,6 +103,7 @@ struct DGJob {
     const unsigned char *refs[12][3];
     const unsigned char *blobs[12];
     unsigned char *dst[3];
+    int fieldShift;          // compensate only (MVCompensate.c:188-225)
 };
 
 // plan record: one per (frame, plane class luma/chroma, block)
@@ -415,11 +416,11 @@ __global__ __launch_bounds__(256) void compensate_plan_kernel(const DGParams *Pp
     CPlanRec rec;
     if (b.sad < P.cthSAD) { // MVCompensate.c:238-242,286-290
         blx = bx * P.pl[0].stepX * P.pel + b.x * P.time256 / 256;
-        bly = by * P.pl[0].stepY * P.pel + b.y * P.time256 / 256;
+        bly = by * P.pl[0].stepY * P.pel + b.y * P.time256 / 256 + jobs[f].fieldShift;
         rec.fromRef = 1;
     } else { // :243-247,291-295 (no-overlap: stepX == blkW)
         blx = bx * P.pl[0].stepX * P.pel;
-        bly = by * P.pl[0].stepY * P.pel;
+        bly = by * P.pl[0].stepY * P.pel + jobs[f].fieldShift;
         rec.fromRef = 0;
     }
     rec.off[0] = sup_offset(P.pl[0], P.pel, P.logPel, P.bps, blx, bly);
@@ -715,6 +716,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_compensate_create(cons
     thSAD = thSAD * nSCD1 / nSCD1_old; // :521
     if (ad->nHeight != si.height || ad->nWidth != si.super_width - si.hpad * 2 || ad->nWidth != si.width || ad->nPel != si.pel)
         DFAIL("Compensate: wrong source or super clip frame size.");
+    if (a->fields != MVX_UNSET && a->fields && ad->nPel < 2) DFAIL("Compensate: fields option requires pel > 1."); // :514-517
     mvx_compensate *h = new mvx_compensate();
     memset(&h->P, 0, sizeof(h->P));
     int rc = fill_common(h, ad, si, nullptr, super_pitch, dst_pitch, err);
@@ -747,6 +749,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_compensate_frames(mvx_
             hj[f].dst[p] = (unsigned char *)jobs[f].dst[p];
         }
         hj[f].blobs[0] = (const unsigned char *)jobs[f].blob;
+        hj[f].fieldShift = jobs[f].field_shift;
     }
     HIP_CHECK(hipMemcpyAsync(c->dJobs, hj.data(), sizeof(DGJob) * nframes, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(usable_kernel, dim3(1, nframes), dim3(256), 0, st, c->dP, c->dJobs, c->dUsable, 0);

@@ -322,7 +322,7 @@ struct PtrScratch { // per-thread device scratch for the frame-pointer tables
     size_t cap = 0;
     int dev = -1;
 };
-static thread_local PtrScratch g_scratch[2];
+static thread_local PtrScratch g_scratch[3];
 
 static int upload_ptrs(int which, const void *const *host, size_t n, hipStream_t st, void **dev_out) {
     PtrScratch &s = g_scratch[which];
@@ -354,8 +354,86 @@ template <typename T, bool FS> static void launch_reduce(const SuperReduceArgs &
 #undef RD
 }
 
+// mv.Super(pelclip=...): MVFrame.cpp:1529-1631 mvpRefineExt.  One thread per padded level-0 sample position; it fills the
+// sub-pel planes 1..pel^2-1 there.  mode 1 (plain pelclip): plane i at padded (X, Y) = pelclip[(y*pel + i/pel)][(x*pel + i%pel)]
+// with (x, y) the interior coordinate clamped into the picture (== copy + PadReferenceFrame :1548-1562).  mode 2 (padded
+// pelclip): the reference reads the pelclip from its origin into the plane's origin over w x h samples only (:1543-1558);
+// the rest of the plane keeps the frame's memset value, written here as 0 so the result does not depend on what the buffer held.
+struct SuperExtArgs {
+    const void *const *pel; // [nframes*3]
+    void *const *dst;       // [nframes*3]
+    SuperPlaneGeom g[3];
+    long long pel_pitch[3];
+    int pel_n, mode, modeYUV, nplanes;
+};
+
+template <typename T, int PEL>
+__global__ __launch_bounds__(256) void super_ext_kernel(SuperExtArgs A) {
+    const int z = blockIdx.z, f = z / 3, p = z % 3;
+    if (p >= A.nplanes || !(A.modeYUV & (1 << p))) return;
+    const SuperPlaneGeom g = A.g[p];
+    const int X = blockIdx.x * 256 + threadIdx.x, Y = blockIdx.y;
+    if (X >= g.pw || Y >= g.ph) return;
+    const unsigned char *pc = (const unsigned char *)A.pel[f * 3 + p];
+    unsigned char *dst = (unsigned char *)A.dst[f * 3 + p];
+    const long long planeStride = g.dst_pitch * g.ph;
+    typedef T vecp __attribute__((ext_vector_type(PEL)));
+    int x, y;
+    bool zero = false;
+    if (A.mode == 1) { x = iclamp(X - g.hpad, 0, g.w - 1); y = iclamp(Y - g.vpad, 0, g.h - 1); }
+    else { x = X; y = Y; zero = X >= g.w || Y >= g.h; }
+#pragma unroll
+    for (int r = 0; r < PEL; r++) {
+        vecp v = (vecp)0;
+        if (!zero) v = *(const vecp *)(pc + (long long)(y * PEL + r) * A.pel_pitch[p] + (long long)x * PEL * sizeof(T));
+#pragma unroll
+        for (int c = 0; c < PEL; c++) {
+            const int i = r * PEL + c;
+            if (i == 0) continue;
+            ((T *)(dst + i * planeStride + (long long)Y * g.dst_pitch))[X] = v[c];
+        }
+    }
+}
+
+static int super_frames_impl(mvx_super *s, int nframes, const void *const *src, const ptrdiff_t src_pitch[3], const void *const *pelclip,
+                             const ptrdiff_t pelclip_pitch[3], int pelMode, void *const *dst, const ptrdiff_t dst_pitch[3], void *stream);
+
 extern "C" __attribute__((visibility("default"))) int mvx_super_frames(mvx_super *s, int nframes, const void *const *src, const ptrdiff_t src_pitch[3],
                                 void *const *dst, const ptrdiff_t dst_pitch[3], void *stream) {
+    return super_frames_impl(s, nframes, src, src_pitch, nullptr, nullptr, 0, dst, dst_pitch, stream);
+}
+
+// MVSuper.c:229-256
+extern "C" __attribute__((visibility("default"))) int mvx_super_pelclip_mode(const mvx_super *s, int pelclip_width, int pelclip_height, int32_t *mode, char *err) {
+    const mvx_super_info &si = s->info;
+    if (err) err[0] = 0;
+    *mode = 0;
+    if (si.pel < 2) return MVX_OK;
+    if (pelclip_width == si.width * si.pel && pelclip_height == si.height * si.pel) { *mode = 1; return MVX_OK; }
+    if (pelclip_width == (si.width + si.hpad * 2) * si.pel && pelclip_height == (si.height + si.vpad * 2) * si.pel) { *mode = 2; return MVX_OK; }
+    if (err) snprintf(err, MVX_ERRLEN, "Super: pelclip's dimensions must be multiples of the input clip's dimensions.");
+    mvx_set_error("Super: pelclip's dimensions must be multiples of the input clip's dimensions.");
+    return MVX_E_ARG;
+}
+
+extern "C" __attribute__((visibility("default"))) int mvx_super_frames_pelclip(mvx_super *s, int nframes, const void *const *src, const ptrdiff_t src_pitch[3],
+                                const void *const *pelclip, const ptrdiff_t pelclip_pitch[3], int pelclip_mode, void *const *dst,
+                                const ptrdiff_t dst_pitch[3], void *stream) {
+    if (pelclip_mode < 0 || pelclip_mode > 2 || (pelclip_mode && s->info.pel < 2)) { mvx_set_error("mvx_super_frames_pelclip: bad pelclip mode"); return MVX_E_ARG; }
+    if (pelclip_mode) {
+        if (!pelclip || !pelclip_pitch) { mvx_set_error("mvx_super_frames_pelclip: no pelclip frames"); return MVX_E_ARG; }
+        const int align = s->info.pel * (s->info.bits <= 8 ? 1 : 2); // the kernel loads pel samples at once
+        for (int p = 0; p < s->info.num_planes; p++)
+            if (pelclip_pitch[p] % align) { mvx_set_error("mvx_super_frames_pelclip: pelclip pitch must be a multiple of pel samples"); return MVX_E_ARG; }
+        for (int f = 0; f < nframes; f++)
+            for (int p = 0; p < s->info.num_planes; p++)
+                if (((uintptr_t)pelclip[f * 3 + p]) % align) { mvx_set_error("mvx_super_frames_pelclip: pelclip planes must be aligned to pel samples"); return MVX_E_ARG; }
+    }
+    return super_frames_impl(s, nframes, src, src_pitch, pelclip, pelclip_pitch, pelclip_mode, dst, dst_pitch, stream);
+}
+
+static int super_frames_impl(mvx_super *s, int nframes, const void *const *src, const ptrdiff_t src_pitch[3], const void *const *pelclip,
+                             const ptrdiff_t pelclip_pitch[3], int pelMode, void *const *dst, const ptrdiff_t dst_pitch[3], void *stream) {
     if (nframes <= 0) return MVX_OK;
     const mvx_super_info &si = s->info;
     hipStream_t st = (hipStream_t)stream;
@@ -380,9 +458,23 @@ extern "C" __attribute__((visibility("default"))) int mvx_super_frames(mvx_super
         if (lp.ph > maxph) maxph = lp.ph;
     }
     dim3 grid((maxpw + L0_TW - 1) / L0_TW, (maxph + L0_TH - 1) / L0_TH, nframes * 3);
-    if (u8) launch_level0<uint8_t>(A, si.sharp, si.pel, grid, st); else launch_level0<uint16_t>(A, si.sharp, si.pel, grid, st);
+    // with a pelclip only plane 0 comes from the source (PEL=1 instantiation); the sub-pel planes are taken from the pelclip
+    const int l0pel = pelMode ? 1 : si.pel;
+    if (u8) launch_level0<uint8_t>(A, si.sharp, l0pel, grid, st); else launch_level0<uint16_t>(A, si.sharp, l0pel, grid, st);
 
-    if (si.pel == 4) { // MVFrame.cpp:1511-1523, two dependent passes
+    if (pelMode) {
+        void *dpel = nullptr;
+        if ((rc = upload_ptrs(2, pelclip, (size_t)nframes * 3, st, &dpel))) return rc;
+        SuperExtArgs E;
+        memset(&E, 0, sizeof(E));
+        E.pel = (const void *const *)dpel; E.dst = (void *const *)ddst; E.mode = pelMode; E.modeYUV = si.modeYUV; E.nplanes = si.num_planes;
+        for (int p = 0; p < si.num_planes; p++) { E.g[p] = A.g[p]; E.pel_pitch[p] = pelclip_pitch[p]; }
+        dim3 ge((maxpw + 255) / 256, maxph, nframes * 3);
+        if (si.pel == 2) { if (u8) hipLaunchKernelGGL((super_ext_kernel<uint8_t, 2>), ge, dim3(256), 0, st, E); else hipLaunchKernelGGL((super_ext_kernel<uint16_t, 2>), ge, dim3(256), 0, st, E); }
+        else { if (u8) hipLaunchKernelGGL((super_ext_kernel<uint8_t, 4>), ge, dim3(256), 0, st, E); else hipLaunchKernelGGL((super_ext_kernel<uint16_t, 4>), ge, dim3(256), 0, st, E); }
+    }
+
+    if (si.pel == 4 && !pelMode) { // MVFrame.cpp:1511-1523, two dependent passes
         SuperAvgArgs B;
         memset(&B, 0, sizeof(B));
         B.dst = (void *const *)ddst; B.modeYUV = si.modeYUV; B.nplanes = si.num_planes;

@@ -67,11 +67,13 @@ class DegrainJob(C.Structure):
 
 
 class CompensateArgs(C.Structure):
-    _fields_ = [("scbehavior", C.c_int32), ("thsad", C.c_int64), ("time", C.c_double), ("thscd1", C.c_int64), ("thscd2", C.c_int32)]
+    _fields_ = [("scbehavior", C.c_int32), ("thsad", C.c_int64), ("time", C.c_double), ("thscd1", C.c_int64), ("thscd2", C.c_int32),
+                ("fields", C.c_int32)]
 
 
 class CompensateJob(C.Structure):
-    _fields_ = [("src_super", C.c_void_p * 3), ("ref_super", C.c_void_p * 3), ("blob", C.c_void_p), ("dst", C.c_void_p * 3)]
+    _fields_ = [("src_super", C.c_void_p * 3), ("ref_super", C.c_void_p * 3), ("blob", C.c_void_p), ("dst", C.c_void_p * 3),
+                ("field_shift", C.c_int32), ("reserved", C.c_int32)]
 
 
 RECALC_ARGS = ("thsad", "smooth", "blksize", "blksizev", "search", "searchparam", "lambda_", "chroma", "truemotion", "pnew", "overlap", "overlapv", "divide",
@@ -124,6 +126,9 @@ def lib():
         L.mvx_super_destroy.argtypes = [C.c_void_p]
         L.mvx_super_get_info.argtypes = [C.c_void_p, P(SuperInfo)]
         L.mvx_super_frames.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p), P(C.c_ssize_t), P(C.c_void_p), P(C.c_ssize_t), C.c_void_p]
+        L.mvx_super_pelclip_mode.argtypes = [C.c_void_p, C.c_int, C.c_int, P(C.c_int32), C.c_char_p]
+        L.mvx_super_frames_pelclip.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p), P(C.c_ssize_t), P(C.c_void_p), P(C.c_ssize_t), C.c_int, P(C.c_void_p),
+                                               P(C.c_ssize_t), C.c_void_p]
         L.mvx_analyse_create.argtypes = [P(AnalyseArgs), C.c_void_p, C.c_int, P(C.c_ssize_t), P(C.c_void_p), C.c_char_p]
         L.mvx_analyse_destroy.argtypes = [C.c_void_p]
         L.mvx_analyse_get_data.argtypes = [C.c_void_p, P(AnalysisData)]
@@ -284,9 +289,31 @@ class Super:
         _check(lib().mvx_finest_frames(self.h, n, src, pad(self.pitch), dst, pad(pitch), _stream()))
         return out
 
-    def build(self, frames, out=None):
-        """frames: list of device frames (list of plane tensors sharing pitches) -> list of super frames."""
+    def pelclip_mode(self, pel_width, pel_height):
+        """MVSuper.c:229-256: 0 = a pelclip is ignored (pel 1), 1 = plain, 2 = padded; raises on any other size."""
+        mode = C.c_int32()
+        err = C.create_string_buffer(ERRLEN)
+        _check(lib().mvx_super_pelclip_mode(self.h, int(pel_width), int(pel_height), C.byref(mode), err), err)
+        return mode.value
+
+    def build(self, frames, out=None, pelclip=None, pelclip_size=None):
+        """frames: list of device frames (list of plane tensors sharing pitches) -> list of super frames.
+        pelclip: the matching frames of mv.Super's pelclip argument, pelclip_size = its (width, height)."""
         n = len(frames)
+        if pelclip is not None:
+            mode = self.pelclip_mode(*pelclip_size)
+            if out is None:
+                out = self.alloc(n, device=frames[0][0].device)
+            src = (C.c_void_p * (3 * n))()
+            pel = (C.c_void_p * (3 * n))()
+            dst = (C.c_void_p * (3 * n))()
+            for f in range(n):
+                for p in range(self.nplanes):
+                    src[f * 3 + p] = frames[f][p].data_ptr()
+                    pel[f * 3 + p] = pelclip[f][p].data_ptr()
+                    dst[f * 3 + p] = out[f][p].data_ptr()
+            _check(lib().mvx_super_frames_pelclip(self.h, n, src, _pitches(frames[0]), pel, _pitches(pelclip[0]), mode, dst, _pitches(out[0]), _stream()))
+            return out
         if out is None:
             out = self.alloc(n, device=frames[0][0].device)
         src = (C.c_void_p * (3 * n))()
@@ -397,9 +424,9 @@ class Degrain:
 class Compensate:
     """mv.Compensate -- MVCompensate.c:419-575."""
 
-    def __init__(self, sup, analysis_data, dst_pitch=None, scbehavior=None, thsad=None, time=100.0, thscd1=None, thscd2=None):
+    def __init__(self, sup, analysis_data, dst_pitch=None, scbehavior=None, thsad=None, time=100.0, thscd1=None, thscd2=None, fields=None):
         self.sup = sup
-        a = CompensateArgs(_u(scbehavior), _u(thsad), float(time), _u(thscd1), _u(thscd2))
+        a = CompensateArgs(_u(scbehavior), _u(thsad), float(time), _u(thscd1), _u(thscd2), _u(fields))
         ad = AnalysisData.from_buffer_copy(bytes(analysis_data))
         i = sup.info
         if dst_pitch is None:
@@ -419,7 +446,7 @@ class Compensate:
             pass
 
     def run(self, jobs, out=None):
-        """jobs: list of (src_super, ref_super_or_None, blob)."""
+        """jobs: list of (src_super, ref_super_or_None, blob[, field_shift])."""
         torch = _torch()
         i = self.sup.info
         n = len(jobs)
@@ -428,12 +455,14 @@ class Compensate:
             dev = jobs[0][0][0].device
             out = [[torch.zeros((hs[p], self.dst_pitch[p]), dtype=torch.uint8, device=dev) for p in range(self.sup.nplanes)] for _ in range(n)]
         arr = (CompensateJob * n)()
-        for k, (s, r, blob) in enumerate(jobs):
+        for k, job in enumerate(jobs):
+            s, r, blob = job[:3]
             for p in range(self.sup.nplanes):
                 arr[k].src_super[p] = s[p].data_ptr()
                 arr[k].ref_super[p] = r[p].data_ptr() if r is not None else None
                 arr[k].dst[p] = out[k][p].data_ptr()
             arr[k].blob = blob.data_ptr()
+            arr[k].field_shift = int(job[3]) if len(job) > 3 else 0
         _check(lib().mvx_compensate_frames(self.h, n, arr, _stream()))
         return out
 

@@ -285,6 +285,8 @@ static void init_api(void) {
 
 /* ---------------------------------------------------------------------------------------------------- driver */
 
+static int g_field_order = -1; /* x.fieldorder=0|1: source frame n carries _Field = order ^ (n % 2), like separated fields */
+
 static VSNode *source_clip(const char *path, int w, int h, int bits, int nframes) {
     VSNode *n = (VSNode *)calloc(1, sizeof(VSNode));
     n->refs = 1;
@@ -303,10 +305,24 @@ static VSNode *source_clip(const char *path, int w, int h, int bits, int nframes
                 if (fp) { if (fread(row, 1, rb, fp) != rb) { fprintf(stderr, "short read\n"); exit(2); } }
                 else memset(row, 0, rb);
             }
+        if (g_field_order >= 0) mapSetInt(fr->props, "_Field", g_field_order ^ (f % 2), maReplace);
         n->cache[f] = fr;
     }
     if (fp) fclose(fp);
     return n;
+}
+
+/* x.pelw=W x.pelh=H [x.pelclip=path] [x.pelbits=B]: a second source clip handed to mv.Super as pelclip */
+static VSNode *pelclip_from_args(int argc, char **argv, int bits, int nframes) {
+    const char *path = NULL;
+    int pw = 0, ph = 0;
+    for (int i = 0; i < argc; i++) {
+        if (!strncmp(argv[i], "x.pelclip=", 10)) path = argv[i] + 10;
+        else if (!strncmp(argv[i], "x.pelw=", 7)) pw = atoi(argv[i] + 7);
+        else if (!strncmp(argv[i], "x.pelh=", 7)) ph = atoi(argv[i] + 7);
+        else if (!strncmp(argv[i], "x.pelbits=", 10)) bits = atoi(argv[i] + 10);
+    }
+    return pw && ph ? source_clip(path, pw, ph, bits, nframes) : NULL;
 }
 
 /* key=value arguments with a one-letter filter prefix ("a.blksize=8") */
@@ -349,7 +365,12 @@ int main(int argc, char **argv) {
         VSNode *clip = source_clip(NULL, w, hh, bits, 4);
         VSMap *m = createMap();
         VSNode *out = NULL;
-        if (!strcmp(filter, "Super")) { mapSetNode(m, "clip", clip, maReplace); add_args(m, 'f', argc - 7, argv + 7); out = invoke("Super", m, err, sizeof(err)); }
+        if (!strcmp(filter, "Super")) {
+            mapSetNode(m, "clip", clip, maReplace); add_args(m, 'f', argc - 7, argv + 7);
+            VSNode *pc = pelclip_from_args(argc - 7, argv + 7, bits, 4);
+            if (pc) mapSetNode(m, "pelclip", pc, maReplace);
+            out = invoke("Super", m, err, sizeof(err));
+        }
         else {
             VSMap *sm = createMap(); mapSetNode(sm, "clip", clip, maReplace); add_args(sm, 's', argc - 7, argv + 7);
             VSNode *sup = invoke("Super", sm, err, sizeof(err));
@@ -378,11 +399,14 @@ int main(int argc, char **argv) {
     const char *pipeline = argv[3], *inPath = argv[4], *outPath = argv[9];
     const int w = atoi(argv[5]), hh = atoi(argv[6]), bits = atoi(argv[7]), nframes = atoi(argv[8]);
     char **extra = argv + 10; const int nextra = argc - 10;
+    for (int i = 0; i < nextra; i++) if (!strncmp(extra[i], "x.fieldorder=", 13)) g_field_order = atoi(extra[i] + 13);
     VSNode *clip = source_clip(inPath, w, hh, bits, nframes);
     FILE *fo = fopen(outPath, "wb");
     if (!fo) { fprintf(stderr, "cannot write %s\n", outPath); return 2; }
 
     VSMap *sm = createMap(); mapSetNode(sm, "clip", clip, maReplace); add_args(sm, 's', nextra, extra);
+    VSNode *pelclip = pelclip_from_args(nextra, extra, bits, nframes);
+    if (pelclip) mapSetNode(sm, "pelclip", pelclip, maReplace);
     VSNode *sup = invoke("Super", sm, err, sizeof(err));
     if (!sup) die("Super", err);
     if (!strcmp(pipeline, "super")) {

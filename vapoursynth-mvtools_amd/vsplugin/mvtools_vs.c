@@ -17,7 +17,7 @@
  * concurrently requested frames into one search launch (where the throughput is) is the next step and
  * does not change this interface.
  *
- * Not supported (fail loudly at creation, like the C ABI): pelclip, fields/tff, dct 1..4.
+ * Not supported (fail loudly at creation, like the C ABI): dct 1..4.
  */
 #include <pthread.h>
 #include <stdio.h>
@@ -144,7 +144,29 @@ static int64_t opt_int64(const VSMap *in, const char *key, const VSAPI *vs) {
     const int64_t v = vs->mapGetInt(in, key, 0, &err);
     return err ? (int64_t)MVX_UNSET : v;
 }
-static int arg_given(const VSMap *in, const char *key, const VSAPI *vs) { return vs->mapNumElements(in, key) > 0; }
+
+/* fields / tff (src/MVAnalyse.c:367-370, MVRecalculate.c:332-335, MVCompensate.c:435,453-454) */
+typedef struct FieldOpt { int fields, tff, tffExists; } FieldOpt;
+
+static void field_opt(FieldOpt *o, const VSMap *in, const VSAPI *vs) {
+    int e;
+    o->fields = !!vs->mapGetInt(in, "fields", 0, &e);
+    o->tff = !!vs->mapGetInt(in, "tff", 0, &e);
+    o->tffExists = !e;
+}
+
+/* parity of frame n: its _Field prop unless tff was passed (src/MVAnalyse.c:135-145); *missing is set when neither exists */
+static int frame_top_field(const FieldOpt *o, const VSFrame *f, int n, int *missing, const VSAPI *vs) {
+    int e;
+    int top = !!vs->mapGetInt(vs->getFramePropertiesRO(f), "_Field", 0, &e);
+    if (e && !o->tffExists) *missing = 1;
+    if (o->tffExists) top = o->tff ^ (n % 2);
+    return top;
+}
+
+static int field_shift_of(int srcTop, int refTop, int pel) { /* src/MVAnalyse.c:177 */
+    return (srcTop && !refTop) ? pel / 2 : ((refTop && !srcTop) ? -(pel / 2) : 0);
+}
 
 /* Super_* props of frame 0 of a super clip -> a geometry-only mvx_super handle (consumers: src/MVAnalyse.c:519-553,
  * src/MVDegrains.cpp:556-581, src/MVCompensate.c:470-500).  `filter` prefixes the reference's messages. */
@@ -248,22 +270,28 @@ static void upload_plane_set(void *dst[3], void **arena, const VSFrame *f, const
 
 /* ------------------------------------------------------------------------------------------------ mv.Super */
 
-typedef struct SuperData { VSNode *node; VSVideoInfo vi; mvx_super *sup; SuperGeo geo; ptrdiff_t srcPitch[3]; int64_t instance; } SuperData;
+typedef struct SuperData { VSNode *node, *pelclip; VSVideoInfo vi; mvx_super *sup; SuperGeo geo; ptrdiff_t srcPitch[3], pelPitch[3]; int32_t pelMode; int64_t instance; } SuperData;
 
 static const VSFrame *VS_CC superGetFrame(int n, int reason, void *inst, void **fd, VSFrameContext *ctx, VSCore *core, const VSAPI *vs) {
     (void)fd;
     SuperData *d = (SuperData *)inst;
-    if (reason == arInitial) { vs->requestFrameFilter(n, d->node, ctx); return NULL; }
+    if (reason == arInitial) { /* src/MVSuper.c:47-52 */
+        vs->requestFrameFilter(n, d->node, ctx);
+        if (d->pelMode) vs->requestFrameFilter(n, d->pelclip, ctx);
+        return NULL;
+    }
     if (reason != arAllFramesReady) return NULL;
     const VSFrame *src = vs->getFrameFilter(n, d->node, ctx);
     const SuperGeo *g = &d->geo;
-    void *srcArena = NULL, *dsrc[3], *ddst[3] = { NULL, NULL, NULL };
+    void *srcArena = NULL, *pelArena = NULL, *dsrc[3], *dpel[3] = { NULL, NULL, NULL }, *ddst[3] = { NULL, NULL, NULL };
     upload_plane_set(dsrc, &srcArena, src, d->srcPitch, g->si.num_planes, g->bps, vs);
+    const VSFrame *pf = d->pelMode ? vs->getFrameFilter(n, d->pelclip, ctx) : NULL; /* src/MVSuper.c:62-64 */
+    if (pf) upload_plane_set(dpel, &pelArena, pf, d->pelPitch, g->si.num_planes, g->bps, vs);
     void *arena = mvx_dev_alloc(g->bytes); /* zero-filled: only the defined rectangles are written (MVSuper.c:73 memsets too) */
-    int rc = (!srcArena || !arena) ? MVX_E_NOMEM : 0;
+    int rc = (!srcArena || !arena || (d->pelMode && !pelArena)) ? MVX_E_NOMEM : 0;
     if (!rc) {
         for (int p = 0; p < g->si.num_planes; p++) ddst[p] = (char *)arena + g->off[p];
-        rc = mvx_super_frames(d->sup, 1, (const void *const *)dsrc, d->srcPitch, (void *const *)ddst, g->pitch, NULL);
+        rc = mvx_super_frames_pelclip(d->sup, 1, (const void *const *)dsrc, d->srcPitch, (const void *const *)dpel, d->pelPitch, d->pelMode, (void *const *)ddst, g->pitch, NULL);
     }
     VSFrame *dst = NULL;
     if (!rc) {
@@ -273,6 +301,8 @@ static const VSFrame *VS_CC superGetFrame(int n, int reason, void *inst, void **
         if (!rc) rc = mvx_stream_sync(NULL);
     }
     if (srcArena) mvx_dev_free(srcArena);
+    if (pelArena) mvx_dev_free(pelArena);
+    if (pf) vs->freeFrame(pf);
     vs->freeFrame(src);
     if (rc) {
         if (arena) mvx_dev_free(arena);
@@ -301,13 +331,13 @@ static void VS_CC superFree(void *inst, VSCore *core, const VSAPI *vs) {
     (void)core;
     SuperData *d = (SuperData *)inst;
     vs->freeNode(d->node);
+    if (d->pelclip) vs->freeNode(d->pelclip);
     mvx_super_destroy(d->sup);
     free(d);
 }
 
 static void VS_CC superCreate(const VSMap *in, VSMap *out, void *user, VSCore *core, const VSAPI *vs) {
     (void)user;
-    if (arg_given(in, "pelclip", vs)) { vs->mapSetError(out, "Super: pelclip is not supported by the MI355X build."); return; }
     VSNode *node = vs->mapGetNode(in, "clip", 0, 0);
     const VSVideoInfo *vi = vs->getVideoInfo(node);
     if (!mvx_vsh_is_constant_video_format(vi) || vi->format.bitsPerSample > 16 || vi->format.sampleType != stInteger || vi->format.subSamplingW > 1 ||
@@ -327,25 +357,46 @@ static void VS_CC superCreate(const VSMap *in, VSMap *out, void *user, VSCore *c
     mvx_super *sup = NULL;
     char err[MVX_ERRLEN];
     if (mvx_super_create(&a, &sup, err)) { vs->mapSetError(out, err); vs->freeNode(node); return; }
+    /* src/MVSuper.c:229-256 */
+    int perr = 0;
+    int32_t pelMode = 0;
+    VSNode *pelclip = vs->mapGetNode(in, "pelclip", 0, &perr);
+    if (perr) pelclip = NULL;
+    if (pelclip) {
+        const VSVideoInfo *pvi = vs->getVideoInfo(pelclip);
+        const int same = pvi->format.colorFamily == vi->format.colorFamily && pvi->format.sampleType == vi->format.sampleType &&
+                         pvi->format.bitsPerSample == vi->format.bitsPerSample && pvi->format.subSamplingW == vi->format.subSamplingW &&
+                         pvi->format.subSamplingH == vi->format.subSamplingH;
+        err[0] = 0;
+        if (!mvx_vsh_is_constant_video_format(pvi) || !same) snprintf(err, sizeof(err), "Super: pelclip must have the same format as the input clip, and it must have constant dimensions.");
+        else mvx_super_pelclip_mode(sup, pvi->width, pvi->height, &pelMode, err);
+        if (err[0]) { vs->mapSetError(out, err); mvx_super_destroy(sup); vs->freeNode(node); vs->freeNode(pelclip); return; }
+    }
     SuperData *d = (SuperData *)calloc(1, sizeof(*d));
     d->node = node; d->sup = sup; d->vi = *vi;
+    d->pelclip = pelclip; d->pelMode = pelMode;
     super_geo(&d->geo, sup);
     d->vi.width = d->geo.si.super_width; d->vi.height = d->geo.si.super_height;
     const int bps = d->geo.bps;
     for (int p = 0; p < 3; p++) {
         const int w = p ? vi->width >> vi->format.subSamplingW : vi->width;
         d->srcPitch[p] = ((ptrdiff_t)w * bps + 255) / 256 * 256;
+        if (pelMode) {
+            const VSVideoInfo *pvi = vs->getVideoInfo(pelclip);
+            const int pw = p ? pvi->width >> vi->format.subSamplingW : pvi->width;
+            d->pelPitch[p] = ((ptrdiff_t)pw * bps + 255) / 256 * 256;
+        }
     }
     pthread_mutex_lock(&g_lock);
     d->instance = g_next_instance++;
     pthread_mutex_unlock(&g_lock);
-    VSFilterDependency deps[1] = { { node, rpStrictSpatial } };
-    vs->createVideoFilter(out, "Super", &d->vi, superGetFrame, superFree, fmParallel, deps, 1, d, core);
+    VSFilterDependency deps[2] = { { node, rpStrictSpatial }, { pelclip, rpStrictSpatial } };
+    vs->createVideoFilter(out, "Super", &d->vi, superGetFrame, superFree, fmParallel, deps, pelMode ? 2 : 1, d, core);
 }
 
 /* ------------------------------------------------------------------------------------------------ mv.Analyse */
 
-typedef struct AnalyseData { VSNode *node; const VSVideoInfo *vi; mvx_super *sup; SuperGeo geo; mvx_analyse *an; mvx_analysis_data ad; int blobSize; } AnalyseData;
+typedef struct AnalyseData { VSNode *node; const VSVideoInfo *vi; mvx_super *sup; SuperGeo geo; mvx_analyse *an; mvx_analysis_data ad; int blobSize; FieldOpt fo; } AnalyseData;
 
 static int analyse_nref(const AnalyseData *d, int n) { /* src/MVAnalyse.c:84-104 */
     if (d->ad.nDeltaFrame > 0) return n + (d->ad.isBackward ? d->ad.nDeltaFrame : -d->ad.nDeltaFrame);
@@ -366,6 +417,19 @@ static const VSFrame *VS_CC analyseGetFrame(int n, int reason, void *inst, void 
     if (reason != arAllFramesReady) return NULL;
     const VSFrame *src = vs->getFrameFilter(n, d->node, ctx);
     const VSFrame *ref = haveRef ? vs->getFrameFilter(nref, d->node, ctx) : NULL;
+    int fieldShift = 0;
+    { /* src/MVAnalyse.c:135-179 */
+        int missing = 0;
+        const int srcTop = frame_top_field(&d->fo, src, n, &missing, vs);
+        const int refTop = ref ? frame_top_field(&d->fo, ref, nref, &missing, vs) : 0;
+        if (missing && d->fo.fields) {
+            vs->setFilterError("Analyse: _Field property not found in input frame. Therefore, you must pass tff argument.", ctx);
+            if (ref) vs->freeFrame(ref);
+            vs->freeFrame(src);
+            return NULL;
+        }
+        if (ref && d->fo.fields && d->ad.nPel > 1 && (d->ad.nDeltaFrame % 2)) fieldShift = field_shift_of(srcTop, refTop, d->ad.nPel);
+    }
     DevRef ds, dr;
     memset(&dr, 0, sizeof(dr));
     int rc = super_to_device(&ds, src, &d->geo, vs);
@@ -378,6 +442,7 @@ static const VSFrame *VS_CC analyseGetFrame(int n, int reason, void *inst, void 
         memset(&job, 0, sizeof(job));
         for (int p = 0; p < 3; p++) { job.src[p] = ds.plane[p]; job.ref[p] = ref ? dr.plane[p] : NULL; }
         job.blob = dblob;
+        job.field_shift = fieldShift;
         rc = mvx_analyse_frames(d->an, 1, &job, NULL);
         if (!rc) rc = mvx_copy_to_host(blob, d->blobSize, dblob, d->blobSize, (size_t)d->blobSize, 1, NULL);
         if (!rc) rc = mvx_stream_sync(NULL);
@@ -428,6 +493,7 @@ static void VS_CC analyseCreate(const VSMap *in, VSMap *out, void *user, VSCore 
     if (!sup) { vs->mapSetError(out, err); vs->freeNode(node); return; }
     AnalyseData *d = (AnalyseData *)calloc(1, sizeof(*d));
     d->node = node; d->vi = vi; d->sup = sup;
+    field_opt(&d->fo, in, vs);
     super_geo(&d->geo, sup);
     char lerr[MVX_ERRLEN];
     if (mvx_analyse_create(&a, sup, vi->numFrames, d->geo.pitch, &d->an, lerr)) {
@@ -551,7 +617,7 @@ static void VS_CC scdCreate(const VSMap *in, VSMap *out, void *user, VSCore *cor
 
 /* ------------------------------------------------------------------------------------------------ mv.Recalculate */
 
-typedef struct RecalcData { VSNode *node, *vectors; const VSVideoInfo *vi; mvx_super *sup; SuperGeo geo; mvx_recalculate *rc; mvx_analysis_data ad, old; int blobSize; } RecalcData;
+typedef struct RecalcData { VSNode *node, *vectors; const VSVideoInfo *vi; mvx_super *sup; SuperGeo geo; mvx_recalculate *rc; mvx_analysis_data ad, old; int blobSize; FieldOpt fo; } RecalcData;
 
 static int recalc_nref(const RecalcData *d, int n) { /* src/MVRecalculate.c:78-85 */
     const int off = d->ad.nDeltaFrame;
@@ -574,6 +640,17 @@ static const VSFrame *VS_CC recalcGetFrame(int n, int reason, void *inst, void *
     if (reason != arAllFramesReady) return NULL;
     const VSFrame *src = vs->getFrameFilter(n, d->node, ctx);
     const VSFrame *ref = haveRef ? vs->getFrameFilter(nref, d->node, ctx) : NULL;
+    if (d->fo.fields) { /* src/MVRecalculate.c:121-163: only the error survives, the shift itself never reaches a result */
+        int missing = 0;
+        frame_top_field(&d->fo, src, n, &missing, vs);
+        if (ref) frame_top_field(&d->fo, ref, nref, &missing, vs);
+        if (missing) {
+            vs->setFilterError("Recalculate: _Field property not found in input frame. Therefore, you must pass tff argument.", ctx);
+            if (ref) vs->freeFrame(ref);
+            vs->freeFrame(src);
+            return NULL;
+        }
+    }
     const VSFrame *mvn = vs->getFrameFilter(n, d->vectors, ctx);
     DevRef ds, dr;
     memset(&dr, 0, sizeof(dr));
@@ -629,6 +706,7 @@ static void VS_CC recalcCreate(const VSMap *in, VSMap *out, void *user, VSCore *
     for (size_t i = 0; i < sizeof(keys) / sizeof(keys[0]); i++) av[i] = opt_int64(in, keys[i], vs);
     RecalcData *d = (RecalcData *)calloc(1, sizeof(*d));
     char err[1400] = "";
+    field_opt(&d->fo, in, vs);
     d->node = vs->mapGetNode(in, "super", 0, 0);
     d->vi = vs->getVideoInfo(d->node);
     d->sup = super_from_props(d->node, "Recalculate", err, sizeof(err), vs);
@@ -817,7 +895,7 @@ static void VS_CC degrainCreate(const VSMap *in, VSMap *out, void *user, VSCore 
 
 /* ------------------------------------------------------------------------------------------------ mv.Compensate */
 
-typedef struct CompData { VSNode *node, *super, *vectors; const VSVideoInfo *vi; mvx_super *sup; SuperGeo geo; mvx_compensate *cp; mvx_analysis_data ad; ptrdiff_t pitch[3]; int blobSize; } CompData;
+typedef struct CompData { VSNode *node, *super, *vectors; const VSVideoInfo *vi; mvx_super *sup; SuperGeo geo; mvx_compensate *cp; mvx_analysis_data ad; ptrdiff_t pitch[3]; int blobSize; FieldOpt fo; } CompData;
 
 static int comp_nref(const CompData *d, int n) { /* src/MVCompensate.c:84-92 */
     if (d->ad.nDeltaFrame > 0) return n + (d->ad.isBackward ? d->ad.nDeltaFrame : -d->ad.nDeltaFrame);
@@ -843,6 +921,20 @@ static const VSFrame *VS_CC compGetFrame(int n, int reason, void *inst, void **f
     const VSFrame *rsup = haveRef ? vs->getFrameFilter(nref, d->super, ctx) : NULL;
     const VSFrame *vf = vs->getFrameFilter(n, d->vectors, ctx);
     const int np = d->vi->format.numPlanes, bps = d->vi->format.bytesPerSample;
+    int fieldShift = 0;
+    if (rsup && d->fo.fields && d->ad.nPel > 1 && ((nref - n) % 2 != 0)) { /* src/MVCompensate.c:188-225 (the props of the two super frames).
+        * The reference only looks at _Field when the vectors are usable (:162); usability is decided on the device here, so a missing _Field is
+        * reported for scene-change frames too. */
+        int missing = 0;
+        const int srcTop = frame_top_field(&d->fo, ssup, n, &missing, vs);
+        const int refTop = frame_top_field(&d->fo, rsup, nref, &missing, vs);
+        if (missing) {
+            vs->setFilterError("Compensate: _Field property not found in input frame. Therefore, you must pass tff argument.", ctx);
+            vs->freeFrame(vf); vs->freeFrame(ssup); vs->freeFrame(rsup); vs->freeFrame(src);
+            return NULL;
+        }
+        fieldShift = field_shift_of(srcTop, refTop, d->ad.nPel);
+    }
     DevRef ds, dr;
     memset(&dr, 0, sizeof(dr));
     int rc = super_to_device(&ds, ssup, &d->geo, vs);
@@ -859,6 +951,7 @@ static const VSFrame *VS_CC compGetFrame(int n, int reason, void *inst, void **f
         for (int p = 0; p < 3; p++) { job.src_super[p] = ds.plane[p]; job.ref_super[p] = rsup ? dr.plane[p] : NULL; }
         for (int p = 0; p < np; p++) job.dst[p] = (char *)dstArena + dstOff[p];
         job.blob = dblob;
+        job.field_shift = fieldShift;
         if (!rc) rc = mvx_compensate_frames(d->cp, 1, &job, NULL);
     }
     VSFrame *dst = NULL;
@@ -899,7 +992,8 @@ static void VS_CC compCreate(const VSMap *in, VSMap *out, void *user, VSCore *co
     int e = 0;
     a.time = vs->mapGetFloat(in, "time", 0, &e);
     if (e) a.time = 100.0;
-    if (opt_int(in, "fields", vs) != MVX_UNSET && opt_int(in, "fields", vs) != 0) snprintf(err, sizeof(err), "Compensate: fields=True is not supported by the MI355X build.");
+    field_opt(&d->fo, in, vs);
+    a.fields = d->fo.fields;
     if (!err[0]) {
         d->super = vs->mapGetNode(in, "super", 0, NULL);
         d->sup = super_from_props(d->super, "Compensate", err, sizeof(err), vs);
