@@ -339,6 +339,26 @@ def test_fields_shift_parity(oracle, mv, w, h, bits, pel, akw, shift):
     assert not all(np.array_equal(a, b) for a, b in zip(want, oc.frame(osf[0], osf[1], ob)))
 
 
+def test_analyse_two_chains_per_simd(oracle, mv):
+    """a launch with more chains than the device has SIMDs takes the 256-register build of the 8-bit 8x8 kernel (two chains per
+    SIMD, mvx_analyse_u8.hip): every one of its results must still be the oracle's"""
+    import torch
+    w, h, bits = 96, 64, 8
+    akw = dict(blksize=8, overlap=4)
+    frames, osup, gsup, osf, gsrc, gsf = _pipeline(oracle, mv, w, h, bits, 1, {}, akw, nframes=3)
+    oan = oracle.Analyse(osup, isb=1, **akw)
+    gan = mv.Analyse(gsup, isb=1, **akw)
+    want = [oan.frame(osf[0], osf[1]), oan.frame(osf[1], osf[2]), oan.frame(osf[2], None)]
+    pairs = [(gsf[0], gsf[1]), (gsf[1], gsf[2]), (gsf[2], None)]
+    nsimd = 4 * torch.cuda.get_device_properties(0).multi_processor_count
+    njobs = nsimd + 64
+    got = gan.run([pairs[i % 3] for i in range(njobs)])
+    torch.cuda.synchronize()
+    got = torch.stack(list(got)).cpu().numpy()
+    for i in range(njobs):
+        assert np.array_equal(got[i], want[i % 3]), "job %d differs" % i
+
+
 def _golden_cases():
     import json, os
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden.json")) as f:

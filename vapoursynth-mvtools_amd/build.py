@@ -18,8 +18,6 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-Wno-unused-function", "-Wno-unused-variable"]
 if os.environ.get("MVX_NT_REF"):  # developer-only experiment: non-temporal reference loads
     FLAGS.append("-DMVX_NT_REF")
-if os.environ.get("MVX_WAVES_PER_EU"):  # developer-only: register budget of the search kernel (waves per SIMD)
-    FLAGS.append("-DMVX_WAVES_PER_EU=" + os.environ["MVX_WAVES_PER_EU"])
 if os.environ.get("MVX_DEFS"):  # developer-only: extra -D switches for A/B builds, e.g. MVX_DEFS="MVX_NO_EARLY"
     FLAGS += ["-D" + d for d in os.environ["MVX_DEFS"].split()]
 if os.environ.get("MVX_PROFILE"):  # developer-only: per-phase cycle counters inside the search kernel

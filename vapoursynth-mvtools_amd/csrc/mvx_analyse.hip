@@ -252,7 +252,8 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
     int ldsRow = (srcBytes + 15) & ~15;
     int maxBlkX = 0;
     for (int i = 0; i < P.nLevels; i++) if (P.lv[i].nBlkX > maxBlkX) maxBlkX = P.lv[i].nBlkX;
-    int ldsHist = ldsRow + maxBlkX * 48; // previous-row results + two rows of hierarchical predictors, 16 bytes per block each
+    // previous-row results + (16-bit kernels only, PRED_ROWS) two rows of hierarchical predictors, 16 bytes per block each
+    int ldsHist = ldsRow + maxBlkX * (P.bps == 2 ? 48 : 16);
     const int histBins = 1024;
     int ldsBytes = ldsHist + histBins * 4;
     if (ldsBytes > 160 * 1024) { mvx_set_error("mvx_analyse_frames: frame too wide for the LDS row buffer"); return MVX_E_ARG; }
@@ -272,12 +273,20 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
     }
     // One chain per SIMD is the measured optimum: asking for a little more than a fifth of the CU's
     // 160 KiB of LDS makes the dispatcher spread the chains four per CU instead of stacking some CUs (+5 % at 1008 chains).
+    const int ldsNeed = ldsBytes;
     {
         int v = 33 * 1024;
         if (const char *e = getenv("MVX_LDS_MIN")) v = atoi(e); // developer override
         if (v > ldsBytes && v <= 160 * 1024) ldsBytes = v;
     }
-    ALaunch L = { njobs, ldsBytes, ldsRow, ldsHist, histBins, ldsWin, winCap, st, a->dP, a->dJobs };
+    static int simds = 0;
+    if (!simds) {
+        int dev = 0, cus = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        simds = 4 * cus;
+    }
+    ALaunch L = { njobs, ldsBytes, ldsRow, ldsHist, histBins, ldsWin, winCap, ldsNeed, simds, st, a->dP, a->dJobs };
     int rc = P.dctmode != 0 ? 1 : P.bps == 1 ? mvx_analyse_launch_u8(P, L) : mvx_analyse_launch_u16(P, L); // specialised 4:2:0 geometries (SAD cost only)
     if (rc == 1) rc = mvx_analyse_launch_any(P, L);                                     // everything else
     if (rc) return rc;

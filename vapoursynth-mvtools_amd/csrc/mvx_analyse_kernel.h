@@ -483,7 +483,10 @@ template <int BPS, typename GEO> struct Searcher {
             return acc;
         }
         constexpr int N = T >= G ? T / G : 1;        // items per lane
-        constexpr int NB = N < 8 ? N : 8;            // loads in flight per batch
+#ifndef MVX_NB
+#define MVX_NB 4 // chunks in flight per region: four measured +2 % over eight at 4K16 (register pressure), and keeps the 8-bit kernels spill-free at 256 registers
+#endif
+        constexpr int NB = N < MVX_NB ? N : MVX_NB;  // loads in flight per batch
         if (G >= C) { // the chunk column is fixed per lane, rows advance by G / C per item
             const int row0 = s >> LOGC, xb = (s & (C - 1)) * CB;
             gl_u8 *p = ref + (long long)row0 * refPitch + xb;
@@ -1762,7 +1765,9 @@ template <int BPS, typename GEO> struct Searcher {
             if (GEO::DCT && (dctmode == 7 || dctmode == 8 || dctmode == 10)) srcLuma = src_luma(); // :829-830 (only these modes read it)
             const long long bt1 = PROF_T();
             if (ablate == 1) { bestMV = predictor; bestMV.sad = 0; }
-            else if (fast) { if (!search_block_fast<EARLY_K>(&preA)) search_block(1); }
+            // (the hints matter: the general state machine is an inner loop, which the register allocator would otherwise favour
+            // over the straight-line path that actually runs; measured +2 % at 4K16)
+            else if (__builtin_expect(fast, 1)) { if (__builtin_expect(!search_block_fast<EARLY_K>(&preA), 0)) search_block(1); }
             else search_block(0);
             const long long bt2 = PROF_T();
             __builtin_amdgcn_wave_barrier();
@@ -1831,19 +1836,21 @@ template <int BPS, typename GEO> struct Searcher {
     }
 };
 
-#ifndef MVX_WAVES_PER_EU
-#define MVX_WAVES_PER_EU 1 // two chains per SIMD were measured slower (r1): the CU's texture addresser / L1 is the shared bottleneck
-#endif
-template <int BPS, typename GEO>
-__global__ __launch_bounds__(64, MVX_WAVES_PER_EU) void analyse_kernel(const AParams *Pp, const AJob *jobs, int ldsRow, int ldsHist, int histBins, int ldsWin, int winCap) {
+// WPE = chains per SIMD the kernel is compiled for.  1: all 512 registers of a SIMD lane, for launches of at most one chain per
+// SIMD.  2: at most 256 registers; only the 8-bit kernels fit that without spilling, and they gain 53 % from the second chain
+// when a launch carries two chains per SIMD (1080p: 961 -> 1475 fps) -- their loads are light on the CU's texture path.  The
+// 16-bit kernels do not (4K16: no gain even without spills; five chains per CU take as long as four, the shared L1/TA is
+// the limit), so they stay at WPE = 1.
+template <int BPS, typename GEO, int WPE = 1>
+__global__ __launch_bounds__(64, WPE) void analyse_kernel(const AParams *Pp, const AJob *jobs, int ldsRow, int ldsHist, int histBins, int ldsWin, int winCap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // One chain per SIMD is the measured optimum.  The host's LDS request limits a CU to four chains, but a
+    // WPE == 1 is for launches with at most one chain per SIMD.  The host's LDS request limits a CU to four chains, but a
     // kernel that fits 256 VGPRs would let the dispatcher stack two of them on one SIMD while another SIMD idles (measured:
     // -12 % on the 8-bit 8x8 kernel when an unrelated refactoring moved it from 262 to 256 registers).  Touching the last
     // accumulator register pushes the wave's register allocation above 256, i.e. at most one wave per SIMD, for every variant.
     // (Four chains per 256-thread workgroup, one workgroup per CU, was also tried: deterministic too, but 5 % slower at 4K16 --
     // the four chains of a CU then run in lockstep and hit the texture path in the same phases.)
-    asm volatile("" ::: "a255");
+    if (WPE == 1) asm volatile("" ::: "a255");
     const AParams &P = *Pp;
     const AJob &J = jobs[blockIdx.x];
     const int l = threadIdx.x;
@@ -1986,15 +1993,17 @@ int mvx_recalc_launch(const AParams &P, const RLaunch &L);
 
 struct ALaunch {
     int njobs, ldsBytes, ldsRow, ldsHist, histBins, ldsWin, winCap;
+    int ldsNeed; // what the kernel really uses (ldsBytes may carry the one-chain-per-SIMD floor)
+    int simds;   // SIMDs of the device (4 per CU)
     hipStream_t st;
     const AParams *dP;
     const AJob *dJobs;
 };
-template <int BPS_, typename GEO_> static int launch_analyse_kernel(const ALaunch &L) {
+template <int BPS_, typename GEO_, int WPE_ = 1> static int launch_analyse_kernel(const ALaunch &L) {
     if (L.ldsBytes > 64 * 1024)
-        HIP_CHECK(hipFuncSetAttribute((const void *)analyse_kernel<BPS_, GEO_>, hipFuncAttributeMaxDynamicSharedMemorySize, L.ldsBytes));
+        HIP_CHECK(hipFuncSetAttribute((const void *)analyse_kernel<BPS_, GEO_, WPE_>, hipFuncAttributeMaxDynamicSharedMemorySize, L.ldsBytes));
     const bool win = GEO_::SX != 0 && L.ldsWin >= 0;
-    hipLaunchKernelGGL((analyse_kernel<BPS_, GEO_>), dim3(L.njobs), dim3(64), win ? L.ldsBytes : L.ldsWin >= 0 ? L.ldsWin + L.histBins * 4 : L.ldsBytes, L.st, L.dP, L.dJobs,
+    hipLaunchKernelGGL((analyse_kernel<BPS_, GEO_, WPE_>), dim3(L.njobs), dim3(64), win ? L.ldsBytes : L.ldsWin >= 0 ? L.ldsWin + L.histBins * 4 : L.ldsBytes, L.st, L.dP, L.dJobs,
                        L.ldsRow, L.ldsHist, L.histBins, win ? L.ldsWin : -1, win ? L.winCap : 0);
     return MVX_OK;
 }

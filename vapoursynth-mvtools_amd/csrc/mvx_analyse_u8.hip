@@ -5,6 +5,13 @@ int mvx_analyse_launch_u8(const AParams &P, const ALaunch &L) {
     // The LDS search-window kernels (Geo<..., scan step>) are bit-exact but measured SLOWER than the plain ones in round 1
     // (DESIGN.md 4.2): opt-in via MVX_WINDOW=1 until the window path is cheaper in instructions.
     const int S = L.ldsWin >= 0 ? P.blkX - P.ovX : 0;
+    // More chains than SIMDs: the 8-bit kernels have a 256-register build so that two chains share a SIMD (+53 % at 1080p,
+    // DESIGN.md 4.2).  It drops the LDS floor that spreads a small launch one chain per SIMD.
+    if (S == 0 && L.njobs > L.simds) {
+        ALaunch L2 = L;
+        L2.ldsBytes = L.ldsNeed;
+        if (P.blkX == 8 && P.blkY == 8) return launch_analyse_kernel<1, Geo<8, 8, 2, 2>, 2>(L2); // (the 16x16 kernel would spill at 256 registers)
+    }
     if (P.blkX == 8 && P.blkY == 8) return S == 4 ? launch_analyse_kernel<1, Geo<8, 8, 2, 2, 4>>(L) : launch_analyse_kernel<1, Geo<8, 8, 2, 2>>(L);
     if (P.blkX == 16 && P.blkY == 16) return S == 8 ? launch_analyse_kernel<1, Geo<16, 16, 2, 2, 8>>(L) : launch_analyse_kernel<1, Geo<16, 16, 2, 2>>(L);
     return 1;
