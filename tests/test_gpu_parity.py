@@ -339,6 +339,28 @@ def test_fields_shift_parity(oracle, mv, w, h, bits, pel, akw, shift):
     assert not all(np.array_equal(a, b) for a, b in zip(want, oc.frame(osf[0], osf[1], ob)))
 
 
+@pytest.mark.parametrize("w,h,bits,skw,akw", [
+    (384, 224, 16, {}, dict(blksize=16, overlap=8)),
+    (384, 224, 16, dict(pel=4), dict(blksize=16, overlap=8)),
+    (320, 180, 16, {}, dict(blksize=8, overlap=4)),
+    (320, 180, 8, {}, dict(blksize=8, overlap=4)),
+    (384, 224, 8, dict(pel=1), dict(blksize=16, overlap=8, search=3, searchparam=2)),
+    (320, 180, 16, {}, dict(blksize=16, overlap=8, chroma=0)),
+])
+def test_analyse_window_kernels(oracle, mv, monkeypatch, w, h, bits, skw, akw):
+    """the opt-in LDS search-window kernels (MVX_WINDOW=1): candidates inside the window are compared from LDS
+    (aligned dword reads + v_alignbit), the others from global memory -- the vectors must not depend on which"""
+    monkeypatch.setenv("MVX_WINDOW", "1")
+    frames, osup, gsup, osf, gsrc, gsf = _pipeline(oracle, mv, w, h, bits, 1, skw, akw, nframes=3, seed=5)
+    for isb in (1, 0):
+        oan = oracle.Analyse(osup, isb=isb, **akw)
+        gan = mv.Analyse(gsup, isb=isb, **akw)
+        ref = 2 if isb else 0
+        ob = oan.frame(osf[1], osf[ref])
+        gb = gan.run([(gsf[1], gsf[ref])])[0]
+        assert np.array_equal(gb.cpu().numpy(), ob)
+
+
 def test_analyse_two_chains_per_simd(oracle, mv):
     """a launch with more chains than the device has SIMDs takes the 256-register build of the 8-bit 8x8 kernel (two chains per
     SIMD, mvx_analyse_u8.hip): every one of its results must still be the oracle's"""

@@ -252,25 +252,32 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
     int ldsRow = (srcBytes + 15) & ~15;
     int maxBlkX = 0;
     for (int i = 0; i < P.nLevels; i++) if (P.lv[i].nBlkX > maxBlkX) maxBlkX = P.lv[i].nBlkX;
-    // previous-row results + (16-bit kernels only, PRED_ROWS) two rows of hierarchical predictors, 16 bytes per block each
-    int ldsHist = ldsRow + maxBlkX * (P.bps == 2 ? 48 : 16);
     const int histBins = 1024;
+    // LDS of a chain: [source block | previous block row's results, 16 B per block | A | histogram of the global-motion estimate]
+    // with A = two rows of hierarchical predictors (16-bit kernels without a search window, PRED_ROWS) or nothing.
+    // Search-window kernels (Geo<..., scan step>, 4:2:0 16x16 / 8x8 blocks with half-block overlap, SAD cost): the window follows
+    // the row buffer and the histogram aliases its start (it is only used between levels); everything must fit a quarter of
+    // the CU's 160 KiB so that four chains still share a CU.
+    int ldsHist = ldsRow + maxBlkX * (P.bps == 2 ? 48 : 16);
     int ldsBytes = ldsHist + histBins * 4;
-    if (ldsBytes > 160 * 1024) { mvx_set_error("mvx_analyse_frames: frame too wide for the LDS row buffer"); return MVX_E_ARG; }
-    // LDS search window of the specialised kernels (level-0 geometry is the largest; the histogram aliases its start: it is
-    // only used between levels).  Experimental (MVX_WINDOW=1): needs four workgroups to still fit into a CU's 160 KiB.
     int ldsWin = -1, winCap = 0;
     {
         auto p2 = [](int v) { int r = 1; while (r < v) r <<= 1; return r; };
         const int S = P.blkX - P.ovX, npp = P.lv[0].pel * P.lv[0].pel;
-        const int MX = ((8 + S - 1) / S) * S, MY = 8;
-        const int lumaB = npp * (P.blkY + 2 * MY) * (p2(P.blkX + 2 * MX + 2 * S) * P.bps + 16);
-        const int chromaB = P.chroma ? 2 * npp * (P.blkY / P.yr + 2 * (MY / P.yr)) * (p2(P.blkX / P.xr + 2 * (MX / P.xr) + 2 * (S / P.xr)) * P.bps + 16) : 0;
-        const int winOff = ldsHist; // alias
-        int total = winOff + lumaB + chromaB;
-        if (total < ldsBytes) total = ldsBytes;
-        if (getenv("MVX_WINDOW") && atoi(getenv("MVX_WINDOW")) && total <= 40 * 1024) { ldsWin = winOff; winCap = lumaB + chromaB; ldsBytes = total; }
+        const bool winGeom = P.dctmode == 0 && P.xr == 2 && P.yr == 2 && P.blkX == P.blkY && ((P.blkX == 16 && S == 8) || (P.blkX == 8 && S == 4));
+        const char *e = getenv("MVX_WINDOW");
+        const bool want = e ? atoi(e) != 0 : false;
+        if (winGeom && want) {
+            const int MX = ((8 + S - 1) / S) * S, MY = MVX_WIN_MY;
+            const int lumaB = npp * (P.blkY + 2 * MY) * (p2(P.blkX + 2 * MX + 2 * S) * P.bps + MVX_WIN_MIRROR);
+            const int chromaB = P.chroma ? 2 * npp * (P.blkY / P.yr + 2 * (MY / P.yr)) * (p2(P.blkX / P.xr + 2 * (MX / P.xr) + 2 * (S / P.xr)) * P.bps + MVX_WIN_MIRROR) : 0;
+            const int histW = ldsRow + maxBlkX * 16; // window kernels keep the predictors in registers
+            int total = histW + lumaB + chromaB;
+            if (total < histW + histBins * 4) total = histW + histBins * 4;
+            if (total <= 40 * 1024) { ldsHist = histW; ldsWin = histW; winCap = lumaB + chromaB; ldsBytes = total; }
+        }
     }
+    if (ldsBytes > 160 * 1024) { mvx_set_error("mvx_analyse_frames: frame too wide for the LDS row buffer"); return MVX_E_ARG; }
     // One chain per SIMD is the measured optimum: asking for a little more than a fifth of the CU's
     // 160 KiB of LDS makes the dispatcher spread the chains four per CU instead of stacking some CUs (+5 % at 1008 chains).
     const int ldsNeed = ldsBytes;

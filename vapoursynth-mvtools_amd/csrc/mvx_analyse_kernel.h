@@ -314,6 +314,12 @@ __device__ unsigned long long g_prof[32];
 #define PROF_ADD(i, v) ((void)0)
 #endif
 #define PF_MAX 4 // source-block prefetch registers per lane (16 B each)
+// LDS search window (host layout and kernel agree through these): rows above / below the block at the row's expected motion,
+// and the bytes after each ring row that mirror its start.  The reads are aligned dwords, so a chunk that starts in the last
+// bytes of the ring reads up to 20 bytes past its end; 48 makes the row stride an odd multiple of 16 bytes (176 / 112), which
+// spreads the rows of a candidate over all LDS banks.
+#define MVX_WIN_MY 6
+#define MVX_WIN_MIRROR 48
 
 // Compile-time block geometry for the specialised kernels (BW == 0: geometry only known at run time -> generic loops).
 constexpr int pow2c(int v, int r = 1) { return r >= v ? r : pow2c(v, r * 2); }
@@ -858,14 +864,17 @@ template <int BPS, typename GEO> struct Searcher {
     // realigned with v_alignbit); all others (large deviation from the row's expected motion, plane borders) take the
     // global-memory path, so results never depend on the window.  This is the north star's "search window staged in
     // LDS", adapted to the serial-chain design: the window follows the chain instead of being loaded per macroblock.
+    // Status (r1, 4K16): bit-exact; vector-memory instructions per block drop from 22 to 7 and the time a chain waits from
+    // 54 % to 44 %, but the block needs 1200 instead of 1020 instructions and a single chain per SIMD issues one instruction
+    // every four cycles -- 204 fps against 214 without the window.  Opt-in (MVX_WINDOW=1) until its bookkeeping is cheaper.
     static constexpr bool W_ON = GEO::SX != 0 && GEO::BW != 0;
     static constexpr int W_S = W_ON ? GEO::SX : 8, W_SC = W_S / G_XR;
-    static constexpr int W_MX = ((8 + W_S - 1) / W_S) * W_S, W_MY = 8, W_MXC = W_MX / G_XR, W_MYC = W_MY / G_YR;
+    static constexpr int W_MX = ((8 + W_S - 1) / W_S) * W_S, W_MY = MVX_WIN_MY, W_MXC = W_MX / G_XR, W_MYC = W_MY / G_YR;
     static constexpr int W_NS = (G_BW + 2 * W_MX) / W_S;
     static constexpr int W_WW = pow2c(G_BW + 2 * W_MX + 2 * W_S), W_WH = G_BH + 2 * W_MY;
     static constexpr int W_WWC = pow2c(G_BW / G_XR + 2 * W_MXC + 2 * W_SC), W_WHC = G_BH / G_YR + 2 * W_MYC;
     static constexpr int W_RB = W_WW * BPS, W_RBC = W_WWC * BPS;       // ring bytes per row
-    static constexpr int W_RS = W_RB + 16, W_RSC = W_RBC + 16;         // row stride: + 16-byte mirror of the ring start (reads never wrap)
+    static constexpr int W_RS = W_RB + MVX_WIN_MIRROR, W_RSC = W_RBC + MVX_WIN_MIRROR; // row stride: ring + mirror of its start (reads never wrap)
     static constexpr int W_CBS = W_S * BPS < 16 ? W_S * BPS : 16, W_SCL = W_S * BPS / W_CBS;
     static constexpr int W_CBSC = W_SC * BPS < 16 ? W_SC * BPS : 16, W_SCC = W_SC * BPS / W_CBSC;
     // Strip items (one CBS-byte piece of one window row of one sub-pel plane) are dealt to per-plane slots: slots
@@ -944,14 +953,14 @@ template <int BPS, typename GEO> struct Searcher {
         const int rcc = ((blkScanDir == 1 ? k * W_SC : -(k + 1) * W_SC) & (W_WWC - 1)) * BPS;
         st_chunk_l(lds + wLdsL[0] + rc, wpf[0], W_CBS);
         if (wQY > 1) st_chunk_l(lds + wLdsL[1] + rc, wpf[1], W_CBS);
-        if (rc < 16) { // mirror of the ring start
+        if (rc < 32) { // mirror of the ring start
             st_chunk_l(lds + wLdsL[0] + rc + W_RB, wpf[0], W_CBS);
             if (wQY > 1) st_chunk_l(lds + wLdsL[1] + rc + W_RB, wpf[1], W_CBS);
         }
         if (chroma) {
             st_chunk_l(lds + wLdsU + rcc, wpf[WQY], W_CBSC);
             st_chunk_l(lds + wLdsU + wVstep + rcc, wpf[WQY + 1], W_CBSC);
-            if (rcc < 16) {
+            if (rcc < 32) {
                 st_chunk_l(lds + wLdsU + rcc + W_RBC, wpf[WQY], W_CBSC);
                 st_chunk_l(lds + wLdsU + wVstep + rcc + W_RBC, wpf[WQY + 1], W_CBSC);
             }
@@ -993,19 +1002,34 @@ template <int BPS, typename GEO> struct Searcher {
     }
 
     // SAD of this lane's items of one plane region against the LDS window; winRow = LDS offset of the window row holding
-    // the candidate's first row, b0 = byte offset of its first column relative to the ring origin (any sign)
-    // unaligned LDS read of CB bytes (the gfx950 DS unit handles under-aligned b64/b128 reads natively) + SAD against the
-    // naturally aligned source chunk
-    template <int CB> __device__ __forceinline__ unsigned win_chunk(const lds_u8 *sp, const lds_u8 *rp, unsigned acc) const {
+    // the candidate's first row, b0 = byte offset of its first column relative to the ring origin (any sign).
+    // A reference chunk sits at sample alignment in the window.  gfx950 executes an under-aligned ds_read_b64/b128 at one lane
+    // per cycle (64 cycles of the CU's LDS pipe per wave instruction; four chains per CU saturate it: tools/micro/lds_read2.hip),
+    // so the chunk is read as CB/4 + 1 ALIGNED dwords (ds_read2_b32) from rp4 = its address rounded down to 4 and shifted into
+    // place with v_alignbit (sh = 8 * (address & 3)); the source chunk is naturally aligned.
+    typedef unsigned w2a4 __attribute__((ext_vector_type(2), aligned(4)));
+    template <int CB> __device__ __forceinline__ unsigned win_chunk(const lds_u8 *sp, const lds_u8 *rp4, unsigned sh, unsigned acc) const {
         if (CB == 16) {
-            v4u a = *(const LDS_AS v4u *)sp; uv4 b = *(const LDS_AS uv4 *)rp;
-            acc = sad32<BPS>(a[0], b[0], acc); acc = sad32<BPS>(a[1], b[1], acc);
-            acc = sad32<BPS>(a[2], b[2], acc); acc = sad32<BPS>(a[3], b[3], acc);
+            const v4u a = *(const LDS_AS v4u *)sp;
+            const w2a4 d01 = *(const LDS_AS w2a4 *)rp4, d23 = *(const LDS_AS w2a4 *)(rp4 + 8);
+            const unsigned d4 = *(const LDS_AS unsigned *)(rp4 + 16);
+            acc = sad32<BPS>(a[0], __builtin_amdgcn_alignbit(d01[1], d01[0], sh), acc);
+            acc = sad32<BPS>(a[1], __builtin_amdgcn_alignbit(d23[0], d01[1], sh), acc);
+            acc = sad32<BPS>(a[2], __builtin_amdgcn_alignbit(d23[1], d23[0], sh), acc);
+            acc = sad32<BPS>(a[3], __builtin_amdgcn_alignbit(d4, d23[1], sh), acc);
         } else if (CB == 8) {
-            v2u a = *(const LDS_AS v2u *)sp; uv2 b = *(const LDS_AS uv2 *)rp;
-            acc = sad32<BPS>(a[0], b[0], acc); acc = sad32<BPS>(a[1], b[1], acc);
-        } else if (CB == 4) acc = sad32<BPS>(*(const LDS_AS unsigned *)sp, *(const LDS_AS uv1 *)rp, acc);
-        else acc = sad32<BPS>(*(const LDS_AS unsigned short *)sp, *(const LDS_AS uh1 *)rp, acc);
+            const v2u a = *(const LDS_AS v2u *)sp;
+            const w2a4 d01 = *(const LDS_AS w2a4 *)rp4;
+            const unsigned d2 = *(const LDS_AS unsigned *)(rp4 + 8);
+            acc = sad32<BPS>(a[0], __builtin_amdgcn_alignbit(d01[1], d01[0], sh), acc);
+            acc = sad32<BPS>(a[1], __builtin_amdgcn_alignbit(d2, d01[1], sh), acc);
+        } else if (CB == 4) {
+            const w2a4 d01 = *(const LDS_AS w2a4 *)rp4;
+            acc = sad32<BPS>(*(const LDS_AS unsigned *)sp, __builtin_amdgcn_alignbit(d01[1], d01[0], sh), acc);
+        } else {
+            const w2a4 d01 = *(const LDS_AS w2a4 *)rp4;
+            acc = sad32<BPS>(*(const LDS_AS unsigned short *)sp, __builtin_amdgcn_alignbit(d01[1], d01[0], sh) & 0xffffu, acc);
+        }
         return acc;
     }
     template <int LOGG, int T, int LOGC, int CB, int ROWB, int RB, int RS>
@@ -1016,17 +1040,18 @@ template <int BPS, typename GEO> struct Searcher {
         if (G >= C) { // chunk column fixed per lane; rows advance by G / C per item -> one base address, immediate offsets
             const int row0 = s >> LOGC, xb = (s & (C - 1)) * CB;
             const int bo = (b0 + xb) & (RB - 1);
-            const lds_u8 *rp = lds + winRow + row0 * RS + bo;
+            const lds_u8 *rp4 = lds + winRow + row0 * RS + (bo & ~3); // rows and the ring start are 16-byte aligned
+            const unsigned sh = (unsigned)(bo & 3) * 8;
             const lds_u8 *sp = src + row0 * ROWB + xb;
             constexpr int rstep = (G >> LOGC) * RS, sstep = (G >> LOGC) * ROWB;
 #pragma unroll
-            for (int k = 0; k < N; k++) acc = win_chunk<CB>(sp + k * sstep, rp + k * rstep, acc);
+            for (int k = 0; k < N; k++) acc = win_chunk<CB>(sp + k * sstep, rp4 + k * rstep, sh, acc);
         } else {
 #pragma unroll
             for (int k = 0; k < N; k++) {
                 const int t = s + k * G, row = t >> LOGC, xb = (t & (C - 1)) * CB;
                 const int bo = (b0 + xb) & (RB - 1);
-                acc = win_chunk<CB>(src + row * ROWB + xb, lds + winRow + row * RS + bo, acc);
+                acc = win_chunk<CB>(src + row * ROWB + xb, lds + winRow + row * RS + (bo & ~3), (unsigned)(bo & 3) * 8, acc);
             }
         }
         return acc;
@@ -1520,7 +1545,6 @@ template <int BPS, typename GEO> struct Searcher {
         unsigned char *rec = J.blob + L.blobOff;
         vectors = (GL_AS GVec *)(rec + 4);
         if (lane_id() == 0) *(int *)rec = 4 + nBlkX * nBlkY * 16; // pobWriteHeaderToArray :413-416
-
     }
 
     // GroupOfPlanes.c:69-125 + PlaneOfBlocks.cpp:971-1131 for one level
@@ -1624,7 +1648,7 @@ template <int BPS, typename GEO> struct Searcher {
         // park (and wait for) before every search.
         // Measured (r1, A/B in one session): +5 % at full load / +9 % unloaded on 4K 16-bit, -7 % on 1080p 8-bit, whose
         // lighter kernels keep the prefetched vectors in registers for free -- hence the compile-time choice.
-        constexpr bool PRED_ROWS = BPS == 2;
+        constexpr bool PRED_ROWS = BPS == 2 && !W_ON; // (the window kernels need that LDS for the window)
         const int predStride = (ldsHist - ldsRow) / 48; // host layout: [row buffer | 2 predictor rows], 16 bytes per block
         LDS_AS Vec *predRows = (LDS_AS Vec *)(lds + ldsRow + predStride * 16);
         auto load_pred_row = [&](int row) {
@@ -1871,7 +1895,7 @@ __global__ __launch_bounds__(64, WPE) void analyse_kernel(const AParams *Pp, con
     Searcher<BPS, GEO> S(P, J);
     S.lds = (lds_u8 *)smem; S.ldsRow = ldsRow; S.ldsHist = ldsHist; S.histBins = histBins;
     S.ldsWin = ldsWin; S.winCap = winCap; S.winOn = 0;
-    S.ablate = uni(P.ablate);
+    S.ablate = uni(P.ablate) & 0xff;
 #ifdef MVX_PROFILE
     for (int i = 0; i < 16; i++) S.prof[i] = 0;
     const long long kt0 = PROF_T();
@@ -1887,7 +1911,7 @@ __global__ __launch_bounds__(64, WPE) void analyse_kernel(const AParams *Pp, con
     }
 #ifdef MVX_PROFILE
     S.prof[9] = PROF_T() - kt0;
-    if (l == 0 && blockIdx.x == 0) for (int i = 0; i < 16; i++) g_prof[i] = (unsigned long long)S.prof[i];
+    if (l == 0 && (int)blockIdx.x == (P.ablate >> 8)) for (int i = 0; i < 16; i++) g_prof[i] = (unsigned long long)S.prof[i]; // MVX_ABLATE = chain << 8
 #endif
 }
 
