@@ -361,6 +361,27 @@ def test_analyse_window_kernels(oracle, mv, monkeypatch, w, h, bits, skw, akw):
         assert np.array_equal(gb.cpu().numpy(), ob)
 
 
+@pytest.mark.parametrize("w,h,skw,akw", [
+    (384, 224, {}, dict(blksize=16, overlap=8)),
+    (384, 224, dict(pel=1), dict(blksize=16, overlap=8)),
+    (200, 120, {}, dict(blksize=16, overlap=8, search=3, searchparam=2)),
+    (384, 224, {}, dict(blksize=16, overlap=0, chroma=0)),
+    (384, 224, dict(pel=4), dict(blksize=16, overlap=8)),   # pel 4: the host keeps the plain kernel
+])
+def test_analyse_refinement_tile_kernel(oracle, mv, monkeypatch, w, h, skw, akw):
+    """the opt-in refinement-tile kernel (MVX_TILE=1): hexagon / square / exhaustive rounds read the reference
+    from an LDS tile around the predictor round's winner; same samples, same vectors (plane borders included: small frames)"""
+    monkeypatch.setenv("MVX_TILE", "1")
+    frames, osup, gsup, osf, gsrc, gsf = _pipeline(oracle, mv, w, h, 16, 1, skw, akw, nframes=3, seed=6)
+    for isb in (1, 0):
+        oan = oracle.Analyse(osup, isb=isb, **akw)
+        gan = mv.Analyse(gsup, isb=isb, **akw)
+        ref = 2 if isb else 0
+        ob = oan.frame(osf[1], osf[ref])
+        gb = gan.run([(gsf[1], gsf[ref])])[0]
+        assert np.array_equal(gb.cpu().numpy(), ob)
+
+
 def test_analyse_two_chains_per_simd(oracle, mv):
     """a launch with more chains than the device has SIMDs takes the 256-register build of the 8-bit 8x8 kernel (two chains per
     SIMD, mvx_analyse_u8.hip): every one of its results must still be the oracle's"""

@@ -260,21 +260,40 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
     // the CU's 160 KiB so that four chains still share a CU.
     int ldsHist = ldsRow + maxBlkX * (P.bps == 2 ? 48 : 16);
     int ldsBytes = ldsHist + histBins * 4;
-    int ldsWin = -1, winCap = 0;
+    int ldsWin = -1, winCap = 0, mode = 0;
     {
         auto p2 = [](int v) { int r = 1; while (r < v) r <<= 1; return r; };
         const int S = P.blkX - P.ovX, npp = P.lv[0].pel * P.lv[0].pel;
-        const bool winGeom = P.dctmode == 0 && P.xr == 2 && P.yr == 2 && P.blkX == P.blkY && ((P.blkX == 16 && S == 8) || (P.blkX == 8 && S == 4));
+        const bool sq420 = P.dctmode == 0 && P.xr == 2 && P.yr == 2 && P.blkX == P.blkY;
+        const bool winGeom = sq420 && ((P.blkX == 16 && S == 8) || (P.blkX == 8 && S == 4));
         const char *e = getenv("MVX_WINDOW");
-        const bool want = e ? atoi(e) != 0 : false;
-        if (winGeom && want) {
+        const bool wantWin = e ? atoi(e) != 0 : false;
+        const int histW = ldsRow + maxBlkX * 16; // window / tile kernels keep the predictors in registers
+        if (winGeom && wantWin) {
             const int MX = ((8 + S - 1) / S) * S, MY = MVX_WIN_MY;
             const int lumaB = npp * (P.blkY + 2 * MY) * (p2(P.blkX + 2 * MX + 2 * S) * P.bps + MVX_WIN_MIRROR);
             const int chromaB = P.chroma ? 2 * npp * (P.blkY / P.yr + 2 * (MY / P.yr)) * (p2(P.blkX / P.xr + 2 * (MX / P.xr) + 2 * (S / P.xr)) * P.bps + MVX_WIN_MIRROR) : 0;
-            const int histW = ldsRow + maxBlkX * 16; // window kernels keep the predictors in registers
             int total = histW + lumaB + chromaB;
             if (total < histW + histBins * 4) total = histW + histBins * 4;
-            if (total <= 40 * 1024) { ldsHist = histW; ldsWin = histW; winCap = lumaB + chromaB; ldsBytes = total; }
+            if (total <= 40 * 1024) { mode = 1; ldsHist = histW; ldsWin = histW; winCap = lumaB + chromaB; ldsBytes = total; }
+        }
+        // refinement tile (16-bit 16x16 4:2:0): opt-in (MVX_TILE=1), no faster than the plain kernels yet
+        const char *et = getenv("MVX_TILE");
+        const bool wantTile = et ? atoi(et) != 0 : false;
+        if (mode == 0 && wantTile && sq420 && P.bps == 2 && P.blkX == 16) {
+            int tb = mvx_tile_lds_bytes(P.blkX, P.blkY, P.xr, P.yr, P.bps, P.lv[0].pel, P.chroma);
+            const int tb1 = mvx_tile_lds_bytes(P.blkX, P.blkY, P.xr, P.yr, P.bps, 1, P.chroma);
+            bool fits = tb > 0 && tb1 > 0 && P.lv[0].pel <= 2;
+            for (int i = 0; i < P.nLevels && fits; i++) { // what Searcher::tile_setup_level insists on
+                const ALevel &lv = P.lv[i];
+                if (lv.pw < 24 || lv.ph < 24 || (lv.pw >> 1) < 16 || (lv.ph >> 1) < 16 || (long long)lv.pel * lv.pel * lv.pstride[0] >= 0x7fffffffLL) fits = false;
+            }
+            if (fits) {
+                if (tb1 > tb) tb = tb1;
+                int total = histW + tb;
+                if (total < histW + histBins * 4) total = histW + histBins * 4;
+                mode = 2; ldsHist = histW; ldsWin = histW; winCap = tb; ldsBytes = total;
+            }
         }
     }
     if (ldsBytes > 160 * 1024) { mvx_set_error("mvx_analyse_frames: frame too wide for the LDS row buffer"); return MVX_E_ARG; }
@@ -293,7 +312,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         simds = 4 * cus;
     }
-    ALaunch L = { njobs, ldsBytes, ldsRow, ldsHist, histBins, ldsWin, winCap, ldsNeed, simds, st, a->dP, a->dJobs };
+    ALaunch L = { mode, njobs, ldsBytes, ldsRow, ldsHist, histBins, ldsWin, winCap, ldsNeed, simds, st, a->dP, a->dJobs };
     int rc = P.dctmode != 0 ? 1 : P.bps == 1 ? mvx_analyse_launch_u8(P, L) : mvx_analyse_launch_u16(P, L); // specialised 4:2:0 geometries (SAD cost only)
     if (rc == 1) rc = mvx_analyse_launch_any(P, L);                                     // everything else
     if (rc) return rc;

@@ -320,13 +320,25 @@ __device__ unsigned long long g_prof[32];
 // spreads the rows of a candidate over all LDS banks.
 #define MVX_WIN_MY 6
 #define MVX_WIN_MIRROR 48
+// LDS bytes of the refinement tile (Searcher::tile_setup_level computes the same numbers); 0: geometry not supported
+static inline int mvx_tile_lds_bytes(int bw, int bh, int xr, int yr, int bps, int pel, int chroma) {
+    const int R = 3, m = pel - 1, lp = pel == 4 ? 2 : pel == 2 ? 1 : 0, npp = pel * pel;
+    const int pw = ((bw + 2 * R + 1) * bps + 15) / 16, pwc = ((bw / xr + (2 * R) / xr + 2) * bps + 15) / 16;
+    const int th = bh + ((2 * R + m) >> lp), thc = bh / yr + (((2 * R) / yr + m) >> lp);
+    if ((npp * th * pw + 63) / 64 > 4 || (npp * thc * pwc + 63) / 64 > 2) return 0; // TQL / TQC item slots per lane
+    return npp * th * (pw | 1) * 16 + (chroma ? 2 * npp * thc * (pwc | 1) * 16 : 0);
+}
 
 // Compile-time block geometry for the specialised kernels (BW == 0: geometry only known at run time -> generic loops).
 constexpr int pow2c(int v, int r = 1) { return r >= v ? r : pow2c(v, r * 2); }
 // SX = blkW - overlapX (the scan step) enables the LDS search window (0: no window).
 // DCT: the SATD cost modes (dct 5..10) are compiled into their own generic kernel only -- their code costs the default
 // kernels 5-7 % through register allocation even when it never runs (measured)
-template <int BW_, int BH_, int XR_, int YR_, int SX_ = 0, bool DCT_ = false> struct Geo { static constexpr int BW = BW_, BH = BH_, XR = XR_, YR = YR_, SX = SX_; static constexpr bool DCT = DCT_; };
+// TILE: the refinement rounds of the default search (hexagon / square at level 0, the exhaustive rings above) read the
+// reference from a small LDS tile around the predictor round's winner instead of from global memory (see "refinement tile").
+template <int BW_, int BH_, int XR_, int YR_, int SX_ = 0, bool DCT_ = false, bool TILE_ = false> struct Geo {
+    static constexpr int BW = BW_, BH = BH_, XR = XR_, YR = YR_, SX = SX_; static constexpr bool DCT = DCT_, TILE = TILE_;
+};
 typedef Geo<0, 0, 0, 0, 0> GeoAny;
 typedef Geo<0, 0, 0, 0, 0, true> GeoAnyDct;
 
@@ -1085,6 +1097,134 @@ template <int BPS, typename GEO> struct Searcher {
         return true;
     }
 
+    // ---- refinement tile ------------------------------------------------------------------------------------------
+    // After the predictor round the default search only looks at most T_R = 3 vector units around its winner (hexagon +-2,
+    // then the square +-1 around the moved centre; the exhaustive rings of the coarse levels +-2).  Those rounds re-read nearly
+    // the same reference samples 14 + 8 (or 24) times, and every 16-byte-per-lane load of such a round touches up to 64
+    // different cache lines -- the CU's texture path is what keeps a second chain per SIMD from paying off on 16-bit clips.
+    // Here the (block + 2*T_R) neighbourhood of every sub-pel plane is fetched ONCE per block (three 16-byte pieces per row,
+    // adjacent lanes on one line) into LDS, and the refinement rounds compare from there: aligned dword reads shifted into
+    // place (win_chunk), no validity test -- every admissible candidate (vector_ok) of those rounds lies inside the tile by
+    // construction, the tile origin being clamped into the padded plane.  Results cannot differ: same samples, same sums.
+    static constexpr bool T_ON = GEO::TILE && GEO::BW != 0;
+    static constexpr int T_R = 3;
+    static constexpr int T_PW = ((G_BW + 2 * T_R + 1) * BPS + 15) / 16;                     // 16-byte pieces per luma tile row (pel 1 is the widest)
+    static constexpr int T_PWC = ((G_BW / G_XR + (2 * T_R) / G_XR + 2) * BPS + 15) / 16;    // chroma
+    static constexpr int T_RS = (T_PW | 1) * 16, T_RSC = (T_PWC | 1) * 16;                   // row strides: odd multiples of 16 bytes (bank spread)
+    static constexpr int T_TWB = T_PW * 16 / BPS, T_TWBC = T_PWC * 16 / BPS;                 // columns a tile row loads
+#define TQL 4
+#define TQC 2
+    int tileOn, tTH, tTHC, tNQL, tNQC, tVstep;
+    int tfx0, tfy0, tfcx0, tfcy0;                      // tile origins (full-pel, clamped into the padded plane)
+    unsigned tOffL[TQL], tOffC[TQC];                   // per lane: byte offset of the item inside the plane set, relative to the tile origin
+    int tLdsL[TQL], tLdsC[TQC];                        // per lane: LDS offset of the item
+
+    __device__ __forceinline__ static int t_extent(int r2, int m, int lp) { return (r2 + m) >> lp; } // full-pel positions spanned by r2 + 1 vector units
+    __device__ __forceinline__ void tile_setup_level() {
+        tileOn = 0;
+        if (!T_ON) return;
+        const int npp = pel * pel, m = pel - 1;
+        tTH = G_BH + t_extent(2 * T_R, m, logPel);
+        tTHC = G_BH / G_YR + t_extent((2 * T_R) / G_YR, m, logPel);
+        const int tw = G_BW + t_extent(2 * T_R, m, logPel), twc = G_BW / G_XR + t_extent((2 * T_R) / G_XR, m, logPel);
+        const int NIL = npp * tTH * T_PW, NIC = chroma ? npp * tTHC * T_PWC : 0;
+        tNQL = (NIL + WAVE - 1) / WAVE; tNQC = (NIC + WAVE - 1) / WAVE;
+        const int lumaBytes = npp * tTH * T_RS, chromaBytes = chroma ? 2 * npp * tTHC * T_RSC : 0;
+        // the host (mvx_analyse_frames) only launches a tile kernel when all of this holds for every level
+        if (ldsWin < 0 || tNQL > TQL || tNQC > TQC || lumaBytes + chromaBytes > winCap || tw > T_TWB || twc > T_TWBC || pw < T_TWB || ph < tTH ||
+            (pw >> logxr) < T_TWBC || (ph >> logyr) < tTHC || (long long)npp * pstrideY >= 0x7fffffffLL) __builtin_trap();
+        tVstep = npp * tTHC * T_RSC;
+        const int l = lane_id();
+#pragma unroll
+        for (int q = 0; q < TQL; q++) {
+            const int i = min(l + q * WAVE, NIL - 1); // surplus lanes repeat the last item: same address, same data, same LDS target
+            const int pp = i / (tTH * T_PW), rem = i - pp * (tTH * T_PW), row = rem / T_PW, pc = rem - row * T_PW;
+            tOffL[q] = (unsigned)(pp * (int)pstrideY) + (unsigned)row * (unsigned)pitchY + (unsigned)(pc * 16);
+            tLdsL[q] = ldsWin + (pp * tTH + row) * T_RS + pc * 16;
+        }
+#pragma unroll
+        for (int q = 0; q < TQC; q++) {
+            const int i = min(l + q * WAVE, max(NIC - 1, 0));
+            const int pp = i / (tTHC * T_PWC), rem = i - pp * (tTHC * T_PWC), row = rem / T_PWC, pc = rem - row * T_PWC;
+            tOffC[q] = (unsigned)(pp * (int)pstrideC) + (unsigned)row * (unsigned)pitchC + (unsigned)(pc * 16);
+            tLdsC[q] = ldsWin + lumaBytes + (pp * tTHC + row) * T_RSC + pc * 16;
+        }
+        tileOn = 1;
+    }
+    // fetch the tile around vector (cx, cy) of the current block and put it into LDS
+    __device__ __forceinline__ void tile_load(int cx, int cy) {
+        {
+            const int ax = (x0 << logPel) + cx - T_R, ay = (y0 << logPel) + cy - T_R;
+            tfx0 = min(max(ax >> logPel, 0), pw - T_TWB); tfy0 = min(max(ay >> logPel, 0), ph - tTH);
+        }
+        gl_u8 *bL = refY + (long long)tfy0 * pitchY + (long long)tfx0 * BPS;
+        A4x32 tl[TQL], tu[TQC], tv[TQC];
+#pragma unroll
+        for (int q = 0; q < TQL; q++) if (q < tNQL) tl[q] = ld_chunk_g(bL + tOffL[q], 16);
+        if (chroma) {
+            const int vx = cx - T_R, vy = cy - T_R; // same arithmetic as ref_chroma_off; monotonic in the vector, so this is the smallest position
+            const int xb = (vx < 0) ? ((1 << logxr) - 1) : 0, yb = (vy < 0) ? ((1 << logyr) - 1) : 0;
+            const int cax = (cx0 << logPel) + ((vx + xb) >> logxr), cay = (cy0 << logPel) + ((vy + yb) >> logyr);
+            tfcx0 = min(max(cax >> logPel, 0), (pw >> logxr) - T_TWBC); tfcy0 = min(max(cay >> logPel, 0), (ph >> logyr) - tTHC);
+            const long long co = (long long)tfcy0 * pitchC + (long long)tfcx0 * BPS;
+#pragma unroll
+            for (int q = 0; q < TQC; q++) if (q < tNQC) { tu[q] = ld_chunk_g(refU + co + tOffC[q], 16); tv[q] = ld_chunk_g(refV + co + tOffC[q], 16); }
+        }
+#pragma unroll
+        for (int q = 0; q < TQL; q++) if (q < tNQL) st_chunk_l(lds + tLdsL[q], tl[q], 16);
+        if (chroma) {
+#pragma unroll
+            for (int q = 0; q < TQC; q++) if (q < tNQC) { st_chunk_l(lds + tLdsC[q], tu[q], 16); st_chunk_l(lds + tLdsC[q] + tVstep, tv[q], 16); }
+        }
+        __builtin_amdgcn_wave_barrier(); // single wave, DS ops execute in order: only keeps the compiler from hoisting tile reads above the stores
+    }
+    template <int LOGG, int T, int LOGC, int CB, int ROWB, int RS>
+    __device__ __forceinline__ unsigned tile_region(int s, const lds_u8 *src, int tileRow, int b0, unsigned acc) const {
+        constexpr int G = 1 << LOGG, C = 1 << LOGC;
+        constexpr int N = T >= G ? T / G : 1;
+        if (T < G && s >= T) return acc;
+        if (G >= C) {
+            const int row0 = s >> LOGC, xb = (s & (C - 1)) * CB;
+            const int a = tileRow + row0 * RS + b0 + xb;
+            const lds_u8 *rp4 = lds + (a & ~3);
+            const unsigned sh = (unsigned)(a & 3) * 8;
+            const lds_u8 *sp = src + row0 * ROWB + xb;
+            constexpr int rstep = (G >> LOGC) * RS, sstep = (G >> LOGC) * ROWB;
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+#ifdef MVX_TILE_NB
+                if (k && k % MVX_TILE_NB == 0) __builtin_amdgcn_sched_barrier(0); // bounds the LDS reads in flight (registers)
+#endif
+                acc = win_chunk<CB>(sp + k * sstep, rp4 + k * rstep, sh, acc);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                const int t = s + k * G, row = t >> LOGC, xb = (t & (C - 1)) * CB;
+                const int a = tileRow + row * RS + b0 + xb;
+                acc = win_chunk<CB>(src + row * ROWB + xb, lds + (a & ~3), (unsigned)(a & 3) * 8, acc);
+            }
+        }
+        return acc;
+    }
+    template <int LOGG> __device__ __forceinline__ void eval_tile(int s, int vx, int vy, unsigned &aL, unsigned &aC) const {
+        const int m = pel - 1, npp = pel * pel;
+        {
+            const int ax = (x0 << logPel) + vx, ay = (y0 << logPel) + vy;
+            const int pp = (ax & m) | ((ay & m) << logPel);
+            aL = tile_region<LOGG, G_LT, ilog2c(G_LC), G_LCB, G_LROWB, T_RS>(s, lds, ldsWin + (pp * tTH + ((ay >> logPel) - tfy0)) * T_RS, ((ax >> logPel) - tfx0) * BPS, aL);
+        }
+        if (chroma) {
+            const int xb = (vx < 0) ? ((1 << logxr) - 1) : 0, yb = (vy < 0) ? ((1 << logyr) - 1) : 0;
+            const int cax = (cx0 << logPel) + ((vx + xb) >> logxr), cay = (cy0 << logPel) + ((vy + yb) >> logyr);
+            const int pp = (cax & m) | ((cay & m) << logPel);
+            const int rowU = ldsWin + npp * tTH * T_RS + (pp * tTHC + ((cay >> logPel) - tfcy0)) * T_RSC;
+            const int b0 = ((cax >> logPel) - tfcx0) * BPS;
+            aC = tile_region<LOGG, G_CT, ilog2c(G_CC), G_CCB, G_CROWB, T_RSC>(s, lds + G_UOFF, rowU, b0, aC);
+            aC = tile_region<LOGG, G_CT, ilog2c(G_CC), G_CCB, G_CROWB, T_RSC>(s, lds + G_VOFF, rowU + tVstep, b0, aC);
+        }
+    }
+
     // ---- fast path -----------------------------------------------------------------------------------------------
     // The default search (predictor set, then Hex2 hexagon + square at level 0 or the 24-point exhaustive rings at the
     // coarse levels, no tryMany) as straight-line code with compile-time candidate tables; semantics identical to the
@@ -1153,6 +1293,8 @@ template <int BPS, typename GEO> struct Searcher {
         const long long ft0 = PROF_T();
         if (PRE) {
             if (ok) pre_sad(s, *pre, aL, aC);
+        } else if (T_ON && KIND != FR_A) { // tile kernels: always (the host only picks them when every level can have its tile)
+            if (ok) eval_tile<LOGG>(s, vx, vy, aL, aC);
         } else if (ok) {
             bool done = false;
             if (W_ON) { if (winOn) done = eval_win<LOGG>(s, vx, vy, vyc, aL, aC); }
@@ -1236,6 +1378,7 @@ template <int BPS, typename GEO> struct Searcher {
         if (!PRE) globalMVPredictor = clip_mv(globalMVPredictor); // cumulative clip (:859); done before the early request otherwise
         nMinCost = BIG64;
         round_fast<FR_A, PRE>(0, 0, pre);
+        if (T_ON) tile_load(bestMV.x, bestMV.y);
         if (searchType == SearchHex2) { // pobHex2Search :667-724 with i_me_range <= 3: no half-hexagon iterations
             int bmx = bestMV.x, bmy = bestMV.y;
             if (nSearchParam > 1) {
@@ -1648,7 +1791,7 @@ template <int BPS, typename GEO> struct Searcher {
         // park (and wait for) before every search.
         // Measured (r1, A/B in one session): +5 % at full load / +9 % unloaded on 4K 16-bit, -7 % on 1080p 8-bit, whose
         // lighter kernels keep the prefetched vectors in registers for free -- hence the compile-time choice.
-        constexpr bool PRED_ROWS = BPS == 2 && !W_ON; // (the window kernels need that LDS for the window)
+        constexpr bool PRED_ROWS = BPS == 2 && !W_ON && !T_ON; // (the window / tile kernels spend that LDS differently)
         const int predStride = (ldsHist - ldsRow) / 48; // host layout: [row buffer | 2 predictor rows], 16 bytes per block
         LDS_AS Vec *predRows = (LDS_AS Vec *)(lds + ldsRow + predStride * 16);
         auto load_pred_row = [&](int row) {
@@ -1690,6 +1833,7 @@ template <int BPS, typename GEO> struct Searcher {
         prefetch();
         int curIb = 0, curBy = 0;
         win_setup_level();
+        tile_setup_level();
         A4x32 wpf[WQ_MAX];
         const bool fast = !tryMany && dctmode == 0 && ((searchType == SearchHex2 && nSearchParam <= 3) || (searchType == SearchExhaustive && nSearchParam == 2));
         // early request of the predictor round (specialised kernels, reference samples from global memory)
@@ -1791,8 +1935,12 @@ template <int BPS, typename GEO> struct Searcher {
             if (ablate == 1) { bestMV = predictor; bestMV.sad = 0; }
             // (the hints matter: the general state machine is an inner loop, which the register allocator would otherwise favour
             // over the straight-line path that actually runs; measured +2 % at 4K16)
+#ifdef MVX_X1 // developer experiment: no general state machine at all (WRONG results for bad blocks / other searches)
+            else if (fast) search_block_fast<EARLY_K>(&preA);
+#else
             else if (__builtin_expect(fast, 1)) { if (__builtin_expect(!search_block_fast<EARLY_K>(&preA), 0)) search_block(1); }
             else search_block(0);
+#endif
             const long long bt2 = PROF_T();
             __builtin_amdgcn_wave_barrier();
 
@@ -2016,6 +2164,7 @@ struct RLaunch { int njobs, nBlk, ldsBytes, ldsRow, ldsHist, histBins; hipStream
 int mvx_recalc_launch(const AParams &P, const RLaunch &L);
 
 struct ALaunch {
+    int mode; // 0 plain kernels, 1 LDS search window (Geo<..., scan step>), 2 refinement tile (Geo<..., TILE>): decides the LDS layout
     int njobs, ldsBytes, ldsRow, ldsHist, histBins, ldsWin, winCap;
     int ldsNeed; // what the kernel really uses (ldsBytes may carry the one-chain-per-SIMD floor)
     int simds;   // SIMDs of the device (4 per CU)
@@ -2026,7 +2175,7 @@ struct ALaunch {
 template <int BPS_, typename GEO_, int WPE_ = 1> static int launch_analyse_kernel(const ALaunch &L) {
     if (L.ldsBytes > 64 * 1024)
         HIP_CHECK(hipFuncSetAttribute((const void *)analyse_kernel<BPS_, GEO_, WPE_>, hipFuncAttributeMaxDynamicSharedMemorySize, L.ldsBytes));
-    const bool win = GEO_::SX != 0 && L.ldsWin >= 0;
+    const bool win = (GEO_::SX != 0 || GEO_::TILE) && L.ldsWin >= 0;
     hipLaunchKernelGGL((analyse_kernel<BPS_, GEO_, WPE_>), dim3(L.njobs), dim3(64), win ? L.ldsBytes : L.ldsWin >= 0 ? L.ldsWin + L.histBins * 4 : L.ldsBytes, L.st, L.dP, L.dJobs,
                        L.ldsRow, L.ldsHist, L.histBins, win ? L.ldsWin : -1, win ? L.winCap : 0);
     return MVX_OK;

@@ -4,7 +4,7 @@ int mvx_analyse_launch_u8(const AParams &P, const ALaunch &L) {
     if (P.xr != 2 || P.yr != 2) return 1;
     // The LDS search-window kernels (Geo<..., scan step>) are bit-exact but measured SLOWER than the plain ones in round 1
     // (DESIGN.md 4.2): opt-in via MVX_WINDOW=1 until the window path is cheaper in instructions.
-    const int S = L.ldsWin >= 0 ? P.blkX - P.ovX : 0;
+    const int S = L.mode == 1 ? P.blkX - P.ovX : 0;
     // More chains than SIMDs: the 8-bit kernels have a 256-register build so that two chains share a SIMD (+53 % at 1080p,
     // DESIGN.md 4.2).  It drops the LDS floor that spreads a small launch one chain per SIMD.
     if (S == 0 && L.njobs > L.simds) {
