@@ -89,7 +89,7 @@ typedef __attribute__((address_space(3))) unsigned char lds_u8;
 #define GL_AS __attribute__((address_space(1)))
 typedef GL_AS const unsigned char gl_u8;
 
-__device__ __forceinline__ int lane_id() { return threadIdx.x; }
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; } // (a no-op for the 64-thread kernels: launch bounds)
 
 __device__ __forceinline__ int bcast_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ long long bcast_ll(long long v, int l) {
@@ -896,6 +896,7 @@ template <int BPS, typename GEO> struct Searcher {
 #define WQY 2
 #define WQ_MAX (WQY + 2)
     int ablate;                                        // developer switch (MVX_ABLATE), copied once: never re-read from memory inside the block loop
+    int blockSync;                                     // four chains per workgroup: barrier per block (analyse_kernel, CPW)
     int winOn, ldsWin, winCap;
     int wLdsC;                                         // LDS offset of the chroma windows (U planes then V planes)
     int wQY;                                           // luma slots in use (1 or 2)
@@ -1852,6 +1853,7 @@ template <int BPS, typename GEO> struct Searcher {
         PreA preA;
         for (int n = 0; n < nBlk; n++) {
             const long long bt0 = PROF_T();
+            if (blockSync && (curIb & (blockSync - 1)) == 0) __builtin_amdgcn_s_barrier(); // every blockSync blocks (a power of two) and at every row start
             blky = curBy;
             blkx = (blky % 2 == 0 || meander == 0) ? curIb : nBlkX - 1 - curIb;
             const bool rowStart = curIb == 0;
@@ -2013,8 +2015,11 @@ template <int BPS, typename GEO> struct Searcher {
 // when a launch carries two chains per SIMD (1080p: 961 -> 1475 fps) -- their loads are light on the CU's texture path.  The
 // 16-bit kernels do not (4K16: no gain even without spills; five chains per CU take as long as four, the shared L1/TA is
 // the limit), so they stay at WPE = 1.
-template <int BPS, typename GEO, int WPE = 1>
-__global__ __launch_bounds__(64, WPE) void analyse_kernel(const AParams *Pp, const AJob *jobs, int ldsRow, int ldsHist, int histBins, int ldsWin, int winCap) {
+// CPW = chains per workgroup (1 or 4).  4: the waves of a workgroup are four chains the host has ordered so that they search
+// the SAME reference frame (different current frames); a workgroup barrier per block keeps them on the same block, so the
+// reference lines one of them pulls into the CU's L1 (and the XCD's L2) serve the others.
+template <int BPS, typename GEO, int WPE = 1, int CPW = 1>
+__global__ __launch_bounds__(64 * CPW, WPE) void analyse_kernel(const AParams *Pp, const AJob *jobs, int njobs, int ldsChain, int syncEvery, int ldsRow, int ldsHist, int histBins, int ldsWin, int winCap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // WPE == 1 is for launches with at most one chain per SIMD.  The host's LDS request limits a CU to four chains, but a
     // kernel that fits 256 VGPRs would let the dispatcher stack two of them on one SIMD while another SIMD idles (measured:
@@ -2024,8 +2029,10 @@ __global__ __launch_bounds__(64, WPE) void analyse_kernel(const AParams *Pp, con
     // the four chains of a CU then run in lockstep and hit the texture path in the same phases.)
     if (WPE == 1) asm volatile("" ::: "a255");
     const AParams &P = *Pp;
-    const AJob &J = jobs[blockIdx.x];
-    const int l = threadIdx.x;
+    const int chain = CPW == 1 ? (int)blockIdx.x : uni((int)blockIdx.x * CPW + (int)(threadIdx.x >> 6));
+    if (CPW > 1 && chain >= njobs) return; // (a finished wave no longer counts for the workgroup's barriers)
+    const AJob &J = jobs[chain];
+    const int l = lane_id();
     int *hdr = (int *)J.blob;
     if (!J.valid) { // gopWriteDefaultToArray GroupOfPlanes.c:150-164, pobWriteDefaultToArray PlaneOfBlocks.cpp:1529-1556
         if (l == 0) { hdr[0] = P.blobSize; hdr[1] = 0; }
@@ -2041,8 +2048,10 @@ __global__ __launch_bounds__(64, WPE) void analyse_kernel(const AParams *Pp, con
     }
     if (l == 0) { hdr[0] = P.blobSize; hdr[1] = 1; } // GroupOfPlanes.c:77-85
     Searcher<BPS, GEO> S(P, J);
-    S.lds = (lds_u8 *)smem; S.ldsRow = ldsRow; S.ldsHist = ldsHist; S.histBins = histBins;
+    S.lds = (lds_u8 *)smem + (CPW == 1 ? 0 : uni((int)(threadIdx.x >> 6)) * ldsChain);
+    S.ldsRow = ldsRow; S.ldsHist = ldsHist; S.histBins = histBins;
     S.ldsWin = ldsWin; S.winCap = winCap; S.winOn = 0;
+    S.blockSync = CPW > 1 ? syncEvery : 0;
     S.ablate = uni(P.ablate) & 0xff;
 #ifdef MVX_PROFILE
     for (int i = 0; i < 16; i++) S.prof[i] = 0;
@@ -2059,7 +2068,7 @@ __global__ __launch_bounds__(64, WPE) void analyse_kernel(const AParams *Pp, con
     }
 #ifdef MVX_PROFILE
     S.prof[9] = PROF_T() - kt0;
-    if (l == 0 && (int)blockIdx.x == (P.ablate >> 8)) for (int i = 0; i < 16; i++) g_prof[i] = (unsigned long long)S.prof[i]; // MVX_ABLATE = chain << 8
+    if (l == 0 && chain == (P.ablate >> 8)) for (int i = 0; i < 16; i++) g_prof[i] = (unsigned long long)S.prof[i]; // MVX_ABLATE = chain << 8
 #endif
 }
 
@@ -2085,7 +2094,7 @@ __global__ __launch_bounds__(64, 1) void recalc_kernel(const AParams *Pp, const 
     typedef Searcher<BPS, GeoAnyDct> S_t;
     S_t S(P, J);
     S.lds = (lds_u8 *)smem; S.ldsRow = ldsRow; S.ldsHist = ldsHist; S.histBins = histBins;
-    S.ldsWin = -1; S.winCap = 0; S.winOn = 0; S.ablate = 0;
+    S.ldsWin = -1; S.winCap = 0; S.winOn = 0; S.ablate = 0; S.blockSync = 0;
     for (int i = 0; i < 16; i++) S.prof[i] = 0;
     const int l = lane_id();
     S.setup_geometry(0);
@@ -2168,16 +2177,20 @@ struct ALaunch {
     int njobs, ldsBytes, ldsRow, ldsHist, histBins, ldsWin, winCap;
     int ldsNeed; // what the kernel really uses (ldsBytes may carry the one-chain-per-SIMD floor)
     int simds;   // SIMDs of the device (4 per CU)
+    int cpw;     // chains per workgroup the host ordered the jobs for (1 or 4)
+    int syncEvery; // cpw > 1: workgroup barrier every that many blocks of a row (power of two; a row start always syncs)
     hipStream_t st;
     const AParams *dP;
     const AJob *dJobs;
 };
-template <int BPS_, typename GEO_, int WPE_ = 1> static int launch_analyse_kernel(const ALaunch &L) {
-    if (L.ldsBytes > 64 * 1024)
-        HIP_CHECK(hipFuncSetAttribute((const void *)analyse_kernel<BPS_, GEO_, WPE_>, hipFuncAttributeMaxDynamicSharedMemorySize, L.ldsBytes));
+template <int BPS_, typename GEO_, int WPE_ = 1, int CPW_ = 1> static int launch_analyse_kernel(const ALaunch &L) {
     const bool win = (GEO_::SX != 0 || GEO_::TILE) && L.ldsWin >= 0;
-    hipLaunchKernelGGL((analyse_kernel<BPS_, GEO_, WPE_>), dim3(L.njobs), dim3(64), win ? L.ldsBytes : L.ldsWin >= 0 ? L.ldsWin + L.histBins * 4 : L.ldsBytes, L.st, L.dP, L.dJobs,
-                       L.ldsRow, L.ldsHist, L.histBins, win ? L.ldsWin : -1, win ? L.winCap : 0);
+    const int perChain = CPW_ > 1 ? ((L.ldsNeed + 255) & ~255) : (win ? L.ldsBytes : L.ldsWin >= 0 ? L.ldsWin + L.histBins * 4 : L.ldsBytes);
+    const int lds = perChain * CPW_;
+    if (lds > 64 * 1024)
+        HIP_CHECK(hipFuncSetAttribute((const void *)analyse_kernel<BPS_, GEO_, WPE_, CPW_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((analyse_kernel<BPS_, GEO_, WPE_, CPW_>), dim3((L.njobs + CPW_ - 1) / CPW_), dim3(64 * CPW_), lds, L.st, L.dP, L.dJobs,
+                       L.njobs, perChain, L.syncEvery, L.ldsRow, L.ldsHist, L.histBins, win ? L.ldsWin : -1, win ? L.winCap : 0);
     return MVX_OK;
 }
 // returns MVX_OK after launching, or 1 when this translation unit has no kernel for the geometry

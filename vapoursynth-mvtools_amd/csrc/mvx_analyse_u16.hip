@@ -10,6 +10,11 @@ int mvx_analyse_launch_u16(const AParams &P, const ALaunch &L) {
     // build of it for two chains per SIMD was measured too (r1): every chain then takes 2.5x as long (2016 chains: 175 fps
     // against 214) -- see DESIGN.md 4.2.
     if (L.mode == 2 && P.blkX == 16 && P.blkY == 16) return launch_analyse_kernel<2, Geo<16, 16, 2, 2, 0, false, true>>(L);
+    if (L.mode == 0 && L.cpw == 4) { // four chains per workgroup (mvx_analyse_frames sorted the job table by reference frame)
+        if (P.blkX == 16 && P.blkY == 16) return launch_analyse_kernel<2, Geo<16, 16, 2, 2>, 1, 4>(L);
+        if (P.blkX == 32 && P.blkY == 32) return launch_analyse_kernel<2, Geo<32, 32, 2, 2>, 1, 4>(L);
+        if (P.blkX == 8 && P.blkY == 8) return launch_analyse_kernel<2, Geo<8, 8, 2, 2>, 1, 4>(L);
+    }
     if (P.blkX == 16 && P.blkY == 16) return S == 8 ? launch_analyse_kernel<2, Geo<16, 16, 2, 2, 8>>(L) : launch_analyse_kernel<2, Geo<16, 16, 2, 2>>(L);
     if (P.blkX == 32 && P.blkY == 32) return launch_analyse_kernel<2, Geo<32, 32, 2, 2>>(L);
     if (P.blkX == 8 && P.blkY == 8) return S == 4 ? launch_analyse_kernel<2, Geo<8, 8, 2, 2, 4>>(L) : launch_analyse_kernel<2, Geo<8, 8, 2, 2>>(L);
