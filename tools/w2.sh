@@ -1,10 +1,6 @@
 r() { name=$1; shift; envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
   env "${envs[@]}" python bench.py --no-cpu --steps 2 --warmup 1 "$@" 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(\"$name\", round(d[\"value\"],1), \"fps\", round(d[\"roofline\"][\"avg_launch_ms\"],1), \"ms/launch\")"; }
-r cfg3-cpw4 X=1 -- --config cfg3
-r cfg3-cpw1 MVX_CPW=1 -- --config cfg3
-r cfg2-cpw4 X=1 -- --config cfg2
-r cfg2-cpw1 MVX_CPW=1 -- --config cfg2
-r cfg1-cpw4 X=1 -- --config cfg1
-r cfg1-cpw1 MVX_CPW=1 -- --config cfg1
-r cfg5-cpw4 X=1 -- --config cfg5
-r cfg5-cpw1 MVX_CPW=1 -- --config cfg5
+r cfg3 X=1 -- --config cfg3
+r cfg2 X=1 -- --config cfg2
+r cfg5 X=1 -- --config cfg5
+r cfg3 X=1 -- --config cfg3

@@ -410,6 +410,22 @@ template <int BPS, typename GEO> struct Searcher {
         return idx * pstrideC + (long long)(ay >> logPel) * pitchC + (long long)(ax >> logPel) * BPS;
     }
 
+    // 32-bit forms for the specialised kernels (the host checks that a level's plane set is smaller than 2 GiB): the loads then
+    // address "uniform 64-bit base + per-lane 32-bit offset" directly, which saves ~40 vector instructions of 64-bit address
+    // arithmetic per search round.  Offsets of inadmissible candidates may wrap; their lanes never load.
+    __device__ __forceinline__ unsigned ref_luma_off32(int vx, int vy) const {
+        const int ax = (x0 << logPel) + vx, ay = (y0 << logPel) + vy, m = pel - 1;
+        const unsigned idx = (unsigned)((ax & m) | ((ay & m) << logPel));
+        return idx * (unsigned)pstrideY + (unsigned)(ay >> logPel) * (unsigned)pitchY + (unsigned)(ax >> logPel) * BPS;
+    }
+    __device__ __forceinline__ unsigned ref_chroma_off32(int vx, int vy) const {
+        const int lxr = GEO::BW ? (GEO::XR == 2 ? 1 : 0) : logxr, lyr = GEO::BW ? (GEO::YR == 2 ? 1 : 0) : logyr; // compile-time in the specialised kernels
+        const int xbias = (vx < 0) ? ((1 << lxr) - 1) : 0, ybias = (vy < 0) ? ((1 << lyr) - 1) : 0;
+        const int ax = (cx0 << logPel) + ((vx + xbias) >> lxr), ay = (cy0 << logPel) + ((vy + ybias) >> lyr), m = pel - 1;
+        const unsigned idx = (unsigned)((ax & m) | ((ay & m) << logPel));
+        return idx * (unsigned)pstrideC + (unsigned)(ay >> logPel) * (unsigned)pitchC + (unsigned)(ax >> logPel) * BPS;
+    }
+
     // item t of the block -> LDS offset and (plane, row, byte offset in row)
     __device__ __forceinline__ void item(int t, int &pl, int &row, int &xb, int &loff, int &cb) const {
         if (t < TL) { pl = 0; row = t >> logCL; xb = (t & ((1 << logCL) - 1)) * CBL; loff = row * lumaRowB + xb; cb = CBL; }
@@ -568,6 +584,87 @@ template <int BPS, typename GEO> struct Searcher {
         return acc;
     }
 
+    template <int LOGG, int T, int LOGC, int CB, int ROWB>
+    __device__ __forceinline__ unsigned region_fixed32(int s, const lds_u8 *src, gl_u8 *base, unsigned off, unsigned refPitch, unsigned acc) const {
+        constexpr int G = 1 << LOGG, C = 1 << LOGC;
+        if (T < G) { // fewer items than lanes in the group: lanes s < T own one item each
+            if (s < T) {
+                const int row = s >> LOGC, xb = (s & (C - 1)) * CB;
+                acc = sad_chunk<BPS>(src + row * ROWB + xb, base + (off + (unsigned)row * refPitch + (unsigned)xb), CB, acc);
+            }
+            return acc;
+        }
+        constexpr int N = T >= G ? T / G : 1;        // items per lane
+#ifndef MVX_NB
+#define MVX_NB 4 // chunks in flight per region: four measured +2 % over eight at 4K16 (register pressure), and keeps the 8-bit kernels spill-free at 256 registers
+#endif
+        constexpr int NB = N < MVX_NB ? N : MVX_NB;  // loads in flight per batch
+        if (G >= C) { // the chunk column is fixed per lane, rows advance by G / C per item
+            const int row0 = s >> LOGC, xb = (s & (C - 1)) * CB;
+            const unsigned p = off + (unsigned)row0 * refPitch + (unsigned)xb;
+            const lds_u8 *sp = src + row0 * ROWB + xb;
+            const unsigned step = (unsigned)(G >> LOGC) * refPitch;
+            constexpr int lstep = (G >> LOGC) * ROWB;
+            unsigned po = p; // running offset: one add per chunk (kept as a chain: as p + k * step the compiler multiplies per chunk)
+#pragma unroll 2
+            for (int k0 = 0; k0 < N; k0 += NB) {
+                v4u r[NB];
+#pragma unroll
+                for (int k = 0; k < NB; k++) {
+                    gl_u8 *q = base + po;
+                    po += step;
+                    asm("" : "+v"(po)); // (not volatile: must not become a scheduling barrier)
+                    if (CB == 16) { uv4 v = LDREF((GL_AS const uv4 *)q); r[k] = v4u{v[0], v[1], v[2], v[3]}; }
+                    else if (CB == 8) { uv2 v = LDREF((GL_AS const uv2 *)q); r[k] = v4u{v[0], v[1], 0, 0}; }
+                    else if (CB == 4) r[k] = v4u{LDREF((GL_AS const uv1 *)q), 0, 0, 0};
+                    else r[k] = v4u{LDREF((GL_AS const uh1 *)q), 0, 0, 0};
+                }
+#pragma unroll
+                for (int k = 0; k < NB; k++) {
+                    const lds_u8 *l = sp + (k0 + k) * lstep;
+                    if (CB == 16) {
+                        v4u a = *(const LDS_AS v4u *)l;
+                        acc = sad32<BPS>(a[0], r[k][0], acc); acc = sad32<BPS>(a[1], r[k][1], acc);
+                        acc = sad32<BPS>(a[2], r[k][2], acc); acc = sad32<BPS>(a[3], r[k][3], acc);
+                    } else if (CB == 8) {
+                        v2u a = *(const LDS_AS v2u *)l;
+                        acc = sad32<BPS>(a[0], r[k][0], acc); acc = sad32<BPS>(a[1], r[k][1], acc);
+                    } else if (CB == 4) acc = sad32<BPS>(*(const LDS_AS unsigned *)l, r[k][0], acc);
+                    else acc = sad32<BPS>(*(const LDS_AS unsigned short *)l, r[k][0], acc);
+                }
+            }
+        } else { // several lanes' worth of chunks per row: general item -> (row, chunk) mapping, still compile-time counts
+#pragma unroll 2
+            for (int k0 = 0; k0 < N; k0 += NB) {
+                v4u r[NB];
+#pragma unroll
+                for (int k = 0; k < NB; k++) {
+                    const int t = s + (k0 + k) * G, row = t >> LOGC, xb = (t & (C - 1)) * CB;
+                    gl_u8 *q = base + (off + (unsigned)row * refPitch + (unsigned)xb);
+                    if (CB == 16) { uv4 v = LDREF((GL_AS const uv4 *)q); r[k] = v4u{v[0], v[1], v[2], v[3]}; }
+                    else if (CB == 8) { uv2 v = LDREF((GL_AS const uv2 *)q); r[k] = v4u{v[0], v[1], 0, 0}; }
+                    else if (CB == 4) r[k] = v4u{LDREF((GL_AS const uv1 *)q), 0, 0, 0};
+                    else r[k] = v4u{LDREF((GL_AS const uh1 *)q), 0, 0, 0};
+                }
+#pragma unroll
+                for (int k = 0; k < NB; k++) {
+                    const int t = s + (k0 + k) * G, row = t >> LOGC, xb = (t & (C - 1)) * CB;
+                    const lds_u8 *l = src + row * ROWB + xb;
+                    if (CB == 16) {
+                        v4u a = *(const LDS_AS v4u *)l;
+                        acc = sad32<BPS>(a[0], r[k][0], acc); acc = sad32<BPS>(a[1], r[k][1], acc);
+                        acc = sad32<BPS>(a[2], r[k][2], acc); acc = sad32<BPS>(a[3], r[k][3], acc);
+                    } else if (CB == 8) {
+                        v2u a = *(const LDS_AS v2u *)l;
+                        acc = sad32<BPS>(a[0], r[k][0], acc); acc = sad32<BPS>(a[1], r[k][1], acc);
+                    } else if (CB == 4) acc = sad32<BPS>(*(const LDS_AS unsigned *)l, r[k][0], acc);
+                    else acc = sad32<BPS>(*(const LDS_AS unsigned short *)l, r[k][0], acc);
+                }
+            }
+        }
+        return acc;
+    }
+
     static constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v / 2); }
 
     template <int LOGG> __device__ __forceinline__ void eval_fixed(int s, int vx, int vy, int vyc, unsigned &aL, unsigned &aC) const {
@@ -575,11 +672,11 @@ template <int BPS, typename GEO> struct Searcher {
         constexpr int LROWB = BW * BPS, LCB = LROWB < 16 ? LROWB : 16, LLOGC = ilog2c(LROWB / LCB), LT = BH * (LROWB / LCB);
         constexpr int CROWB = (BW / XR) * BPS, CCB = CROWB < 16 ? CROWB : 16, CLOGC = ilog2c(CROWB / CCB), CT = (BH / YR) * (CROWB / CCB);
         constexpr int UOFF = BH * LROWB, VOFF = UOFF + (BH / YR) * CROWB;
-        aL = region_fixed<LOGG, LT, LLOGC, LCB, LROWB>(s, lds, ref_luma(vx, vy), pitchY, aL);
+        aL = region_fixed32<LOGG, LT, LLOGC, LCB, LROWB>(s, lds, refY, ref_luma_off32(vx, vy), (unsigned)pitchY, aL);
         if (chroma) {
-            const long long co = ref_chroma_off(vx, vyc);
-            aC = region_fixed<LOGG, CT, CLOGC, CCB, CROWB>(s, lds + UOFF, refU + co, pitchC, aC);
-            aC = region_fixed<LOGG, CT, CLOGC, CCB, CROWB>(s, lds + VOFF, refV + co, pitchC, aC);
+            const unsigned co = ref_chroma_off32(vx, vyc);
+            aC = region_fixed32<LOGG, CT, CLOGC, CCB, CROWB>(s, lds + UOFF, refU, co, (unsigned)pitchC, aC);
+            aC = region_fixed32<LOGG, CT, CLOGC, CCB, CROWB>(s, lds + VOFF, refV, co, (unsigned)pitchC, aC);
         }
     }
 
@@ -1241,6 +1338,7 @@ template <int BPS, typename GEO> struct Searcher {
 
     // the predictor set of pobPseudoEPZSearch (:832-915): zero, global, hierarchical predictor, median, left, up, ahead
     __device__ __forceinline__ void cand_A(int g, int &vx, int &vy, int &vyc) const {
+        asm("" : "+v"(g)); // keeps the seven (g == k) lane masks from being hoisted out of the block loop as scalar pairs that are then spilled
         vx = 0; vy = zeroMVfieldShifted.y;
         vx = g == 1 ? globalMVPredictor.x : vx; vy = g == 1 ? globalMVPredictor.y : vy;
         vx = g == 2 ? predictor.x : vx; vy = g == 2 ? predictor.y : vy;
