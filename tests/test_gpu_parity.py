@@ -382,24 +382,26 @@ def test_analyse_refinement_tile_kernel(oracle, mv, monkeypatch, w, h, skw, akw)
         assert np.array_equal(gb.cpu().numpy(), ob)
 
 
-def test_analyse_two_chains_per_simd(oracle, mv):
-    """a launch with more chains than the device has SIMDs takes the 256-register build of the 8-bit 8x8 kernel (two chains per
-    SIMD, mvx_analyse_u8.hip): every one of its results must still be the oracle's"""
+@pytest.mark.parametrize("bits,akw", [(8, dict(blksize=8, overlap=4)), (16, dict(blksize=16, overlap=8)), (16, dict(blksize=8, overlap=4)),
+                                      (8, dict(blksize=16, overlap=8))])
+def test_analyse_two_chains_per_simd(oracle, mv, bits, akw):
+    """a launch with more chains than the device has SIMDs takes the 256-register builds (two chains per SIMD; 16-bit: eight
+    chains per workgroup, job table sorted by reference frame): every one of its results must still be the oracle's, whatever
+    the order the chains were given in"""
     import torch
-    w, h, bits = 96, 64, 8
-    akw = dict(blksize=8, overlap=4)
+    w, h = 128, 96
     frames, osup, gsup, osf, gsrc, gsf = _pipeline(oracle, mv, w, h, bits, 1, {}, akw, nframes=3)
     oan = oracle.Analyse(osup, isb=1, **akw)
     gan = mv.Analyse(gsup, isb=1, **akw)
-    want = [oan.frame(osf[0], osf[1]), oan.frame(osf[1], osf[2]), oan.frame(osf[2], None)]
-    pairs = [(gsf[0], gsf[1]), (gsf[1], gsf[2]), (gsf[2], None)]
+    want = [oan.frame(osf[0], osf[1]), oan.frame(osf[1], osf[2]), oan.frame(osf[2], None), oan.frame(osf[0], osf[2])]
+    pairs = [(gsf[0], gsf[1]), (gsf[1], gsf[2]), (gsf[2], None), (gsf[0], gsf[2])]
     nsimd = 4 * torch.cuda.get_device_properties(0).multi_processor_count
-    njobs = nsimd + 64
-    got = gan.run([pairs[i % 3] for i in range(njobs)])
+    njobs = nsimd + 61
+    got = gan.run([pairs[(i * 7) % 4] for i in range(njobs)])
     torch.cuda.synchronize()
     got = torch.stack(list(got)).cpu().numpy()
     for i in range(njobs):
-        assert np.array_equal(got[i], want[i % 3]), "job %d differs" % i
+        assert np.array_equal(got[i], want[(i * 7) % 4]), "job %d differs" % i
 
 
 def _golden_cases():

@@ -247,14 +247,28 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         if (((uintptr_t)jobs[i].blob) & 15) { mvx_set_error("mvx_analyse_frames: blob must be 16-byte aligned"); return MVX_E_ARG; }
     }
     // Chain placement.  Chains that search the same reference frame read the same lines at about the same time (they start
-    // together and advance at the same pace).  The specialised kernels run FOUR chains per workgroup (one per SIMD of a CU),
-    // and the job table is sorted by reference frame first, so the four waves of a workgroup share their reference lines in
-    // the CU's L1 (+4.7 % at 4K16; measured r1: a barrier between them only costs -- per block -13 %, per 16 blocks 0 %, per row
-    // +3.7 % -- and dealing the groups out so that each XCD gets a contiguous range of frames changes nothing).
-    const bool fourPerGroup = P.dctmode == 0 && P.xr == 2 && P.yr == 2 && P.blkX == P.blkY && (P.blkX == 16 || P.blkX == 8 || (P.blkX == 32 && P.bps == 2)) &&
-                              !(getenv("MVX_CPW") && atoi(getenv("MVX_CPW")) == 1) && !(getenv("MVX_TILE") && atoi(getenv("MVX_TILE"))) &&
-                              !(getenv("MVX_WINDOW") && atoi(getenv("MVX_WINDOW")));
-    int cpw = fourPerGroup ? 4 : 1;
+    // together and advance at the same pace).  The specialised kernels run FOUR (or eight) chains per workgroup, one (two) per
+    // SIMD of a CU, and the job table is sorted by reference frame first, so the waves of a workgroup share their reference
+    // lines in the CU's L1 (+4.7 % at 4K16; measured r1: a barrier between them only costs -- per block -13 %, per 16 blocks 0 %,
+    // per row +3.7 % -- and dealing the groups out so that each XCD gets a contiguous range of frames changes nothing).
+    const bool spec = P.dctmode == 0 && P.xr == 2 && P.yr == 2 && P.blkX == P.blkY && (P.blkX == 16 || P.blkX == 8 || (P.blkX == 32 && P.bps == 2)) &&
+                      !(getenv("MVX_CPW") && atoi(getenv("MVX_CPW")) == 1) && !(getenv("MVX_TILE") && atoi(getenv("MVX_TILE"))) &&
+                      !(getenv("MVX_WINDOW") && atoi(getenv("MVX_WINDOW")));
+    static int simds = 0;
+    if (!simds) {
+        int dev = 0, cus = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        simds = 4 * cus;
+    }
+    // A launch with more chains than SIMDs runs TWO chains per SIMD where a 256-register build of the kernel exists without
+    // spills (8-bit 8x8; 16-bit 8x8, 16x16): 8-bit 1080p +53 %; 16-bit 4K +13 %, and there only as workgroups of EIGHT chains
+    // that share a reference frame -- eight unrelated chains per CU thrash its L1 / the XCD's L2 and lose.
+    int cpw = spec ? 4 : 1, wpe = 1;
+    if (spec && njobs > simds && !getenv("MVX_NO_WPE2")) {
+        if (P.bps == 1 && P.blkX == 8) wpe = 2;
+        if (P.bps == 2 && (P.blkX == 16 || P.blkX == 8 || (P.blkX == 32 && getenv("MVX_W2_32")))) { wpe = 2; cpw = 8; }
+    }
     if (cpw > 1) std::stable_sort(hj.begin(), hj.end(), [](const AJob &x, const AJob &y) { return (uintptr_t)x.ref[0] > (uintptr_t)y.ref[0]; }); // (no reference: last)
     HIP_CHECK(hipMemcpyAsync(a->dJobs, hj.data(), sizeof(AJob) * njobs, hipMemcpyHostToDevice, st));
     // LDS: [source block (Y,U,V) | previous-row vectors | predictor rows (this, below) | histogram]
@@ -264,12 +278,11 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
     int maxBlkX = 0;
     for (int i = 0; i < P.nLevels; i++) if (P.lv[i].nBlkX > maxBlkX) maxBlkX = P.lv[i].nBlkX;
     const int histBins = 1024;
-    // LDS of a chain: [source block | previous block row's results, 16 B per block | A | histogram of the global-motion estimate]
-    // with A = two rows of hierarchical predictors (16-bit kernels without a search window, PRED_ROWS) or nothing.
+    // LDS of a chain: [source block | previous block row's results, 16 B per block | histogram of the global-motion estimate]
     // Search-window kernels (Geo<..., scan step>, 4:2:0 16x16 / 8x8 blocks with half-block overlap, SAD cost): the window follows
     // the row buffer and the histogram aliases its start (it is only used between levels); everything must fit a quarter of
     // the CU's 160 KiB so that four chains still share a CU.
-    int ldsHist = ldsRow + maxBlkX * (P.bps == 2 ? 48 : 16);
+    int ldsHist = ldsRow + maxBlkX * 16;
     int ldsBytes = ldsHist + histBins * 4;
     int ldsWin = -1, winCap = 0, mode = 0;
     {
@@ -316,18 +329,15 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         if (const char *e = getenv("MVX_LDS_MIN")) v = atoi(e); // developer override
         if (v > ldsBytes && v <= 160 * 1024) ldsBytes = v;
     }
-    static int simds = 0;
-    if (!simds) {
-        int dev = 0, cus = 0;
-        HIP_CHECK(hipGetDevice(&dev));
-        HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        simds = 4 * cus;
-    }
-    if (mode != 0) cpw = 1;
+    if (mode != 0) { cpw = 1; wpe = 1; }
     int syncEvery = 0; // developer experiment: barrier between the chains of a workgroup every that many blocks (power of two)
     if (const char *e = getenv("MVX_CPW_SYNC")) { int v = atoi(e); if (v >= 0 && (v & (v - 1)) == 0) syncEvery = v; }
-    ALaunch L = { mode, njobs, ldsBytes, ldsRow, ldsHist, histBins, ldsWin, winCap, ldsNeed, simds, cpw, syncEvery, st, a->dP, a->dJobs };
-    int rc = P.dctmode != 0 ? 1 : P.bps == 1 ? mvx_analyse_launch_u8(P, L) : mvx_analyse_launch_u16(P, L); // specialised 4:2:0 geometries (SAD cost only)
+    ALaunch L = { mode, njobs, ldsBytes, ldsRow, ldsHist, histBins, ldsWin, winCap, ldsNeed, simds, cpw, wpe, syncEvery, st, a->dP, a->dJobs };
+    // the specialised kernels address the reference as "64-bit base + 32-bit offset inside the level's plane set" (all sub-pel planes)
+    bool off32 = true;
+    for (int i = 0; i < P.nLevels; i++)
+        if ((long long)P.lv[i].pel * P.lv[i].pel * P.lv[i].pstride[0] >= 0xffffffffLL || (long long)P.lv[i].pel * P.lv[i].pel * P.lv[i].pstride[1] >= 0xffffffffLL) off32 = false;
+    int rc = (P.dctmode != 0 || !off32) ? 1 : P.bps == 1 ? mvx_analyse_launch_u8(P, L) : mvx_analyse_launch_u16(P, L); // specialised 4:2:0 geometries (SAD cost only)
     if (rc == 1) rc = mvx_analyse_launch_any(P, L);                                     // everything else
     if (rc) return rc;
     if (P.divide) hipLaunchKernelGGL(analyse_divide_kernel, dim3((P.lv[0].nBlkX * P.lv[0].nBlkY + 255) / 256, njobs), dim3(256), 0, st, a->dP, a->dJobs);

@@ -1890,7 +1890,9 @@ template <int BPS, typename GEO> struct Searcher {
         // park (and wait for) before every search.
         // Measured (r1, A/B in one session): +5 % at full load / +9 % unloaded on 4K 16-bit, -7 % on 1080p 8-bit, whose
         // lighter kernels keep the prefetched vectors in registers for free -- hence the compile-time choice.
-        constexpr bool PRED_ROWS = BPS == 2 && !W_ON && !T_ON; // (the window / tile kernels spend that LDS differently)
+                // (Was on for the 16-bit kernels while one chain per workgroup was the rule: +5 % there.  With four / eight chains per
+        // workgroup it no longer measures -- 223.2 against 224.6 fps -- and its 15 KiB per chain would keep eight chains out of a CU.)
+        constexpr bool PRED_ROWS = false;
         const int predStride = (ldsHist - ldsRow) / 48; // host layout: [row buffer | 2 predictor rows], 16 bytes per block
         LDS_AS Vec *predRows = (LDS_AS Vec *)(lds + ldsRow + predStride * 16);
         auto load_pred_row = [&](int row) {
@@ -2275,7 +2277,8 @@ struct ALaunch {
     int njobs, ldsBytes, ldsRow, ldsHist, histBins, ldsWin, winCap;
     int ldsNeed; // what the kernel really uses (ldsBytes may carry the one-chain-per-SIMD floor)
     int simds;   // SIMDs of the device (4 per CU)
-    int cpw;     // chains per workgroup the host ordered the jobs for (1 or 4)
+    int cpw;     // chains per workgroup the host ordered the jobs for (1, 4 or 8)
+    int wpe;     // chains per SIMD: 2 = the 256-register builds (launches with more chains than SIMDs, geometries that fit)
     int syncEvery; // cpw > 1: workgroup barrier every that many blocks of a row (power of two; a row start always syncs)
     hipStream_t st;
     const AParams *dP;
