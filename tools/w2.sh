@@ -1,4 +1,4 @@
 r() { name=$1; shift; envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
   env "${envs[@]}" python bench.py --no-cpu --steps 2 --warmup 1 "$@" 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(\"$name\", round(d[\"value\"],1), \"fps\", round(d[\"roofline\"][\"avg_launch_ms\"],1), \"ms/launch\")"; }
-r cfg2-sync256 MVX_CPW_SYNC=256 -- --config cfg2
-r cfg2 X=1 -- --config cfg2
+r cfg5-w2-b168 MVX_W2_32=1 -- --config cfg5 --batch 168
+r cfg5-b84 X=1 -- --config cfg5

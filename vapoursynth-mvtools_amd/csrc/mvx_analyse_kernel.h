@@ -518,7 +518,7 @@ template <int BPS, typename GEO> struct Searcher {
         }
         constexpr int N = T >= G ? T / G : 1;        // items per lane
 #ifndef MVX_NB
-#define MVX_NB 4 // chunks in flight per region: four measured +2 % over eight at 4K16 (register pressure), and keeps the 8-bit kernels spill-free at 256 registers
+#define MVX_NB 4 // chunks in flight per region: four measured +2 % over eight at 4K16 (register pressure), and keeps the 8x8 / 16x16 kernels spill-free at 256 registers (two would do that for the 16-bit 32x32 kernel too, but costs it 17 %: 8K 48.2 -> 40.1 fps)
 #endif
         constexpr int NB = N < MVX_NB ? N : MVX_NB;  // loads in flight per batch
         if (G >= C) { // the chunk column is fixed per lane, rows advance by G / C per item
@@ -596,7 +596,7 @@ template <int BPS, typename GEO> struct Searcher {
         }
         constexpr int N = T >= G ? T / G : 1;        // items per lane
 #ifndef MVX_NB
-#define MVX_NB 4 // chunks in flight per region: four measured +2 % over eight at 4K16 (register pressure), and keeps the 8-bit kernels spill-free at 256 registers
+#define MVX_NB 4 // chunks in flight per region: four measured +2 % over eight at 4K16 (register pressure), and keeps the 8x8 / 16x16 kernels spill-free at 256 registers (two would do that for the 16-bit 32x32 kernel too, but costs it 17 %: 8K 48.2 -> 40.1 fps)
 #endif
         constexpr int NB = N < MVX_NB ? N : MVX_NB;  // loads in flight per batch
         if (G >= C) { // the chunk column is fixed per lane, rows advance by G / C per item
