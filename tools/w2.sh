@@ -1,4 +1,5 @@
+# developer experiment runner: r <name> <env assignments...> -- <bench args>
 r() { name=$1; shift; envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
   env "${envs[@]}" python bench.py --no-cpu --steps 2 --warmup 1 "$@" 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(\"$name\", round(d[\"value\"],1), \"fps\", round(d[\"roofline\"][\"avg_launch_ms\"],1), \"ms/launch\")"; }
-r cfg5-w2-b168 MVX_W2_32=1 -- --config cfg5 --batch 168
-r cfg5-b84 X=1 -- --config cfg5
+r tile-w2c8 MVX_TILE=1 MVX_TILE_W2=1 -- --config cfg3
+r plain-w2c8 X=1 -- --config cfg3
