@@ -382,6 +382,17 @@ def test_analyse_refinement_tile_kernel(oracle, mv, monkeypatch, w, h, skw, akw)
         assert np.array_equal(gb.cpu().numpy(), ob)
 
 
+@pytest.mark.parametrize("bits,akw", [(8, dict(blksize=8, overlap=4)), (16, dict(blksize=16, overlap=8)), (16, dict(blksize=32, overlap=16))])
+def test_analyse_one_chain_per_workgroup(oracle, mv, monkeypatch, bits, akw):
+    """MVX_CPW=1 keeps the one-chain-per-workgroup builds of the specialised kernels reachable (they are also what the opt-in
+    window / tile modes and A/B timing use): same vectors"""
+    monkeypatch.setenv("MVX_CPW", "1")
+    frames, osup, gsup, osf, gsrc, gsf = _pipeline(oracle, mv, 256, 160, bits, 1, {}, akw, nframes=2, seed=9)
+    ob = oracle.Analyse(osup, isb=1, **akw).frame(osf[0], osf[1])
+    gb = mv.Analyse(gsup, isb=1, **akw).run([(gsf[0], gsf[1])])[0]
+    assert np.array_equal(gb.cpu().numpy(), ob)
+
+
 @pytest.mark.parametrize("bits,akw", [(8, dict(blksize=8, overlap=4)), (16, dict(blksize=16, overlap=8)), (16, dict(blksize=8, overlap=4)),
                                       (8, dict(blksize=16, overlap=8))])
 def test_analyse_two_chains_per_simd(oracle, mv, bits, akw):
