@@ -415,6 +415,25 @@ def test_analyse_two_chains_per_simd(oracle, mv, bits, akw):
         assert np.array_equal(got[i], want[(i * 7) % 4]), "job %d differs" % i
 
 
+def test_analyse_wide_frame_many_chains(oracle, mv):
+    """8K-wide 16-bit frames: the row buffer of a chain is ~20 KiB, so eight chains no longer fit a CU's LDS and a launch with more
+    chains than SIMDs falls back to four per workgroup (mvx_analyse_frames)"""
+    import torch
+    w, h, bits = 7680, 80, 16
+    akw = dict(blksize=16, overlap=8)
+    frames, osup, gsup, osf, gsrc, gsf = _pipeline(oracle, mv, w, h, bits, 1, {}, akw, nframes=2, seed=12)
+    oan = oracle.Analyse(osup, isb=1, **akw)
+    gan = mv.Analyse(gsup, isb=1, **akw)
+    want = [oan.frame(osf[0], osf[1]), oan.frame(osf[1], osf[0])]
+    pairs = [(gsf[0], gsf[1]), (gsf[1], gsf[0])]
+    njobs = 4 * torch.cuda.get_device_properties(0).multi_processor_count + 8
+    got = gan.run([pairs[i % 2] for i in range(njobs)])
+    torch.cuda.synchronize()
+    got = torch.stack(list(got)).cpu().numpy()
+    for i in range(njobs):
+        assert np.array_equal(got[i], want[i % 2]), "job %d differs" % i
+
+
 def _golden_cases():
     import json, os
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden.json")) as f:

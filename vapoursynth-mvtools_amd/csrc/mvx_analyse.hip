@@ -330,6 +330,11 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         if (v > ldsBytes && v <= 160 * 1024) ldsBytes = v;
     }
     if (mode != 0) { cpw = 1; wpe = 1; }
+    // a workgroup's chains share the CU's 160 KiB of LDS: very wide frames (long row buffers) get fewer chains per workgroup
+    while (cpw > 1 && (long long)((ldsNeed + 255) & ~255) * cpw > 160 * 1024) {
+        cpw = cpw == 8 ? 4 : 1;
+        if (P.bps == 2) wpe = 1; // (the 16-bit two-per-SIMD builds exist for eight chains per workgroup only)
+    }
     // barrier between the chains of a workgroup every that many blocks (power of two) and at every row start: keeps the chains
     // of a two-per-SIMD workgroup on neighbouring blocks (+2 % at 4K16 for any interval from 64 blocks to a row, +2.8 % at 1080p
     // 8-bit); with one chain per SIMD it costs 1 %
