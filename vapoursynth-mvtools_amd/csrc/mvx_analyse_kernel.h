@@ -1938,16 +1938,14 @@ template <int BPS, typename GEO> struct Searcher {
         A4x32 wpf[WQ_MAX];
         const bool fast = !tryMany && dctmode == 0 && ((searchType == SearchHex2 && nSearchParam <= 3) || (searchType == SearchExhaustive && nSearchParam == 2));
         // early request of the predictor round (specialised kernels, reference samples from global memory)
-#ifdef MVX_NO_EARLY
-        constexpr bool EARLY_K = false;
-#else
-        // compile-time: one variant of the fast path per kernel.  Measured (r1, A/B in one session): +1.7 % on 1080p 8-bit,
-        // -11 % on 4K 16-bit at full load (more loads in flight per CU when the texture path is already the bottleneck)
+        // compile-time: one variant of the fast path per kernel.  Measured (r1, A/B in one session): at one chain per SIMD +1.7 % on
+        // 1080p 8-bit and -11 % on 4K 16-bit (more loads in flight per CU when the texture path is already the bottleneck); at two
+        // chains per SIMD -4 % on 1080p 8-bit (1573 against 1639 fps) and 0 % on 4K 16-bit: the other chain hides that latency
+        // already.  Off; MVX_FORCE_EARLY builds it for experiments.
 #ifdef MVX_FORCE_EARLY
         constexpr bool EARLY_K = GEO::BW != 0 && G_PF && !W_ON;
 #else
-        constexpr bool EARLY_K = BPS == 1 && GEO::BW != 0 && G_PF && !W_ON;
-#endif
+        constexpr bool EARLY_K = false;
 #endif
         const bool early = EARLY_K && fast;
         PreA preA;
