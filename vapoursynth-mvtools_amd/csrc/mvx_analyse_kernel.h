@@ -1481,12 +1481,18 @@ template <int BPS, typename GEO> struct Searcher {
         if (searchType == SearchHex2) { // pobHex2Search :667-724 with i_me_range <= 3: no half-hexagon iterations
             int bmx = bestMV.x, bmy = bestMV.y;
             if (nSearchParam > 1) {
+#ifdef MVX_NO_HEXSQ // developer experiment: hexagon, then square, as two passes (no speculative square)
+                const int dir = round_fast<FR_HEX6>(bmx, bmy);
+                if (dir >= 0) { bmx += tab8(HEX2X, dir + 1); bmy += tab8(HEX2Y, dir + 1); bestMV.x = bmx; bestMV.y = bmy; }
+                round_fast<FR_SQUARE>(bmx, bmy);
+#else
                 const int dir = round_fast<FR_HEXSQ>(bmx, bmy); // >= 0: a hexagon point won; < 0: the square around (bmx, bmy) is done too
                 if (dir >= 0) {
                     bmx += tab8(HEX2X, dir + 1); bmy += tab8(HEX2Y, dir + 1);
                     bestMV.x = bmx; bestMV.y = bmy;
                     round_fast<FR_SQUARE>(bmx, bmy);
                 }
+#endif
             } else
                 round_fast<FR_SQUARE>(bmx, bmy);
         } else
