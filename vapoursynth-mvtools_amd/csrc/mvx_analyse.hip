@@ -264,7 +264,9 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
     // A launch with more chains than SIMDs runs TWO chains per SIMD where a 256-register build of the kernel exists without
     // spills (8-bit 8x8, 16x16; 16-bit 8x8, 16x16): 8-bit 1080p +53 %; 16-bit 4K +13 %, and there only as workgroups of EIGHT chains
     // that share a reference frame -- eight unrelated chains per CU thrash its L1 / the XCD's L2 and lose.
-    int cpw = spec ? 4 : 1, wpe = 1;
+    const bool oneChain = (getenv("MVX_CPW") && atoi(getenv("MVX_CPW")) == 1) || (getenv("MVX_TILE") && atoi(getenv("MVX_TILE"))) ||
+                          (getenv("MVX_WINDOW") && atoi(getenv("MVX_WINDOW")));
+    int cpw = oneChain ? 1 : 4, wpe = 1; // (the generic kernels have four-chain builds too)
     if (spec && njobs > simds && !getenv("MVX_NO_WPE2")) {
         if (P.bps == 1 && (P.blkX == 8 || P.blkX == 16)) wpe = 2;
         if (P.bps == 2 && (P.blkX == 16 || P.blkX == 8 || (P.blkX == 32 && getenv("MVX_W2_32")))) { wpe = 2; cpw = 8; }
@@ -321,8 +323,9 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         }
     }
     if (ldsBytes > 160 * 1024) { mvx_set_error("mvx_analyse_frames: frame too wide for the LDS row buffer"); return MVX_E_ARG; }
-    // One chain per SIMD is the measured optimum: asking for a little more than a fifth of the CU's
-    // 160 KiB of LDS makes the dispatcher spread the chains four per CU instead of stacking some CUs (+5 % at 1008 chains).
+    // One-chain-per-workgroup launches (generic kernels, MVX_CPW=1, window / tile modes): asking for a little more than a fifth of
+    // the CU's 160 KiB of LDS makes the dispatcher spread the chains four per CU instead of stacking some CUs (+5 % at 1008 chains).
+    // The multi-chain workgroups are sized from ldsNeed instead.
     const int ldsNeed = ldsBytes;
     {
         int v = 33 * 1024;
