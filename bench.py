@@ -24,7 +24,7 @@ CONFIGS = {
     "cfg1": (640, 360, 8, 1, dict(blksize=8), dict(pel=1), 1008, "640x360 YUV420P8 Degrain1 blksize=8 pel=1"),
     "cfg2": (1920, 1080, 8, 1, dict(blksize=8, overlap=4, search=4), dict(pel=2), 1008, "1080p YUV420P8 Degrain1 blksize=8 overlap=4 pel=2 search=4"),
     "cfg3": (3840, 2160, 16, 3, dict(blksize=16, overlap=8), dict(pel=2), 336, "4K YUV420P16 Degrain3 blksize=16 overlap=8 pel=2"),
-    "cfg5": (7680, 4320, 16, 6, dict(blksize=32, overlap=16), dict(pel=2), 84, "8K YUV420P16 Degrain6 blksize=32 overlap=16 pel=2"),
+    "cfg5": (7680, 4320, 16, 6, dict(blksize=32, overlap=16), dict(pel=2), 168, "8K YUV420P16 Degrain6 blksize=32 overlap=16 pel=2"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 

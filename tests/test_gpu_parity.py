@@ -394,7 +394,7 @@ def test_analyse_one_chain_per_workgroup(oracle, mv, monkeypatch, bits, akw):
 
 
 @pytest.mark.parametrize("bits,akw", [(8, dict(blksize=8, overlap=4)), (16, dict(blksize=16, overlap=8)), (16, dict(blksize=8, overlap=4)),
-                                      (8, dict(blksize=16, overlap=8))])
+                                      (8, dict(blksize=16, overlap=8)), (16, dict(blksize=32, overlap=16))])
 def test_analyse_two_chains_per_simd(oracle, mv, bits, akw):
     """a launch with more chains than the device has SIMDs takes the 256-register builds (two chains per SIMD; 16-bit: eight
     chains per workgroup, job table sorted by reference frame): every one of its results must still be the oracle's, whatever

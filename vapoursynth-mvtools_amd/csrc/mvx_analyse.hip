@@ -262,14 +262,14 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         simds = 4 * cus;
     }
     // A launch with more chains than SIMDs runs TWO chains per SIMD where a 256-register build of the kernel exists without
-    // spills (8-bit 8x8, 16x16; 16-bit 8x8, 16x16): 8-bit 1080p +53 %; 16-bit 4K +13 %, and there only as workgroups of EIGHT chains
+    // spills (8-bit 8x8, 16x16; 16-bit 8x8, 16x16, 32x32): 8-bit 1080p +53 %; 16-bit 4K +13 %, and there only as workgroups of EIGHT chains
     // that share a reference frame -- eight unrelated chains per CU thrash its L1 / the XCD's L2 and lose.
     const bool oneChain = (getenv("MVX_CPW") && atoi(getenv("MVX_CPW")) == 1) || (getenv("MVX_TILE") && atoi(getenv("MVX_TILE"))) ||
                           (getenv("MVX_WINDOW") && atoi(getenv("MVX_WINDOW")));
     int cpw = oneChain ? 1 : 4, wpe = 1; // (the generic kernels have four-chain builds too)
     if (spec && njobs > simds && !getenv("MVX_NO_WPE2")) {
         if (P.bps == 1 && (P.blkX == 8 || P.blkX == 16)) wpe = 2;
-        if (P.bps == 2 && (P.blkX == 16 || P.blkX == 8 || (P.blkX == 32 && getenv("MVX_W2_32")))) { wpe = 2; cpw = 8; }
+        if (P.bps == 2 && (P.blkX == 16 || P.blkX == 8 || P.blkX == 32)) { wpe = 2; cpw = 8; }
     }
     if (cpw > 1) std::stable_sort(hj.begin(), hj.end(), [](const AJob &x, const AJob &y) { return (uintptr_t)x.ref[0] > (uintptr_t)y.ref[0]; }); // (no reference: last)
     HIP_CHECK(hipMemcpyAsync(a->dJobs, hj.data(), sizeof(AJob) * njobs, hipMemcpyHostToDevice, st));

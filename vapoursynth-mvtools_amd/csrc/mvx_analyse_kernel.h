@@ -342,7 +342,8 @@ template <int BW_, int BH_, int XR_, int YR_, int SX_ = 0, bool DCT_ = false, bo
 typedef Geo<0, 0, 0, 0, 0> GeoAny;
 typedef Geo<0, 0, 0, 0, 0, true> GeoAnyDct;
 
-template <int BPS, typename GEO> struct Searcher {
+// WPE: chains per SIMD the enclosing kernel is built for (register budget; picks register-saving variants below)
+template <int BPS, typename GEO, int WPE = 1> struct Searcher {
     const AParams &P;
     const AJob &J;
     lds_u8 *lds;          // [srcblock | rowbuf | hist]
@@ -1888,6 +1889,10 @@ template <int BPS, typename GEO> struct Searcher {
         // software pipeline: the next block's hierarchical predictors and source samples are static data, so their
         // global loads are issued one block ahead and only consumed at the top of the next iteration.
         const bool usePF = TT <= PF_MAX * WAVE;
+        // PF_LATE: the source block is fetched at the top of its own block instead of one block ahead -- one exposed latency per
+        // block, but its registers are not live across the search (the 16-bit 32x32 kernel needs that to fit 256 registers)
+        // (measured r1: 8K 32x32 at two chains per SIMD 48.2 -> 55.6 fps with it; 4K 16x16, which fits anyway, 260 -> 257 fps)
+        constexpr bool PF_LATE = WPE == 2 && G_NPF > 1;
         A4x32 pf[PF_MAX];
         if (G_PF) pf_setup();
         // The hierarchical predictors (this level's interpolated vectors, static during the level) of the current block
@@ -1928,7 +1933,7 @@ template <int BPS, typename GEO> struct Searcher {
                 nBelow.x = 0; nBelow.y = 0; nBelow.sad = 0;
                 if (by < nBlkY - 1 && aheadColN) nBelow = ld_vec(&vectors[idx + nBlkX + dir]);
             }
-            if (G_PF) pf_issue(bx, by, stepX, stepY, pf);
+            if (G_PF) { if (!PF_LATE) pf_issue(bx, by, stepX, stepY, pf); }
             else if (usePF) {
 #pragma unroll
                 for (int k = 0; k < PF_MAX; k++) {
@@ -1981,7 +1986,7 @@ template <int BPS, typename GEO> struct Searcher {
             if (!useBelow) { below.x = 0; below.y = 0; below.sad = 0; }
             if (blky == 0) { up.x = 0; up.y = 0; up.sad = 0; }
             // consume the prefetched data: source block -> LDS (PlaneOfBlocks.cpp:1058-1079)
-            if (G_PF) pf_store(pf);
+            if (G_PF) { if (PF_LATE) pf_issue(blkx, blky, stepX, stepY, pf); pf_store(pf); }
             else if (usePF) {
 #pragma unroll
                 for (int k = 0; k < PF_MAX; k++) {
@@ -2151,7 +2156,7 @@ __global__ __launch_bounds__(64 * CPW, WPE) void analyse_kernel(const AParams *P
         return;
     }
     if (l == 0) { hdr[0] = P.blobSize; hdr[1] = 1; } // GroupOfPlanes.c:77-85
-    Searcher<BPS, GEO> S(P, J);
+    Searcher<BPS, GEO, WPE> S(P, J);
     S.lds = (lds_u8 *)smem + (CPW == 1 ? 0 : uni((int)(threadIdx.x >> 6)) * ldsChain);
     S.ldsRow = ldsRow; S.ldsHist = ldsHist; S.histBins = histBins;
     S.ldsWin = ldsWin; S.winCap = winCap; S.winOn = 0;

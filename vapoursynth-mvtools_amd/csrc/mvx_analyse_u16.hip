@@ -12,7 +12,7 @@ int mvx_analyse_launch_u16(const AParams &P, const ALaunch &L) {
         if (L.wpe == 2 && L.cpw == 8) { // two per SIMD, eight per CU
             if (P.blkX == 16 && P.blkY == 16) return launch_analyse_kernel<2, Geo<16, 16, 2, 2>, 2, 8>(L);
             if (P.blkX == 8 && P.blkY == 8) return launch_analyse_kernel<2, Geo<8, 8, 2, 2>, 2, 8>(L);
-            if (P.blkX == 32 && P.blkY == 32) return launch_analyse_kernel<2, Geo<32, 32, 2, 2>, 2, 8>(L); // (developer experiment MVX_W2_32: 18 spilled registers)
+            if (P.blkX == 32 && P.blkY == 32) return launch_analyse_kernel<2, Geo<32, 32, 2, 2>, 2, 8>(L); // (fits 256 registers because it fetches the source block late, Searcher::PF_LATE)
         }
         if (P.blkX == 16 && P.blkY == 16) return launch_analyse_kernel<2, Geo<16, 16, 2, 2>, 1, 4>(L);
         if (P.blkX == 32 && P.blkY == 32) return launch_analyse_kernel<2, Geo<32, 32, 2, 2>, 1, 4>(L);
