@@ -21,8 +21,8 @@ for _p in (os.path.join(ROOT, "vapoursynth-mvtools_amd"), os.path.join(ROOT, "te
 
 CONFIGS = {
     # name: (width, height, bits, radius, analyse kwargs, super kwargs, default batch, BASELINE.json config string)
-    "cfg1": (640, 360, 8, 1, dict(blksize=8), dict(pel=1), 1008, "640x360 YUV420P8 Degrain1 blksize=8 pel=1"),
-    "cfg2": (1920, 1080, 8, 1, dict(blksize=8, overlap=4, search=4), dict(pel=2), 1008, "1080p YUV420P8 Degrain1 blksize=8 overlap=4 pel=2 search=4"),
+    "cfg1": (640, 360, 8, 1, dict(blksize=8), dict(pel=1), 1536, "640x360 YUV420P8 Degrain1 blksize=8 pel=1"),
+    "cfg2": (1920, 1080, 8, 1, dict(blksize=8, overlap=4, search=4), dict(pel=2), 1536, "1080p YUV420P8 Degrain1 blksize=8 overlap=4 pel=2 search=4"),
     "cfg3": (3840, 2160, 16, 3, dict(blksize=16, overlap=8), dict(pel=2), 336, "4K YUV420P16 Degrain3 blksize=16 overlap=8 pel=2"),
     "cfg5": (7680, 4320, 16, 6, dict(blksize=32, overlap=16), dict(pel=2), 168, "8K YUV420P16 Degrain6 blksize=32 overlap=16 pel=2"),
 }

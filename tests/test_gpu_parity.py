@@ -415,6 +415,23 @@ def test_analyse_two_chains_per_simd(oracle, mv, bits, akw):
         assert np.array_equal(got[i], want[(i * 7) % 4]), "job %d differs" % i
 
 
+def test_analyse_three_chains_per_simd(oracle, mv):
+    """more than two chains per SIMD: the 8-bit 8x8 kernel's 168-register build (three chains per SIMD)"""
+    import torch
+    akw = dict(blksize=8, overlap=4)
+    frames, osup, gsup, osf, gsrc, gsf = _pipeline(oracle, mv, 96, 64, 8, 1, {}, akw, nframes=3)
+    oan = oracle.Analyse(osup, isb=0, **akw)
+    gan = mv.Analyse(gsup, isb=0, **akw)
+    want = [oan.frame(osf[1], osf[0]), oan.frame(osf[2], osf[1]), oan.frame(osf[0], None)]
+    pairs = [(gsf[1], gsf[0]), (gsf[2], gsf[1]), (gsf[0], None)]
+    njobs = 8 * torch.cuda.get_device_properties(0).multi_processor_count + 37
+    got = gan.run([pairs[(i * 5) % 3] for i in range(njobs)])
+    torch.cuda.synchronize()
+    got = torch.stack(list(got)).cpu().numpy()
+    for i in range(njobs):
+        assert np.array_equal(got[i], want[(i * 5) % 3]), "job %d differs" % i
+
+
 def test_analyse_wide_frame_many_chains(oracle, mv):
     """8K-wide 16-bit frames: the row buffer of a chain is ~20 KiB, so eight chains no longer fit a CU's LDS and a launch with more
     chains than SIMDs falls back to four per workgroup (mvx_analyse_frames)"""

@@ -269,6 +269,8 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
     int cpw = oneChain ? 1 : 4, wpe = 1; // (the generic kernels have four-chain builds too)
     if (spec && njobs > simds && !getenv("MVX_NO_WPE2")) {
         if (P.bps == 1 && (P.blkX == 8 || P.blkX == 16)) wpe = 2;
+        // three per SIMD for the lightest kernel: its 168-register build spills 72 registers and still gains 14 % (1080p 1642 -> 1867 fps)
+        if (P.bps == 1 && P.blkX == 8 && njobs > 2 * simds && !getenv("MVX_NO_WPE3")) wpe = 3;
         if (P.bps == 2 && (P.blkX == 16 || P.blkX == 8 || P.blkX == 32)) { wpe = 2; cpw = 8; }
     }
     if (cpw > 1) std::stable_sort(hj.begin(), hj.end(), [](const AJob &x, const AJob &y) { return (uintptr_t)x.ref[0] > (uintptr_t)y.ref[0]; }); // (no reference: last)
@@ -341,7 +343,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
     // barrier between the chains of a workgroup every that many blocks (power of two) and at every row start: keeps the chains
     // of a two-per-SIMD workgroup on neighbouring blocks (+2 % at 4K16 for any interval from 64 blocks to a row, +2.8 % at 1080p
     // 8-bit); with one chain per SIMD it costs 1 %
-    int syncEvery = wpe == 2 ? 256 : 0;
+    int syncEvery = wpe >= 2 ? 256 : 0;
     if (const char *e = getenv("MVX_CPW_SYNC")) { int v = atoi(e); if (v >= 0 && (v & (v - 1)) == 0) syncEvery = v; }
     ALaunch L = { mode, njobs, ldsBytes, ldsRow, ldsHist, histBins, ldsWin, winCap, ldsNeed, simds, cpw, wpe, syncEvery, st, a->dP, a->dJobs };
     // the specialised kernels address the reference as "64-bit base + 32-bit offset inside the level's plane set" (all sub-pel planes)

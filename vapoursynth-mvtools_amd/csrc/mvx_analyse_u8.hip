@@ -8,6 +8,7 @@ int mvx_analyse_launch_u8(const AParams &P, const ALaunch &L) {
     // More chains than SIMDs: the 8-bit kernels have a 256-register build so that two chains share a SIMD (+53 % at 1080p,
     // DESIGN.md 4.2).  It drops the LDS floor that spreads a small launch one chain per SIMD.
     if (L.mode == 0 && L.cpw == 4) { // four chains per workgroup (mvx_analyse_frames sorted the job table by reference frame)
+        if (P.blkX == 8 && P.blkY == 8 && L.wpe == 3) return launch_analyse_kernel<1, Geo<8, 8, 2, 2>, 3, 4>(L); // three chains per SIMD (launches with more than two chains per SIMD)
         if (P.blkX == 8 && P.blkY == 8) return L.wpe == 2 ? launch_analyse_kernel<1, Geo<8, 8, 2, 2>, 2, 4>(L) : launch_analyse_kernel<1, Geo<8, 8, 2, 2>, 1, 4>(L);
         if (P.blkX == 16 && P.blkY == 16) return L.wpe == 2 ? launch_analyse_kernel<1, Geo<16, 16, 2, 2>, 2, 4>(L) : launch_analyse_kernel<1, Geo<16, 16, 2, 2>, 1, 4>(L);
     }
