@@ -129,3 +129,17 @@ def test_no_cpu_fallback(mv):
     sup = mv.Super(64, 48, 8)
     with pytest.raises(mv.MvtoolsError):
         sup.alloc(1)
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """the drop-in boundary is a C ABI: include/mvtools_amd.h must compile as C99 and as C++ on its own (no torch / HIP types)"""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.c"
+    src.write_text('#include "mvtools_amd.h"\nint main(void) { mvx_super_args a; (void)a; return (int)sizeof(mvx_analysis_data) == 84 ? 0 : 1; }\n')
+    for cc, std in (("gcc", "-std=c99"), ("g++", "-std=c++11")):
+        exe = tmp_path / ("t_" + cc)
+        r = subprocess.run([cc, std, "-pedantic", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-x", "c" if cc == "gcc" else "c++", str(src), "-o", str(exe)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert subprocess.run([str(exe)]).returncode == 0
