@@ -7,6 +7,12 @@ A "step" is one pass of the hot path over one batch of B synthetic frames alread
 Super of the B+2*tr frames (batch + temporal halo), 2*tr*B motion searches (one chain per frame and direction, all in
 one launch per vector clip), DegrainN of the B frames.  value = frames/s over all ranks (frames are independent, so
 N GPUs = N disjoint frame ranges, no data-path collective: weak scaling).  Prints ONE JSON line on rank 0.
+
+--gpus N: one process per GPU.  Started by a launcher (WORLD_SIZE set, e.g. python -m torch.distributed.run) the process
+is one of N ranks and N must equal WORLD_SIZE; started directly with N > 1 it launches the N ranks itself through
+torch.distributed.run on 127.0.0.1 and fails loudly when the node has fewer than N GPUs.  The ranks' frame ranges come
+from mvtools_amd.shard.RankPlan (the clip is N*B output frames plus a tr-frame lead-in / lead-out; rank r owns a
+contiguous range and holds its tr-frame halo, which it runs Super on itself).
 """
 import argparse
 import json
@@ -83,11 +89,15 @@ def synth_clip_device(torch, width, height, bits, nframes, seed, device):
 class Pipeline:
     """Super -> Analyse x 2tr -> DegrainN over a resident batch, all on the current HIP stream."""
 
-    def __init__(self, mv, torch, cfg, batch, device, seed, src=None):
+    def __init__(self, mv, torch, cfg, batch, device, seed, src=None, plan=None):
         (self.w, self.h, self.bits, self.tr, akw, skw, _, self.label) = cfg
         self.mv, self.torch, self.B, self.device = mv, torch, batch, device
         tr = self.tr
-        self.n = batch + 2 * tr
+        from mvtools_amd import shard
+        # the rank's share of the clip: which frames it outputs, which it holds (share + tr halo), and its job tables
+        self.plan = plan if plan is not None else shard.RankPlan(batch + 2 * tr, 0, 1, tr, first_out=tr, last_out=batch + tr)
+        assert len(self.plan.outputs()) == batch
+        self.n = self.plan.held[1] - self.plan.held[0]
         # `src` lets a second pipeline slot (own filter handles, own super / vector / output buffers, own stream) share
         # the read-only input clip
         self.src = src if src is not None else synth_clip_device(torch, self.w, self.h, self.bits, self.n, seed, device)
@@ -114,12 +124,9 @@ class Pipeline:
         # all 2*tr vector clips share one parameter block (delta / isb only pick the reference frame), so every chain
         # of the step goes into ONE launch: 2*tr*B chains resident at once
         jobs, blobs = [], []
-        for (d, isb), a in self.an.items():
-            for i in range(B):
-                n = tr + i
-                nref = n + d if isb else n - d
-                jobs.append((self.supers[n], self.supers[nref]))
-            blobs += self.blobs[(d, isb)]
+        for key, pairs in self.plan.searches().items():
+            jobs += [(self.supers[n], self.supers[nref] if nref is not None else None) for n, nref in pairs]
+            blobs += self.blobs[key]
         if time_search:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -128,14 +135,8 @@ class Pipeline:
             e1.record()
             self.ev.append((e0, e1))
         djobs = []
-        for i in range(B):
-            n = tr + i
-            refs, blobs = [], []
-            for d in range(1, tr + 1):
-                for isb in (1, 0):
-                    refs.append(self.supers[n + d if isb else n - d])
-                    blobs.append(self.blobs[(d, isb)][i])
-            djobs.append((self.src[n], refs, blobs))
+        for n, refs, i in self.plan.degrains():
+            djobs.append((self.src[n], [self.supers[r] if r is not None else None for r in refs], [self.blobs[key][i] for key in self.plan.clips]))
         self.dg.run(djobs, out=self.out)
 
     def algorithmic_bytes_per_chain(self):
@@ -197,6 +198,33 @@ def cpu_baseline(cfg, threads):
                 F, label, n, 2 * tr * F, F, tr, threads, dt)}
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU) through torch.distributed.run, the
+    same way the driver does, and hand back its exit status.  Fails loudly when the node has fewer than N GPUs."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write("bench.py: --gpus %d requested but this node exposes %d GPU(s); refusing to run fewer ranks than asked for\n" % (n, have))
+        return 2
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd)
+
+
+def world_from_env(gpus, env=None):
+    """(rank, local_rank, world) of this process; the launcher's WORLD_SIZE must agree with --gpus"""
+    env = os.environ if env is None else env
+    world = int(env.get("WORLD_SIZE", "1"))
+    if world != gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (gpus, world))
+    return int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0")), world
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,12 +238,16 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    rank, local_rank, world = world_from_env(args.gpus)
+
     import torch
     import mvtools_amd as mv
+    from mvtools_amd import shard
     mv.lib()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d has no GPU (local rank %d, %d visible)" % (rank, local_rank, torch.cuda.device_count()))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -226,8 +258,11 @@ def main():
 
     cfg = CONFIGS[args.config]
     B = args.batch or cfg[6]
-    pipe = Pipeline(mv, torch, cfg, B, device, seed=1000 + rank)  # every rank owns a different frame range
-    pipes = [pipe] + [Pipeline(mv, torch, cfg, B, device, seed=1000 + rank, src=pipe.src) for _ in range(max(1, args.slots) - 1)]
+    tr = cfg[3]
+    # the job: world*B output frames of one clip with a tr-frame lead-in / lead-out; this rank's contiguous share + halo
+    plan = shard.RankPlan(world * B + 2 * tr, rank, world, tr, first_out=tr, last_out=world * B + tr)
+    pipe = Pipeline(mv, torch, cfg, B, device, seed=1000 + rank, plan=plan)  # (synthetic content is generated per rank for the frames it holds)
+    pipes = [pipe] + [Pipeline(mv, torch, cfg, B, device, seed=1000 + rank, src=pipe.src, plan=plan) for _ in range(max(1, args.slots) - 1)]
     torch.cuda.synchronize()
 
     def barrier():
@@ -269,7 +304,8 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16" if cfg[2] > 8 else "u8", "data": "synthetic",
             "config": {"workload": cfg[7], "frames_per_step_per_gpu": B, "chains_per_step_per_gpu": 2 * cfg[3] * B,
-                       "sharding": "frame ranges, no collective", "batches_in_flight": len(pipes)},
+                       "sharding": "frame ranges, no collective", "batches_in_flight": len(pipes),
+                       "rank0_output_frames": list(plan.out), "rank0_held_frames": list(plan.held)},
             "roofline": {"bound": "hbm", "kernel": "analyse_kernel (one launch = %d chains)" % chains, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_chain * chains, "avg_launch_ms": avg_launch_ms,

@@ -36,23 +36,19 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     N, tr, w, h = 9, 2, 96, 64
     clip = pl.moving_clip(w, h, 8, N, seed=4)           # the "file" every rank can read
-    s, e = shard.frame_range(N, rank, world)
-    lo, hi = shard.halo_range(N, rank, world, tr)
+    plan = shard.RankPlan(N, rank, world, tr)           # the same planner bench.py's Pipeline builds its job tables from
+    lo, hi = plan.held
+    assert (lo, hi) == shard.halo_range(N, rank, world, tr) and plan.out == shard.frame_range(N, rank, world)
     sup = mo.Super(w, h, 8)
-    supers = {n: sup.frame(clip[n]) for n in range(lo, hi)}    # the rank only touches its shard + halo
+    supers = [sup.frame(clip[n]) for n in range(lo, hi)]       # the rank only touches its shard + halo (local indices)
     kw = dict(blksize=8, overlap=4)
-    ans = {(d, isb): mo.Analyse(sup, isb=isb, delta=d, num_frames=N, **kw) for d in range(1, tr + 1) for isb in (1, 0)}
+    ans = {(d, isb): mo.Analyse(sup, isb=isb, delta=d, num_frames=N, **kw) for d, isb in plan.clips}
     dg = mo.Degrain(tr, sup, ans[(1, 1)].ad)
+    blobs = {key: [ans[key].frame(supers[n], supers[nref] if nref is not None else None) for n, nref in pairs]
+             for key, pairs in plan.searches().items()}
     out = {}
-    for n in range(s, e):
-        refs, blobs = [], []
-        for d in range(1, tr + 1):
-            for isb in (1, 0):
-                nref = shard.ref_index(n, d, isb, N)
-                assert nref is None or lo <= nref < hi, "halo too small"
-                refs.append(supers[nref] if nref is not None else None)
-                blobs.append(ans[(d, isb)].frame(supers[n], supers[nref] if nref is not None else None))
-        out[n] = [int(mo.fnv1a(p)) for p in dg.frame(clip[n], refs, blobs)]
+    for (n, refs, i), gn in zip(plan.degrains(), plan.outputs()):
+        out[gn] = [int(mo.fnv1a(p)) for p in dg.frame(clip[gn], [supers[r] if r is not None else None for r in refs], [blobs[key][i] for key in plan.clips])]
     gathered = [None] * world
     dist.all_gather_object(gathered, out)               # control plane only (test bookkeeping), not a data-path collective
     dist.barrier()
@@ -83,3 +79,43 @@ def test_two_rank_sharding_matches_single_process():
         res[world] = merged
     assert sorted(res[1]) == list(range(9)) == sorted(res[2])
     assert res[1] == res[2]
+
+
+def test_rank_plan_matches_bench_layout():
+    """bench.py's clip: world*B output frames + a tr-frame lead-in / lead-out; every rank gets B frames and a full halo"""
+    from mvtools_amd import shard
+    B, tr = 5, 3
+    for world in (1, 2, 8):
+        seen = []
+        for r in range(world):
+            p = shard.RankPlan(world * B + 2 * tr, r, world, tr, first_out=tr, last_out=world * B + tr)
+            assert len(p.outputs()) == B and p.held == (p.out[0] - tr, p.out[1] + tr)
+            seen += list(p.outputs())
+            s = p.searches()
+            assert list(s) == [(d, isb) for d in range(1, tr + 1) for isb in (1, 0)]
+            for (d, isb), pairs in s.items():
+                assert all(nref == (n + d if isb else n - d) and 0 <= nref < B + 2 * tr for n, nref in pairs)
+            for n, refs, i in p.degrains():
+                assert n == tr + i and refs == [n + 1, n - 1, n + 2, n - 2, n + 3, n - 3]
+        assert seen == list(range(tr, world * B + tr))
+    # a plain clip (no lead-in): references beyond the clip ends are None, exactly like the filters (MVAnalyse.c:120-129)
+    p = shard.RankPlan(4, 0, 1, 2)
+    assert p.searches()[(2, 0)][:3] == [(0, None), (1, None), (2, 0)] and p.degrains()[3][1] == [None, 2, None, 1]
+
+
+def test_bench_rank_plumbing(monkeypatch, capsys):
+    """bench.py --gpus N: WORLD_SIZE must agree with --gpus, and without a launcher it starts N ranks itself -- or refuses loudly"""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.world_from_env(2, {"WORLD_SIZE": "2", "RANK": "1", "LOCAL_RANK": "1"}) == (1, 1, 2)
+    assert bench.world_from_env(1, {}) == (0, 0, 1)
+    with pytest.raises(SystemExit):
+        bench.world_from_env(8, {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    with pytest.raises(SystemExit):
+        bench.world_from_env(1, {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    import torch
+    if torch.cuda.device_count() < 2:  # (here: no GPU at all) asking for two ranks must fail, not silently run one
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=240)
+        assert r.returncode != 0 and "--gpus 2" in r.stderr and not r.stdout.strip()

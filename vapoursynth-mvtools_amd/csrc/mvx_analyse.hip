@@ -272,6 +272,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         // three per SIMD for the lightest kernel: its 168-register build spills 72 registers and still gains 14 % (1080p 1642 -> 1867 fps)
         if (P.bps == 1 && P.blkX == 8 && njobs > 2 * simds && !getenv("MVX_NO_WPE3")) wpe = 3;
         if (P.bps == 2 && (P.blkX == 16 || P.blkX == 8 || P.blkX == 32)) { wpe = 2; cpw = 8; }
+        if (P.bps == 2 && P.blkX == 16 && njobs > 2 * simds && getenv("MVX_WPE3")) { wpe = 3; cpw = 12; }
     }
     if (cpw > 1) std::stable_sort(hj.begin(), hj.end(), [](const AJob &x, const AJob &y) { return (uintptr_t)x.ref[0] > (uintptr_t)y.ref[0]; }); // (no reference: last)
     HIP_CHECK(hipMemcpyAsync(a->dJobs, hj.data(), sizeof(AJob) * njobs, hipMemcpyHostToDevice, st));
@@ -337,7 +338,8 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
     if (mode != 0) { cpw = 1; wpe = 1; }
     // a workgroup's chains share the CU's 160 KiB of LDS: very wide frames (long row buffers) get fewer chains per workgroup
     while (cpw > 1 && (long long)((ldsNeed + 255) & ~255) * cpw > 160 * 1024) {
-        cpw = cpw == 8 ? 4 : 1;
+        cpw = cpw == 12 ? 8 : cpw == 8 ? 4 : 1;
+        if (wpe == 3) wpe = 2;
         if (P.bps == 2) wpe = 1; // (the 16-bit two-per-SIMD builds exist for eight chains per workgroup only)
     }
     // barrier between the chains of a workgroup every that many blocks (power of two) and at every row start: keeps the chains

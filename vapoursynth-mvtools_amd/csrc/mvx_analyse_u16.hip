@@ -9,6 +9,9 @@ int mvx_analyse_launch_u16(const AParams &P, const ALaunch &L) {
     // refinement-tile kernel (opt-in, MVX_TILE=1): bit-exact, as fast as the plain kernel at one chain per SIMD
     if (L.mode == 2 && P.blkX == 16 && P.blkY == 16) return launch_analyse_kernel<2, Geo<16, 16, 2, 2, 0, false, true>>(L);
     if (L.mode == 0 && L.cpw >= 4) { // several chains per workgroup (mvx_analyse_frames sorted the job table by reference frame)
+        if (L.wpe == 3 && L.cpw == 12) { // three per SIMD, twelve per CU
+            if (P.blkX == 16 && P.blkY == 16) return launch_analyse_kernel<2, Geo<16, 16, 2, 2>, 3, 12>(L);
+        }
         if (L.wpe == 2 && L.cpw == 8) { // two per SIMD, eight per CU
             if (P.blkX == 16 && P.blkY == 16) return launch_analyse_kernel<2, Geo<16, 16, 2, 2>, 2, 8>(L);
             if (P.blkX == 8 && P.blkY == 8) return launch_analyse_kernel<2, Geo<8, 8, 2, 2>, 2, 8>(L);
