@@ -82,6 +82,17 @@ void mvx_super_get_info(const mvx_super *s, mvx_super_info *info);
 int mvx_super_frames(mvx_super *s, int nframes, const void *const *src, const ptrdiff_t src_pitch[3],
                      void *const *dst, const ptrdiff_t dst_pitch[3], void *stream);
 
+/* Optional device-side layout extension for search throughput ("shadow copies").  gfx950 serves vector loads at addresses that
+ * are not multiples of four several times slower than aligned ones, and a motion search reads reference blocks at arbitrary
+ * sample positions.  A caller may therefore keep, behind every plane of a super frame, mvx_super_shadow_copies() further copies
+ * of the whole plane buffer (plane_height * pitch bytes), copy k = 1.. at plane + k * copy_stride[p] and shifted left by k
+ * samples; mvx_super_shadow_frames fills them from planes that mvx_super_frames has written (same stream).  The copies never
+ * leave the device and are not part of the super clip's frame format; a search uses them after mvx_analyse_set_ref_shadow.
+ * (no reference counterpart: memory layout only, results are unchanged) */
+int mvx_super_shadow_copies(const mvx_super *s);   /* 4 / bytes per sample - 1 */
+int mvx_super_shadow_frames(const mvx_super *s, int nframes, void *const *planes /* [f*3+p] */, const ptrdiff_t pitch[3],
+                            const ptrdiff_t copy_stride[3], void *stream);
+
 /* mv.Super(pelclip=...): the sub-pel planes of level 0 are taken from the user's upsized clip instead of being interpolated.
  * replaces MVSuper.c:229-256 (mvx_super_pelclip_mode: 0 = ignored because pel is 1, 1 = pelclip is pel x the clip size,
  * 2 = pel x the padded size; other sizes -> MVX_E_ARG with the reference's message) and MVSuper.c:91-102 +
@@ -126,6 +137,10 @@ typedef struct mvx_analyse_job {
     int32_t field_shift;/* MVAnalyse.c:172-176; 0 unless fields=1 */
     int32_t reserved;
 } mvx_analyse_job;
+
+/* The caller promises that every job's reference planes carry shadow copies (mvx_super_shadow_frames) at ref[p] + k * copy_stride[p];
+ * copy_stride NULL or all zero: none (the default).  Only changes which addresses the search loads from, never a result. */
+int mvx_analyse_set_ref_shadow(mvx_analyse *a, const ptrdiff_t copy_stride[3]);
 
 /* One chain (frame, direction) per job; all jobs run concurrently in one launch. `jobs` is a HOST array.
  * With divide > 0 the blob carries the extra array of half-size blocks and mvx_analyse_get_data reports the divided
@@ -268,6 +283,11 @@ void mvx_scale_thscd(int64_t *thscd1, int32_t *thscd2, const mvx_analysis_data *
 /* bytes of the MVTools_vectors property of a vector clip with this analysis data (Fakery.c:110-121 level geometry,
  * GroupOfPlanes.c:127-148 array layout) */
 int mvx_vectors_size(const mvx_analysis_data *ad);
+
+/* ---- test / measurement hook: selects among kernel variants that compute identical results (e.g. "general" = 1 keeps the
+ * default search out of its specialised kernel so that the parity suite can run both).  The library never reads the
+ * environment; a production host never needs this call. */
+int mvx_debug_option(const char *name, int value);
 
 /* ---- small device-memory helpers so that a C host (e.g. the VapourSynth shell) needs no HIP headers */
 void *mvx_dev_alloc(size_t bytes);            /* zero-filled */

@@ -113,6 +113,19 @@ def test_super_gray(oracle, mv):
     assert not pl.defined_equal(osup, osup.frame(frames[0]), _sup_to_numpy(mv, gsup, gout[0]))
 
 
+@pytest.fixture
+def dbg(mv):
+    """kernel-variant switches for one test (mvx_debug_option: selects among kernels that compute identical results); reset afterwards"""
+    used = []
+
+    def set_(name, value):
+        mv.debug_option(name, value)
+        used.append(name)
+    yield set_
+    for name in used:
+        mv.debug_option(name, -1 if name in ("cpw_sync", "lds_min") else 0)
+
+
 ANALYSE_CASES = [
     # w, h, bits, super kwargs, analyse kwargs
     (128, 96, 8, {}, dict(blksize=8, overlap=4)),
@@ -182,15 +195,7 @@ def test_analyse_parity(oracle, mv, w, h, bits, skw, akw):
             assert getattr(gan.ad, k) == getattr(oan.ad, k), k
     osf = [osup.frame(f) for f in frames]
     # feed the ORACLE's super frames to the GPU search so that this test isolates Analyse
-    gsf = []
-    for sf in osf:
-        dev = []
-        for p in range(gsup.nplanes):
-            t = torch.zeros((gsup.info.plane_height[p], gsup.pitch[p]), dtype=torch.uint8, device="cuda")
-            a = sf[p][:, :gsup.info.plane_width[p]]
-            t[:, :a.shape[1] * a.dtype.itemsize] = torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(a.shape[0], -1)).cuda()
-            dev.append(t)
-        gsf.append(dev)
+    gsf = [gsup.from_host(sf) for sf in osf]
     blobs = gan.run([(gsf[0], gsf[1]), (gsf[1], gsf[0]), (gsf[0], None)])
     torch.cuda.synchronize()
     want = [oan.frame(osf[0], osf[1]), oan.frame(osf[1], osf[0]), oan.frame(osf[0], None)]
@@ -347,10 +352,10 @@ def test_fields_shift_parity(oracle, mv, w, h, bits, pel, akw, shift):
     (384, 224, 8, dict(pel=1), dict(blksize=16, overlap=8, search=3, searchparam=2)),
     (320, 180, 16, {}, dict(blksize=16, overlap=8, chroma=0)),
 ])
-def test_analyse_window_kernels(oracle, mv, monkeypatch, w, h, bits, skw, akw):
+def test_analyse_window_kernels(oracle, mv, dbg, w, h, bits, skw, akw):
     """the opt-in LDS search-window kernels (MVX_WINDOW=1): candidates inside the window are compared from LDS
     (aligned dword reads + v_alignbit), the others from global memory -- the vectors must not depend on which"""
-    monkeypatch.setenv("MVX_WINDOW", "1")
+    dbg("window", 1)
     frames, osup, gsup, osf, gsrc, gsf = _pipeline(oracle, mv, w, h, bits, 1, skw, akw, nframes=3, seed=5)
     for isb in (1, 0):
         oan = oracle.Analyse(osup, isb=isb, **akw)
@@ -368,10 +373,10 @@ def test_analyse_window_kernels(oracle, mv, monkeypatch, w, h, bits, skw, akw):
     (384, 224, {}, dict(blksize=16, overlap=0, chroma=0)),
     (384, 224, dict(pel=4), dict(blksize=16, overlap=8)),   # pel 4: the host keeps the plain kernel
 ])
-def test_analyse_refinement_tile_kernel(oracle, mv, monkeypatch, w, h, skw, akw):
+def test_analyse_refinement_tile_kernel(oracle, mv, dbg, w, h, skw, akw):
     """the opt-in refinement-tile kernel (MVX_TILE=1): hexagon / square / exhaustive rounds read the reference
     from an LDS tile around the predictor round's winner; same samples, same vectors (plane borders included: small frames)"""
-    monkeypatch.setenv("MVX_TILE", "1")
+    dbg("tile", 1)
     frames, osup, gsup, osf, gsrc, gsf = _pipeline(oracle, mv, w, h, 16, 1, skw, akw, nframes=3, seed=6)
     for isb in (1, 0):
         oan = oracle.Analyse(osup, isb=isb, **akw)
@@ -383,10 +388,10 @@ def test_analyse_refinement_tile_kernel(oracle, mv, monkeypatch, w, h, skw, akw)
 
 
 @pytest.mark.parametrize("bits,akw", [(8, dict(blksize=8, overlap=4)), (16, dict(blksize=16, overlap=8)), (16, dict(blksize=32, overlap=16))])
-def test_analyse_one_chain_per_workgroup(oracle, mv, monkeypatch, bits, akw):
+def test_analyse_one_chain_per_workgroup(oracle, mv, dbg, bits, akw):
     """MVX_CPW=1 keeps the one-chain-per-workgroup builds of the specialised kernels reachable (they are also what the opt-in
     window / tile modes and A/B timing use): same vectors"""
-    monkeypatch.setenv("MVX_CPW", "1")
+    dbg("cpw1", 1)
     frames, osup, gsup, osf, gsrc, gsf = _pipeline(oracle, mv, 256, 160, bits, 1, {}, akw, nframes=2, seed=9)
     ob = oracle.Analyse(osup, isb=1, **akw).frame(osf[0], osf[1])
     gb = mv.Analyse(gsup, isb=1, **akw).run([(gsf[0], gsf[1])])[0]
@@ -395,11 +400,14 @@ def test_analyse_one_chain_per_workgroup(oracle, mv, monkeypatch, bits, akw):
 
 @pytest.mark.parametrize("bits,akw", [(8, dict(blksize=8, overlap=4)), (16, dict(blksize=16, overlap=8)), (16, dict(blksize=8, overlap=4)),
                                       (8, dict(blksize=16, overlap=8)), (16, dict(blksize=32, overlap=16))])
-def test_analyse_two_chains_per_simd(oracle, mv, bits, akw):
+@pytest.mark.parametrize("kernel", ["lean", "general"])
+def test_analyse_two_chains_per_simd(oracle, mv, dbg, kernel, bits, akw):
     """a launch with more chains than the device has SIMDs takes the 256-register builds (two chains per SIMD; 16-bit: eight
     chains per workgroup, job table sorted by reference frame): every one of its results must still be the oracle's, whatever
     the order the chains were given in"""
     import torch
+    if kernel == "general":
+        dbg("general", 1)
     w, h = 128, 96
     frames, osup, gsup, osf, gsrc, gsf = _pipeline(oracle, mv, w, h, bits, 1, {}, akw, nframes=3)
     oan = oracle.Analyse(osup, isb=1, **akw)
@@ -415,8 +423,62 @@ def test_analyse_two_chains_per_simd(oracle, mv, bits, akw):
         assert np.array_equal(got[i], want[(i * 7) % 4]), "job %d differs" % i
 
 
-def test_analyse_three_chains_per_simd(oracle, mv):
-    """more than two chains per SIMD: the 8-bit 8x8 kernel's 168-register build (three chains per SIMD)"""
+@pytest.mark.parametrize("w,h,bits,skw,akw", [
+    (128, 96, 8, {}, dict(blksize=8, overlap=4)),
+    (384, 224, 16, {}, dict(blksize=16, overlap=8)),
+    (512, 288, 16, {}, dict(blksize=32, overlap=16)),
+    (256, 144, 8, {}, dict(blksize=16, overlap=0)),
+    (256, 144, 8, {}, dict(blksize=8, overlap=4, search=3, searchparam=2)),
+    (256, 144, 8, {}, dict(blksize=8, overlap=4, badsad=300, badrange=8)),
+    (256, 144, 8, {}, dict(blksize=8, overlap=4, badsad=300, badrange=-4)),
+    (320, 192, 16, {}, dict(blksize=16, overlap=8, _noise=14)),
+    (256, 144, 8, dict(pel=4), dict(blksize=8, overlap=2)),
+    (256, 144, 8, dict(pel=1), dict(blksize=8, chroma=0)),
+])
+@pytest.mark.parametrize("variant", ["general", "plain-layout"])
+def test_analyse_default_search_other_kernels(oracle, mv, dbg, variant, w, h, bits, skw, akw):
+    """The default search normally runs in the lean kernel (mvx_analyse_fast.h) on super frames that carry shadow copies.
+    The same cases through the general kernel ("general" = 1) and through the lean kernel on the plain layout (no shadow
+    copies: unaligned loads) must give the same blobs."""
+    akw = dict(akw)
+    noise = akw.pop("_noise", 3)
+    if variant == "general":
+        dbg("general", 1)
+    frames = pl.moving_clip(w, h, bits, 3, seed=13, noise=noise)
+    osup = oracle.Super(w, h, bits, **skw)
+    gsup = mv.Super(w, h, bits, shadow=(variant != "plain-layout"), **skw)
+    osf = [osup.frame(f) for f in frames]
+    gsf = gsup.build([mv.frame_to_device(f) for f in frames])
+    for isb in (1, 0):
+        oan = oracle.Analyse(osup, isb=isb, **akw)
+        gan = mv.Analyse(gsup, isb=isb, **akw)
+        ref = 2 if isb else 0
+        assert np.array_equal(gan.run([(gsf[1], gsf[ref])])[0].cpu().numpy(), oan.frame(osf[1], osf[ref]))
+
+
+@pytest.mark.parametrize("bits,akw,per_simd", [(8, dict(blksize=8, overlap=4), 3), (8, dict(blksize=8, overlap=4), 4), (16, dict(blksize=16, overlap=8), 3),
+                                               (16, dict(blksize=16, overlap=8), 4), (8, dict(blksize=16, overlap=8), 4), (16, dict(blksize=32, overlap=16), 3),
+                                               (16, dict(blksize=8, overlap=4), 4)])
+def test_analyse_many_chains_per_simd(oracle, mv, bits, akw, per_simd):
+    """launches with more than two (three) chains per SIMD take the lean kernel's 168- (128-) register builds, workgroups of twelve
+    (sixteen) chains: every result must still be the oracle's, whatever the order the chains were given in"""
+    import torch
+    frames, osup, gsup, osf, gsrc, gsf = _pipeline(oracle, mv, 96, 64, bits, 1, {}, akw, nframes=3)
+    oan = oracle.Analyse(osup, isb=0, **akw)
+    gan = mv.Analyse(gsup, isb=0, **akw)
+    want = [oan.frame(osf[1], osf[0]), oan.frame(osf[2], osf[1]), oan.frame(osf[0], None), oan.frame(osf[2], osf[0])]
+    pairs = [(gsf[1], gsf[0]), (gsf[2], gsf[1]), (gsf[0], None), (gsf[2], gsf[0])]
+    njobs = (per_simd - 1) * 4 * torch.cuda.get_device_properties(0).multi_processor_count + 53
+    got = gan.run([pairs[(i * 5) % 4] for i in range(njobs)])
+    torch.cuda.synchronize()
+    got = torch.stack(list(got)).cpu().numpy()
+    for i in range(njobs):
+        assert np.array_equal(got[i], want[(i * 5) % 4]), "job %d differs" % i
+
+
+def test_analyse_three_chains_per_simd(oracle, mv, dbg):
+    """more than two chains per SIMD: the general 8-bit 8x8 kernel's 168-register build (three chains per SIMD)"""
+    dbg("general", 1)
     import torch
     akw = dict(blksize=8, overlap=4)
     frames, osup, gsup, osf, gsrc, gsf = _pipeline(oracle, mv, 96, 64, 8, 1, {}, akw, nframes=3)

@@ -84,10 +84,20 @@ def main():
         else:
             i += 1
     out = keep or tempfile.mktemp(suffix=".s")
-    p = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + defs + [src, "-o", out], stderr=subprocess.PIPE, text=True)
-    if p.returncode:
-        sys.stderr.write(p.stderr)
-        sys.exit(1)
+    rpt = None
+    for a in args:
+        if a.startswith("--report="):
+            rpt = a.split("=", 1)[1]
+    if rpt and os.path.exists(rpt) and os.path.exists(out):  # re-read an earlier compilation
+        class P_: pass
+        p = P_(); p.stderr = open(rpt).read(); p.returncode = 0
+    else:
+        p = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + defs + [src, "-o", out], stderr=subprocess.PIPE, text=True)
+        if p.returncode:
+            sys.stderr.write(p.stderr)
+            sys.exit(1)
+        if rpt:
+            open(rpt, "w").write(p.stderr)
     res = {}
     name = None
     for line in p.stderr.splitlines():
@@ -95,7 +105,7 @@ def main():
         if m:
             name = m.group(1); res[name] = {}
             continue
-        m = re.search(r"remark: [^:]*:\d+:\d+:\s+([A-Za-z ]+?)(?: \[bytes/lane\])?: (\d+)", line)
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[a-zA-Z/]+\])?: (\d+)", line)
         if m and name:
             res[name][m.group(1).strip()] = int(m.group(2))
     asm = open(out).read()

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include "mvx_analyse_kernel.h"
+#include "mvx_analyse_fast.h"
 
 // ------------------------------------------------------------------------------------------------ host
 
@@ -16,6 +17,34 @@ void mvx_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 extern "C" __attribute__((visibility("default"))) const char *mvx_last_error(void) { return g_err; }
+
+// ---- developer / test options.  The library never reads the environment: kernel-variant choices that exist for A/B
+// measurements and for running the parity suite through every kernel are set through ONE entry point, mvx_debug_option
+// (the Python test binding forwards MVX_* environment variables to it; the VapourSynth shell never calls it).  None of them
+// changes results, except "ablate", which only exists in MVX_LAB builds.
+struct MvxDebug {
+    int general = 0;   // 1: never use the lean kernel of the default search (mvx_analyse_fast.h)
+    int fast_wpe = 0;  // > 0: chains per SIMD the lean kernel is launched at (when such a build exists)
+    int cpw1 = 0;      // one chain per workgroup (general kernels)
+    int window = 0;    // LDS search-window kernels
+    int tile = 0;      // refinement-tile kernel
+    int no_wpe2 = 0, no_wpe3 = 0, wpe3_u16 = 0;
+    int cpw_sync = -1; // barrier interval inside a workgroup (power of two, 0 = none)
+    int lds_min = -1;  // LDS floor of the one-chain launches
+    int ablate = 0;
+};
+static MvxDebug g_dbg;
+extern "C" __attribute__((visibility("default"))) int mvx_debug_option(const char *name, int value) {
+    struct { const char *n; int *p; } tab[] = { { "general", &g_dbg.general }, { "fast_wpe", &g_dbg.fast_wpe }, { "cpw1", &g_dbg.cpw1 }, { "window", &g_dbg.window },
+        { "tile", &g_dbg.tile }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min },
+#ifdef MVX_LAB
+        { "ablate", &g_dbg.ablate },
+#endif
+    };
+    for (auto &t : tab) if (!strcmp(t.n, name)) { *t.p = value; return MVX_OK; }
+    mvx_set_error("mvx_debug_option: unknown option %s", name);
+    return MVX_E_ARG;
+}
 
 #define AFAIL(...) do { snprintf(err, MVX_ERRLEN, __VA_ARGS__); mvx_set_error("%s", err); return MVX_E_ARG; } while (0)
 static int A(int v, int d) { return v == MVX_UNSET ? d : v; }
@@ -178,7 +207,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_create(const m
     P.lambda = nLambda; P.lsad = lsad; P.badSAD = badSAD;
     P.verybigSAD = (long long)P.blkX * P.blkY * (1 << si.bits);
     P.superHPad = si.hpad; P.superVPad = si.vpad;
-    P.ablate = getenv("MVX_ABLATE") ? atoi(getenv("MVX_ABLATE")) : 0;
+    P.ablate = g_dbg.ablate;
     for (int p = 0; p < 3; p++) P.pitch[p] = p < si.num_planes ? super_pitch[p] : 0;
     if (si.num_planes > 1 && super_pitch[1] != super_pitch[2]) AFAIL("Analyse: the U and V planes of the super clip must share one pitch.");
     int blobOff = 8;
@@ -221,6 +250,15 @@ extern "C" __attribute__((visibility("default"))) void mvx_analyse_destroy(mvx_a
     if (a->dJobs) (void)hipFree(a->dJobs);
     delete a;
 }
+extern "C" __attribute__((visibility("default"))) int mvx_analyse_set_ref_shadow(mvx_analyse *a, const ptrdiff_t copy_stride[3]) {
+    for (int p = 0; p < 3; p++) {
+        const long long v = copy_stride ? (long long)copy_stride[p] : 0;
+        if (v < 0 || v % 16) { mvx_set_error("mvx_analyse_set_ref_shadow: copy strides must be non-negative multiples of 16 bytes"); return MVX_E_ARG; }
+        a->P.shadow[p] = v;
+    }
+    if (a->dP) HIP_CHECK(hipMemcpy(a->dP, &a->P, sizeof(AParams), hipMemcpyHostToDevice)); // (synchronous: no launch of this handle is reading it concurrently unless the caller races)
+    return MVX_OK;
+}
 extern "C" __attribute__((visibility("default"))) void mvx_analyse_get_data(const mvx_analyse *a, mvx_analysis_data *out) { *out = a->adOut; }
 extern "C" __attribute__((visibility("default"))) int mvx_analyse_blob_size(const mvx_analyse *a) { return a->P.blobSize; }
 
@@ -252,10 +290,9 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
     // lines in the CU's L1 (+4.7 % at 4K16; measured r1: a barrier between them only costs -- per block -13 %, per 16 blocks 0 %,
     // per row +3.7 % -- and dealing the groups out so that each XCD gets a contiguous range of frames changes nothing).
     const bool spec = P.dctmode == 0 && P.xr == 2 && P.yr == 2 && P.blkX == P.blkY && (P.blkX == 16 || P.blkX == 8 || (P.blkX == 32 && P.bps == 2)) &&
-                      !(getenv("MVX_CPW") && atoi(getenv("MVX_CPW")) == 1) && !(getenv("MVX_TILE") && atoi(getenv("MVX_TILE"))) &&
-                      !(getenv("MVX_WINDOW") && atoi(getenv("MVX_WINDOW")));
-    static int simds = 0;
-    if (!simds) {
+                      !g_dbg.cpw1 && !g_dbg.tile && !g_dbg.window;
+    int simds = 0; // of the device this call runs on
+    {
         int dev = 0, cus = 0;
         HIP_CHECK(hipGetDevice(&dev));
         HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -264,15 +301,51 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
     // A launch with more chains than SIMDs runs TWO chains per SIMD where a 256-register build of the kernel exists without
     // spills (8-bit 8x8, 16x16; 16-bit 8x8, 16x16, 32x32): 8-bit 1080p +53 %; 16-bit 4K +13 %, and there only as workgroups of EIGHT chains
     // that share a reference frame -- eight unrelated chains per CU thrash its L1 / the XCD's L2 and lose.
-    const bool oneChain = (getenv("MVX_CPW") && atoi(getenv("MVX_CPW")) == 1) || (getenv("MVX_TILE") && atoi(getenv("MVX_TILE"))) ||
-                          (getenv("MVX_WINDOW") && atoi(getenv("MVX_WINDOW")));
+    // ---- the default search runs in the lean kernel (mvx_analyse_fast.h): workgroups of 4 * k chains that share a reference
+    // frame, k = 1..4 chains per SIMD depending on how many chains the launch carries and which builds exist / pay off.
+    if (mvx_fast_eligible(P) && !g_dbg.general && !g_dbg.cpw1 && !g_dbg.tile && !g_dbg.window) {
+        int srcB = P.blkX * P.blkY * P.bps + 2 * (P.blkX / 2) * (P.blkY / 2) * P.bps;
+        const int fRow = (srcB + 15) & ~15;
+        int fMaxBlkX = 0;
+        for (int i = 0; i < P.nLevels; i++) if (P.lv[i].nBlkX > fMaxBlkX) fMaxBlkX = P.lv[i].nBlkX;
+        // [source block | previous row's results, 16 B per block]; the histogram of the global-motion estimate (only used between
+        // levels) lies over the row buffer
+        const int fBins = 1024;
+        int fNeed = fRow + fMaxBlkX * 16;
+        if (fNeed < fRow + fBins * 4) fNeed = fRow + fBins * 4;
+        const int perChain = (fNeed + 255) & ~255;
+        // builds per (sample size, block size): chains per SIMD that exist (mvx_analyse_u8.hip / _u16.hip)
+        auto have = [&](int k) {
+            if (P.bps == 2 && P.blkX == 8) return k == 1 || k == 2 || k == 4;
+            if (P.bps == 2 && P.blkX == 32) return k >= 1 && k <= 3;
+            return k >= 1 && k <= 4;
+        };
+        int k = njobs > 3 * simds ? 4 : njobs > 2 * simds ? 3 : njobs > simds ? 2 : 1;
+        if (g_dbg.fast_wpe > 0 && g_dbg.fast_wpe < k) k = g_dbg.fast_wpe;
+        while (k > 1 && (!have(k) || (long long)perChain * 4 * k > 160 * 1024)) k--;
+        if ((long long)perChain * 4 * k <= 160 * 1024) {
+            std::stable_sort(hj.begin(), hj.end(), [](const AJob &x, const AJob &y) { return (uintptr_t)x.ref[0] > (uintptr_t)y.ref[0]; }); // (no reference: last)
+            HIP_CHECK(hipMemcpyAsync(a->dJobs, hj.data(), sizeof(AJob) * njobs, hipMemcpyHostToDevice, st));
+            int syncEvery = k >= 2 ? 256 : 0;
+            if (g_dbg.cpw_sync >= 0 && (g_dbg.cpw_sync & (g_dbg.cpw_sync - 1)) == 0) syncEvery = g_dbg.cpw_sync;
+            ALaunch L = { 0, njobs, fNeed, fRow, fRow, fBins, -1, 0, fNeed, simds, 4 * k, k, syncEvery, k, st, a->dP, a->dJobs };
+            int rc = P.bps == 1 ? mvx_analyse_launch_fast_u8(P, L) : mvx_analyse_launch_fast_u16(P, L);
+            if (rc == MVX_OK) {
+                if (P.divide) hipLaunchKernelGGL(analyse_divide_kernel, dim3((P.lv[0].nBlkX * P.lv[0].nBlkY + 255) / 256, njobs), dim3(256), 0, st, a->dP, a->dJobs);
+                HIP_CHECK(hipGetLastError());
+                return MVX_OK;
+            }
+            if (rc != 1) return rc;
+        }
+    }
+    const bool oneChain = g_dbg.cpw1 || g_dbg.tile || g_dbg.window;
     int cpw = oneChain ? 1 : 4, wpe = 1; // (the generic kernels have four-chain builds too)
-    if (spec && njobs > simds && !getenv("MVX_NO_WPE2")) {
+    if (spec && njobs > simds && !g_dbg.no_wpe2) {
         if (P.bps == 1 && (P.blkX == 8 || P.blkX == 16)) wpe = 2;
         // three per SIMD for the lightest kernel: its 168-register build spills 72 registers and still gains 14 % (1080p 1642 -> 1867 fps)
-        if (P.bps == 1 && P.blkX == 8 && njobs > 2 * simds && !getenv("MVX_NO_WPE3")) wpe = 3;
+        if (P.bps == 1 && P.blkX == 8 && njobs > 2 * simds && !g_dbg.no_wpe3) wpe = 3;
         if (P.bps == 2 && (P.blkX == 16 || P.blkX == 8 || P.blkX == 32)) { wpe = 2; cpw = 8; }
-        if (P.bps == 2 && P.blkX == 16 && njobs > 2 * simds && getenv("MVX_WPE3")) { wpe = 3; cpw = 12; }
+        if (P.bps == 2 && P.blkX == 16 && njobs > 2 * simds && g_dbg.wpe3_u16) { wpe = 3; cpw = 12; }
     }
     if (cpw > 1) std::stable_sort(hj.begin(), hj.end(), [](const AJob &x, const AJob &y) { return (uintptr_t)x.ref[0] > (uintptr_t)y.ref[0]; }); // (no reference: last)
     HIP_CHECK(hipMemcpyAsync(a->dJobs, hj.data(), sizeof(AJob) * njobs, hipMemcpyHostToDevice, st));
@@ -295,8 +368,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         const int S = P.blkX - P.ovX, npp = P.lv[0].pel * P.lv[0].pel;
         const bool sq420 = P.dctmode == 0 && P.xr == 2 && P.yr == 2 && P.blkX == P.blkY;
         const bool winGeom = sq420 && ((P.blkX == 16 && S == 8) || (P.blkX == 8 && S == 4));
-        const char *e = getenv("MVX_WINDOW");
-        const bool wantWin = e ? atoi(e) != 0 : false;
+        const bool wantWin = g_dbg.window != 0;
         const int histW = ldsRow + maxBlkX * 16; // window / tile kernels keep the predictors in registers
         if (winGeom && wantWin) {
             const int MX = ((8 + S - 1) / S) * S, MY = MVX_WIN_MY;
@@ -307,8 +379,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
             if (total <= 40 * 1024) { mode = 1; ldsHist = histW; ldsWin = histW; winCap = lumaB + chromaB; ldsBytes = total; }
         }
         // refinement tile (16-bit 16x16 4:2:0): opt-in (MVX_TILE=1), no faster than the plain kernels yet
-        const char *et = getenv("MVX_TILE");
-        const bool wantTile = et ? atoi(et) != 0 : false;
+        const bool wantTile = g_dbg.tile != 0;
         if (mode == 0 && wantTile && sq420 && P.bps == 2 && P.blkX == 16) {
             int tb = mvx_tile_lds_bytes(P.blkX, P.blkY, P.xr, P.yr, P.bps, P.lv[0].pel, P.chroma);
             const int tb1 = mvx_tile_lds_bytes(P.blkX, P.blkY, P.xr, P.yr, P.bps, 1, P.chroma);
@@ -332,7 +403,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
     const int ldsNeed = ldsBytes;
     {
         int v = 33 * 1024;
-        if (const char *e = getenv("MVX_LDS_MIN")) v = atoi(e); // developer override
+        if (g_dbg.lds_min >= 0) v = g_dbg.lds_min; // developer override
         if (v > ldsBytes && v <= 160 * 1024) ldsBytes = v;
     }
     if (mode != 0) { cpw = 1; wpe = 1; }
@@ -346,8 +417,8 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
     // of a two-per-SIMD workgroup on neighbouring blocks (+2 % at 4K16 for any interval from 64 blocks to a row, +2.8 % at 1080p
     // 8-bit); with one chain per SIMD it costs 1 %
     int syncEvery = wpe >= 2 ? 256 : 0;
-    if (const char *e = getenv("MVX_CPW_SYNC")) { int v = atoi(e); if (v >= 0 && (v & (v - 1)) == 0) syncEvery = v; }
-    ALaunch L = { mode, njobs, ldsBytes, ldsRow, ldsHist, histBins, ldsWin, winCap, ldsNeed, simds, cpw, wpe, syncEvery, st, a->dP, a->dJobs };
+    if (g_dbg.cpw_sync >= 0 && (g_dbg.cpw_sync & (g_dbg.cpw_sync - 1)) == 0) syncEvery = g_dbg.cpw_sync;
+    ALaunch L = { mode, njobs, ldsBytes, ldsRow, ldsHist, histBins, ldsWin, winCap, ldsNeed, simds, cpw, wpe, syncEvery, 0, st, a->dP, a->dJobs };
     // the specialised kernels address the reference as "64-bit base + 32-bit offset inside the level's plane set" (all sub-pel planes)
     bool off32 = true;
     for (int i = 0; i < P.nLevels; i++)

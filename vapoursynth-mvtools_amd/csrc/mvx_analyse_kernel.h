@@ -48,6 +48,7 @@ struct AParams {
     long long pitch[3];
     int blobSize;
     int superHPad, superVPad;
+    long long shadow[3]; // byte distance between the shifted copies of a reference plane (mvx_analyse_set_ref_shadow), 0 = none
     int ablate; // developer-only (MVX_ABLATE env): 1 = skip the search, 2 = predictor round only; results are then WRONG
     ALevel lv[MVX_MAX_LEVELS];
 };
@@ -2289,6 +2290,7 @@ struct ALaunch {
     int cpw;     // chains per workgroup the host ordered the jobs for (1, 4 or 8)
     int wpe;     // chains per SIMD: 2 = the 256-register builds (launches with more chains than SIMDs, geometries that fit)
     int syncEvery; // cpw > 1: workgroup barrier every that many blocks of a row (power of two; a row start always syncs)
+    int fast;      // > 0: the lean kernel of the default search (mvx_analyse_fast.h) at that many chains per SIMD
     hipStream_t st;
     const AParams *dP;
     const AJob *dJobs;
@@ -2307,3 +2309,5 @@ template <int BPS_, typename GEO_, int WPE_ = 1, int CPW_ = 1> static int launch
 int mvx_analyse_launch_any(const AParams &P, const ALaunch &L);
 int mvx_analyse_launch_u8(const AParams &P, const ALaunch &L);
 int mvx_analyse_launch_u16(const AParams &P, const ALaunch &L);
+int mvx_analyse_launch_fast_u8(const AParams &P, const ALaunch &L);
+int mvx_analyse_launch_fast_u16(const AParams &P, const ALaunch &L);

@@ -398,6 +398,56 @@ __global__ __launch_bounds__(256) void super_ext_kernel(SuperExtArgs A) {
 static int super_frames_impl(mvx_super *s, int nframes, const void *const *src, const ptrdiff_t src_pitch[3], const void *const *pelclip,
                              const ptrdiff_t pelclip_pitch[3], int pelMode, void *const *dst, const ptrdiff_t dst_pitch[3], void *stream);
 
+// ---- shifted copies of a super frame's planes ("shadows") ---------------------------------------------------------------
+// The search reads reference blocks at arbitrary sample positions, i.e. at byte addresses that are mostly NOT multiples of
+// four, and gfx950's texture-addresser path handles a wave-level 16-byte-per-lane load at such addresses ~3.7x slower than at
+// dword-aligned ones (tools/micro/ta_pattern.hip: 85 against 23 CU-cycles for 32 rows x 32 bytes).  With 288 GB of HBM the fix
+// is a layout one: next to every plane of a super frame the caller keeps 4 / bytes-per-sample - 1 copies of the WHOLE plane
+// buffer shifted left by 1 .. n samples (copy k, byte i = plane byte i + k * bps).  A block at a sample position x with
+// x % (4 / bps) == k is then read from copy k at x - k: same samples, dword-aligned address.  mvx_analyse_set_ref_shadow tells
+// a search where the copies are.
+struct ShadowArgs { void *const *planes; long long size[3], stride[3]; int nplanes, bps; };
+__global__ __launch_bounds__(256) void super_shadow_kernel(ShadowArgs A) {
+    const int fp = blockIdx.y, p = fp % 3;
+    if (p >= A.nplanes) return;
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (i >= A.size[p]) return;
+    unsigned char *base = (unsigned char *)A.planes[fp];
+    const uint4 a = *(const uint4 *)(base + i);
+    const unsigned b = i + 16 < A.size[p] ? *(const unsigned *)(base + i + 16) : 0u;
+    const int n = 4 / A.bps;
+    for (int k = 1; k < n; k++) {
+        const unsigned sh = 8u * k * A.bps;
+        uint4 o;
+        o.x = __builtin_amdgcn_alignbit(a.y, a.x, sh); o.y = __builtin_amdgcn_alignbit(a.z, a.y, sh);
+        o.z = __builtin_amdgcn_alignbit(a.w, a.z, sh); o.w = __builtin_amdgcn_alignbit(b, a.w, sh);
+        *(uint4 *)(base + k * A.stride[p] + i) = o;
+    }
+}
+extern "C" __attribute__((visibility("default"))) int mvx_super_shadow_copies(const mvx_super *s) { return 4 / (s->info.bits <= 8 ? 1 : 2) - 1; }
+extern "C" __attribute__((visibility("default"))) int mvx_super_shadow_frames(const mvx_super *s, int nframes, void *const *planes, const ptrdiff_t pitch[3],
+                                                                              const ptrdiff_t copy_stride[3], void *stream) {
+    if (nframes <= 0) return MVX_OK;
+    const mvx_super_info &si = s->info;
+    hipStream_t st = (hipStream_t)stream;
+    ShadowArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nplanes = si.num_planes; A.bps = si.bits <= 8 ? 1 : 2;
+    long long maxsize = 0;
+    for (int p = 0; p < si.num_planes; p++) {
+        A.size[p] = (long long)si.plane_height[p] * pitch[p]; A.stride[p] = copy_stride[p];
+        if (pitch[p] % 16 || copy_stride[p] % 16 || copy_stride[p] < A.size[p]) { mvx_set_error("mvx_super_shadow_frames: pitch and copy stride must be multiples of 16 bytes, the stride at least one plane"); return MVX_E_ARG; }
+        if (A.size[p] > maxsize) maxsize = A.size[p];
+    }
+    void *dpl = nullptr;
+    int rc;
+    if ((rc = upload_ptrs(1, (const void *const *)planes, (size_t)nframes * 3, st, &dpl))) return rc;
+    A.planes = (void *const *)dpl;
+    hipLaunchKernelGGL(super_shadow_kernel, dim3((unsigned)((maxsize / 16 + 255) / 256), nframes * 3), dim3(256), 0, st, A);
+    HIP_CHECK(hipGetLastError());
+    return MVX_OK;
+}
+
 extern "C" __attribute__((visibility("default"))) int mvx_super_frames(mvx_super *s, int nframes, const void *const *src, const ptrdiff_t src_pitch[3],
                                 void *const *dst, const ptrdiff_t dst_pitch[3], void *stream) {
     return super_frames_impl(s, nframes, src, src_pitch, nullptr, nullptr, 0, dst, dst_pitch, stream);

@@ -129,6 +129,10 @@ def lib():
         L.mvx_super_pelclip_mode.argtypes = [C.c_void_p, C.c_int, C.c_int, P(C.c_int32), C.c_char_p]
         L.mvx_super_frames_pelclip.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p), P(C.c_ssize_t), P(C.c_void_p), P(C.c_ssize_t), C.c_int, P(C.c_void_p),
                                                P(C.c_ssize_t), C.c_void_p]
+        L.mvx_super_shadow_copies.argtypes = [C.c_void_p]
+        L.mvx_super_shadow_frames.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p), P(C.c_ssize_t), P(C.c_ssize_t), C.c_void_p]
+        L.mvx_analyse_set_ref_shadow.argtypes = [C.c_void_p, P(C.c_ssize_t)]
+        L.mvx_debug_option.argtypes = [C.c_char_p, C.c_int]
         L.mvx_analyse_create.argtypes = [P(AnalyseArgs), C.c_void_p, C.c_int, P(C.c_ssize_t), P(C.c_void_p), C.c_char_p]
         L.mvx_analyse_destroy.argtypes = [C.c_void_p]
         L.mvx_analyse_get_data.argtypes = [C.c_void_p, P(AnalysisData)]
@@ -160,7 +164,20 @@ def lib():
         L.mvx_vectors_size.argtypes = [P(AnalysisData)]
         L.mvx_vectors_size.restype = C.c_int
         _lib = L
+        # developer / test switches: the library itself never reads the environment (mvx_debug_option is its one hook);
+        # this TEST binding forwards the MVX_* variables the tools/ scripts use
+        for env, opt in (("MVX_GENERAL", "general"), ("MVX_FAST_WPE", "fast_wpe"), ("MVX_WINDOW", "window"), ("MVX_TILE", "tile"), ("MVX_NO_WPE2", "no_wpe2"),
+                         ("MVX_NO_WPE3", "no_wpe3"), ("MVX_WPE3", "wpe3_u16"), ("MVX_CPW_SYNC", "cpw_sync"), ("MVX_LDS_MIN", "lds_min"), ("MVX_ABLATE", "ablate")):
+            if os.environ.get(env) is not None:
+                L.mvx_debug_option(opt.encode(), int(os.environ[env]))
+        if os.environ.get("MVX_CPW") == "1":
+            L.mvx_debug_option(b"cpw1", 1)
     return _lib
+
+
+def debug_option(name, value):
+    """kernel-variant selection for tests / measurements (never changes results): see mvx_debug_option in mvtools_amd.h"""
+    _check(lib().mvx_debug_option(name.encode(), int(value)))
 
 
 def _u(v):
@@ -180,11 +197,12 @@ def _torch():
     return torch
 
 
-def arena_frames(n, plane_shapes, device="cuda", zero=True):
-    """n frames x len(plane_shapes) planes (rows, pitch_bytes) carved out of ONE uint8 device allocation (see Super.alloc)."""
+def arena_frames(n, plane_shapes, device="cuda", zero=True, copies=1):
+    """n frames x len(plane_shapes) planes (rows, pitch_bytes) carved out of ONE uint8 device allocation (see Super.alloc).
+    copies > 1: every plane is followed by copies - 1 further slots of the same (256-byte rounded) size: the shadow copies."""
     torch = _torch()
     sizes = [r * p for r, p in plane_shapes]
-    step = [(sz + 255) // 256 * 256 for sz in sizes]
+    step = [(sz + 255) // 256 * 256 * copies for sz in sizes]
     total = n * sum(step)
     big = torch.zeros(total, dtype=torch.uint8, device=device) if zero else torch.empty(total, dtype=torch.uint8, device=device)
     out, o = [], 0
@@ -236,7 +254,7 @@ class Super:
     """mv.Super -- MVSuper.c:140-275."""
 
     def __init__(self, width, height, bits=8, subsampling=(1, 1), gray=False, hpad=None, vpad=None, pel=None, levels=None,
-                 chroma=None, sharp=None, rfilter=None):
+                 chroma=None, sharp=None, rfilter=None, shadow=None):
         a = SuperArgs(width, height, bits, subsampling[0], subsampling[1], int(gray), _u(hpad), _u(vpad), _u(pel), _u(levels),
                       _u(chroma), _u(sharp), _u(rfilter))
         self.h = C.c_void_p()
@@ -248,6 +266,13 @@ class Super:
         self.bps = 1 if bits <= 8 else 2
         self.nplanes = self.info.num_planes
         self.pitch = [((self.info.plane_width[p] * self.bps + 255) // 256) * 256 for p in range(self.nplanes)]
+        # shadow copies (mvx_super_shadow_frames): every plane of a super frame is followed by its 4 / bps - 1 shifted copies, so
+        # that the search only issues dword-aligned loads.  On by default (MVX_SHADOW=0 / shadow=False: the plain layout).
+        if shadow is None:
+            shadow = os.environ.get("MVX_SHADOW", "1") != "0"
+        self.shadow = bool(shadow)
+        self.copies = 1 + (lib().mvx_super_shadow_copies(self.h) if self.shadow else 0)
+        self.shadow_stride = [(self.info.plane_height[p] * self.pitch[p] + 255) // 256 * 256 for p in range(self.nplanes)]
 
     def __del__(self):
         try:
@@ -264,9 +289,32 @@ class Super:
         # is mapped with large page fragments and keeps the TLBs effective).  MVX_ALLOC_ARENA=0 restores per-plane tensors.
         sizes = [self.info.plane_height[p] * self.pitch[p] for p in range(self.nplanes)]
         if os.environ.get("MVX_ALLOC_ARENA", "1") == "0":
-            return [[torch.zeros((self.info.plane_height[p], self.pitch[p]), dtype=torch.uint8, device=device) for p in range(self.nplanes)]
-                    for _ in range(n)]
-        return arena_frames(n, [(self.info.plane_height[p], self.pitch[p]) for p in range(self.nplanes)], device)
+            return [[torch.zeros(self.shadow_stride[p] * self.copies, dtype=torch.uint8, device=device)[:self.info.plane_height[p] * self.pitch[p]].view(self.info.plane_height[p], self.pitch[p])
+                     for p in range(self.nplanes)] for _ in range(n)]
+        return arena_frames(n, [(self.info.plane_height[p], self.pitch[p]) for p in range(self.nplanes)], device, copies=self.copies)
+
+    def from_host(self, planes, device="cuda"):
+        """a super frame given as host arrays (numpy planes of plane_height x >= plane_width samples, e.g. from another
+        implementation) -> device super frame in this object's layout, shadow copies included"""
+        torch = _torch()
+        fr = self.alloc(1, device=device)[0]
+        for p in range(self.nplanes):
+            a = np.ascontiguousarray(planes[p][:, :self.info.plane_width[p]])
+            fr[p][:, :a.shape[1] * a.dtype.itemsize] = torch.from_numpy(a.view(np.uint8).reshape(a.shape[0], -1)).to(device)
+        self._shadows([fr])
+        return fr
+
+    def _shadows(self, out):
+        """fills the shifted copies behind the planes of freshly built super frames"""
+        if not self.shadow:
+            return
+        n = len(out)
+        pl = (C.c_void_p * (3 * n))()
+        for f in range(n):
+            for p in range(self.nplanes):
+                pl[f * 3 + p] = out[f][p].data_ptr()
+        pad = lambda l: (C.c_ssize_t * 3)(*(list(l) + [0] * (3 - len(l))))
+        _check(lib().mvx_super_shadow_frames(self.h, n, pl, pad(self.pitch), pad(self.shadow_stride), _stream()))
 
     def finest(self, super_frames, out=None):
         """mv.Finest(super) -- MVFinest.c: interleaved sub-pel planes of level 0, one output frame per super frame."""
@@ -313,6 +361,7 @@ class Super:
                     pel[f * 3 + p] = pelclip[f][p].data_ptr()
                     dst[f * 3 + p] = out[f][p].data_ptr()
             _check(lib().mvx_super_frames_pelclip(self.h, n, src, _pitches(frames[0]), pel, _pitches(pelclip[0]), mode, dst, _pitches(out[0]), _stream()))
+            self._shadows(out)
             return out
         if out is None:
             out = self.alloc(n, device=frames[0][0].device)
@@ -324,6 +373,7 @@ class Super:
                 dst[f * 3 + p] = out[f][p].data_ptr()
                 assert frames[f][p].stride(0) == frames[0][p].stride(0) and out[f][p].stride(0) == out[0][p].stride(0)
         _check(lib().mvx_super_frames(self.h, n, src, _pitches(frames[0]), dst, _pitches(out[0]), _stream()))
+        self._shadows(out)
         return out
 
 
@@ -346,6 +396,8 @@ class Analyse:
         self.ad = AnalysisData()
         lib().mvx_analyse_get_data(self.h, C.byref(self.ad))
         self.blob_size = lib().mvx_analyse_blob_size(self.h)
+        if sup.shadow:  # super frames from sup.alloc / sup.build carry their shifted copies
+            _check(lib().mvx_analyse_set_ref_shadow(self.h, (C.c_ssize_t * 3)(*(sup.shadow_stride + [0] * (3 - len(sup.shadow_stride))))))
 
     def __del__(self):
         try:
