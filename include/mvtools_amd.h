@@ -89,7 +89,7 @@ int mvx_super_frames(mvx_super *s, int nframes, const void *const *src, const pt
  * samples; mvx_super_shadow_frames fills them from planes that mvx_super_frames has written (same stream).  The copies never
  * leave the device and are not part of the super clip's frame format; a search uses them after mvx_analyse_set_ref_shadow.
  * (no reference counterpart: memory layout only, results are unchanged) */
-int mvx_super_shadow_copies(const mvx_super *s);   /* 4 / bytes per sample - 1 */
+int mvx_super_shadow_copies(const mvx_super *s);   /* copies worth keeping for this format: 1 for 9..16-bit clips, 0 for 8-bit clips */
 int mvx_super_shadow_frames(const mvx_super *s, int nframes, void *const *planes /* [f*3+p] */, const ptrdiff_t pitch[3],
                             const ptrdiff_t copy_stride[3], void *stream);
 
@@ -191,6 +191,9 @@ int mvx_degrain_create(const mvx_degrain_args *args, const mvx_analysis_data *ve
                        const mvx_super *super_clip, const ptrdiff_t src_pitch[3], const ptrdiff_t super_pitch[3],
                        const ptrdiff_t dst_pitch[3], mvx_degrain **out, char *err);
 void mvx_degrain_destroy(mvx_degrain *d);
+
+/* the reference super frames of every job carry shadow copies (see mvx_super_shadow_frames); NULL / zeros: none.  Layout hint only. */
+int mvx_degrain_set_ref_shadow(mvx_degrain *d, const ptrdiff_t copy_stride[3]);
 
 typedef struct mvx_degrain_job {
     const void *src[3];          /* clip frame n */

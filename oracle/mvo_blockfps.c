@@ -49,6 +49,8 @@ static void simple_resize_u8(uint8_t *dst, int dstStride, const uint8_t *src, in
     free(vo); free(vw); free(ho); free(hw); free(work);
 }
 
+void mvo_simple_resize_u8(uint8_t *dst, int dstStride, const uint8_t *src, int srcStride, int dw, int dh, int sw, int sh) { simple_resize_u8(dst, dstStride, src, srcStride, dw, dh, sw, sh); }
+
 /* MaskFun.cpp:83-89 */
 static void byte_occ_mask(uint8_t *m, int occlusion, double occnorm, double gamma) {
     int v = gamma == 1.0 ? VMIN((int)(255 * occlusion * occnorm), 255) : VMIN((int)(255 * pow(occlusion * occnorm, gamma)), 255);

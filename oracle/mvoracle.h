@@ -175,6 +175,7 @@ int mvo_blockfps_frame(const mvo_blockfps *d, int time256, const uint8_t *const 
                        const int refPitch[3], const uint8_t *blobF, const uint8_t *blobB, const uint8_t *const clipL[3], const int clipLPitch[3],
                        const uint8_t *const clipR[3], const int clipRPitch[3], uint8_t *const dst[3], const int dstPitch[3]);
 void mvo_resize_tables(int *offsets, int *weights, int out, int in);
+void mvo_simple_resize_u8(uint8_t *dst, int dstStride, const uint8_t *src, int srcStride, int dw, int dh, int sw, int sh); /* SimpleResize.cpp:62-121 */
 
 /* ---- kernel-level entry points (for pinning against oracle/_ref) ---- */
 unsigned mvo_sad(int w, int h, int bits, const uint8_t *src, intptr_t srcPitch, const uint8_t *ref, intptr_t refPitch);

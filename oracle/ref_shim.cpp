@@ -7,7 +7,10 @@ extern "C" {
 #include "Overlap.h"
 #include "CopyCode.h"
 #include "Luma.h"
+#include "SimpleResize.h"
 }
+// SimpleResize_AVX2.cpp (C++ linkage there)
+void simpleResize_uint8_t_avx2(const SimpleResize *simple, uint8_t *dstp, int dst_stride, const uint8_t *srcp, int src_stride, int horizontal_vectors);
 
 // MVFrame_AVX2.cpp (C++ linkage there)
 void Average2_avx2(uint8_t *pDst, const uint8_t *pSrc1, const uint8_t *pSrc2, intptr_t nPitch, intptr_t nWidth, intptr_t nHeight);
@@ -68,5 +71,17 @@ int ref_refine_avx2(int kind, uint8_t *dst, const uint8_t *src, intptr_t pitch, 
     return -1;
 }
 void ref_average2_avx2(uint8_t *dst, const uint8_t *a, const uint8_t *b, intptr_t pitch, intptr_t w, intptr_t h) { Average2_avx2(dst, a, b, pitch, w, h); }
+
+
+// the reference's AVX2 mask upsizer on caller-supplied offset / weight tables (SimpleResize.cpp's InitTables needs <VSHelper.h>
+// and is not built: the tables come from the oracle's restatement, the resampling arithmetic is the reference's object code)
+void ref_simple_resize_u8_avx2(uint8_t *dst, int dst_stride, const uint8_t *src, int src_stride, int dw, int dh, int sw, int sh,
+                               int *voff, int *vw, int *hoff, int *hw) {
+    SimpleResize s;
+    memset(&s, 0, sizeof(s));
+    s.dst_width = dw; s.dst_height = dh; s.src_width = sw; s.src_height = sh;
+    s.vertical_offsets = voff; s.vertical_weights = vw; s.horizontal_offsets = hoff; s.horizontal_weights = hw;
+    simpleResize_uint8_t_avx2(&s, dst, dst_stride, src, src_stride, 0);
+}
 
 }

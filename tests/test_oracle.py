@@ -163,3 +163,29 @@ def test_golden_fixtures(oracle, case):
     import make_golden
     got = make_golden.run_case(oracle, case["params"])
     assert got == case["expect"], case["name"]
+
+
+def test_mask_upsizer_against_reference_object(oracle):
+    """mv.BlockFPS's bilinear mask upsizer (SimpleResize.cpp:62-121): the oracle's restatement against the reference's own AVX2
+    object code (SimpleResize_AVX2.cpp), fed with the same offset / weight tables (InitTables itself needs <VSHelper.h> and is
+    not built; the table restatement is the one the GPU path is checked against)."""
+    r = _ref()
+    vp = C.c_void_p
+    r.ref_simple_resize_u8_avx2.argtypes = [vp, C.c_int, vp, C.c_int] + [C.c_int] * 4 + [vp] * 4
+    L = oracle.lib()
+    L.mvo_simple_resize_u8.argtypes = [vp, C.c_int, vp, C.c_int] + [C.c_int] * 4
+    L.mvo_resize_tables.argtypes = [vp, vp, C.c_int, C.c_int]
+    rng = np.random.default_rng(3)
+    for (sw, sh, dw, dh) in [(60, 34, 480, 272), (31, 18, 248, 144), (240, 135, 1920, 1080), (16, 9, 64, 36), (40, 30, 43, 33), (12, 7, 200, 113)]:
+        src = rng.integers(0, 256, (sh + 1, sw + 8), dtype=np.uint8)  # (+1 row: the last output rows read offset + 1; +8: vpgatherdd over-read)
+        src[::3, ::5] = 255
+        src[1::4, 2::7] = 0
+        want = np.zeros((dh, dw + 8), np.uint8)
+        got = np.zeros_like(want)
+        L.mvo_simple_resize_u8(got.ctypes.data, got.shape[1], src.ctypes.data, src.shape[1], dw, dh, sw, sh)
+        vo, vw, ho, hw = (np.zeros(dh, np.int32), np.zeros(dh, np.int32), np.zeros(dw + 8, np.int32), np.zeros(dw + 8, np.int32))
+        L.mvo_resize_tables(ho.ctypes.data, hw.ctypes.data, dw, sw)
+        L.mvo_resize_tables(vo.ctypes.data, vw.ctypes.data, dh, sh)
+        hw[:dw] = (hw[:dw] << 16) | (16384 - hw[:dw])  # the AVX2 kernel's packed form of the weights (simpleInit, SimpleResize.cpp:152-155)
+        r.ref_simple_resize_u8_avx2(want.ctypes.data, want.shape[1], src.ctypes.data, src.shape[1], dw, dh, sw, sh, vo.ctypes.data, vw.ctypes.data, ho.ctypes.data, hw.ctypes.data)
+        assert np.array_equal(got[:, :dw], want[:, :dw]), (sw, sh, dw, dh)

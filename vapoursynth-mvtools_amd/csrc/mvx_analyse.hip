@@ -29,6 +29,10 @@ struct MvxDebug {
     int window = 0;    // LDS search-window kernels
     int tile = 0;      // refinement-tile kernel
     int no_wpe2 = 0, no_wpe3 = 0, wpe3_u16 = 0;
+    int fast_cpw = 0;  // lean kernel: chains per workgroup (<= 4 * chains per SIMD)
+    int fast_flags = -1; // lean kernel: MVX_FAST_* bits, -1 = default
+    int pad_runs = -1;   // lean kernel: 1 = pad the job table so that the chains of one reference frame never straddle two workgroups
+    int shadow_planes = 3; // 1 = luma only, 2 = chroma only uses the shadow copies
     int cpw_sync = -1; // barrier interval inside a workgroup (power of two, 0 = none)
     int lds_min = -1;  // LDS floor of the one-chain launches
     int ablate = 0;
@@ -36,7 +40,7 @@ struct MvxDebug {
 static MvxDebug g_dbg;
 extern "C" __attribute__((visibility("default"))) int mvx_debug_option(const char *name, int value) {
     struct { const char *n; int *p; } tab[] = { { "general", &g_dbg.general }, { "fast_wpe", &g_dbg.fast_wpe }, { "cpw1", &g_dbg.cpw1 }, { "window", &g_dbg.window },
-        { "tile", &g_dbg.tile }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min },
+        { "tile", &g_dbg.tile }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "fast_cpw", &g_dbg.fast_cpw }, { "fast_flags", &g_dbg.fast_flags }, { "pad_runs", &g_dbg.pad_runs }, { "shadow_planes", &g_dbg.shadow_planes }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min },
 #ifdef MVX_LAB
         { "ablate", &g_dbg.ablate },
 #endif
@@ -75,6 +79,7 @@ __device__ __forceinline__ void mvx_get_median(GVec &o, const GVec &v1, const GV
 __global__ __launch_bounds__(256) void analyse_divide_kernel(const AParams *Pp, const AJob *jobs) {
     const AParams &P = *Pp;
     unsigned char *blob = jobs[blockIdx.y].blob;
+    if (!blob) return; // padding entry of the job table
     const int valid = ((const int *)blob)[1];
     const int nBlkX = P.lv[0].nBlkX, nBlkY = P.lv[0].nBlkY, nBlk = nBlkX * nBlkY;
     unsigned char *rec0 = blob + P.lv[0].blobOff;
@@ -254,8 +259,9 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_set_ref_shadow
     for (int p = 0; p < 3; p++) {
         const long long v = copy_stride ? (long long)copy_stride[p] : 0;
         if (v < 0 || v % 16) { mvx_set_error("mvx_analyse_set_ref_shadow: copy strides must be non-negative multiples of 16 bytes"); return MVX_E_ARG; }
-        a->P.shadow[p] = v;
+        a->P.shadow[p] = ((p == 0 && !(g_dbg.shadow_planes & 1)) || (p > 0 && !(g_dbg.shadow_planes & 2))) ? 0 : v;
     }
+    std::lock_guard<std::mutex> lk(a->guard.mu);
     if (a->dP) HIP_CHECK(hipMemcpy(a->dP, &a->P, sizeof(AParams), hipMemcpyHostToDevice)); // (synchronous: no launch of this handle is reading it concurrently unless the caller races)
     return MVX_OK;
 }
@@ -265,6 +271,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_blob_size(cons
 extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_analyse *a, int njobs, const mvx_analyse_job *jobs, void *stream) {
     if (njobs <= 0) return MVX_OK;
     hipStream_t st = (hipStream_t)stream;
+    CallGuard::Scope scope(a->guard, st);
     const AParams &P = a->P;
     if (!a->dP) {
         HIP_CHECK(hipGetDevice(&a->device));
@@ -325,13 +332,39 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         while (k > 1 && (!have(k) || (long long)perChain * 4 * k > 160 * 1024)) k--;
         if ((long long)perChain * 4 * k <= 160 * 1024) {
             std::stable_sort(hj.begin(), hj.end(), [](const AJob &x, const AJob &y) { return (uintptr_t)x.ref[0] > (uintptr_t)y.ref[0]; }); // (no reference: last)
-            HIP_CHECK(hipMemcpyAsync(a->dJobs, hj.data(), sizeof(AJob) * njobs, hipMemcpyHostToDevice, st));
+            int cpw = 4 * k;
+            if (g_dbg.fast_cpw > 0 && g_dbg.fast_cpw < cpw) cpw = g_dbg.fast_cpw;
+            // keep the chains that share a reference frame in one workgroup where they fit: a run of the sorted table that would
+            // straddle a workgroup boundary starts a new workgroup instead (the skipped slots become padding entries, blob == NULL)
+            std::vector<AJob> padded;
+            const std::vector<AJob> *table = &hj;
+            if (g_dbg.pad_runs == 1) {
+                AJob none;
+                memset(&none, 0, sizeof(none));
+                for (size_t i = 0; i < hj.size();) {
+                    size_t j = i;
+                    while (j < hj.size() && hj[j].ref[0] == hj[i].ref[0]) j++;
+                    const size_t len = j - i, used = padded.size() % cpw;
+                    if (used && len <= (size_t)cpw && used + len > (size_t)cpw) padded.resize(padded.size() + (cpw - used), none);
+                    padded.insert(padded.end(), hj.begin() + i, hj.begin() + j);
+                    i = j;
+                }
+                table = &padded;
+            }
+            const int ntab = (int)table->size();
+            if ((size_t)ntab > a->jobsCap) {
+                if (a->dJobs) (void)hipFree(a->dJobs);
+                a->jobsCap = (size_t)ntab * 2;
+                HIP_CHECK(hipMalloc((void **)&a->dJobs, a->jobsCap * sizeof(AJob)));
+            }
+            HIP_CHECK(hipMemcpyAsync(a->dJobs, table->data(), sizeof(AJob) * ntab, hipMemcpyHostToDevice, st));
             int syncEvery = k >= 2 ? 256 : 0;
             if (g_dbg.cpw_sync >= 0 && (g_dbg.cpw_sync & (g_dbg.cpw_sync - 1)) == 0) syncEvery = g_dbg.cpw_sync;
-            ALaunch L = { 0, njobs, fNeed, fRow, fRow, fBins, -1, 0, fNeed, simds, 4 * k, k, syncEvery, k, st, a->dP, a->dJobs };
+            const int flags = g_dbg.fast_flags >= 0 ? g_dbg.fast_flags : 0;
+            ALaunch L = { 0, ntab, fNeed, fRow, fRow, fBins, -1, 0, fNeed, simds, cpw, k, syncEvery, k, flags, st, a->dP, a->dJobs };
             int rc = P.bps == 1 ? mvx_analyse_launch_fast_u8(P, L) : mvx_analyse_launch_fast_u16(P, L);
             if (rc == MVX_OK) {
-                if (P.divide) hipLaunchKernelGGL(analyse_divide_kernel, dim3((P.lv[0].nBlkX * P.lv[0].nBlkY + 255) / 256, njobs), dim3(256), 0, st, a->dP, a->dJobs);
+                if (P.divide) hipLaunchKernelGGL(analyse_divide_kernel, dim3((P.lv[0].nBlkX * P.lv[0].nBlkY + 255) / 256, ntab), dim3(256), 0, st, a->dP, a->dJobs);
                 HIP_CHECK(hipGetLastError());
                 return MVX_OK;
             }
@@ -418,7 +451,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
     // 8-bit); with one chain per SIMD it costs 1 %
     int syncEvery = wpe >= 2 ? 256 : 0;
     if (g_dbg.cpw_sync >= 0 && (g_dbg.cpw_sync & (g_dbg.cpw_sync - 1)) == 0) syncEvery = g_dbg.cpw_sync;
-    ALaunch L = { mode, njobs, ldsBytes, ldsRow, ldsHist, histBins, ldsWin, winCap, ldsNeed, simds, cpw, wpe, syncEvery, 0, st, a->dP, a->dJobs };
+    ALaunch L = { mode, njobs, ldsBytes, ldsRow, ldsHist, histBins, ldsWin, winCap, ldsNeed, simds, cpw, wpe, syncEvery, 0, 0, st, a->dP, a->dJobs };
     // the specialised kernels address the reference as "64-bit base + 32-bit offset inside the level's plane set" (all sub-pel planes)
     bool off32 = true;
     for (int i = 0; i < P.nLevels; i++)
@@ -442,6 +475,7 @@ struct mvx_recalculate {
     RParams *dR = nullptr;
     AJob *dJobs = nullptr;
     size_t jobsCap = 0;
+    CallGuard guard;
 };
 
 #define RFAIL(...) do { snprintf(err, MVX_ERRLEN, __VA_ARGS__); mvx_set_error("%s", err); return MVX_E_ARG; } while (0)
@@ -568,6 +602,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_recalculate_blob_size(
 extern "C" __attribute__((visibility("default"))) int mvx_recalculate_frames(mvx_recalculate *r, int njobs, const mvx_recalculate_job *jobs, void *stream) {
     if (njobs <= 0) return MVX_OK;
     hipStream_t st = (hipStream_t)stream;
+    CallGuard::Scope scope(r->guard, st);
     const AParams &P = r->P;
     if (!r->dP) {
         HIP_CHECK(hipMalloc((void **)&r->dP, sizeof(AParams)));

@@ -558,15 +558,19 @@ template <int BPS, int BW> struct FastSearcher {
     __device__ __forceinline__ void search_level(int lvl, int globalX, int globalY, GL_AS const GVec *coarse, int coarseBlkX, int coarseBlkY, int coarseLogPel, int syncEvery) {
         const int l = lane_id();
         const ALevel &L = P.lv[lvl];
-        nBlkX = L.nBlkX; nBlkY = L.nBlkY; pel = L.pel; logPel = L.logPel;
-        chroma = P.chroma;
-        pw = L.pw; ph = L.ph; hpad = L.hpad; vpad = L.vpad;
-        srcY = (gl_u8 *)(J.src[0] + L.off[0]); refY = (gl_u8 *)(J.ref[0] + L.off[0]);
-        srcU = (gl_u8 *)(J.src[1] + L.off[1]); refU = (gl_u8 *)(J.ref[1] + L.off[1]);
-        srcV = (gl_u8 *)(J.src[2] + L.off[2]); refV = (gl_u8 *)(J.ref[2] + L.off[2]);
-        pitchY = (unsigned)P.pitch[0]; pitchC = (unsigned)P.pitch[1]; pstrideY = (unsigned)L.pstride[0]; pstrideC = (unsigned)L.pstride[1];
-        shadowY = (unsigned)P.shadow[0]; shadowC = (unsigned)P.shadow[1];
-        unsigned char *rec = J.blob + L.blobOff;
+        nBlkX = uni(L.nBlkX); nBlkY = uni(L.nBlkY); pel = uni(L.pel); logPel = uni(L.logPel);
+        chroma = uni(P.chroma);
+        pw = uni(L.pw); ph = uni(L.ph); hpad = uni(L.hpad); vpad = uni(L.vpad);
+        // (uni: the job table and the parameter block are read with vector loads -- the kernel also stores to global memory, so the
+        // compiler cannot prove them invariant -- and a value that arrives in a vector register drags every address computed from
+        // it into vector registers too)
+        auto uptr = [](const unsigned char *p) { return (gl_u8 *)(unsigned long long)uni((long long)(unsigned long long)p); };
+        srcY = uptr(J.src[0] + L.off[0]); refY = uptr(J.ref[0] + L.off[0]);
+        srcU = uptr(J.src[1] + L.off[1]); refU = uptr(J.ref[1] + L.off[1]);
+        srcV = uptr(J.src[2] + L.off[2]); refV = uptr(J.ref[2] + L.off[2]);
+        pitchY = (unsigned)uni((int)P.pitch[0]); pitchC = (unsigned)uni((int)P.pitch[1]); pstrideY = (unsigned)uni((int)L.pstride[0]); pstrideC = (unsigned)uni((int)L.pstride[1]);
+        shadowY = (unsigned)uni((int)P.shadow[0]); shadowC = (unsigned)uni((int)P.shadow[1]);
+        unsigned char *rec = (unsigned char *)(unsigned long long)uni((long long)(unsigned long long)(J.blob + L.blobOff));
         vectors = (GL_AS GVec *)(rec + 4);
         if (l == 0) *(int *)rec = 4 + nBlkX * nBlkY * 16; // pobWriteHeaderToArray :413-416
         const int nBlk = nBlkX * nBlkY;
@@ -580,17 +584,19 @@ template <int BPS, int BW> struct FastSearcher {
         // ---- plane scan set-up (doPobSearchMVs :979-1034); tryMany is off, the search types were checked by the host
         if (smallestPlane) { searchType = P.nLevels == 1 ? P.searchType : P.searchTypeCoarse; nSearchParam = P.nLevels == 1 ? P.nPelSearch : P.nSearchParam; }
         else { searchType = lvl == 0 ? P.searchType : P.searchTypeCoarse; nSearchParam = lvl == 0 ? P.nPelSearch : P.nSearchParam; }
-        fieldShift = lvl == 0 ? J.fieldShift : 0;
-        badSAD = P.badSAD; badrange = P.badrange; badcount = 0;
+        searchType = uni(searchType); nSearchParam = uni(nSearchParam);
+        fieldShift = uni(lvl == 0 ? J.fieldShift : 0);
+        badSAD = uni(P.badSAD); badrange = uni(P.badrange); badcount = 0;
         gmvx = pel * globalX; gmvy = pel * globalY + fieldShift;
         int nLambdaLevel = P.lambda / (pel * pel);
         const int nScale = 1 << lvl;
         if (P.plevel == 1) nLambdaLevel = nLambdaLevel * nScale;
         else if (P.plevel == 2) nLambdaLevel = nLambdaLevel * nScale * nScale;
-        penaltyZero = P.pzero; pglobal = P.global ? P.pglobal : P.pzero; penaltyNew = P.pnew; LSAD = P.lsad;
-        const int stepX = P.blkX - P.ovX, stepY = P.blkY - P.ovY;
+        nLambdaLevel = uni(nLambdaLevel);
+        penaltyZero = uni(P.pzero); pglobal = uni(P.global ? P.pglobal : P.pzero); penaltyNew = uni(P.pnew); LSAD = uni((long long)P.lsad);
+        const int stepX = uni(P.blkX - P.ovX), stepY = uni(P.blkY - P.ovY);
         const int hps = hpad >> lvl, vps = vpad >> lvl; // :1091-1092
-        const bool meander = P.meander != 0;
+        const bool meander = uni(P.meander) != 0;
         LDS_AS v4u *rowbuf = (LDS_AS v4u *)(lds + ldsRow);
         pf_setup();
 
@@ -693,15 +699,25 @@ template <int BPS, int BW> struct FastSearcher {
     }
 };
 
-// WPE = chains per SIMD the kernel is built for (register budget), CPW = chains per workgroup: the host orders the job table so
-// that the chains of a workgroup search the same reference frame (shared lines in the CU's L1 and the XCD's L2).
-template <int BPS, int BW, int WPE, int CPW>
-__global__ __launch_bounds__(64 * CPW, WPE) void analyse_fast_kernel(const AParams *Pp, const AJob *jobs, int njobs, int ldsChain, int syncEvery, int ldsRow, int ldsHist, int histBins) {
+// WPE = chains per SIMD the kernel is built for (register budget), MAXCPW = 4 * WPE the largest workgroup it may be launched with;
+// the workgroup's chains (blockDim.x / 64 of them) are consecutive entries of the job table, which the host orders so that the
+// chains of a workgroup search the same reference frame(s) (shared lines in the CU's L1 and the XCD's L2).
+// flags: bit 0 = deal the workgroups out so that consecutive ones (which share reference frames) run on the same XCD.
+#define MVX_FAST_XCD_REMAP 1
+template <int BPS, int BW, int WPE, int MAXCPW>
+__global__ __launch_bounds__(64 * MAXCPW, WPE) void analyse_fast_kernel(const AParams *Pp, const AJob *jobs, int njobs, int ldsChain, int syncEvery, int ldsRow, int ldsHist, int histBins, int flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const AParams &P = *Pp;
-    const int chain = CPW == 1 ? (int)blockIdx.x : uni((int)blockIdx.x * CPW + (int)(threadIdx.x >> 6));
-    if (CPW > 1 && chain >= njobs) return; // (a finished wave no longer counts for the workgroup's barriers)
+    const int cpw = (int)(blockDim.x >> 6);
+    int wg = (int)blockIdx.x;
+    if (flags & MVX_FAST_XCD_REMAP) { // workgroup b runs on XCD b % 8 (round-robin dispatch): give every XCD a contiguous range of the table
+        const int n = (int)gridDim.x, x = wg & 7, slot = wg >> 3;
+        wg = x * (n >> 3) + min(x, n & 7) + slot;
+    }
+    const int chain = uni(wg * cpw + (int)(threadIdx.x >> 6));
+    if (chain >= njobs) return; // (a finished wave no longer counts for the workgroup's barriers)
     const AJob &J = jobs[chain];
+    if (!J.blob) return;        // padding entry of the job table (the host keeps the chains of one reference frame in one workgroup)
     const int l = lane_id();
     int *hdr = (int *)J.blob;
     if (!J.valid) { // gopWriteDefaultToArray GroupOfPlanes.c:150-164, pobWriteDefaultToArray PlaneOfBlocks.cpp:1529-1556
@@ -718,24 +734,25 @@ __global__ __launch_bounds__(64 * CPW, WPE) void analyse_fast_kernel(const APara
     }
     if (l == 0) { hdr[0] = P.blobSize; hdr[1] = 1; } // GroupOfPlanes.c:77-85
     FastSearcher<BPS, BW> S(P, J);
-    S.lds = (lds_u8 *)smem + (CPW == 1 ? 0 : uni((int)(threadIdx.x >> 6)) * ldsChain);
+    S.lds = (lds_u8 *)smem + uni((int)(threadIdx.x >> 6)) * ldsChain;
     S.ldsRow = ldsRow; S.ldsHist = ldsHist; S.histBins = histBins;
     int gx = 0, gy = 0; // zeroMV, MVAnalysisData.h:79
     GL_AS const GVec *coarse = nullptr;
     int cbx = 0, cby = 0, clp = 0;
     for (int lvl = P.nLevels - 1; lvl >= 0; lvl--) {
         if (coarse && P.global) S.estimate_global(coarse, cbx * cby, 8192 * P.lv[lvl + 1].pel, &gx, &gy);
-        S.search_level(lvl, gx, gy, coarse, cbx, cby, clp, CPW > 1 ? syncEvery : 0);
+        S.search_level(lvl, gx, gy, coarse, cbx, cby, clp, cpw > 1 ? syncEvery : 0);
         coarse = S.vectors; cbx = P.lv[lvl].nBlkX; cby = P.lv[lvl].nBlkY; clp = P.lv[lvl].logPel;
     }
 }
 
-template <int BPS, int BW, int WPE, int CPW> static int launch_analyse_fast(const ALaunch &L) {
+template <int BPS, int BW, int WPE, int MAXCPW> static int launch_analyse_fast(const ALaunch &L) {
     const int perChain = (L.ldsNeed + 255) & ~255;
-    const int lds = perChain * CPW;
+    const int cpw = L.cpw < MAXCPW ? L.cpw : MAXCPW;
+    const int lds = perChain * cpw;
     if (lds > 64 * 1024)
-        HIP_CHECK(hipFuncSetAttribute((const void *)analyse_fast_kernel<BPS, BW, WPE, CPW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL((analyse_fast_kernel<BPS, BW, WPE, CPW>), dim3((L.njobs + CPW - 1) / CPW), dim3(64 * CPW), lds, L.st, L.dP, L.dJobs,
-                       L.njobs, perChain, L.syncEvery, L.ldsRow, L.ldsHist, L.histBins);
+        HIP_CHECK(hipFuncSetAttribute((const void *)analyse_fast_kernel<BPS, BW, WPE, MAXCPW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((analyse_fast_kernel<BPS, BW, WPE, MAXCPW>), dim3((L.njobs + cpw - 1) / cpw), dim3(64 * cpw), lds, L.st, L.dP, L.dJobs,
+                       L.njobs, perChain, L.syncEvery, L.ldsRow, L.ldsHist, L.histBins, L.flags);
     return MVX_OK;
 }

@@ -77,6 +77,7 @@ struct mvx_analyse {
     size_t jobsCap = 0;
     int ldsBytes = 0;
     int device = 0;
+    CallGuard guard;
 };
 
 // ------------------------------------------------------------------------------------------------ device
@@ -2291,6 +2292,7 @@ struct ALaunch {
     int wpe;     // chains per SIMD: 2 = the 256-register builds (launches with more chains than SIMDs, geometries that fit)
     int syncEvery; // cpw > 1: workgroup barrier every that many blocks of a row (power of two; a row start always syncs)
     int fast;      // > 0: the lean kernel of the default search (mvx_analyse_fast.h) at that many chains per SIMD
+    int flags;     // lean kernel: MVX_FAST_* bits
     hipStream_t st;
     const AParams *dP;
     const AJob *dJobs;

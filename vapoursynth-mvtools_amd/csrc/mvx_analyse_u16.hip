@@ -5,20 +5,20 @@
 // the lean kernel of the default search (mvx_analyse_fast.h): L.fast = chains per SIMD it is launched at, L.cpw chains per workgroup
 int mvx_analyse_launch_fast_u16(const AParams &P, const ALaunch &L) {
     if (P.blkX == 16) {
-        if (L.fast == 4 && L.cpw == 16) return launch_analyse_fast<2, 16, 4, 16>(L);
-        if (L.fast == 3 && L.cpw == 12) return launch_analyse_fast<2, 16, 3, 12>(L);
-        if (L.fast == 2 && L.cpw == 8) return launch_analyse_fast<2, 16, 2, 8>(L);
-        if (L.fast == 1 && L.cpw == 4) return launch_analyse_fast<2, 16, 1, 4>(L);
+        if (L.fast == 4) return launch_analyse_fast<2, 16, 4, 16>(L);
+        if (L.fast == 3) return launch_analyse_fast<2, 16, 3, 12>(L);
+        if (L.fast == 2) return launch_analyse_fast<2, 16, 2, 8>(L);
+        if (L.fast == 1) return launch_analyse_fast<2, 16, 1, 4>(L);
     }
     if (P.blkX == 8) {
-        if (L.fast == 4 && L.cpw == 16) return launch_analyse_fast<2, 8, 4, 16>(L);
-        if (L.fast == 2 && L.cpw == 8) return launch_analyse_fast<2, 8, 2, 8>(L);
-        if (L.fast == 1 && L.cpw == 4) return launch_analyse_fast<2, 8, 1, 4>(L);
+        if (L.fast == 4) return launch_analyse_fast<2, 8, 4, 16>(L);
+        if (L.fast == 2) return launch_analyse_fast<2, 8, 2, 8>(L);
+        if (L.fast == 1) return launch_analyse_fast<2, 8, 1, 4>(L);
     }
     if (P.blkX == 32) {
-        if (L.fast == 3 && L.cpw == 12) return launch_analyse_fast<2, 32, 3, 12>(L);
-        if (L.fast == 2 && L.cpw == 8) return launch_analyse_fast<2, 32, 2, 8>(L);
-        if (L.fast == 1 && L.cpw == 4) return launch_analyse_fast<2, 32, 1, 4>(L);
+        if (L.fast == 3) return launch_analyse_fast<2, 32, 3, 12>(L);
+        if (L.fast == 2) return launch_analyse_fast<2, 32, 2, 8>(L);
+        if (L.fast == 1) return launch_analyse_fast<2, 32, 1, 4>(L);
     }
     return 1;
 }

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -22,6 +23,27 @@ void mvx_divided_data(const mvx_analysis_data *in, mvx_analysis_data *out);
             return MVX_E_DEVICE;                                                                  \
         }                                                                                         \
     } while (0)
+
+// ---- thread / stream safety of the *_frames entry points.  A handle owns device scratch (job tables, plans, masks) that every
+// call overwrites.  VapourSynth calls a filter's getFrame concurrently (fmParallel), possibly with different streams, so each
+// call (a) holds the handle's mutex while it enqueues, and (b) makes its stream wait for the event the previous call on the same
+// handle recorded after its last kernel -- so the scratch is never rewritten (or freed: hipFree synchronises the device) while
+// an earlier call's kernels still read it.  Calls on one handle therefore run back to back on the GPU; calls on different
+// handles overlap.  Declare one CallGuard per scratch owner and open a Scope at the top of the entry point.
+struct CallGuard {
+    std::mutex mu;
+    hipEvent_t ev = nullptr;
+    ~CallGuard() { if (ev) (void)hipEventDestroy(ev); }
+    struct Scope {
+        CallGuard &g; hipStream_t st;
+        Scope(CallGuard &g_, hipStream_t s) : g(g_), st(s) { g.mu.lock(); if (g.ev) (void)hipStreamWaitEvent(st, g.ev, 0); }
+        ~Scope() {
+            if (!g.ev) (void)hipEventCreateWithFlags(&g.ev, hipEventDisableTiming);
+            if (g.ev) (void)hipEventRecord(g.ev, st);
+            g.mu.unlock();
+        }
+    };
+};
 
 // ---- pyramid geometry (MVFrame.cpp:1209-1247) -- host only
 int mvx_plane_height_luma(int src_height, int level, int yRatioUV, int vpad);

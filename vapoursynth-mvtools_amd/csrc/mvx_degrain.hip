@@ -85,6 +85,7 @@ struct PlaneG { // one plane of the clip / of level 0 of the super frame
     int thIdx;               // 0 luma threshold, 1 chroma threshold
     int process;
     int limit;
+    long long shadow;        // byte distance between the shifted copies of a super plane (mvx_super_shadow_frames), 0 = none
 };
 
 struct DGParams {
@@ -176,6 +177,10 @@ __global__ __launch_bounds__(256) void degrain_plan_kernel(const DGParams *Pp, c
             if (us[r]) { // MVDegrains.h:192-200 useBlock; block origin Fakery.c:31-32
                 const int blx = ((bx * P.pl[0].stepX) << P.logPel) + vx[r], bly = ((by * P.pl[0].stepY) << P.logPel) + vy[r];
                 rec.off[r] = sup_offset(g, P.pel, P.logPel, P.bps, c ? blx >> g.subX : blx, c ? bly >> g.subY : bly);
+                if (g.shadow) { // the copy in which this block starts at a dword-aligned address (same samples; see mvx_super_shadow_frames)
+                    const unsigned k = P.bps == 2 ? (rec.off[r] >> 1) & 1u : rec.off[r] & 3u;
+                    rec.off[r] = (rec.off[r] & ~3u) + k * (unsigned)g.shadow;
+                }
                 W[r] = degrain_weight(P.thSAD[g.thIdx], sad[r]);
             }
             WSum += W[r];
@@ -487,6 +492,7 @@ __global__ __launch_bounds__(256) void compensate_kernel(const DGParams *Pp, con
 // ------------------------------------------------------------------------------------------------ host objects
 
 struct DGCommon {
+    CallGuard guard;
     DGParams P;
     DGParams *dP = nullptr;
     DGJob *dJobs = nullptr;
@@ -635,6 +641,17 @@ extern "C" __attribute__((visibility("default"))) int mvx_degrain_create(const m
 
 extern "C" __attribute__((visibility("default"))) void mvx_degrain_destroy(mvx_degrain *d) { delete d; }
 
+extern "C" __attribute__((visibility("default"))) int mvx_degrain_set_ref_shadow(mvx_degrain *d, const ptrdiff_t copy_stride[3]) {
+    std::lock_guard<std::mutex> lk(d->guard.mu);
+    for (int p = 0; p < 3; p++) {
+        const long long v = copy_stride ? (long long)copy_stride[p] : 0;
+        if (v < 0 || v % 16 || 3 * v + (long long)d->P.pl[p].supPlaneStride * d->P.pel * d->P.pel >= 0xffffffffLL) { mvx_set_error("mvx_degrain_set_ref_shadow: bad copy stride"); return MVX_E_ARG; }
+        d->P.pl[p].shadow = v;
+    }
+    if (d->dP) HIP_CHECK(hipMemcpy(d->dP, &d->P, sizeof(DGParams), hipMemcpyHostToDevice));
+    return MVX_OK;
+}
+
 template <typename T> static void launch_degrain(int nr, dim3 grid, hipStream_t st, const DGParams *dP, const DGJob *dJ, const PlanRec *plan) {
 #define DG(N) hipLaunchKernelGGL((degrain_kernel<T, N>), grid, dim3(256), 0, st, dP, dJ, plan)
     switch (nr) { case 2: DG(2); break; case 4: DG(4); break; case 6: DG(6); break; case 8: DG(8); break; case 10: DG(10); break; default: DG(12); break; }
@@ -658,6 +675,7 @@ template <typename T> static void launch_degrain_cells(int nr, int W, dim3 grid,
 extern "C" __attribute__((visibility("default"))) int mvx_degrain_frames(mvx_degrain *d, int nframes, const mvx_degrain_job *jobs, void *stream) {
     if (nframes <= 0) return MVX_OK;
     hipStream_t st = (hipStream_t)stream;
+    CallGuard::Scope scope(d->guard, st);
     int rc = finish_common(d);
     if (rc) return rc;
     const DGParams &P = d->P;
@@ -736,6 +754,7 @@ extern "C" __attribute__((visibility("default"))) void mvx_compensate_destroy(mv
 extern "C" __attribute__((visibility("default"))) int mvx_compensate_frames(mvx_compensate *c, int nframes, const mvx_compensate_job *jobs, void *stream) {
     if (nframes <= 0) return MVX_OK;
     hipStream_t st = (hipStream_t)stream;
+    CallGuard::Scope scope(c->guard, st);
     int rc = finish_common(c);
     if (rc) return rc;
     const DGParams &P = c->P;
@@ -1097,6 +1116,7 @@ extern "C" __attribute__((visibility("default"))) void mvx_blockfps_map(const mv
 extern "C" __attribute__((visibility("default"))) int mvx_blockfps_frames(mvx_blockfps *b, int nframes, const mvx_blockfps_job *jobs, void *stream) {
     if (nframes <= 0) return MVX_OK;
     hipStream_t st = (hipStream_t)stream;
+    CallGuard::Scope scope(b->guard, st);
     int rc = finish_common(b);
     if (rc) return rc;
     const DGParams &P = b->P;

@@ -324,6 +324,7 @@ struct PtrScratch { // per-thread device scratch for the frame-pointer tables
 };
 static thread_local PtrScratch g_scratch[3];
 
+static thread_local CallGuard g_scratch_guard; // (per thread like the tables: a thread that alternates streams must not rewrite a table an earlier launch still reads)
 static int upload_ptrs(int which, const void *const *host, size_t n, hipStream_t st, void **dev_out) {
     PtrScratch &s = g_scratch[which];
     int dev = 0;
@@ -406,7 +407,7 @@ static int super_frames_impl(mvx_super *s, int nframes, const void *const *src, 
 // buffer shifted left by 1 .. n samples (copy k, byte i = plane byte i + k * bps).  A block at a sample position x with
 // x % (4 / bps) == k is then read from copy k at x - k: same samples, dword-aligned address.  mvx_analyse_set_ref_shadow tells
 // a search where the copies are.
-struct ShadowArgs { void *const *planes; long long size[3], stride[3]; int nplanes, bps; };
+struct ShadowArgs { void *const *planes; long long size[3], stride[3]; int nplanes, bps, ncopies; };
 __global__ __launch_bounds__(256) void super_shadow_kernel(ShadowArgs A) {
     const int fp = blockIdx.y, p = fp % 3;
     if (p >= A.nplanes) return;
@@ -415,8 +416,8 @@ __global__ __launch_bounds__(256) void super_shadow_kernel(ShadowArgs A) {
     unsigned char *base = (unsigned char *)A.planes[fp];
     const uint4 a = *(const uint4 *)(base + i);
     const unsigned b = i + 16 < A.size[p] ? *(const unsigned *)(base + i + 16) : 0u;
-    const int n = 4 / A.bps;
-    for (int k = 1; k < n; k++) {
+    const int n = A.ncopies;
+    for (int k = 1; k <= n; k++) {
         const unsigned sh = 8u * k * A.bps;
         uint4 o;
         o.x = __builtin_amdgcn_alignbit(a.y, a.x, sh); o.y = __builtin_amdgcn_alignbit(a.z, a.y, sh);
@@ -424,15 +425,20 @@ __global__ __launch_bounds__(256) void super_shadow_kernel(ShadowArgs A) {
         *(uint4 *)(base + k * A.stride[p] + i) = o;
     }
 }
-extern "C" __attribute__((visibility("default"))) int mvx_super_shadow_copies(const mvx_super *s) { return 4 / (s->info.bits <= 8 ? 1 : 2) - 1; }
+// 16-bit clips: one copy (shift by one sample).  8-bit clips: none -- measured (r2, 1080p Degrain1): the three copies an 8-bit plane
+// would need quadruple the cache footprint of every chain and cost more than the aligned loads save (1250-1340 fps with copies,
+// 2005 without); the search then simply loads from the plane itself.
+extern "C" __attribute__((visibility("default"))) int mvx_super_shadow_copies(const mvx_super *s) { return s->info.bits <= 8 ? 0 : 1; }
 extern "C" __attribute__((visibility("default"))) int mvx_super_shadow_frames(const mvx_super *s, int nframes, void *const *planes, const ptrdiff_t pitch[3],
                                                                               const ptrdiff_t copy_stride[3], void *stream) {
     if (nframes <= 0) return MVX_OK;
     const mvx_super_info &si = s->info;
     hipStream_t st = (hipStream_t)stream;
+    CallGuard::Scope scope(g_scratch_guard, st);
     ShadowArgs A;
     memset(&A, 0, sizeof(A));
-    A.nplanes = si.num_planes; A.bps = si.bits <= 8 ? 1 : 2;
+    A.nplanes = si.num_planes; A.bps = si.bits <= 8 ? 1 : 2; A.ncopies = mvx_super_shadow_copies(s);
+    if (A.ncopies == 0) return MVX_OK;
     long long maxsize = 0;
     for (int p = 0; p < si.num_planes; p++) {
         A.size[p] = (long long)si.plane_height[p] * pitch[p]; A.stride[p] = copy_stride[p];
@@ -487,6 +493,7 @@ static int super_frames_impl(mvx_super *s, int nframes, const void *const *src, 
     if (nframes <= 0) return MVX_OK;
     const mvx_super_info &si = s->info;
     hipStream_t st = (hipStream_t)stream;
+    CallGuard::Scope scope(g_scratch_guard, st);
     for (int p = 0; p < si.num_planes; p++)
         if (dst_pitch[p] % 16) { mvx_set_error("mvx_super_frames: dst pitch must be a multiple of 16 bytes"); return MVX_E_ARG; }
     void *dsrc = nullptr, *ddst = nullptr;

@@ -141,6 +141,7 @@ def lib():
         L.mvx_degrain_create.argtypes = [P(DegrainArgs), P(AnalysisData), C.c_void_p, P(C.c_ssize_t), P(C.c_ssize_t), P(C.c_ssize_t),
                                          P(C.c_void_p), C.c_char_p]
         L.mvx_degrain_destroy.argtypes = [C.c_void_p]
+        L.mvx_degrain_set_ref_shadow.argtypes = [C.c_void_p, P(C.c_ssize_t)]
         L.mvx_degrain_frames.argtypes = [C.c_void_p, C.c_int, P(DegrainJob), C.c_void_p]
         L.mvx_compensate_create.argtypes = [P(CompensateArgs), P(AnalysisData), C.c_void_p, P(C.c_ssize_t), P(C.c_ssize_t),
                                             P(C.c_void_p), C.c_char_p]
@@ -167,7 +168,7 @@ def lib():
         # developer / test switches: the library itself never reads the environment (mvx_debug_option is its one hook);
         # this TEST binding forwards the MVX_* variables the tools/ scripts use
         for env, opt in (("MVX_GENERAL", "general"), ("MVX_FAST_WPE", "fast_wpe"), ("MVX_WINDOW", "window"), ("MVX_TILE", "tile"), ("MVX_NO_WPE2", "no_wpe2"),
-                         ("MVX_NO_WPE3", "no_wpe3"), ("MVX_WPE3", "wpe3_u16"), ("MVX_CPW_SYNC", "cpw_sync"), ("MVX_LDS_MIN", "lds_min"), ("MVX_ABLATE", "ablate")):
+                         ("MVX_NO_WPE3", "no_wpe3"), ("MVX_WPE3", "wpe3_u16"), ("MVX_FAST_CPW", "fast_cpw"), ("MVX_FAST_FLAGS", "fast_flags"), ("MVX_PAD_RUNS", "pad_runs"), ("MVX_SHADOW_PLANES", "shadow_planes"), ("MVX_CPW_SYNC", "cpw_sync"), ("MVX_LDS_MIN", "lds_min"), ("MVX_ABLATE", "ablate")):
             if os.environ.get(env) is not None:
                 L.mvx_debug_option(opt.encode(), int(os.environ[env]))
         if os.environ.get("MVX_CPW") == "1":
@@ -270,8 +271,8 @@ class Super:
         # that the search only issues dword-aligned loads.  On by default (MVX_SHADOW=0 / shadow=False: the plain layout).
         if shadow is None:
             shadow = os.environ.get("MVX_SHADOW", "1") != "0"
-        self.shadow = bool(shadow)
-        self.copies = 1 + (lib().mvx_super_shadow_copies(self.h) if self.shadow else 0)
+        self.copies = 1 + (lib().mvx_super_shadow_copies(self.h) if shadow else 0)
+        self.shadow = self.copies > 1
         self.shadow_stride = [(self.info.plane_height[p] * self.pitch[p] + 255) // 256 * 256 for p in range(self.nplanes)]
 
     def __del__(self):
@@ -444,6 +445,8 @@ class Degrain:
         err = C.create_string_buffer(ERRLEN)
         _check(lib().mvx_degrain_create(C.byref(a), C.byref(ad), sup.h, pad(src_pitch), pad(sup.pitch), pad(dst_pitch), C.byref(self.h), err), err)
         self.src_pitch, self.dst_pitch = list(src_pitch), list(dst_pitch)
+        if sup.shadow and os.environ.get("MVX_DEGRAIN_SHADOW", "1") != "0":
+            _check(lib().mvx_degrain_set_ref_shadow(self.h, pad(sup.shadow_stride)))
 
     def __del__(self):
         try:
