@@ -28,8 +28,10 @@ for _p in (os.path.join(ROOT, "vapoursynth-mvtools_amd"), os.path.join(ROOT, "te
 CONFIGS = {
     # name: (width, height, bits, radius, analyse kwargs, super kwargs, default batch, BASELINE.json config string)
     "cfg1": (640, 360, 8, 1, dict(blksize=8), dict(pel=1), 1536, "640x360 YUV420P8 Degrain1 blksize=8 pel=1"),
-    "cfg2": (1920, 1080, 8, 1, dict(blksize=8, overlap=4, search=4), dict(pel=2), 1536, "1080p YUV420P8 Degrain1 blksize=8 overlap=4 pel=2 search=4"),
-    "cfg3": (3840, 2160, 16, 3, dict(blksize=16, overlap=8), dict(pel=2), 336, "4K YUV420P16 Degrain3 blksize=16 overlap=8 pel=2"),
+    # (default batches: the number of chains = 2 * radius * batch decides how many chains share a SIMD -- cfg3: 3072 chains = three per
+    # SIMD, cfg2: 4096 = four per SIMD, cfg5: 2016 = two per SIMD, all its 1 GB super frames leave room for)
+    "cfg2": (1920, 1080, 8, 1, dict(blksize=8, overlap=4, search=4), dict(pel=2), 2048, "1080p YUV420P8 Degrain1 blksize=8 overlap=4 pel=2 search=4"),
+    "cfg3": (3840, 2160, 16, 3, dict(blksize=16, overlap=8), dict(pel=2), 512, "4K YUV420P16 Degrain3 blksize=16 overlap=8 pel=2"),
     "cfg5": (7680, 4320, 16, 6, dict(blksize=32, overlap=16), dict(pel=2), 168, "8K YUV420P16 Degrain6 blksize=32 overlap=16 pel=2"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
@@ -295,7 +297,7 @@ def main():
             with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as f:
                 t = json.load(f)
             if t.get("config") == "%s batch %d" % (args.config, B):
-                traffic = [v["hbm_bytes_per_dispatch_corrected"] for k, v in t["kernels"].items() if "analyse_kernel" in k][0]
+                traffic = [v["hbm_bytes_per_dispatch_corrected"] for k, v in t["kernels"].items() if "analyse" in k and "divide" not in k][0]
         except Exception:
             traffic = None
         out = {
@@ -306,7 +308,7 @@ def main():
             "config": {"workload": cfg[7], "frames_per_step_per_gpu": B, "chains_per_step_per_gpu": 2 * cfg[3] * B,
                        "sharding": "frame ranges, no collective", "batches_in_flight": len(pipes),
                        "rank0_output_frames": list(plan.out), "rank0_held_frames": list(plan.held)},
-            "roofline": {"bound": "hbm", "kernel": "analyse_kernel (one launch = %d chains)" % chains, "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "analyse_fast_kernel (the motion search; one launch = %d chains)" % chains, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_chain * chains, "avg_launch_ms": avg_launch_ms,
                          "search_share_of_step": sum(search_ms) / (dt * 1e3)},

@@ -294,7 +294,11 @@ int mvx_debug_option(const char *name, int value);
 
 /* ---- small device-memory helpers so that a C host (e.g. the VapourSynth shell) needs no HIP headers */
 void *mvx_dev_alloc(size_t bytes);            /* zero-filled */
-void mvx_dev_free(void *p);
+void *mvx_dev_alloc_uninit(size_t bytes);     /* contents undefined (scratch, upload targets) */
+void mvx_dev_free(void *p);                   /* goes to a size-keyed free list (no device synchronisation); wait for the work that uses p first */
+void mvx_dev_pool_limit(size_t bytes);        /* bytes the free list may hold (default 24 GiB) */
+void *mvx_stream_create(void);                /* a non-blocking stream for the `stream` arguments; NULL on failure */
+void mvx_stream_destroy(void *stream);
 int mvx_copy_to_device(void *dst, ptrdiff_t dst_pitch, const void *src_host, ptrdiff_t src_pitch, size_t row_bytes, size_t rows, void *stream);
 int mvx_copy_to_host(void *dst_host, ptrdiff_t dst_pitch, const void *src, ptrdiff_t src_pitch, size_t row_bytes, size_t rows, void *stream);
 int mvx_stream_sync(void *stream);

@@ -171,6 +171,17 @@ ANALYSE_CASES = [
     (256, 144, 16, {}, dict(blksize=8, overlap=4, dct=9, _lumaramp=40)),
     (256, 144, 8, {}, dict(blksize=4, overlap=2, dct=10, _lumaramp=40)),
     (256, 144, 8, {}, dict(blksize=32, overlap=16, dct=5, chroma=0)),
+    # every remaining block size of MVAnalyse.c:412 (generic kernel: run-time geometry)
+    (512, 384, 8, {}, dict(blksize=64, overlap=32)),
+    (512, 384, 16, {}, dict(blksize=64, blksizev=32, overlap=32, overlapv=16)),
+    (640, 512, 8, {}, dict(blksize=128, overlap=64)),
+    (640, 512, 16, {}, dict(blksize=128, blksizev=64, overlap=0)),
+    (256, 144, 8, {}, dict(blksize=32, blksizev=16, overlap=16, overlapv=8)),
+    (256, 144, 16, {}, dict(blksize=32, blksizev=16, overlap=0)),
+    (256, 144, 8, {}, dict(blksize=16, blksizev=2, overlap=8, overlapv=0)),
+    (256, 144, 16, {}, dict(blksize=16, blksizev=2, overlap=0, overlapv=0)),
+    (256, 144, 8, {}, dict(blksize=32, overlap=16)),                       # 8-bit 32x32: generic kernel (the lean kernel has no 8-bit 32x32 build)
+    (320, 192, 8, {}, dict(blksize=64, overlap=32, _noise=14, badsad=500)),  # rescue with big blocks
 ]
 
 
@@ -244,6 +255,13 @@ DEGRAIN_CASES = [
     (128, 96, 8, 1, {}, dict(blksize=8, overlap=4), dict(plane=3, thsadc=150)),
     (128, 96, 8, 1, {}, dict(blksize=8, overlap=4), dict(thsad=100, thscd1=200, thscd2=60)),
     (128, 96, 8, 1, {}, dict(blksize=8, overlap=4), dict(thscd1=20, thscd2=10)),  # scene change: refs unusable
+    (192, 112, 8, 4, {}, dict(blksize=16, overlap=8), {}),            # Degrain4 / Degrain5 (MVDegrains.cpp:432-469)
+    (192, 112, 16, 5, {}, dict(blksize=8, overlap=4), {}),
+    (512, 384, 8, 1, {}, dict(blksize=64, overlap=32), {}),           # big blocks: the per-sample gather
+    (512, 384, 16, 2, {}, dict(blksize=64, blksizev=32, overlap=32, overlapv=16), {}),
+    (640, 512, 8, 1, {}, dict(blksize=128, overlap=64), {}),
+    (256, 144, 16, 1, {}, dict(blksize=32, blksizev=16, overlap=0), {}),
+    (256, 144, 8, 1, {}, dict(blksize=16, blksizev=2, overlap=8, overlapv=0), {}),
 ]
 
 

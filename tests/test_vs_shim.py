@@ -374,3 +374,25 @@ def test_shell_finest_and_scdetection(oracle, tmp_path):
     for n in range(nf):
         for p in range(3):
             assert np.array_equal(passthrough[n][p], frames[n][p])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits,pipeline,extra", [(8, "degrain1", ("a.blksize=8", "a.overlap=4")), (16, "degrain3", ("a.blksize=16", "a.overlap=8")), (16, "analyse", ("a.blksize=16", "a.overlap=8"))])
+def test_concurrent_requests_are_batched_and_bit_identical(tmp_path, bits, pipeline, extra):
+    """fmParallel (src/MVAnalyse.c:634): 64 worker threads request frames at once.  The shell's combining queue turns the concurrent
+    getFrame calls of one Analyse instance into a single search launch; the clip that comes out must be the one the frame-by-frame
+    evaluation gives (which the other tests compare with the oracle)."""
+    w, h, n = 192, 112, 70
+    frames = pl.moving_clip(w, h, bits, n, seed=17, noise=3)
+    src, seq, par = str(tmp_path / "in.raw"), str(tmp_path / "seq.raw"), str(tmp_path / "par.raw")
+    _write_clip(src, frames)
+    assert "DONE" in host("run", pipeline, src, w, h, bits, n, seq, *extra)
+    env = dict(os.environ, MVX_VS_STATS="1", MVX_VS_BATCH_WAIT_US="20000")
+    r = subprocess.run([HOST, PLUGIN, "run", pipeline, src, w, h, bits, n, par] + list(extra) + ["x.threads=64"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "DONE" in r.stdout, r.stdout + r.stderr
+    assert open(seq, "rb").read() == open(par, "rb").read()
+    stats = [l for l in r.stderr.splitlines() if l.startswith("mvtools_vs: Analyse")]
+    assert stats, r.stderr
+    for l in stats:  # every Analyse instance served its 70 frames in a handful of launches, the largest with most of the 64 requests
+        kv = dict(t.split("=") for t in l.split()[2:])
+        assert int(kv["jobs"]) == n and int(kv["launches"]) <= 8 and int(kv["largest_batch"]) >= 32, l

@@ -24,10 +24,11 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             k = r['Kernel_Name']
             if r['Counter_Name'] != c: continue
             acc[k][c] += float(r['Counter_Value']); n[(k, c)] += 1
-res = {"config": "cfg3 batch 336", "command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace -- python bench.py --no-cpu --steps 1 --warmup 0 (one pass per counter)",
+bench = json.load(open(sys.argv[1].replace("_pmc_traffic.json", "_bench_default.json")))
+res = {"config": "cfg3 batch %d" % bench["config"]["frames_per_step_per_gpu"], "command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace -- python bench.py --no-cpu --steps 1 --warmup 0 (one pass per counter)",
        "correction": "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (MI355X_MICROARCH.md: gfx950 FETCH_SIZE counts 64 B per 128-B request for 16 B/lane reads)", "kernels": {}}
 for k in acc:
-    if not any(t in k for t in ("analyse_kernel", "degrain", "super_")): continue
+    if not any(t in k for t in ("analyse", "degrain", "super_")): continue
     d = n[(k, "FETCH_SIZE")] or 1
     fs = acc[k]["FETCH_SIZE"] / d; ws = acc[k]["WRITE_SIZE"] / (n[(k, "WRITE_SIZE")] or 1)
     res["kernels"][k.split('(')[0]] = {"dispatches": d, "FETCH_SIZE_KB_per_dispatch": fs, "WRITE_SIZE_KB_per_dispatch": ws,

@@ -358,9 +358,15 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
                 HIP_CHECK(hipMalloc((void **)&a->dJobs, a->jobsCap * sizeof(AJob)));
             }
             HIP_CHECK(hipMemcpyAsync(a->dJobs, table->data(), sizeof(AJob) * ntab, hipMemcpyHostToDevice, st));
-            int syncEvery = k >= 2 ? 256 : 0;
+            // Barrier between the chains of a workgroup every that many blocks of a row.  16-bit clips (shadow layout: the kernel is
+            // bound by what the XCD's L2 must re-fetch): the chains that share a reference frame have to stay within a few blocks of
+            // each other to share its lines -- measured r2 at three chains per SIMD (4K16): 256 blocks 337 fps, 128: 378, 16-64: 389-390,
+            // 8: 388, 4: 383; 8K16 at two per SIMD: 256: 59.5, 16: 64.6.  8-bit clips (plain layout): 256 stays best (1080p: 2005 against
+            // 1953-1970 with 16-64).
+            int syncEvery = k >= 2 ? (P.bps == 2 ? 32 : 256) : 0;
             if (g_dbg.cpw_sync >= 0 && (g_dbg.cpw_sync & (g_dbg.cpw_sync - 1)) == 0) syncEvery = g_dbg.cpw_sync;
-            const int flags = g_dbg.fast_flags >= 0 ? g_dbg.fast_flags : 0;
+            // XCD-contiguous workgroup order: neighbours in the (reference-sorted) job table share an L2 (+0.5 %, 4K16)
+            const int flags = g_dbg.fast_flags >= 0 ? g_dbg.fast_flags : MVX_FAST_XCD_REMAP;
             ALaunch L = { 0, ntab, fNeed, fRow, fRow, fBins, -1, 0, fNeed, simds, cpw, k, syncEvery, k, flags, st, a->dP, a->dJobs };
             int rc = P.bps == 1 ? mvx_analyse_launch_fast_u8(P, L) : mvx_analyse_launch_fast_u16(P, L);
             if (rc == MVX_OK) {

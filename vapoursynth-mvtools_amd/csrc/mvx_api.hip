@@ -12,13 +12,85 @@ extern "C" __attribute__((visibility("default"))) int mvx_device_count(void) {
 
 extern "C" __attribute__((visibility("default"))) int mvx_set_device(int ordinal) { HIP_CHECK(hipSetDevice(ordinal)); return MVX_OK; }
 
-extern "C" __attribute__((visibility("default"))) void *mvx_dev_alloc(size_t bytes) {
-    void *p = nullptr;
-    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { mvx_set_error("hipMalloc(%zu) failed", bytes); return nullptr; }
-    if (hipMemset(p, 0, bytes) != hipSuccess) { (void)hipFree(p); mvx_set_error("hipMemset failed"); return nullptr; }
+// ---- device memory for hosts without HIP headers.  hipMalloc / hipFree are slow and hipFree synchronises the whole device, which
+// would serialise every concurrently running filter of a frame server; released buffers therefore go to a free list keyed by their
+// exact size (a frame server asks for the same few sizes over and over) and are handed out again.  The list is bounded
+// (mvx_dev_pool_limit, default 24 GiB); beyond it buffers are really freed.
+#include <map>
+#include <unordered_map>
+static std::mutex g_pool_mu;
+static std::multimap<size_t, void *> g_pool_free;
+static std::unordered_map<void *, size_t> g_pool_size;
+static size_t g_pool_held = 0, g_pool_limit = (size_t)24 << 30;
+
+static void *pool_take(size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_pool_free.find(bytes);
+    if (it == g_pool_free.end()) return nullptr;
+    void *p = it->second;
+    g_pool_free.erase(it);
+    g_pool_held -= bytes;
     return p;
 }
-extern "C" __attribute__((visibility("default"))) void mvx_dev_free(void *p) { if (p) (void)hipFree(p); }
+extern "C" __attribute__((visibility("default"))) void *mvx_dev_alloc_uninit(size_t bytes) {
+    if (!bytes) bytes = 1;
+    void *p = pool_take(bytes);
+    if (p) return p;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        { // give the pool back and retry once
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            for (auto &e : g_pool_free) { (void)hipFree(e.second); g_pool_size.erase(e.second); }
+            g_pool_free.clear(); g_pool_held = 0;
+        }
+        if (hipMalloc(&p, bytes) != hipSuccess) { mvx_set_error("hipMalloc(%zu) failed", bytes); return nullptr; }
+    }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool_size[p] = bytes;
+    return p;
+}
+extern "C" __attribute__((visibility("default"))) void *mvx_dev_alloc(size_t bytes) { // zero-filled
+    void *p = mvx_dev_alloc_uninit(bytes);
+    if (!p) return nullptr;
+    // (on the legacy default stream and waited for: the caller may touch the buffer from any stream next)
+    if (hipMemsetAsync(p, 0, bytes ? bytes : 1, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { mvx_set_error("hipMemset failed"); return nullptr; }
+    return p;
+}
+// The caller must have waited for the work that uses the buffer (every host in this repository synchronises its stream before it
+// releases per-frame buffers).
+extern "C" __attribute__((visibility("default"))) void mvx_dev_free(void *p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_pool_size.find(p);
+        if (it != g_pool_size.end() && g_pool_held + it->second <= g_pool_limit) {
+            g_pool_free.emplace(it->second, p);
+            g_pool_held += it->second;
+            return;
+        }
+        if (it != g_pool_size.end()) g_pool_size.erase(it);
+    }
+    (void)hipFree(p);
+}
+extern "C" __attribute__((visibility("default"))) void mvx_dev_pool_limit(size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool_limit = bytes;
+    while (g_pool_held > g_pool_limit && !g_pool_free.empty()) {
+        auto it = std::prev(g_pool_free.end());
+        g_pool_held -= it->first;
+        g_pool_size.erase(it->second);
+        (void)hipFree(it->second);
+        g_pool_free.erase(it);
+    }
+}
+
+// a stream of its own per filter instance lets the launches of different instances overlap (non-blocking: no implicit
+// synchronisation with the default stream -- the caller orders its uploads with mvx_stream_sync)
+extern "C" __attribute__((visibility("default"))) void *mvx_stream_create(void) {
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { mvx_set_error("hipStreamCreate failed"); return nullptr; }
+    return (void *)s;
+}
+extern "C" __attribute__((visibility("default"))) void mvx_stream_destroy(void *s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }
 
 extern "C" __attribute__((visibility("default"))) int mvx_copy_to_device(void *dst, ptrdiff_t dp, const void *src, ptrdiff_t sp, size_t row_bytes, size_t rows, void *stream) {
     HIP_CHECK(hipMemcpy2DAsync(dst, dp, src, sp, row_bytes, rows, hipMemcpyHostToDevice, (hipStream_t)stream));

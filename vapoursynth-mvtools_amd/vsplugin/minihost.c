@@ -1,6 +1,8 @@
 /*
- * minihost.c -- a minimal, single-threaded VapourSynth-API-4-shaped host for testing libmvtools_vs.so without a
- * VapourSynth installation (test infrastructure; shares vs4_api.h with the plugin, see the caveat there).
+ * minihost.c -- a minimal VapourSynth-API-4-shaped host for testing libmvtools_vs.so without a VapourSynth installation
+ * (test infrastructure; shares vs4_api.h with the plugin, see the caveat there).  Single-threaded by default; with
+ * x.threads=N the output frames are requested by N worker threads at once, so that the filters' getFrame callbacks run
+ * concurrently like under VapourSynth's fmParallel (a frame being produced by one thread makes the others wait for it).
  *
  * It implements exactly the VSAPI / VSPLUGINAPI members the mvtools hot path uses: maps, frames, nodes, the two-phase
  * getFrame protocol (arInitial -> requestFrameFilter ... -> arAllFramesReady) evaluated synchronously and recursively,
@@ -16,6 +18,7 @@
  *                 degrainN / compensate -> output frames, planes tightly packed
  */
 #include <dlfcn.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -30,6 +33,8 @@ struct VSMap { Entry *head; char *error; };
 
 static VSNode *node_addref(VSNode *n);
 static void node_free(VSNode *n);
+static pthread_mutex_t g_host_mu = PTHREAD_MUTEX_INITIALIZER; /* reference counts and the per-node frame tables */
+static pthread_cond_t g_host_cv = PTHREAD_COND_INITIALIZER;
 
 static VSMap *VS_CC createMap(void) { return (VSMap *)calloc(1, sizeof(VSMap)); }
 static void VS_CC clearMap(VSMap *m) {
@@ -115,11 +120,15 @@ static VSFrame *VS_CC newVideoFrame(const VSVideoFormat *fmt, int w, int h, cons
 }
 static void VS_CC freeFrame(const VSFrame *cf) {
     VSFrame *f = (VSFrame *)cf;
-    if (!f || --f->refs) return;
+    if (!f) return;
+    pthread_mutex_lock(&g_host_mu);
+    const int left = --f->refs;
+    pthread_mutex_unlock(&g_host_mu);
+    if (left) return;
     for (int p = 0; p < 3; p++) free(f->data[p]);
     freeMap(f->props); free(f);
 }
-static const VSFrame *frame_addref(const VSFrame *f) { ((VSFrame *)f)->refs++; return f; }
+static const VSFrame *frame_addref(const VSFrame *f) { pthread_mutex_lock(&g_host_mu); ((VSFrame *)f)->refs++; pthread_mutex_unlock(&g_host_mu); return f; }
 static VSFrame *VS_CC copyFrame(const VSFrame *s, VSCore *core) {
     VSFrame *f = newVideoFrame(&s->fmt, s->w, s->h, s, core);
     for (int p = 0; p < s->fmt.numPlanes; p++) memcpy(f->data[p], s->data[p], (size_t)s->stride[p] * plane_h(s, p));
@@ -136,16 +145,20 @@ static int VS_CC getFrameHeight(const VSFrame *f, int p) { return plane_h(f, p);
 
 /* ---------------------------------------------------------------------------------------------------- nodes */
 
-struct VSNode { int refs; VSVideoInfo vi; VSFilterGetFrame getFrame; VSFilterFree freeFn; void *inst; const VSFrame **cache; char name[32]; };
+struct VSNode { int refs; VSVideoInfo vi; VSFilterGetFrame getFrame; VSFilterFree freeFn; void *inst; const VSFrame **cache; unsigned char *busy; char name[32]; };
 struct VSFrameContext { int n; struct { int n; VSNode *node; const VSFrame *f; } req[64]; int nreq; char error[1024]; };
 
 static VSAPI g_api;
-static VSNode *node_addref(VSNode *n) { n->refs++; return n; }
+static VSNode *node_addref(VSNode *n) { pthread_mutex_lock(&g_host_mu); n->refs++; pthread_mutex_unlock(&g_host_mu); return n; }
 static void node_free(VSNode *n) {
-    if (!n || --n->refs) return;
+    if (!n) return;
+    pthread_mutex_lock(&g_host_mu);
+    const int left = --n->refs;
+    pthread_mutex_unlock(&g_host_mu);
+    if (left) return;
     for (int i = 0; i < n->vi.numFrames; i++) if (n->cache[i]) freeFrame(n->cache[i]);
     if (n->freeFn) n->freeFn(n->inst, NULL, &g_api);
-    free(n->cache); free(n);
+    free(n->cache); free(n->busy); free(n);
 }
 static void VS_CC freeNode(VSNode *n) { node_free(n); }
 static VSNode *VS_CC addNodeRef(VSNode *n) { return node_addref(n); }
@@ -154,7 +167,11 @@ static const VSVideoInfo *VS_CC getVideoInfo(VSNode *n) { return &n->vi; }
 static const VSFrame *eval_frame(int n, VSNode *node, char *err, int errsz) {
     if (n < 0) n = 0;
     if (n >= node->vi.numFrames) n = node->vi.numFrames - 1;
-    if (node->cache[n]) return frame_addref(node->cache[n]);
+    pthread_mutex_lock(&g_host_mu); /* one producer per frame; the others wait for it (a real core would park the request) */
+    while (node->busy && node->busy[n] && !node->cache[n]) pthread_cond_wait(&g_host_cv, &g_host_mu);
+    if (node->cache[n]) { ((VSFrame *)node->cache[n])->refs++; const VSFrame *hit = node->cache[n]; pthread_mutex_unlock(&g_host_mu); return hit; }
+    if (node->busy) node->busy[n] = 1;
+    pthread_mutex_unlock(&g_host_mu);
     if (!node->getFrame) { snprintf(err, (size_t)errsz, "source frame %d missing", n); return NULL; }
     VSFrameContext ctx;
     memset(&ctx, 0, sizeof(ctx));
@@ -169,9 +186,13 @@ static const VSFrame *eval_frame(int n, VSNode *node, char *err, int errsz) {
         if (!ctx.error[0]) out = node->getFrame(n, arAllFramesReady, node->inst, &fd, &ctx, NULL, &g_api);
     }
     for (int i = 0; i < ctx.nreq; i++) if (ctx.req[i].f) freeFrame(ctx.req[i].f);
+    pthread_mutex_lock(&g_host_mu);
+    if (out) { node->cache[n] = out; ((VSFrame *)out)->refs++; }
+    if (node->busy) node->busy[n] = 0;
+    pthread_cond_broadcast(&g_host_cv);
+    pthread_mutex_unlock(&g_host_mu);
     if (!out) { snprintf(err, (size_t)errsz, "%s", ctx.error[0] ? ctx.error : "filter returned no frame"); return NULL; }
-    node->cache[n] = out;
-    return frame_addref(out);
+    return out;
 }
 static const VSFrame *VS_CC getFrame(int n, VSNode *node, char *err, int sz) { return eval_frame(n, node, err, sz); }
 static void VS_CC requestFrameFilter(int n, VSNode *node, VSFrameContext *ctx) {
@@ -191,6 +212,7 @@ static void VS_CC createVideoFilter(VSMap *out, const char *name, const VSVideoI
     VSNode *n = (VSNode *)calloc(1, sizeof(VSNode));
     n->refs = 1; n->vi = *vi; n->getFrame = gf; n->freeFn = ff; n->inst = inst;
     n->cache = (const VSFrame **)calloc((size_t)vi->numFrames, sizeof(VSFrame *));
+    n->busy = (unsigned char *)calloc((size_t)vi->numFrames, 1);
     snprintf(n->name, sizeof(n->name), "%s", name);
     mapSetNode(out, "clip", n, maAppend);
     node_free(n); /* the map holds the reference */
@@ -343,6 +365,35 @@ static void dump_frame(FILE *fp, const VSFrame *f) {
 }
 static void die(const char *what, const char *err) { printf("ERROR %s: %s\n", what, err); exit(1); }
 
+/* x.threads=N: request frames 0..count-1 of up to four nodes from N threads at once (results stay in the nodes' frame tables) */
+typedef struct Work { VSNode *nodes[4]; int nnodes, count, next; char err[2048]; } Work;
+static void *worker(void *arg) {
+    Work *w = (Work *)arg;
+    for (;;) {
+        pthread_mutex_lock(&g_host_mu);
+        const int i = w->next < w->count * w->nnodes ? w->next++ : -1;
+        pthread_mutex_unlock(&g_host_mu);
+        if (i < 0) return NULL;
+        char err[2048] = "";
+        /* node-major order: every thread first asks the first node, so that one filter instance sees all requests at once */
+        const VSFrame *f = eval_frame(i % w->count, w->nodes[i / w->count], err, sizeof(err));
+        if (f) freeFrame(f);
+        else { pthread_mutex_lock(&g_host_mu); if (!w->err[0]) snprintf(w->err, sizeof(w->err), "%s", err); pthread_mutex_unlock(&g_host_mu); }
+    }
+}
+static void prefetch_parallel(int threads, int count, VSNode **nodes, int nnodes) {
+    if (threads <= 1) return;
+    Work w;
+    memset(&w, 0, sizeof(w));
+    for (int i = 0; i < nnodes; i++) w.nodes[i] = nodes[i];
+    w.nnodes = nnodes; w.count = count;
+    pthread_t *t = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    for (int i = 0; i < threads; i++) pthread_create(&t[i], NULL, worker, &w);
+    for (int i = 0; i < threads; i++) pthread_join(t[i], NULL);
+    free(t);
+    if (w.err[0]) die("parallel request", w.err);
+}
+
 int main(int argc, char **argv) {
     if (argc < 3) { fprintf(stderr, "usage: see minihost.c\n"); return 2; }
     init_api();
@@ -399,7 +450,9 @@ int main(int argc, char **argv) {
     const char *pipeline = argv[3], *inPath = argv[4], *outPath = argv[9];
     const int w = atoi(argv[5]), hh = atoi(argv[6]), bits = atoi(argv[7]), nframes = atoi(argv[8]);
     char **extra = argv + 10; const int nextra = argc - 10;
+    int threads = 1;
     for (int i = 0; i < nextra; i++) if (!strncmp(extra[i], "x.fieldorder=", 13)) g_field_order = atoi(extra[i] + 13);
+    for (int i = 0; i < nextra; i++) if (!strncmp(extra[i], "x.threads=", 10)) threads = atoi(extra[i] + 10);
     VSNode *clip = source_clip(inPath, w, hh, bits, nframes);
     FILE *fo = fopen(outPath, "wb");
     if (!fo) { fprintf(stderr, "cannot write %s\n", outPath); return 2; }
@@ -436,6 +489,7 @@ int main(int argc, char **argv) {
             if (!vec[2 * r + (isb ? 0 : 1)]) die("Analyse", err);
         }
     if (!strcmp(pipeline, "analyse")) {
+        prefetch_parallel(threads, nframes, vec, 2);
         for (int n = 0; n < nframes; n++)
             for (int k = 0; k < 2; k++) {
                 const VSFrame *f = eval_frame(n, vec[k], err, sizeof(err));
@@ -515,6 +569,12 @@ int main(int argc, char **argv) {
         out = invoke(fn, m, err, sizeof(err));
     }
     if (!out) die(pipeline, err);
+    if (threads > 1) { /* the vector clips first (all threads inside one Analyse instance at a time), then the output */
+        prefetch_parallel(threads, nframes, vec, 2 * R < 4 ? 2 * R : 4);
+        if (2 * R > 4) prefetch_parallel(threads, nframes, vec + 4, 2 * R - 4 < 4 ? 2 * R - 4 : 4);
+        if (2 * R > 8) prefetch_parallel(threads, nframes, vec + 8, 2 * R - 8);
+        prefetch_parallel(threads, nframes, &out, 1);
+    }
     for (int n = 0; n < nframes; n++) {
         const VSFrame *f = eval_frame(n, out, err, sizeof(err));
         if (!f) die("output frame", err);

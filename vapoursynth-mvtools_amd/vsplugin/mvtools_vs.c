@@ -11,18 +11,22 @@
  * (src/MVAnalyse.c:224-239).  This file is the only code that touches VSAPI; all arithmetic happens on the GPU behind
  * the C ABI, and every compute failure surfaces through setFilterError (there is no CPU path).
  *
- * Correctness-first form: one C-ABI call per requested frame.  Super frames produced here stay resident in a small
- * device-side cache (keyed by a per-frame id prop) so that Analyse / Degrain / Compensate do not round-trip 131 MB
- * pyramids through host memory; frames that did not come from this Super are uploaded on demand.  Batching the
- * concurrently requested frames into one search launch (where the throughput is) is the next step and
- * does not change this interface.
+ * Super frames produced here stay resident in a device-side cache (keyed by a per-frame id prop and checked against a
+ * fingerprint of the host frame) so that Analyse / Degrain / Compensate do not round-trip 131 MB pyramids through host
+ * memory; frames that did not come from this Super, or that another filter modified, are uploaded on demand.
+ * mv.Analyse batches: the getFrame calls that VapourSynth's worker threads make concurrently (every filter here is
+ * fmParallel, like the reference: MVAnalyse.c:634) are collected by a combining queue into ONE mvx_analyse_frames launch per
+ * instance on the instance's own stream -- the search is a serial chain per frame whose throughput comes from the number
+ * of chains in flight.  The other filters make one C-ABI call per frame; all handles are thread-safe.
  *
  * Not supported (fail loudly at creation, like the C ABI): dct 1..4.
  */
+#include <errno.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "vs4_api.h"
 #include "../../include/mvtools_amd.h"
@@ -33,7 +37,7 @@
 
 /* ------------------------------------------------------------------------------------------------ device frame cache */
 
-typedef struct DevFrame { int64_t id; void *arena; void *plane[3]; size_t bytes; int pins; uint64_t stamp; } DevFrame;
+typedef struct DevFrame { int64_t id; void *arena; void *plane[3]; size_t bytes; int pins; uint64_t stamp; uint64_t print; } DevFrame;
 #define CACHE_MAX 64
 static DevFrame g_cache[CACHE_MAX];
 static int g_cache_cap = -1;
@@ -52,44 +56,78 @@ static int cache_cap(void) {
 }
 
 /* geometry of a super frame on the device: one arena per frame, planes at 256-byte pitches */
-typedef struct SuperGeo { mvx_super_info si; ptrdiff_t pitch[3]; size_t off[3]; size_t bytes; int bps; } SuperGeo;
+/* (every plane is followed by its shadow copies, mvx_super_shadow_frames: the search loads dword-aligned from them) */
+typedef struct SuperGeo { const mvx_super *sup; mvx_super_info si; ptrdiff_t pitch[3], shadowStride[3]; size_t off[3]; size_t bytes; int bps, copies; } SuperGeo;
 
 static void super_geo(SuperGeo *g, const mvx_super *s) {
+    g->sup = s;
     mvx_super_get_info(s, &g->si);
     g->bps = (g->si.bits + 7) / 8;
+    g->copies = 1 + mvx_super_shadow_copies(s);
     size_t o = 0;
     for (int p = 0; p < 3; p++) {
-        g->pitch[p] = 0; g->off[p] = o;
+        g->pitch[p] = 0; g->off[p] = o; g->shadowStride[p] = 0;
         if (p < g->si.num_planes) {
             g->pitch[p] = ((ptrdiff_t)g->si.plane_width[p] * g->bps + 255) / 256 * 256;
-            o += (size_t)g->pitch[p] * g->si.plane_height[p];
+            g->shadowStride[p] = ((ptrdiff_t)g->pitch[p] * g->si.plane_height[p] + 255) / 256 * 256;
+            o += (size_t)g->shadowStride[p] * g->copies;
         }
     }
     g->bytes = o;
 }
+/* the shifted copies behind freshly written planes (no-op for 8-bit clips) */
+static int super_shadows(const SuperGeo *g, void *const plane[3], void *stream) {
+    if (g->copies <= 1) return 0;
+    return mvx_super_shadow_frames(g->sup, 1, plane, g->pitch, g->shadowStride, stream);
+}
+/* cheap fingerprint of a host super frame: a few rows of every plane.  Most filters copy frame props while changing pixels, so the
+ * id prop alone does not prove that the cached device copy still matches the frame a consumer was handed. */
+static uint64_t frame_print(const VSFrame *f, const SuperGeo *g, const VSAPI *vs) {
+    uint64_t h = 1469598103934665603ULL;
+    for (int p = 0; p < g->si.num_planes; p++) {
+        const int H = g->si.plane_height[p];
+        const size_t rb = (size_t)g->si.plane_width[p] * g->bps;
+        const int rows[5] = { 0, H / 5, H / 2, (int)((int64_t)H * 4 / 5), H - 1 };
+        for (int k = 0; k < 5; k++) {
+            const uint8_t *r = vs->getReadPtr(f, p) + (ptrdiff_t)rows[k] * vs->getStride(f, p);
+            for (size_t i = 0; i + 8 <= rb; i += 8) { uint64_t v; memcpy(&v, r + i, 8); h = (h ^ v) * 1099511628211ULL; }
+        }
+    }
+    return h;
+}
 
-/* returns a pinned cache entry holding frame `id`, or NULL */
-static DevFrame *cache_find(int64_t id) {
+/* returns a pinned cache entry holding frame `id` with that fingerprint, or NULL */
+static DevFrame *cache_find(int64_t id, uint64_t print) {
     DevFrame *r = NULL;
     pthread_mutex_lock(&g_lock);
     for (int i = 0; i < cache_cap(); i++)
-        if (g_cache[i].arena && g_cache[i].id == id) { r = &g_cache[i]; r->pins++; r->stamp = g_stamp++; break; }
+        if (g_cache[i].arena && g_cache[i].id == id && g_cache[i].print == print) { r = &g_cache[i]; r->pins++; r->stamp = g_stamp++; break; }
     pthread_mutex_unlock(&g_lock);
     return r;
 }
+/* drops the unpinned entries of one mv.Super instance (its free callback) */
+static void cache_evict_instance(int64_t instance) {
+    void *victims[CACHE_MAX];
+    int nv = 0;
+    pthread_mutex_lock(&g_lock);
+    for (int i = 0; i < cache_cap(); i++)
+        if (g_cache[i].arena && (g_cache[i].id >> 32) == instance && g_cache[i].pins == 0) { victims[nv++] = g_cache[i].arena; g_cache[i].arena = NULL; }
+    pthread_mutex_unlock(&g_lock);
+    for (int i = 0; i < nv; i++) mvx_dev_free(victims[i]);
+}
 /* hands a freshly filled arena to the cache (pinned); returns NULL if the cache is full of pinned frames / disabled */
-static DevFrame *cache_insert(int64_t id, void *arena, const SuperGeo *g) {
+static DevFrame *cache_insert(int64_t id, uint64_t print, void *arena, const SuperGeo *g) {
     DevFrame *slot = NULL;
     void *victim = NULL;
     pthread_mutex_lock(&g_lock);
     for (int i = 0; i < cache_cap(); i++) {
         DevFrame *e = &g_cache[i];
         if (!e->arena) { slot = e; break; }
-        if (e->pins == 0 && (!slot || e->stamp < slot->stamp)) slot = e;
+        if (e->pins == 0 && (e->id == id || !slot || e->stamp < slot->stamp)) { slot = e; if (e->id == id) break; } /* (a stale copy of the same frame goes first) */
     }
     if (slot) {
         victim = slot->arena;
-        slot->id = id; slot->arena = arena; slot->bytes = g->bytes; slot->pins = 1; slot->stamp = g_stamp++;
+        slot->id = id; slot->print = print; slot->arena = arena; slot->bytes = g->bytes; slot->pins = 1; slot->stamp = g_stamp++;
         for (int p = 0; p < 3; p++) slot->plane[p] = p < g->si.num_planes ? (char *)arena + g->off[p] : NULL;
     }
     pthread_mutex_unlock(&g_lock);
@@ -110,19 +148,23 @@ static int super_to_device(DevRef *r, const VSFrame *f, const SuperGeo *g, const
     memset(r, 0, sizeof(*r));
     int err = 0;
     const int64_t id = vs->mapGetInt(vs->getFramePropertiesRO(f), PROP_SUPER_ID, 0, &err);
-    if (!err && (r->cached = cache_find(id)) != NULL) {
+    const uint64_t print = frame_print(f, g, vs);
+    if (!err && (r->cached = cache_find(id, print)) != NULL) {
         for (int p = 0; p < 3; p++) r->plane[p] = r->cached->plane[p];
         return 0;
     }
-    void *arena = mvx_dev_alloc(g->bytes);
-    if (!arena) return -1;
-    for (int p = 0; p < g->si.num_planes; p++) {
+    void *arena = mvx_dev_alloc(g->bytes); /* zero-filled like the frames mv.Super builds */
+    if (!arena) return MVX_E_NOMEM;
+    int rc = 0;
+    for (int p = 0; p < g->si.num_planes && !rc; p++) {
         void *d = (char *)arena + g->off[p];
-        if (mvx_copy_to_device(d, g->pitch[p], vs->getReadPtr(f, p), vs->getStride(f, p), (size_t)g->si.plane_width[p] * g->bps,
-                               (size_t)g->si.plane_height[p], NULL)) { mvx_dev_free(arena); return -1; }
+        rc = mvx_copy_to_device(d, g->pitch[p], vs->getReadPtr(f, p), vs->getStride(f, p), (size_t)g->si.plane_width[p] * g->bps, (size_t)g->si.plane_height[p], NULL);
         r->plane[p] = d;
     }
-    if (!err && (r->cached = cache_insert(id, arena, g)) != NULL) return 0; /* keep it for the next consumer */
+    if (!rc) rc = super_shadows(g, r->plane, NULL);
+    if (!rc) rc = mvx_stream_sync(NULL); /* the host frame may be released, and consumers launch on their own streams */
+    if (rc) { mvx_dev_free(arena); memset(r, 0, sizeof(*r)); return rc; }
+    if (!err && (r->cached = cache_insert(id, print, arena, g)) != NULL) return 0; /* keep it for the next consumer */
     r->temp = arena;
     return 0;
 }
@@ -239,7 +281,7 @@ static int adata_similar(const mvx_analysis_data *a, const mvx_analysis_data *b,
 
 /* MVTools_vectors of a vector-clip frame -> device.  The array states its own size in its first int (gopGetArraySize,
  * GroupOfPlanes.c:167-174); clips made with divide carry an extra array the level formula does not describe. */
-static int blob_to_device(void **dblob, int *size, const VSFrame *vf, const VSAPI *vs) {
+static int blob_to_device(void **dblob, int *size, const mvx_analysis_data *ad, const VSFrame *vf, const VSAPI *vs) {
     int e = 0;
     const VSMap *props = vs->getFramePropertiesRO(vf);
     const char *blob = vs->mapGetData(props, PROP_VECTORS, 0, &e);
@@ -249,23 +291,44 @@ static int blob_to_device(void **dblob, int *size, const VSFrame *vf, const VSAP
     int stated = 0;
     if (n >= 8) memcpy(&stated, blob, sizeof(stated));
     if (n < 8 || stated != n) return MVX_E_ARG;
-    *dblob = mvx_dev_alloc((size_t)n);
+    /* the planes' own size headers must tile the array exactly (fgopUpdate walks them, Fakery.c:112-123): a spliced or truncated
+     * property must not send the device readers out of bounds */
+    int planes = 0, lastOff = 0;
+    for (int off = 8; off < n; planes++) {
+        int psz = 0;
+        if (off + 4 > n) return MVX_E_ARG;
+        memcpy(&psz, blob + off, sizeof(psz));
+        if (psz < 4 + 16 || (psz - 4) % 16 || psz > n - off) return MVX_E_ARG;
+        lastOff = off;
+        off += psz;
+    }
+    if (ad) { /* the readers skip nLvCount - 1 planes and then read nBlkX * nBlkY vectors */
+        int off = 8;
+        for (int i = ad->nLvCount - 1; i >= 1 && off < n; i--) { int psz; memcpy(&psz, blob + off, sizeof(psz)); off += psz; }
+        if (planes < ad->nLvCount || off > lastOff || n - off < 4 + ad->nBlkX * ad->nBlkY * 16) return MVX_E_ARG;
+    }
+    *dblob = mvx_dev_alloc_uninit((size_t)n);
     if (!*dblob) return MVX_E_NOMEM;
     if (mvx_copy_to_device(*dblob, n, blob, n, (size_t)n, 1, NULL) || mvx_stream_sync(NULL)) return MVX_E_DEVICE; /* the prop memory goes away with the frame */
     if (size) *size = n;
     return 0;
 }
 
-static void upload_plane_set(void *dst[3], void **arena, const VSFrame *f, const ptrdiff_t pitch[3], int nplanes, int bps, const VSAPI *vs) {
+/* the planes of a host frame -> one device arena.  Returns 0 or an MVX_E_* code; the copies are complete on return (the host frame
+ * may be released right away) */
+static int upload_plane_set(void *dst[3], void **arena, const VSFrame *f, const ptrdiff_t pitch[3], int nplanes, int bps, const VSAPI *vs) {
     size_t off[3], total = 0;
     for (int p = 0; p < nplanes; p++) { off[p] = total; total += (size_t)pitch[p] * vs->getFrameHeight(f, p); }
-    *arena = mvx_dev_alloc(total);
+    *arena = mvx_dev_alloc_uninit(total);
     for (int p = 0; p < 3; p++) dst[p] = NULL;
-    if (!*arena) return;
-    for (int p = 0; p < nplanes; p++) {
+    if (!*arena) return MVX_E_NOMEM;
+    int rc = 0;
+    for (int p = 0; p < nplanes && !rc; p++) {
         dst[p] = (char *)*arena + off[p];
-        mvx_copy_to_device(dst[p], pitch[p], vs->getReadPtr(f, p), vs->getStride(f, p), (size_t)vs->getFrameWidth(f, p) * bps, (size_t)vs->getFrameHeight(f, p), NULL);
+        rc = mvx_copy_to_device(dst[p], pitch[p], vs->getReadPtr(f, p), vs->getStride(f, p), (size_t)vs->getFrameWidth(f, p) * bps, (size_t)vs->getFrameHeight(f, p), NULL);
     }
+    if (!rc) rc = mvx_stream_sync(NULL);
+    return rc;
 }
 
 /* ------------------------------------------------------------------------------------------------ mv.Super */
@@ -284,14 +347,15 @@ static const VSFrame *VS_CC superGetFrame(int n, int reason, void *inst, void **
     const VSFrame *src = vs->getFrameFilter(n, d->node, ctx);
     const SuperGeo *g = &d->geo;
     void *srcArena = NULL, *pelArena = NULL, *dsrc[3], *dpel[3] = { NULL, NULL, NULL }, *ddst[3] = { NULL, NULL, NULL };
-    upload_plane_set(dsrc, &srcArena, src, d->srcPitch, g->si.num_planes, g->bps, vs);
+    int rc = upload_plane_set(dsrc, &srcArena, src, d->srcPitch, g->si.num_planes, g->bps, vs);
     const VSFrame *pf = d->pelMode ? vs->getFrameFilter(n, d->pelclip, ctx) : NULL; /* src/MVSuper.c:62-64 */
-    if (pf) upload_plane_set(dpel, &pelArena, pf, d->pelPitch, g->si.num_planes, g->bps, vs);
-    void *arena = mvx_dev_alloc(g->bytes); /* zero-filled: only the defined rectangles are written (MVSuper.c:73 memsets too) */
-    int rc = (!srcArena || !arena || (d->pelMode && !pelArena)) ? MVX_E_NOMEM : 0;
+    if (pf && !rc) rc = upload_plane_set(dpel, &pelArena, pf, d->pelPitch, g->si.num_planes, g->bps, vs);
+    void *arena = rc ? NULL : mvx_dev_alloc(g->bytes); /* zero-filled: only the defined rectangles are written (MVSuper.c:73 memsets too) */
+    if (!rc && !arena) rc = MVX_E_NOMEM;
     if (!rc) {
         for (int p = 0; p < g->si.num_planes; p++) ddst[p] = (char *)arena + g->off[p];
         rc = mvx_super_frames_pelclip(d->sup, 1, (const void *const *)dsrc, d->srcPitch, (const void *const *)dpel, d->pelPitch, d->pelMode, (void *const *)ddst, g->pitch, NULL);
+        if (!rc) rc = super_shadows(g, ddst, NULL);
     }
     VSFrame *dst = NULL;
     if (!rc) {
@@ -322,7 +386,7 @@ static const VSFrame *VS_CC superGetFrame(int n, int reason, void *inst, void **
     /* the device copy stays resident for the consumers (harmless extra prop; frames without it are uploaded) */
     const int64_t id = (d->instance << 32) | (uint32_t)n;
     vs->mapSetInt(props, PROP_SUPER_ID, id, maReplace);
-    DevFrame *e = cache_insert(id, arena, g);
+    DevFrame *e = cache_insert(id, frame_print(dst, g, vs), arena, g);
     if (e) cache_unpin(e); else mvx_dev_free(arena);
     return dst;
 }
@@ -332,6 +396,7 @@ static void VS_CC superFree(void *inst, VSCore *core, const VSAPI *vs) {
     SuperData *d = (SuperData *)inst;
     vs->freeNode(d->node);
     if (d->pelclip) vs->freeNode(d->pelclip);
+    cache_evict_instance(d->instance); /* its device-resident frames are of no use to anybody now */
     mvx_super_destroy(d->sup);
     free(d);
 }
@@ -396,7 +461,74 @@ static void VS_CC superCreate(const VSMap *in, VSMap *out, void *user, VSCore *c
 
 /* ------------------------------------------------------------------------------------------------ mv.Analyse */
 
-typedef struct AnalyseData { VSNode *node; const VSVideoInfo *vi; mvx_super *sup; SuperGeo geo; mvx_analyse *an; mvx_analysis_data ad; int blobSize; FieldOpt fo; } AnalyseData;
+/* Combining queue: the getFrame calls of concurrent worker threads become ONE mvx_analyse_frames launch.  The first thread to
+ * arrive leads: it waits a moment for others (until `maxBatch` requests or `waitUs` microseconds), takes the whole queue, launches
+ * it on the instance's stream, waits for it and wakes the others up.  Requests arriving meanwhile form the next batch. */
+typedef struct AnReq { mvx_analyse_job job; int rc, done; struct AnReq *next; } AnReq;
+typedef struct Combiner {
+    pthread_mutex_t mu; pthread_cond_t done, more;
+    AnReq *head, *tail; int n, leader;
+    void *stream; int maxBatch; long waitUs;
+    long batches, jobs, largest; /* statistics (MVX_VS_STATS=1 prints them when the filter is freed) */
+} Combiner;
+
+typedef struct AnalyseData { VSNode *node; const VSVideoInfo *vi; mvx_super *sup; SuperGeo geo; mvx_analyse *an; mvx_analysis_data ad; int blobSize; FieldOpt fo; Combiner cb; } AnalyseData;
+
+static long env_long(const char *name, long def) { const char *e = getenv(name); return e ? atol(e) : def; }
+
+static void combiner_init(Combiner *c) {
+    memset(c, 0, sizeof(*c));
+    pthread_mutex_init(&c->mu, NULL); pthread_cond_init(&c->done, NULL); pthread_cond_init(&c->more, NULL);
+    c->stream = mvx_stream_create(); /* NULL (the default stream) still works, it only serialises the instances */
+    c->maxBatch = (int)env_long("MVX_VS_BATCH_MAX", 1024);
+    c->waitUs = env_long("MVX_VS_BATCH_WAIT_US", 2000);
+    if (c->maxBatch < 1) c->maxBatch = 1;
+}
+static void combiner_free(Combiner *c, const char *what) {
+    if (env_long("MVX_VS_STATS", 0)) fprintf(stderr, "mvtools_vs: %s launches=%ld jobs=%ld largest_batch=%ld\n", what, c->batches, c->jobs, c->largest);
+    mvx_stream_destroy(c->stream);
+    pthread_mutex_destroy(&c->mu); pthread_cond_destroy(&c->done); pthread_cond_destroy(&c->more);
+}
+/* blocks until the request's blob is computed; returns its MVX_* code */
+static int combiner_submit(Combiner *c, mvx_analyse *an, AnReq *r) {
+    pthread_mutex_lock(&c->mu);
+    r->next = NULL; r->done = 0;
+    if (c->tail) c->tail->next = r; else c->head = r;
+    c->tail = r; c->n++;
+    if (c->leader) { /* follower */
+        if (c->n >= c->maxBatch) pthread_cond_signal(&c->more);
+        while (!r->done) pthread_cond_wait(&c->done, &c->mu);
+        pthread_mutex_unlock(&c->mu);
+        return r->rc;
+    }
+    c->leader = 1;
+    if (c->waitUs > 0 && c->n < c->maxBatch) {
+        struct timespec ts;
+        clock_gettime(CLOCK_REALTIME, &ts);
+        ts.tv_nsec += (c->waitUs % 1000000) * 1000; ts.tv_sec += c->waitUs / 1000000 + ts.tv_nsec / 1000000000; ts.tv_nsec %= 1000000000;
+        while (c->n < c->maxBatch) if (pthread_cond_timedwait(&c->more, &c->mu, &ts) == ETIMEDOUT) break;
+    }
+    AnReq *list = c->head;
+    const int n = c->n;
+    c->head = c->tail = NULL; c->n = 0; c->leader = 0; /* the next arrival leads the next batch while this one runs */
+    c->batches++; c->jobs += n; if (n > c->largest) c->largest = n;
+    pthread_mutex_unlock(&c->mu);
+    int rc = 0;
+    mvx_analyse_job *jobs = (mvx_analyse_job *)malloc(sizeof(mvx_analyse_job) * (size_t)n);
+    if (!jobs) rc = MVX_E_NOMEM;
+    else {
+        int i = 0;
+        for (AnReq *q = list; q; q = q->next) jobs[i++] = q->job;
+        rc = mvx_analyse_frames(an, n, jobs, c->stream);
+        if (!rc) rc = mvx_stream_sync(c->stream);
+        free(jobs);
+    }
+    pthread_mutex_lock(&c->mu);
+    for (AnReq *q = list; q;) { AnReq *nx = q->next; q->rc = rc; q->done = 1; q = nx; } /* (q may be freed by its owner once done) */
+    pthread_cond_broadcast(&c->done);
+    pthread_mutex_unlock(&c->mu);
+    return rc;
+}
 
 static int analyse_nref(const AnalyseData *d, int n) { /* src/MVAnalyse.c:84-104 */
     if (d->ad.nDeltaFrame > 0) return n + (d->ad.isBackward ? d->ad.nDeltaFrame : -d->ad.nDeltaFrame);
@@ -434,16 +566,16 @@ static const VSFrame *VS_CC analyseGetFrame(int n, int reason, void *inst, void 
     memset(&dr, 0, sizeof(dr));
     int rc = super_to_device(&ds, src, &d->geo, vs);
     if (!rc && ref) rc = super_to_device(&dr, ref, &d->geo, vs);
-    void *dblob = rc ? NULL : mvx_dev_alloc((size_t)d->blobSize);
+    void *dblob = rc ? NULL : mvx_dev_alloc_uninit((size_t)d->blobSize);
     char *blob = (char *)malloc((size_t)d->blobSize);
     if (!rc && (!dblob || !blob)) rc = MVX_E_NOMEM;
     if (!rc) {
-        mvx_analyse_job job;
-        memset(&job, 0, sizeof(job));
-        for (int p = 0; p < 3; p++) { job.src[p] = ds.plane[p]; job.ref[p] = ref ? dr.plane[p] : NULL; }
-        job.blob = dblob;
-        job.field_shift = fieldShift;
-        rc = mvx_analyse_frames(d->an, 1, &job, NULL);
+        AnReq req;
+        memset(&req, 0, sizeof(req));
+        for (int p = 0; p < 3; p++) { req.job.src[p] = ds.plane[p]; req.job.ref[p] = ref ? dr.plane[p] : NULL; }
+        req.job.blob = dblob;
+        req.job.field_shift = fieldShift;
+        rc = combiner_submit(&d->cb, d->an, &req); /* one launch for all the frames requested right now */
         if (!rc) rc = mvx_copy_to_host(blob, d->blobSize, dblob, d->blobSize, (size_t)d->blobSize, 1, NULL);
         if (!rc) rc = mvx_stream_sync(NULL);
     }
@@ -467,6 +599,7 @@ static void VS_CC analyseFree(void *inst, VSCore *core, const VSAPI *vs) {
     (void)core;
     AnalyseData *d = (AnalyseData *)inst;
     vs->freeNode(d->node);
+    combiner_free(&d->cb, "Analyse");
     mvx_analyse_destroy(d->an);
     mvx_super_destroy(d->sup);
     free(d);
@@ -503,6 +636,8 @@ static void VS_CC analyseCreate(const VSMap *in, VSMap *out, void *user, VSCore 
     }
     mvx_analyse_get_data(d->an, &d->ad);
     d->blobSize = mvx_analyse_blob_size(d->an);
+    if (d->geo.copies > 1) mvx_analyse_set_ref_shadow(d->an, d->geo.shadowStride); /* every device super frame of this shell carries its copies */
+    combiner_init(&d->cb);
     VSFilterDependency deps[1] = { { node, rpGeneral } };
     vs->createVideoFilter(out, "Analyse", vi, analyseGetFrame, analyseFree, fmParallel, deps, 1, d, core);
 }
@@ -585,7 +720,7 @@ static const VSFrame *VS_CC scdGetFrame(int n, int reason, void *inst, void **fd
     vs->freeFrame(src);
     const VSFrame *mvn = vs->getFrameFilter(n, d->vectors, ctx);
     void *dblob = NULL;
-    int rc = blob_to_device(&dblob, NULL, mvn, vs);
+    int rc = blob_to_device(&dblob, NULL, &d->ad, mvn, vs);
     vs->freeFrame(mvn);
     int32_t sc = 0;
     char lerr[MVX_ERRLEN];
@@ -655,7 +790,7 @@ static const VSFrame *VS_CC recalcGetFrame(int n, int reason, void *inst, void *
     DevRef ds, dr;
     memset(&dr, 0, sizeof(dr));
     void *oldBlob = NULL;
-    int rc = blob_to_device(&oldBlob, NULL, mvn, vs);
+    int rc = blob_to_device(&oldBlob, NULL, &d->old, mvn, vs);
     vs->freeFrame(mvn);
     if (!rc) rc = super_to_device(&ds, src, &d->geo, vs); else memset(&ds, 0, sizeof(ds));
     if (!rc && ref) rc = super_to_device(&dr, ref, &d->geo, vs);
@@ -769,15 +904,15 @@ static const VSFrame *VS_CC degrainGetFrame(int n, int reason, void *inst, void 
     memset(refs, 0, sizeof(refs)); memset(blobArena, 0, sizeof(blobArena));
     int rc = 0;
     void *srcArena = NULL, *dsrc[3];
-    upload_plane_set(dsrc, &srcArena, src, d->pitch, np, bps, vs);
+    rc = upload_plane_set(dsrc, &srcArena, src, d->pitch, np, bps, vs);
     size_t dstOff[3], dstBytes = 0;
     for (int p = 0; p < np; p++) { dstOff[p] = dstBytes; dstBytes += (size_t)d->pitch[p] * vs->getFrameHeight(src, p); }
-    void *dstArena = mvx_dev_alloc(dstBytes);
-    if (!srcArena || !dstArena) rc = MVX_E_NOMEM;
+    void *dstArena = mvx_dev_alloc_uninit(dstBytes);
+    if (!rc && (!srcArena || !dstArena)) rc = MVX_E_NOMEM;
     for (int p = 0; p < np && !rc; p++) { job.src[p] = dsrc[p]; job.dst[p] = (char *)dstArena + dstOff[p]; }
     for (int r = 0; r < nr && !rc; r++) {
         const VSFrame *vf = vs->getFrameFilter(n, d->vectors[r], ctx);
-        rc = blob_to_device(&blobArena[r], NULL, vf, vs);
+        rc = blob_to_device(&blobArena[r], NULL, &d->ad[r], vf, vs);
         job.blobs[r] = blobArena[r];
         vs->freeFrame(vf);
         const int nref = (r & 1) ? n - d->ad[r].nDeltaFrame : n + d->ad[r].nDeltaFrame;
@@ -940,7 +1075,7 @@ static const VSFrame *VS_CC compGetFrame(int n, int reason, void *inst, void **f
     int rc = super_to_device(&ds, ssup, &d->geo, vs);
     if (!rc && rsup) rc = super_to_device(&dr, rsup, &d->geo, vs);
     void *dblob = NULL;
-    if (!rc) rc = blob_to_device(&dblob, NULL, vf, vs);
+    if (!rc) rc = blob_to_device(&dblob, NULL, &d->ad, vf, vs);
     size_t dstOff[3], dstBytes = 0;
     for (int p = 0; p < np; p++) { dstOff[p] = dstBytes; dstBytes += (size_t)d->pitch[p] * vs->getFrameHeight(src, p); }
     void *dstArena = rc ? NULL : mvx_dev_alloc(dstBytes);
@@ -1071,12 +1206,12 @@ static const VSFrame *VS_CC fpsGetFrame(int n, int reason, void *inst, void **fd
     memset(&job, 0, sizeof(job));
     job.time256 = time256;
     void *arenaL = NULL, *arenaR = NULL, *dl[3], *dr[3], *blobF = NULL, *blobB = NULL;
-    upload_plane_set(dl, &arenaL, cl, d->pitch, np, bps, vs);
-    upload_plane_set(dr, &arenaR, cr, d->pitch, np, bps, vs);
+    int rc = upload_plane_set(dl, &arenaL, cl, d->pitch, np, bps, vs);
+    if (!rc) rc = upload_plane_set(dr, &arenaR, cr, d->pitch, np, bps, vs);
     size_t dstOff[3], dstBytes = 0;
     for (int p = 0; p < np; p++) { dstOff[p] = dstBytes; dstBytes += (size_t)d->pitch[p] * vs->getFrameHeight(cl, p); }
-    void *dstArena = mvx_dev_alloc(dstBytes);
-    int rc = (!arenaL || !arenaR || !dstArena) ? MVX_E_NOMEM : 0;
+    void *dstArena = mvx_dev_alloc_uninit(dstBytes);
+    if (!rc && (!arenaL || !arenaR || !dstArena)) rc = MVX_E_NOMEM;
     for (int p = 0; p < np && !rc; p++) { job.clip_left[p] = dl[p]; job.clip_right[p] = dr[p]; job.dst[p] = (char *)dstArena + dstOff[p]; }
     DevRef ds, dr2;
     memset(&ds, 0, sizeof(ds)); memset(&dr2, 0, sizeof(dr2));
@@ -1085,8 +1220,8 @@ static const VSFrame *VS_CC fpsGetFrame(int n, int reason, void *inst, void **fd
         const VSFrame *vf = vs->getFrameFilter(nright, d->mvfw, ctx), *vb = vs->getFrameFilter(nleft, d->mvbw, ctx);
         rc = super_to_device(&ds, sl, &d->geo, vs);
         if (!rc) rc = super_to_device(&dr2, sr, &d->geo, vs);
-        if (!rc) rc = blob_to_device(&blobF, NULL, vf, vs);
-        if (!rc) rc = blob_to_device(&blobB, NULL, vb, vs);
+        if (!rc) rc = blob_to_device(&blobF, NULL, &d->fw, vf, vs);
+        if (!rc) rc = blob_to_device(&blobB, NULL, &d->bw, vb, vs);
         for (int p = 0; p < 3; p++) { job.src_super[p] = ds.plane[p]; job.ref_super[p] = dr2.plane[p]; }
         job.blob_fw = blobF; job.blob_bw = blobB;
         vs->freeFrame(sl); vs->freeFrame(sr); vs->freeFrame(vf); vs->freeFrame(vb);
