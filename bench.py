@@ -33,6 +33,8 @@ CONFIGS = {
     "cfg2": (1920, 1080, 8, 1, dict(blksize=8, overlap=4, search=4), dict(pel=2), 2048, "1080p YUV420P8 Degrain1 blksize=8 overlap=4 pel=2 search=4"),
     "cfg3": (3840, 2160, 16, 3, dict(blksize=16, overlap=8), dict(pel=2), 512, "4K YUV420P16 Degrain3 blksize=16 overlap=8 pel=2"),
     "cfg5": (7680, 4320, 16, 6, dict(blksize=32, overlap=16), dict(pel=2), 168, "8K YUV420P16 Degrain6 blksize=32 overlap=16 pel=2"),
+    # BASELINE config 4: frame-rate conversion instead of denoising (radius field = 0 selects PipelineFPS)
+    "cfg4": (1920, 1080, 8, 0, dict(blksize=8), dict(pel=2), 2047, "1080p YUV420P8 Compensate + BlockFPS 24->60 blksize=8 pel=2"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
@@ -165,6 +167,51 @@ class Pipeline:
         return pyr0 + full + self.an[(1, 1)].blob_size, full
 
 
+class PipelineFPS:
+    """BASELINE config 4: Super -> Analyse (backward + forward, delta 1) -> Compensate (every frame towards its successor) +
+    BlockFPS 24 -> 60 over a resident batch of B + 1 input frames; a step produces B compensated frames and (B + 1) * 60 / 24
+    interpolated ones.  The unit of `value` is interpolated output frames per second."""
+
+    def __init__(self, mv, torch, cfg, batch, device, seed, src=None, plan=None):
+        (self.w, self.h, self.bits, _, akw, skw, _, self.label) = cfg
+        self.mv, self.torch, self.B, self.device = mv, torch, batch, device
+        self.tr = 1
+        self.n = batch + 1
+        self.src = src if src is not None else synth_clip_device(torch, self.w, self.h, self.bits, self.n, seed, device)
+        self.stream = torch.cuda.Stream(device=device)
+        self.sup = mv.Super(self.w, self.h, self.bits, **skw)
+        self.supers = self.sup.alloc(self.n, device=device)
+        self.an = {(1, 1): mv.Analyse(self.sup, num_frames=self.n, isb=1, **akw), (1, 0): mv.Analyse(self.sup, num_frames=self.n, isb=0, **akw)}
+        self.blobs = {k: a.alloc_blobs(self.n, device=device) for k, a in self.an.items()}
+        pitch = [p.stride(0) for p in self.src[0]]
+        self.comp = mv.Compensate(self.sup, self.an[(1, 1)].ad, dst_pitch=pitch)
+        self.fps = mv.BlockFPS(self.sup, self.an[(1, 1)].ad, self.an[(1, 0)].ad, self.n, pitch, 24, 1, num=60, den=1)
+        self.nout = self.fps.num_frames
+        shapes = [tuple(p.shape) for p in self.src[0]]
+        self.comp_out = mv.arena_frames(batch, shapes, device, zero=False)
+        self.fps_out = mv.arena_frames(self.nout, shapes, device, zero=False)
+        self.ev = []
+        self.frames_per_step = self.nout
+
+    def step(self, time_search=False):
+        with self.torch.cuda.stream(self.stream):
+            torch, n = self.torch, self.n
+            self.sup.build(self.src, out=self.supers)
+            jobs = [(self.supers[i], self.supers[i + 1] if i + 1 < n else None) for i in range(n)] + [(self.supers[i], self.supers[i - 1] if i >= 1 else None) for i in range(n)]
+            blobs = self.blobs[(1, 1)] + self.blobs[(1, 0)]
+            if time_search:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            self.an[(1, 1)].run(jobs, blobs=blobs)  # both vector clips share one parameter block: one launch, 2 * (B + 1) chains
+            if time_search:
+                e1.record()
+                self.ev.append((e0, e1))
+            self.comp.run([(self.supers[i], self.supers[i + 1], self.blobs[(1, 1)][i]) for i in range(self.B)], out=self.comp_out)
+            self.fps.run(list(range(self.nout)), self.src, self.supers, self.blobs[(1, 1)], self.blobs[(1, 0)], out=self.fps_out)
+
+    algorithmic_bytes_per_chain = Pipeline.algorithmic_bytes_per_chain
+
+
 def cpu_baseline(cfg, threads):
     """The oracle (CPU restatement, kind 'port') on a bounded sample of the same workload: F output frames, F = worker
     threads, each thread owning whole frames (VapourSynth fmParallel style); supers are shared."""
@@ -196,7 +243,7 @@ def cpu_baseline(cfg, threads):
         list(ex.map(one, range(F)))
     dt = time.time() - t0
     return {"value": F / dt, "unit": "fps", "cores": threads, "kind": "port",
-            "sample": "%d output frames of %s (%d Super + %d Analyse + %d Degrain%d), %d threads each owning whole frames, %.1f s wall; scalar C oracle (-O2), not the reference's SIMD build" % (
+            "sample": "%d output frames of %s (%d Super + %d Analyse + %d Degrain%d), %d threads each owning whole frames, %.1f s wall; scalar C oracle (-O2 -mavx2), not the reference's SIMD build (BASELINE.md 4)" % (
                 F, label, n, 2 * tr * F, F, tr, threads, dt)}
 
 
@@ -225,6 +272,34 @@ def world_from_env(gpus, env=None):
     if world != gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (gpus, world))
     return int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0")), world
+
+
+def cpu_baseline_fps(cfg, threads):
+    """cfg4 on the host cores: the oracle's Super / Analyse x2 / Compensate / BlockFPS 24 -> 60 on a bounded sample (F input frames,
+    F = worker threads; every thread owns whole frames)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from concurrent.futures import ThreadPoolExecutor
+    import mvoracle as mo
+    import pipeline as pl
+    (w, h, bits, _, akw, skw, _, label) = cfg
+    F = 8 * threads  # (1080p 8-bit frames are cheap: eight per thread keep the sample in the 10-30 s range)
+    n = F + 1
+    frames = pl.moving_clip(w, h, bits, n, seed=5, noise=2)
+    sup = mo.Super(w, h, bits, **skw)
+    abw, afw = mo.Analyse(sup, num_frames=n, isb=1, **akw), mo.Analyse(sup, num_frames=n, isb=0, **akw)
+    comp = mo.Compensate(sup, abw.ad)
+    fps = mo.BlockFPS(sup, abw.ad, afw.ad, n, 24, 1, num=60, den=1)
+    t0 = time.time()
+    with ThreadPoolExecutor(threads) as ex:
+        supers = list(ex.map(sup.frame, frames))
+        bbw = list(ex.map(lambda i: abw.frame(supers[i], supers[i + 1] if i + 1 < n else None), range(n)))
+        bfw = list(ex.map(lambda i: afw.frame(supers[i], supers[i - 1] if i >= 1 else None), range(n)))
+        list(ex.map(lambda i: comp.frame(supers[i], supers[i + 1], bbw[i]), range(F)))
+        list(ex.map(lambda k: fps.frame(k, frames, supers, bbw, bfw), range(fps.num_frames)))
+    dt = time.time() - t0
+    return {"value": fps.num_frames / dt, "unit": "fps", "cores": threads, "kind": "port",
+            "sample": "%d input frames of %s -> %d interpolated + %d compensated frames, %d threads each owning whole frames, %.1f s wall; scalar C oracle (-O2 -mavx2), not the reference's SIMD build (BASELINE.md 4)" % (
+                n, label, fps.num_frames, F, threads, dt)}
 
 
 def main():
@@ -261,10 +336,13 @@ def main():
     cfg = CONFIGS[args.config]
     B = args.batch or cfg[6]
     tr = cfg[3]
+    fpsconv = tr == 0  # cfg4: Compensate + BlockFPS instead of DegrainN
+    PipeT = PipelineFPS if fpsconv else Pipeline
     # the job: world*B output frames of one clip with a tr-frame lead-in / lead-out; this rank's contiguous share + halo
-    plan = shard.RankPlan(world * B + 2 * tr, rank, world, tr, first_out=tr, last_out=world * B + tr)
-    pipe = Pipeline(mv, torch, cfg, B, device, seed=1000 + rank, plan=plan)  # (synthetic content is generated per rank for the frames it holds)
-    pipes = [pipe] + [Pipeline(mv, torch, cfg, B, device, seed=1000 + rank, src=pipe.src, plan=plan) for _ in range(max(1, args.slots) - 1)]
+    plan = shard.RankPlan(world * B + 2 * max(tr, 1), rank, world, max(tr, 1), first_out=max(tr, 1), last_out=world * B + max(tr, 1))
+    pipe = PipeT(mv, torch, cfg, B, device, seed=1000 + rank, plan=plan)  # (synthetic content is generated per rank for the frames it holds)
+    pipes = [pipe] + [PipeT(mv, torch, cfg, B, device, seed=1000 + rank, src=pipe.src, plan=plan) for _ in range(max(1, args.slots) - 1)]
+    units = pipe.frames_per_step if fpsconv else B  # frames a step delivers
     torch.cuda.synchronize()
 
     def barrier():
@@ -290,7 +368,7 @@ def main():
         search_ms = [a.elapsed_time(b) for pp in pipes for a, b in pp.ev]
         avg_launch_ms = sum(search_ms) / len(search_ms)
         bytes_chain, full = pipe.algorithmic_bytes_per_chain()
-        chains = 2 * cfg[3] * B
+        chains = 2 * (B + 1) if fpsconv else 2 * cfg[3] * B
         achieved = bytes_chain * chains / (avg_launch_ms * 1e-3) / 1e9
         traffic = None  # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (same command)
         try:
@@ -301,11 +379,12 @@ def main():
         except Exception:
             traffic = None
         out = {
-            "metric": "MDegrain%d %s fps (Super+Analyse+Degrain end-to-end)" % (cfg[3], args.config),
-            "value": world * B * args.steps / dt, "unit": "fps", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": ("Compensate+BlockFPS 24->60 %s output fps (Super+Analyse+Compensate+BlockFPS end-to-end)" % args.config) if fpsconv else
+                      ("MDegrain%d %s fps (Super+Analyse+Degrain end-to-end)" % (cfg[3], args.config)),
+            "value": world * units * args.steps / dt, "unit": "fps", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16" if cfg[2] > 8 else "u8", "data": "synthetic",
-            "config": {"workload": cfg[7], "frames_per_step_per_gpu": B, "chains_per_step_per_gpu": 2 * cfg[3] * B,
+            "config": {"workload": cfg[7], "frames_per_step_per_gpu": units, "input_frames_per_step_per_gpu": B + 1 if fpsconv else B, "chains_per_step_per_gpu": chains,
                        "sharding": "frame ranges, no collective", "batches_in_flight": len(pipes),
                        "rank0_output_frames": list(plan.out), "rank0_held_frames": list(plan.held)},
             "roofline": {"bound": "hbm", "kernel": "analyse_fast_kernel (the motion search; one launch = %d chains)" % chains, "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -315,7 +394,7 @@ def main():
         }
         if not args.no_cpu and world == 1:
             th = args.cpu_threads or min(os.cpu_count() or 1, 32)
-            out["cpu_baseline"] = cpu_baseline(cfg, th)
+            out["cpu_baseline"] = cpu_baseline_fps(cfg, th) if fpsconv else cpu_baseline(cfg, th)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

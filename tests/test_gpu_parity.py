@@ -673,6 +673,58 @@ def test_full_size_properties_cfg5(mv):
     _fullsize_props(mv, 7680, 4320, 16, 32, 16, 6, "cfg5")
 
 
+@pytest.mark.gpu
+def test_full_size_properties_cfg4(mv):
+    """BASELINE cfg4: 1080p YUV420P8, blk 8, pel 2, mv.Compensate + mv.BlockFPS 24 -> 60 at full size, through properties that do
+    not depend on the size: identical frames interpolate to themselves; a pure +2 px translation is compensated exactly and the
+    frame half way between (24 -> 48) is the content moved by 1 px; time positions 0 copy the input frame."""
+    import torch
+    w, h, bits, blk = 1920, 1080, 8, 8
+    rng = np.random.default_rng(12)
+    yy, xx = np.mgrid[0:h + 16, 0:w + 16].astype(np.float32)
+    tex = (40 * np.sin(xx * 0.21 + yy * 0.07) + 30 * np.sin(xx * 0.05 - yy * 0.13) + 25 * (((xx.astype(np.int32) // 8) + (yy.astype(np.int32) // 8)) & 1) + 120)
+    tex = (tex + rng.integers(-2, 3, tex.shape)).clip(0, 255)
+    big = [tex.astype(np.uint8), (tex[::2, ::2] * 0.5 + 64).astype(np.uint8), (tex[::2, ::2] * 0.25 + 96).astype(np.uint8)]
+    cut = lambda dx: [np.ascontiguousarray(big[0][8:8 + h, 8 - dx:8 - dx + w]), np.ascontiguousarray(big[1][4:4 + h // 2, 4 - dx // 2:4 - dx // 2 + w // 2]),
+                      np.ascontiguousarray(big[2][4:4 + h // 2, 4 - dx // 2:4 - dx // 2 + w // 2])]
+    f = [cut(0), cut(0), cut(2), cut(4)]   # frames 0 == 1, then the content moves +2 px per frame
+    nf = len(f)
+    sup = mv.Super(w, h, bits)
+    src = [mv.frame_to_device(x) for x in f]
+    sf = sup.build(src)
+    abw = mv.Analyse(sup, num_frames=nf, blksize=blk, isb=1)
+    afw = mv.Analyse(sup, num_frames=nf, blksize=blk, isb=0)
+    bbw = abw.run([(sf[n], sf[n + 1] if n + 1 < nf else None) for n in range(nf)])
+    bfw = afw.run([(sf[n], sf[n - 1] if n >= 1 else None) for n in range(nf)])
+    torch.cuda.synchronize()
+    plane = lambda t, p: t[p].cpu().numpy()[:, :f[0][p].shape[1]]
+    # Compensate: frame 2 fetched with frame 1's backward vectors reproduces frame 1 in the interior (integer motion)
+    comp = mv.Compensate(sup, abw.ad).run([(sf[1], sf[2], bbw[1]), (sf[0], sf[1], bbw[0])])
+    torch.cuda.synchronize()
+    for p in range(3):
+        m = 24 if p == 0 else 12
+        assert np.array_equal(plane(comp[0], p)[m:-m, m:-m], f[1][p][m:-m, m:-m]), "cfg4: compensated translation, plane %d" % p
+        assert np.array_equal(plane(comp[1], p), f[0][p]), "cfg4: compensation of identical frames, plane %d" % p
+    # BlockFPS 24 -> 48: output 2n copies input n; output 1 lies between the identical frames 0 and 1; output 5 half way between 2 and 3
+    fps = mv.BlockFPS(sup, abw.ad, afw.ad, nf, [t.stride(0) for t in src[0]], 24, 1, num=48, den=1)
+    assert fps.map(5) == (2, 3, 128) and fps.map(4)[2] == 0
+    out = fps.run([0, 1, 4, 5], src, sf, bbw, bfw)
+    torch.cuda.synchronize()
+    mid = cut(3)
+    for p in range(3):
+        assert np.array_equal(plane(out[0], p), f[0][p]) and np.array_equal(plane(out[2], p), f[2][p]), "cfg4: time position 0 copies the frame"
+        assert np.array_equal(plane(out[1], p), f[0][p]), "cfg4: identical frames interpolate to themselves, plane %d" % p
+        if p == 0:  # (+3 px is not a whole chroma sample: luma only)
+            assert np.array_equal(plane(out[3], 0)[32:-32, 32:-32], mid[0][32:-32, 32:-32]), "cfg4: half-way frame of a +2 px translation"
+    # BlockFPS 24 -> 60 (the BASELINE rate): runs at full size, time positions as the reference's arithmetic gives them
+    fps60 = mv.BlockFPS(sup, abw.ad, afw.ad, nf, [t.stride(0) for t in src[0]], 24, 1, num=60, den=1)
+    assert fps60.num_frames == nf * 60 // 24 and [fps60.map(k)[:2] for k in (0, 1, 2, 3, 5)] == [(0, 1), (0, 1), (0, 1), (1, 2), (2, 3)]
+    out60 = fps60.run(list(range(5)), src, sf, bbw, bfw)
+    torch.cuda.synchronize()
+    for k in (1, 2):
+        assert np.array_equal(plane(out60[k], 0), f[0][0]), "cfg4: 24 -> 60 between identical frames"
+
+
 BLOCKFPS_CASES = [
     # w, h, bits, analyse kwargs, blockfps kwargs (24 fps input)
     (128, 96, 8, dict(blksize=8, overlap=4), dict(num=60, den=1)),                       # BASELINE cfg4: 24 -> 60

@@ -489,6 +489,34 @@ __global__ __launch_bounds__(256) void compensate_kernel(const DGParams *Pp, con
     drow[x] = (T)(a > pm ? pm : a);
 }
 
+
+// ---- blocks without overlap (MVCompensate.c:227-258,286-306: plain block copies): one thread per CW consecutive samples of one
+// block row -- one vector load from the chosen super frame, one vector store.  CW divides the block width, the covered width and
+// the frame width (the host checks), so a segment is never split between cases; block sizes are powers of two.
+template <typename T, int CW>
+__global__ __launch_bounds__(256) void compensate_rows_kernel(const DGParams *Pp, const DGJob *jobs, const int *usable, const CPlanRec *plan, int planeFirst, int planesPerFrame) {
+    const DGParams &P = *Pp;
+    const int z = blockIdx.z, f = z / planesPerFrame, p = planeFirst + z % planesPerFrame;
+    const PlaneG &g = P.pl[p];
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * CW, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= g.W || y >= g.H) return;
+    const DGJob &J = jobs[f];
+    const unsigned char *srcSup = J.src[p], *refSup = J.refs[0][p];
+    const long long inner = (long long)(g.vpadPel / P.pel + y) * g.supPitch + (long long)(g.hpadPel / P.pel + x) * (long long)sizeof(T);
+    const unsigned char *sp;
+    if (!usable[f * 12]) sp = ((!P.scBehavior && refSup) ? refSup : srcSup) + inner;            // MVCompensate.c:348-364
+    else if (x >= g.WB || y >= g.HB) sp = (P.scBehavior ? srcSup : refSup) + inner;             // :319-342
+    else {
+        const int lbw = __ffs(g.blkW) - 1, lbh = __ffs(g.blkH) - 1;
+        const int bx = x >> lbw, by = y >> lbh, px = x & (g.blkW - 1), py = y & (g.blkH - 1);
+        const CPlanRec R = plan[(size_t)f * P.nBlk + by * P.nBlkX + bx];
+        sp = (R.fromRef ? refSup : srcSup) + R.off[p ? 1 : 0] + (long long)py * g.supPitch + (long long)px * (long long)sizeof(T);
+    }
+    int v[CW];
+    dg_load<T, CW>(sp, v);
+    dg_store<T, CW>(J.dst[p] + (long long)y * g.dstPitch + (long long)x * (long long)sizeof(T), v);
+}
+
 // ------------------------------------------------------------------------------------------------ host objects
 
 struct DGCommon {
@@ -773,9 +801,29 @@ extern "C" __attribute__((visibility("default"))) int mvx_compensate_frames(mvx_
     HIP_CHECK(hipMemcpyAsync(c->dJobs, hj.data(), sizeof(DGJob) * nframes, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(usable_kernel, dim3(1, nframes), dim3(256), 0, st, c->dP, c->dJobs, c->dUsable, 0);
     hipLaunchKernelGGL(compensate_plan_kernel, dim3((P.nBlk + 255) / 256, nframes), dim3(256), 0, st, c->dP, c->dJobs, c->dUsable, (CPlanRec *)c->dPlan);
-    dim3 grid((P.pl[0].W + 63) / 64, (P.pl[0].H + 3) / 4, nframes * 3);
-    if (P.bps == 1) hipLaunchKernelGGL(compensate_kernel<uint8_t>, grid, dim3(256), 0, st, c->dP, c->dJobs, c->dUsable, (const CPlanRec *)c->dPlan);
-    else hipLaunchKernelGGL(compensate_kernel<uint16_t>, grid, dim3(256), 0, st, c->dP, c->dJobs, c->dUsable, (const CPlanRec *)c->dPlan);
+    // blocks without overlap: the vectorised row kernel (one launch per plane class); otherwise the per-sample gather
+    auto rowsCW = [&](int p) { // samples per thread: up to 16 bytes, dividing block, covered and frame width
+        if (P.overlap) return 0;
+        const PlaneG &g = P.pl[p];
+        int cw = 16 / P.bps;
+        while (cw > 1 && (g.blkW % cw || g.W % cw || g.WB % cw)) cw >>= 1;
+        return (cw >= 2 && (g.blkW & (g.blkW - 1)) == 0 && (g.blkH & (g.blkH - 1)) == 0) ? cw : 0;
+    };
+    const int cwY = rowsCW(0), cwC = P.nplanes > 1 ? rowsCW(1) : 1;
+    if (cwY && cwC && (P.nplanes == 1 || P.pl[1].W == P.pl[2].W)) {
+        for (int cls = 0; cls < (P.nplanes > 1 ? 2 : 1); cls++) {
+            const int p0 = cls, npl = cls ? 2 : 1, cw = cls ? cwC : cwY;
+            dim3 grid(((P.pl[p0].W / cw) + 63) / 64, (P.pl[p0].H + 3) / 4, nframes * npl);
+#define CR(TT, W_) hipLaunchKernelGGL((compensate_rows_kernel<TT, W_>), grid, dim3(256), 0, st, c->dP, c->dJobs, c->dUsable, (const CPlanRec *)c->dPlan, p0, npl)
+            if (P.bps == 1) { if (cw == 16) CR(uint8_t, 16); else if (cw == 8) CR(uint8_t, 8); else if (cw == 4) CR(uint8_t, 4); else CR(uint8_t, 2); }
+            else { if (cw == 8) CR(uint16_t, 8); else if (cw == 4) CR(uint16_t, 4); else CR(uint16_t, 2); }
+#undef CR
+        }
+    } else {
+        dim3 grid((P.pl[0].W + 63) / 64, (P.pl[0].H + 3) / 4, nframes * 3);
+        if (P.bps == 1) hipLaunchKernelGGL(compensate_kernel<uint8_t>, grid, dim3(256), 0, st, c->dP, c->dJobs, c->dUsable, (const CPlanRec *)c->dPlan);
+        else hipLaunchKernelGGL(compensate_kernel<uint16_t>, grid, dim3(256), 0, st, c->dP, c->dJobs, c->dUsable, (const CPlanRec *)c->dPlan);
+    }
     HIP_CHECK(hipGetLastError());
     return MVX_OK;
 }
@@ -1003,6 +1051,96 @@ __global__ __launch_bounds__(256) void blockfps_kernel(const DGParams *Pp, const
     drow[x] = (T)out;
 }
 
+
+// ---- blocks without overlap: one thread per CW consecutive samples of one block row (same conditions as compensate_rows_kernel).
+// The four vector loads (left / right frame at the sample, the two motion-compensated fetches) and the plan record are per segment;
+// the mask upsizer (SimpleResize.cpp:62-121) interpolates vertically once per mask column the segment touches.
+template <typename T, int CW>
+__global__ __launch_bounds__(256) void blockfps_rows_kernel(const DGParams *Pp, const BFParams *Bp, const BFJob *jobs, const int *usable, const BFPlan *plan, const unsigned char *masks,
+                                                            int planeFirst, int planesPerFrame) {
+    const DGParams &P = *Pp; const BFParams &B = *Bp;
+    const int z = blockIdx.z, f = z / planesPerFrame, p = planeFirst + z % planesPerFrame;
+    const PlaneG &g = P.pl[p];
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * CW, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= g.W || y >= g.H) return;
+    const BFJob &J = jobs[f];
+    unsigned char *dptr = J.dst[p] + (long long)y * g.dstPitch + (long long)x * (long long)sizeof(T);
+    const int t = J.time256;
+    int out[CW];
+    if (!usable[f]) { // time256 0 / 256, vectors unusable or frames outside the clip (:285-288, :640-673)
+        int l[CW];
+        dg_load<T, CW>(J.clipL[p] + (long long)y * B.clipPitch[p] + (long long)x * (long long)sizeof(T), l);
+        if (t <= 0 || (t < 256 && !B.blend)) { dg_store<T, CW>(dptr, l); return; }
+        int r[CW];
+        dg_load<T, CW>(J.clipR[p] + (long long)y * B.clipPitch[p] + (long long)x * (long long)sizeof(T), r);
+#pragma unroll
+        for (int i = 0; i < CW; i++) out[i] = t >= 256 ? r[i] : (int)(T)((l[i] * (256 - t) + r[i] * t) >> 8);
+        dg_store<T, CW>(dptr, out);
+        return;
+    }
+    int sVal[CW], rVal[CW];
+    const long long inner = B.supInterior[p] + (long long)y * g.supPitch + (long long)x * (long long)sizeof(T);
+    dg_load<T, CW>(J.srcSup[p] + inner, sVal);
+    dg_load<T, CW>(J.refSup[p] + inner, rVal);
+    const int covW = g.blkW * P.nBlkX, covH = g.blkH * P.nBlkY;
+    if (x >= covW || y >= covH) { // Blend of the uncovered strips
+#pragma unroll
+        for (int i = 0; i < CW; i++) out[i] = (int)(T)((sVal[i] * (256 - t) + rVal[i] * t) >> 8);
+        dg_store<T, CW>(dptr, out);
+        return;
+    }
+    const int mode = B.mode, c = p ? 1 : 0;
+    int mF[CW], mB[CW], mO[CW];
+#pragma unroll
+    for (int i = 0; i < CW; i++) { mF[i] = 0; mB[i] = 0; mO[i] = 0; }
+    if (mode >= 3) {
+        const unsigned char *m = masks + (size_t)f * 3 * B.XP * B.YP;
+        const int wb = B.vW[c][y], wt = 16384 - wb;
+        const int rowOff = B.vOff[c][y] * B.XP;
+        const int o0 = B.hOff[c][x];
+        // vertically interpolated values of up to three mask columns; columns further right (upsizing by less than CW) are done on demand
+        auto vcol = [&](const unsigned char *mm, int o) { return (int)(unsigned char)((mm[rowOff + o] * wt + mm[rowOff + B.XP + o] * wb + 8192) >> 14); };
+        auto upsize = [&](const unsigned char *mm, int *dst) {
+            const int a0 = vcol(mm, o0), a1 = vcol(mm, o0 + 1), a2 = vcol(mm, o0 + 2);
+#pragma unroll
+            for (int i = 0; i < CW; i++) {
+                const int o = B.hOff[c][x + i], wr = B.hW[c][x + i], wl = 16384 - wr, k = o - o0;
+                int a, b;
+                if (k == 0) { a = a0; b = a1; } else if (k == 1) { a = a1; b = a2; } else { a = vcol(mm, o); b = vcol(mm, o + 1); }
+                dst[i] = (int)(unsigned char)((a * wl + b * wr + 8192) >> 14);
+            }
+        };
+        if (mode != 5 && mode != 8) { upsize(m, mF); upsize(m + B.XP * B.YP, mB); }
+        if (mode == 4 || mode == 5 || mode == 7 || mode == 8) upsize(m + 2 * B.XP * B.YP, mO);
+    }
+    const int lbw = __ffs(g.blkW) - 1, lbh = __ffs(g.blkH) - 1;
+    const int bx = x >> lbw, by = y >> lbh, px = x & (g.blkW - 1), py = y & (g.blkH - 1);
+    const BFPlan R = plan[(size_t)f * P.nBlk + by * P.nBlkX + bx];
+    int bv[CW], fv[CW];
+    const long long bo = (long long)py * g.supPitch + (long long)px * (long long)sizeof(T);
+    dg_load<T, CW>(J.refSup[p] + R.offB[c] + bo, bv);
+    dg_load<T, CW>(J.srcSup[p] + R.offF[c] + bo, fv);
+#pragma unroll
+    for (int i = 0; i < CW; i++) { // RealResultBlock, MVBlockFPS.c:117-227
+        const int b = bv[i], fw = fv[i];
+        int v;
+        switch (mode) {
+        case 0: v = (b * t + fw * (256 - t)) >> 8; break;
+        case 1: v = bf_median(rVal[i], sVal[i], (int)(T)((b * t + fw * (256 - t)) >> 8)); break;
+        case 2: v = bf_median((int)(T)((rVal[i] * t + sVal[i] * (256 - t)) >> 8), b, fw); break;
+        case 3: case 6: v = (((mB[i] * fw + (255 - mB[i]) * b + 255) >> 8) * t + ((mF[i] * b + (255 - mF[i]) * fw + 255) >> 8) * (256 - t)) >> 8; break;
+        case 4: case 7: {
+            const int ff = (mF[i] * b + (255 - mF[i]) * fw + 255) >> 8, bb = (mB[i] * fw + (255 - mB[i]) * b + 255) >> 8;
+            const int avg = (rVal[i] * t + sVal[i] * (256 - t) + 255) >> 8, mm = (bb * t + ff * (256 - t)) >> 8;
+            v = (avg * mO[i] + mm * (255 - mO[i]) + 255) >> 8; break;
+        }
+        default: v = mO[i] << (P.bits - 8); break;
+        }
+        out[i] = (int)(T)v;
+    }
+    dg_store<T, CW>(dptr, out);
+}
+
 struct mvx_blockfps : DGCommon {
     BFParams B;
     BFParams *dB = nullptr;
@@ -1170,9 +1308,28 @@ extern "C" __attribute__((visibility("default"))) int mvx_blockfps_frames(mvx_bl
         hipLaunchKernelGGL(bf_mask_finish_kernel, dim3((unsigned)((cells + 255) / 256), nframes), dim3(256), 0, st, b->dP, b->dB, b->dUsable, b->dSmall, b->dMasks);
     }
     hipLaunchKernelGGL(bf_plan_kernel, dim3((P.nBlk + 255) / 256, nframes), dim3(256), 0, st, b->dP, b->dBJobs, b->dUsable, (BFPlan *)b->dPlan);
-    dim3 grid((P.pl[0].W + 63) / 64, (P.pl[0].H + 3) / 4, nframes * 3);
-    if (P.bps == 1) hipLaunchKernelGGL(blockfps_kernel<uint8_t>, grid, dim3(256), 0, st, b->dP, b->dB, b->dBJobs, b->dUsable, (const BFPlan *)b->dPlan, b->dMasks);
-    else hipLaunchKernelGGL(blockfps_kernel<uint16_t>, grid, dim3(256), 0, st, b->dP, b->dB, b->dBJobs, b->dUsable, (const BFPlan *)b->dPlan, b->dMasks);
+    auto rowsCW = [&](int p) { // as in mvx_compensate_frames; the uncovered strips start at nBlkX * blkW here
+        if (P.overlap) return 0;
+        const PlaneG &g = P.pl[p];
+        int cw = 16 / P.bps;
+        while (cw > 1 && (g.blkW % cw || g.W % cw)) cw >>= 1;
+        return (cw >= 2 && (g.blkW & (g.blkW - 1)) == 0 && (g.blkH & (g.blkH - 1)) == 0) ? cw : 0;
+    };
+    const int cwY = rowsCW(0), cwC = P.nplanes > 1 ? rowsCW(1) : 1;
+    if (cwY && cwC && (P.nplanes == 1 || P.pl[1].W == P.pl[2].W)) {
+        for (int cls = 0; cls < (P.nplanes > 1 ? 2 : 1); cls++) {
+            const int p0 = cls, npl = cls ? 2 : 1, cw = cls ? cwC : cwY;
+            dim3 grid(((P.pl[p0].W / cw) + 63) / 64, (P.pl[p0].H + 3) / 4, nframes * npl);
+#define BR(TT, W_) hipLaunchKernelGGL((blockfps_rows_kernel<TT, W_>), grid, dim3(256), 0, st, b->dP, b->dB, b->dBJobs, b->dUsable, (const BFPlan *)b->dPlan, b->dMasks, p0, npl)
+            if (P.bps == 1) { if (cw == 16) BR(uint8_t, 16); else if (cw == 8) BR(uint8_t, 8); else if (cw == 4) BR(uint8_t, 4); else BR(uint8_t, 2); }
+            else { if (cw == 8) BR(uint16_t, 8); else if (cw == 4) BR(uint16_t, 4); else BR(uint16_t, 2); }
+#undef BR
+        }
+    } else {
+        dim3 grid((P.pl[0].W + 63) / 64, (P.pl[0].H + 3) / 4, nframes * 3);
+        if (P.bps == 1) hipLaunchKernelGGL(blockfps_kernel<uint8_t>, grid, dim3(256), 0, st, b->dP, b->dB, b->dBJobs, b->dUsable, (const BFPlan *)b->dPlan, b->dMasks);
+        else hipLaunchKernelGGL(blockfps_kernel<uint16_t>, grid, dim3(256), 0, st, b->dP, b->dB, b->dBJobs, b->dUsable, (const BFPlan *)b->dPlan, b->dMasks);
+    }
     HIP_CHECK(hipGetLastError());
     return MVX_OK;
 }

@@ -476,16 +476,24 @@ typedef struct AnalyseData { VSNode *node; const VSVideoInfo *vi; mvx_super *sup
 
 static long env_long(const char *name, long def) { const char *e = getenv(name); return e ? atol(e) : def; }
 
+/* totals over all instances, printed when the plugin is unloaded (MVX_VS_STATS=1): a host need not free its nodes before it exits */
+static long g_stat_launches, g_stat_jobs, g_stat_largest, g_stat_instances;
+__attribute__((destructor)) static void print_stats(void) {
+    if (env_long("MVX_VS_STATS", 0) && g_stat_instances)
+        fprintf(stderr, "mvtools_vs: Analyse instances=%ld launches=%ld jobs=%ld largest_batch=%ld\n", g_stat_instances, g_stat_launches, g_stat_jobs, g_stat_largest);
+}
+
 static void combiner_init(Combiner *c) {
     memset(c, 0, sizeof(*c));
     pthread_mutex_init(&c->mu, NULL); pthread_cond_init(&c->done, NULL); pthread_cond_init(&c->more, NULL);
     c->stream = mvx_stream_create(); /* NULL (the default stream) still works, it only serialises the instances */
+    pthread_mutex_lock(&g_lock); g_stat_instances++; pthread_mutex_unlock(&g_lock);
     c->maxBatch = (int)env_long("MVX_VS_BATCH_MAX", 1024);
     c->waitUs = env_long("MVX_VS_BATCH_WAIT_US", 2000);
     if (c->maxBatch < 1) c->maxBatch = 1;
 }
 static void combiner_free(Combiner *c, const char *what) {
-    if (env_long("MVX_VS_STATS", 0)) fprintf(stderr, "mvtools_vs: %s launches=%ld jobs=%ld largest_batch=%ld\n", what, c->batches, c->jobs, c->largest);
+    (void)what;
     mvx_stream_destroy(c->stream);
     pthread_mutex_destroy(&c->mu); pthread_cond_destroy(&c->done); pthread_cond_destroy(&c->more);
 }
@@ -513,6 +521,9 @@ static int combiner_submit(Combiner *c, mvx_analyse *an, AnReq *r) {
     c->head = c->tail = NULL; c->n = 0; c->leader = 0; /* the next arrival leads the next batch while this one runs */
     c->batches++; c->jobs += n; if (n > c->largest) c->largest = n;
     pthread_mutex_unlock(&c->mu);
+    pthread_mutex_lock(&g_lock);
+    g_stat_launches++; g_stat_jobs += n; if (n > g_stat_largest) g_stat_largest = n;
+    pthread_mutex_unlock(&g_lock);
     int rc = 0;
     mvx_analyse_job *jobs = (mvx_analyse_job *)malloc(sizeof(mvx_analyse_job) * (size_t)n);
     if (!jobs) rc = MVX_E_NOMEM;
