@@ -82,16 +82,20 @@ void mvx_super_get_info(const mvx_super *s, mvx_super_info *info);
 int mvx_super_frames(mvx_super *s, int nframes, const void *const *src, const ptrdiff_t src_pitch[3],
                      void *const *dst, const ptrdiff_t dst_pitch[3], void *stream);
 
-/* Optional device-side layout extension for search throughput ("shadow copies").  gfx950 serves vector loads at addresses that
+/* Optional device-side layout extension for search throughput ("shadow planes").  gfx950 serves vector loads at addresses that
  * are not multiples of four several times slower than aligned ones, and a motion search reads reference blocks at arbitrary
- * sample positions.  A caller may therefore keep, behind every plane of a super frame, mvx_super_shadow_copies() further copies
- * of the whole plane buffer (plane_height * pitch bytes), copy k = 1.. at plane + k * copy_stride[p] and shifted left by k
- * samples; mvx_super_shadow_frames fills them from planes that mvx_super_frames has written (same stream).  The copies never
- * leave the device and are not part of the super clip's frame format; a search uses them after mvx_analyse_set_ref_shadow.
+ * sample positions.  For clips of more than 8 bits (mvx_super_shadow_copies() == 1) a caller may therefore keep, behind the planes
+ * of a super frame, two derived planes that mvx_super_shadow_frames fills from planes mvx_super_frames has written (same stream):
+ *   - at luma plane + copy_stride[0]: the whole luma buffer shifted left by one sample (odd sample positions become aligned);
+ *   - at U plane + copy_stride[1]: the whole U and V buffers interleaved sample by sample (2 x the chroma size; every chroma
+ *     position is aligned, and a block row's U and V samples share one cache line).
+ * mvx_super_shadow_bytes gives the bytes to reserve behind each plane.  The shadow planes never leave the device and are not part
+ * of the super clip's frame format; a search uses them after mvx_analyse_set_ref_shadow.
  * (no reference counterpart: memory layout only, results are unchanged) */
-int mvx_super_shadow_copies(const mvx_super *s);   /* copies worth keeping for this format: 1 for 9..16-bit clips, 0 for 8-bit clips */
+int mvx_super_shadow_copies(const mvx_super *s);   /* 1: shadow planes pay off for this format (9..16 bits), 0: not (8 bits) */
+void mvx_super_shadow_bytes(const mvx_super *s, const ptrdiff_t pitch[3], size_t extra[3]);
 int mvx_super_shadow_frames(const mvx_super *s, int nframes, void *const *planes /* [f*3+p] */, const ptrdiff_t pitch[3],
-                            const ptrdiff_t copy_stride[3], void *stream);
+                            const ptrdiff_t copy_stride[3] /* [2] unused */, void *stream);
 
 /* mv.Super(pelclip=...): the sub-pel planes of level 0 are taken from the user's upsized clip instead of being interpolated.
  * replaces MVSuper.c:229-256 (mvx_super_pelclip_mode: 0 = ignored because pel is 1, 1 = pelclip is pel x the clip size,
@@ -138,8 +142,9 @@ typedef struct mvx_analyse_job {
     int32_t reserved;
 } mvx_analyse_job;
 
-/* The caller promises that every job's reference planes carry shadow copies (mvx_super_shadow_frames) at ref[p] + k * copy_stride[p];
- * copy_stride NULL or all zero: none (the default).  Only changes which addresses the search loads from, never a result. */
+/* The caller promises that the super frames of every job (src and ref) carry their shadow planes (mvx_super_shadow_frames) at
+ * plane[0] + copy_stride[0] and plane[1] + copy_stride[1]; NULL or all zero: none (the default).  Only changes which addresses the
+ * search loads from, never a result. */
 int mvx_analyse_set_ref_shadow(mvx_analyse *a, const ptrdiff_t copy_stride[3]);
 
 /* One chain (frame, direction) per job; all jobs run concurrently in one launch. `jobs` is a HOST array.
@@ -191,9 +196,6 @@ int mvx_degrain_create(const mvx_degrain_args *args, const mvx_analysis_data *ve
                        const mvx_super *super_clip, const ptrdiff_t src_pitch[3], const ptrdiff_t super_pitch[3],
                        const ptrdiff_t dst_pitch[3], mvx_degrain **out, char *err);
 void mvx_degrain_destroy(mvx_degrain *d);
-
-/* the reference super frames of every job carry shadow copies (see mvx_super_shadow_frames); NULL / zeros: none.  Layout hint only. */
-int mvx_degrain_set_ref_shadow(mvx_degrain *d, const ptrdiff_t copy_stride[3]);
 
 typedef struct mvx_degrain_job {
     const void *src[3];          /* clip frame n */

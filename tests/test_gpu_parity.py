@@ -718,7 +718,7 @@ def test_full_size_properties_cfg4(mv):
             assert np.array_equal(plane(out[3], 0)[32:-32, 32:-32], mid[0][32:-32, 32:-32]), "cfg4: half-way frame of a +2 px translation"
     # BlockFPS 24 -> 60 (the BASELINE rate): runs at full size, time positions as the reference's arithmetic gives them
     fps60 = mv.BlockFPS(sup, abw.ad, afw.ad, nf, [t.stride(0) for t in src[0]], 24, 1, num=60, den=1)
-    assert fps60.num_frames == nf * 60 // 24 and [fps60.map(k)[:2] for k in (0, 1, 2, 3, 5)] == [(0, 1), (0, 1), (0, 1), (1, 2), (2, 3)]
+    assert fps60.num_frames == 1 + (nf - 1) * 60 // 24 and [fps60.map(k)[:2] for k in (0, 1, 2, 3, 5)] == [(0, 1), (0, 1), (0, 1), (1, 2), (2, 3)]  # MVBlockFPS.c:955
     out60 = fps60.run(list(range(5)), src, sf, bbw, bfw)
     torch.cuda.synchronize()
     for k in (1, 2):

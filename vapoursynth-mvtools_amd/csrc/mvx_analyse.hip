@@ -33,6 +33,7 @@ struct MvxDebug {
     int fast_flags = -1; // lean kernel: MVX_FAST_* bits, -1 = default
     int pad_runs = -1;   // lean kernel: 1 = pad the job table so that the chains of one reference frame never straddle two workgroups
     int shadow_planes = 3; // 1 = luma only, 2 = chroma only uses the shadow copies
+    int degrain_xcd = -1;  // Degrain cell kernels: XCD-contiguous tile order (1 / 0), -1 = default
     int cpw_sync = -1; // barrier interval inside a workgroup (power of two, 0 = none)
     int lds_min = -1;  // LDS floor of the one-chain launches
     int ablate = 0;
@@ -40,7 +41,7 @@ struct MvxDebug {
 static MvxDebug g_dbg;
 extern "C" __attribute__((visibility("default"))) int mvx_debug_option(const char *name, int value) {
     struct { const char *n; int *p; } tab[] = { { "general", &g_dbg.general }, { "fast_wpe", &g_dbg.fast_wpe }, { "cpw1", &g_dbg.cpw1 }, { "window", &g_dbg.window },
-        { "tile", &g_dbg.tile }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "fast_cpw", &g_dbg.fast_cpw }, { "fast_flags", &g_dbg.fast_flags }, { "pad_runs", &g_dbg.pad_runs }, { "shadow_planes", &g_dbg.shadow_planes }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min },
+        { "tile", &g_dbg.tile }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "fast_cpw", &g_dbg.fast_cpw }, { "fast_flags", &g_dbg.fast_flags }, { "pad_runs", &g_dbg.pad_runs }, { "shadow_planes", &g_dbg.shadow_planes }, { "degrain_xcd", &g_dbg.degrain_xcd }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min },
 #ifdef MVX_LAB
         { "ablate", &g_dbg.ablate },
 #endif
@@ -48,6 +49,11 @@ extern "C" __attribute__((visibility("default"))) int mvx_debug_option(const cha
     for (auto &t : tab) if (!strcmp(t.n, name)) { *t.p = value; return MVX_OK; }
     mvx_set_error("mvx_debug_option: unknown option %s", name);
     return MVX_E_ARG;
+}
+
+int mvx_debug_value(const char *name, int def) {
+    if (!strcmp(name, "degrain_xcd")) return g_dbg.degrain_xcd >= 0 ? g_dbg.degrain_xcd : def;
+    return def;
 }
 
 #define AFAIL(...) do { snprintf(err, MVX_ERRLEN, __VA_ARGS__); mvx_set_error("%s", err); return MVX_E_ARG; } while (0)
@@ -366,7 +372,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
             int syncEvery = k >= 2 ? (P.bps == 2 ? 32 : 256) : 0;
             if (g_dbg.cpw_sync >= 0 && (g_dbg.cpw_sync & (g_dbg.cpw_sync - 1)) == 0) syncEvery = g_dbg.cpw_sync;
             // XCD-contiguous workgroup order: neighbours in the (reference-sorted) job table share an L2 (+0.5 %, 4K16)
-            const int flags = g_dbg.fast_flags >= 0 ? g_dbg.fast_flags : MVX_FAST_XCD_REMAP;
+            const int flags = (g_dbg.fast_flags >= 0 ? g_dbg.fast_flags : MVX_FAST_XCD_REMAP) | ((P.shadow[1] != 0 && P.chroma) ? MVX_FAST_UV : 0);
             ALaunch L = { 0, ntab, fNeed, fRow, fRow, fBins, -1, 0, fNeed, simds, cpw, k, syncEvery, k, flags, st, a->dP, a->dJobs };
             int rc = P.bps == 1 ? mvx_analyse_launch_fast_u8(P, L) : mvx_analyse_launch_fast_u16(P, L);
             if (rc == MVX_OK) {

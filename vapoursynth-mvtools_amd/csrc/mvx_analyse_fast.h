@@ -27,9 +27,11 @@ template <int BPS, int BW> struct FGeo {
     static constexpr int LROWB = BW * BPS, LCB = LROWB < 16 ? LROWB : 16, LC = LROWB / LCB, LT = BH * LC;
     static constexpr int CW = BW / 2, CH = BH / 2, CROWB = CW * BPS, CCB = CROWB < 16 ? CROWB : 16, CC = CROWB / CCB, CT = CH * CC;
     static constexpr int UOFF = BH * LROWB, VOFF = UOFF + CH * CROWB, SRCB = VOFF + CH * CROWB;
-    static constexpr int NPF = (LT + 2 * CT + WAVE - 1) / WAVE; // 16-byte (or smaller) pieces of the source block per lane
+    // chroma from the UV-interleaved shadow plane (one row = the U and V samples of a block row, alternating): same bytes, half the rows
+    static constexpr int UVROWB = 2 * CROWB, UVCB = UVROWB < 16 ? UVROWB : 16, UVC = UVROWB / UVCB, UVT = CH * UVC;
+    static constexpr int NPF = (LT + (2 * CT > UVT ? 2 * CT : UVT) + WAVE - 1) / WAVE; // 16-byte (or smaller) pieces of the source block per lane
     static constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v / 2); }
-    static constexpr int LLOGC = ilog2c(LC), CLOGC = ilog2c(CC);
+    static constexpr int LLOGC = ilog2c(LC), CLOGC = ilog2c(CC), UVLOGC = ilog2c(UVC);
 };
 
 // can the lean kernel run this parameter set?  (host; mirrors the level-wise choice of doPobSearchMVs, PlaneOfBlocks.cpp:979-1034)
@@ -44,14 +46,15 @@ static inline bool mvx_fast_eligible(const AParams &P) {
     for (int i = 0; i < P.nLevels; i++) {
         const ALevel &L = P.lv[i];
         if ((long long)L.pel * L.pel * L.pstride[0] >= 0xffffffffLL || (long long)L.pel * L.pel * L.pstride[1] >= 0xffffffffLL) return false; // 32-bit plane offsets
-        if ((long long)L.pel * L.pel * L.pstride[0] + 3 * P.shadow[0] >= 0xffffffffLL || (long long)L.pel * L.pel * L.pstride[1] + 3 * P.shadow[1] >= 0xffffffffLL) return false;
-        if (P.shadow[1] != P.shadow[2]) return false;
+        if ((long long)L.pel * L.pel * L.pstride[0] + P.shadow[0] >= 0xffffffffLL || 2 * (long long)L.pel * L.pel * L.pstride[1] + P.shadow[1] >= 0xffffffffLL) return false;
+        if (P.shadow[0] && P.bps != 2) return false; // (shadow planes exist for 16-bit clips only)
         if ((L.pw << L.logPel) >= 30000 || (L.ph << L.logPel) >= 30000) return false; // vectors and their squared distances stay well inside int
     }
     return true;
 }
 
-template <int BPS, int BW> struct FastSearcher {
+// UV: chroma is read from the UV-interleaved shadow plane (compile-time: the two chroma paths must not share a register allocation)
+template <int BPS, int BW, bool UV> struct FastSearcher {
     typedef FGeo<BPS, BW> G;
     const AParams &P;
     const AJob &J;
@@ -61,8 +64,10 @@ template <int BPS, int BW> struct FastSearcher {
     // level constants (uniform)
     int nBlkX, nBlkY, pel, logPel, pw, ph, hpad, vpad;
     gl_u8 *srcY, *srcU, *srcV, *refY, *refU, *refV;
+    gl_u8 *srcUV, *refUV;      // level bases inside the UV-interleaved shadow planes (uv != 0)
     unsigned pitchY, pitchC, pstrideY, pstrideC;
-    unsigned shadowY, shadowC; // byte distance between the shifted copies of a reference plane, 0 = none (mvx_super_shadow_frames)
+    unsigned shadowY;          // byte distance from a luma plane to its copy shifted by one sample, 0 = none (mvx_super_shadow_frames)
+    static constexpr bool uv = UV;
     GL_AS GVec *vectors;
     int chroma, searchType, nSearchParam, penaltyNew, penaltyZero, pglobal, badrange, badcount, fieldShift;
     long long badSAD, LSAD;
@@ -110,7 +115,7 @@ template <int BPS, int BW> struct FastSearcher {
         const int xb = vx < 0 ? 1 : 0, yb = vy < 0 ? 1 : 0;
         const int ax = ((x0 >> 1) << logPel) + ((vx + xb) >> 1), ay = ((y0 >> 1) << logPel) + ((vy + yb) >> 1), m = pel - 1;
         const unsigned idx = (unsigned)((ax & m) | ((ay & m) << logPel));
-        return shadow_off(idx * pstrideC + (unsigned)(ay >> logPel) * pitchC + (unsigned)(ax >> logPel) * BPS, shadowC);
+        return idx * pstrideC + (unsigned)(ay >> logPel) * pitchC + (unsigned)(ax >> logPel) * BPS; // (in the UV plane: twice this, always dword-aligned)
     }
 
     // ---- SAD of this lane's share of one plane region (T pieces of CB bytes, 1 << LOGC pieces per row) for a candidate that
@@ -185,8 +190,11 @@ template <int BPS, int BW> struct FastSearcher {
         aL = region<LOGG, G::LT, G::LLOGC, G::LCB, G::LROWB>(s, lds, refY, ref_luma_off(vx, vy), pitchY, aL);
         if (chroma) {
             const unsigned co = ref_chroma_off(vx, vyc);
-            aC = region<LOGG, G::CT, G::CLOGC, G::CCB, G::CROWB>(s, lds + G::UOFF, refU, co, pitchC, aC);
-            aC = region<LOGG, G::CT, G::CLOGC, G::CCB, G::CROWB>(s, lds + G::VOFF, refV, co, pitchC, aC);
+            if (uv) aC = region<LOGG, G::UVT, G::UVLOGC, G::UVCB, G::UVROWB>(s, lds + G::UOFF, refUV, 2 * co, 2 * pitchC, aC); // U and V in one pass
+            else {
+                aC = region<LOGG, G::CT, G::CLOGC, G::CCB, G::CROWB>(s, lds + G::UOFF, refU, co, pitchC, aC);
+                aC = region<LOGG, G::CT, G::CLOGC, G::CCB, G::CROWB>(s, lds + G::VOFF, refV, co, pitchC, aC);
+            }
         }
     }
 
@@ -507,10 +515,13 @@ template <int BPS, int BW> struct FastSearcher {
 #pragma unroll
         for (int k = 0; k < G::NPF; k++) {
             const int t = l + k * WAVE;
-            const int TT = G::LT + (chroma ? 2 * G::CT : 0);
+            const int TT = G::LT + (chroma ? (uv ? G::UVT : 2 * G::CT) : 0);
             if (t < G::LT) {
                 const int row = t / G::LC, xb = (t % G::LC) * G::LCB;
                 pfP[k] = 0; pfG[k] = (int)(row * pitchY) + xb; pfL[k] = row * G::LROWB + xb;
+            } else if (t < TT && uv) { // one piece of a UV row
+                const int tt = t - G::LT, row = tt / G::UVC, xb = (tt % G::UVC) * G::UVCB;
+                pfP[k] = 1; pfG[k] = (int)(row * 2 * pitchC) + xb; pfL[k] = G::UOFF + row * G::UVROWB + xb;
             } else if (t < TT) {
                 int tt = t - G::LT;
                 const int pl = tt >= G::CT ? 2 : 1;
@@ -528,9 +539,9 @@ template <int BPS, int BW> struct FastSearcher {
         for (int k = 0; k < G::NPF; k++) {
             const int pl = pfP[k];
             if (pl < 0) continue;
-            gl_u8 *g = (pl == 0 ? srcY + offY : (pl == 1 ? srcU : srcV) + offC) + pfG[k];
-            if (G::LCB == G::CCB) pf[k] = ld_chunk_g(g, G::LCB);
-            else pf[k] = pl == 0 ? ld_chunk_g(g, G::LCB) : ld_chunk_g(g, G::CCB);
+            if (pl == 0) pf[k] = ld_chunk_g(srcY + offY + pfG[k], G::LCB);
+            else if (uv) pf[k] = ld_chunk_g(srcUV + 2 * offC + pfG[k], G::UVCB);
+            else pf[k] = ld_chunk_g((pl == 1 ? srcU : srcV) + offC + pfG[k], G::CCB);
         }
     }
     __device__ __forceinline__ void pf_store(const A4x32 *pf) const {
@@ -538,8 +549,8 @@ template <int BPS, int BW> struct FastSearcher {
         for (int k = 0; k < G::NPF; k++) {
             const int pl = pfP[k];
             if (pl < 0) continue;
-            if (G::LCB == G::CCB) st_chunk_l(lds + pfL[k], pf[k], G::LCB);
-            else if (pl == 0) st_chunk_l(lds + pfL[k], pf[k], G::LCB);
+            if (pl == 0) st_chunk_l(lds + pfL[k], pf[k], G::LCB);
+            else if (uv) st_chunk_l(lds + pfL[k], pf[k], G::UVCB);
             else st_chunk_l(lds + pfL[k], pf[k], G::CCB);
         }
     }
@@ -569,7 +580,9 @@ template <int BPS, int BW> struct FastSearcher {
         srcU = uptr(J.src[1] + L.off[1]); refU = uptr(J.ref[1] + L.off[1]);
         srcV = uptr(J.src[2] + L.off[2]); refV = uptr(J.ref[2] + L.off[2]);
         pitchY = (unsigned)uni((int)P.pitch[0]); pitchC = (unsigned)uni((int)P.pitch[1]); pstrideY = (unsigned)uni((int)L.pstride[0]); pstrideC = (unsigned)uni((int)L.pstride[1]);
-        shadowY = (unsigned)uni((int)P.shadow[0]); shadowC = (unsigned)uni((int)P.shadow[1]);
+        shadowY = (unsigned)uni((int)P.shadow[0]);
+        // the UV plane mirrors the whole U / V buffers sample for sample: U byte offset o <-> UV byte offset 2 * o
+        srcUV = uptr(J.src[1] + P.shadow[1] + 2 * L.off[1]); refUV = uptr((J.ref[1] ? J.ref[1] : J.src[1]) + P.shadow[1] + 2 * L.off[1]);
         unsigned char *rec = (unsigned char *)(unsigned long long)uni((long long)(unsigned long long)(J.blob + L.blobOff));
         vectors = (GL_AS GVec *)(rec + 4);
         if (l == 0) *(int *)rec = 4 + nBlkX * nBlkY * 16; // pobWriteHeaderToArray :413-416
@@ -704,7 +717,8 @@ template <int BPS, int BW> struct FastSearcher {
 // chains of a workgroup search the same reference frame(s) (shared lines in the CU's L1 and the XCD's L2).
 // flags: bit 0 = deal the workgroups out so that consecutive ones (which share reference frames) run on the same XCD.
 #define MVX_FAST_XCD_REMAP 1
-template <int BPS, int BW, int WPE, int MAXCPW>
+#define MVX_FAST_UV 2 // host -> launcher: the jobs' frames carry the UV-interleaved shadow plane
+template <int BPS, int BW, int WPE, int MAXCPW, bool UV>
 __global__ __launch_bounds__(64 * MAXCPW, WPE) void analyse_fast_kernel(const AParams *Pp, const AJob *jobs, int njobs, int ldsChain, int syncEvery, int ldsRow, int ldsHist, int histBins, int flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const AParams &P = *Pp;
@@ -733,7 +747,7 @@ __global__ __launch_bounds__(64 * MAXCPW, WPE) void analyse_fast_kernel(const AP
         return;
     }
     if (l == 0) { hdr[0] = P.blobSize; hdr[1] = 1; } // GroupOfPlanes.c:77-85
-    FastSearcher<BPS, BW> S(P, J);
+    FastSearcher<BPS, BW, UV> S(P, J);
     S.lds = (lds_u8 *)smem + uni((int)(threadIdx.x >> 6)) * ldsChain;
     S.ldsRow = ldsRow; S.ldsHist = ldsHist; S.histBins = histBins;
     int gx = 0, gy = 0; // zeroMV, MVAnalysisData.h:79
@@ -746,13 +760,18 @@ __global__ __launch_bounds__(64 * MAXCPW, WPE) void analyse_fast_kernel(const AP
     }
 }
 
-template <int BPS, int BW, int WPE, int MAXCPW> static int launch_analyse_fast(const ALaunch &L) {
+template <int BPS, int BW, int WPE, int MAXCPW, bool UV> static int launch_analyse_fast_uv(const ALaunch &L) {
     const int perChain = (L.ldsNeed + 255) & ~255;
     const int cpw = L.cpw < MAXCPW ? L.cpw : MAXCPW;
     const int lds = perChain * cpw;
     if (lds > 64 * 1024)
-        HIP_CHECK(hipFuncSetAttribute((const void *)analyse_fast_kernel<BPS, BW, WPE, MAXCPW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL((analyse_fast_kernel<BPS, BW, WPE, MAXCPW>), dim3((L.njobs + cpw - 1) / cpw), dim3(64 * cpw), lds, L.st, L.dP, L.dJobs,
+        HIP_CHECK(hipFuncSetAttribute((const void *)analyse_fast_kernel<BPS, BW, WPE, MAXCPW, UV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((analyse_fast_kernel<BPS, BW, WPE, MAXCPW, UV>), dim3((L.njobs + cpw - 1) / cpw), dim3(64 * cpw), lds, L.st, L.dP, L.dJobs,
                        L.njobs, perChain, L.syncEvery, L.ldsRow, L.ldsHist, L.histBins, L.flags);
     return MVX_OK;
+}
+// (8-bit clips have no shadow planes: only the plain chroma path is built for them)
+template <int BPS, int BW, int WPE, int MAXCPW> static int launch_analyse_fast(const ALaunch &L) {
+    if (BPS == 2 && (L.flags & MVX_FAST_UV)) return launch_analyse_fast_uv<BPS, BW, WPE, MAXCPW, BPS == 2>(L);
+    return launch_analyse_fast_uv<BPS, BW, WPE, MAXCPW, false>(L);
 }

@@ -13,6 +13,7 @@
 #define MVX_MAX_LEVELS 24
 
 void mvx_set_error(const char *fmt, ...);
+int mvx_debug_value(const char *name, int def); // value of a developer option set through mvx_debug_option (mvx_analyse.hip), or def
 void mvx_divided_data(const mvx_analysis_data *in, mvx_analysis_data *out);
 
 #define HIP_CHECK(expr)                                                                           \

@@ -407,49 +407,66 @@ static int super_frames_impl(mvx_super *s, int nframes, const void *const *src, 
 // buffer shifted left by 1 .. n samples (copy k, byte i = plane byte i + k * bps).  A block at a sample position x with
 // x % (4 / bps) == k is then read from copy k at x - k: same samples, dword-aligned address.  mvx_analyse_set_ref_shadow tells
 // a search where the copies are.
-struct ShadowArgs { void *const *planes; long long size[3], stride[3]; int nplanes, bps, ncopies; };
+struct ShadowArgs { void *const *planes; long long size[3], stride[3]; int nplanes, bps; };
+// blockIdx.y = frame * 2 + kind; kind 0: the luma plane shifted left by one sample; kind 1: U and V interleaved sample by sample
 __global__ __launch_bounds__(256) void super_shadow_kernel(ShadowArgs A) {
-    const int fp = blockIdx.y, p = fp % 3;
-    if (p >= A.nplanes) return;
+    const int f = blockIdx.y >> 1, kind = blockIdx.y & 1;
     const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 16;
-    if (i >= A.size[p]) return;
-    unsigned char *base = (unsigned char *)A.planes[fp];
-    const uint4 a = *(const uint4 *)(base + i);
-    const unsigned b = i + 16 < A.size[p] ? *(const unsigned *)(base + i + 16) : 0u;
-    const int n = A.ncopies;
-    for (int k = 1; k <= n; k++) {
-        const unsigned sh = 8u * k * A.bps;
+    if (kind == 0) {
+        if (i >= A.size[0]) return;
+        unsigned char *base = (unsigned char *)A.planes[f * 3];
+        const uint4 a = *(const uint4 *)(base + i);
+        const unsigned b = i + 16 < A.size[0] ? *(const unsigned *)(base + i + 16) : 0u;
+        const unsigned sh = 8u * A.bps;
         uint4 o;
         o.x = __builtin_amdgcn_alignbit(a.y, a.x, sh); o.y = __builtin_amdgcn_alignbit(a.z, a.y, sh);
         o.z = __builtin_amdgcn_alignbit(a.w, a.z, sh); o.w = __builtin_amdgcn_alignbit(b, a.w, sh);
-        *(uint4 *)(base + k * A.stride[p] + i) = o;
+        *(uint4 *)(base + A.stride[0] + i) = o;
+    } else {
+        if (A.nplanes < 3 || i >= A.size[1]) return;
+        const unsigned char *pu = (const unsigned char *)A.planes[f * 3 + 1], *pv = (const unsigned char *)A.planes[f * 3 + 2];
+        const uint4 u = *(const uint4 *)(pu + i), v = *(const uint4 *)(pv + i);
+        // 16-bit samples: dword k of u holds samples 2k, 2k+1 -> (U 2k | V 2k), (U 2k+1 | V 2k+1)
+        auto lo = [](unsigned a, unsigned b) { return (a & 0xffffu) | (b << 16); };
+        auto hi = [](unsigned a, unsigned b) { return (a >> 16) | (b & 0xffff0000u); };
+        uint4 o0 = { lo(u.x, v.x), hi(u.x, v.x), lo(u.y, v.y), hi(u.y, v.y) }, o1 = { lo(u.z, v.z), hi(u.z, v.z), lo(u.w, v.w), hi(u.w, v.w) };
+        unsigned char *d = (unsigned char *)A.planes[f * 3 + 1] + A.stride[1] + 2 * i;
+        *(uint4 *)d = o0; *(uint4 *)(d + 16) = o1;
     }
 }
-// 16-bit clips: one copy (shift by one sample).  8-bit clips: none -- measured (r2, 1080p Degrain1): the three copies an 8-bit plane
-// would need quadruple the cache footprint of every chain and cost more than the aligned loads save (1250-1340 fps with copies,
-// 2005 without); the search then simply loads from the plane itself.
+// 16-bit clips: shadows exist (1).  8-bit clips: none (0) -- measured (r2, 1080p Degrain1): shifted copies of an 8-bit plane (three are
+// needed) quadruple the cache footprint of every chain and cost more than the aligned loads save (1250-1340 fps with copies, 2005
+// without); the search then simply loads from the planes themselves.
 extern "C" __attribute__((visibility("default"))) int mvx_super_shadow_copies(const mvx_super *s) { return s->info.bits <= 8 ? 0 : 1; }
+// bytes of shadow data a caller must provide behind plane p: the luma plane's shifted copy, and -- behind the U plane -- ONE plane
+// of twice the chroma size holding U and V interleaved (every chroma position is dword-aligned there, no shifted copy needed)
+extern "C" __attribute__((visibility("default"))) void mvx_super_shadow_bytes(const mvx_super *s, const ptrdiff_t pitch[3], size_t extra[3]) {
+    extra[0] = extra[1] = extra[2] = 0;
+    if (!mvx_super_shadow_copies(s)) return;
+    extra[0] = (size_t)s->info.plane_height[0] * pitch[0];
+    if (s->info.num_planes >= 3) extra[1] = 2 * (size_t)s->info.plane_height[1] * pitch[1];
+}
 extern "C" __attribute__((visibility("default"))) int mvx_super_shadow_frames(const mvx_super *s, int nframes, void *const *planes, const ptrdiff_t pitch[3],
                                                                               const ptrdiff_t copy_stride[3], void *stream) {
-    if (nframes <= 0) return MVX_OK;
+    if (nframes <= 0 || !mvx_super_shadow_copies(s)) return MVX_OK;
     const mvx_super_info &si = s->info;
     hipStream_t st = (hipStream_t)stream;
     CallGuard::Scope scope(g_scratch_guard, st);
     ShadowArgs A;
     memset(&A, 0, sizeof(A));
-    A.nplanes = si.num_planes; A.bps = si.bits <= 8 ? 1 : 2; A.ncopies = mvx_super_shadow_copies(s);
-    if (A.ncopies == 0) return MVX_OK;
+    A.nplanes = si.num_planes; A.bps = 2;
     long long maxsize = 0;
-    for (int p = 0; p < si.num_planes; p++) {
+    for (int p = 0; p < si.num_planes && p < 2; p++) {
         A.size[p] = (long long)si.plane_height[p] * pitch[p]; A.stride[p] = copy_stride[p];
-        if (pitch[p] % 16 || copy_stride[p] % 16 || copy_stride[p] < A.size[p]) { mvx_set_error("mvx_super_shadow_frames: pitch and copy stride must be multiples of 16 bytes, the stride at least one plane"); return MVX_E_ARG; }
+        if (pitch[p] % 16 || copy_stride[p] % 16 || copy_stride[p] < A.size[p]) { mvx_set_error("mvx_super_shadow_frames: pitch and shadow offset must be multiples of 16 bytes, the offset at least one plane"); return MVX_E_ARG; }
         if (A.size[p] > maxsize) maxsize = A.size[p];
     }
+    if (si.num_planes >= 3 && pitch[1] != pitch[2]) { mvx_set_error("mvx_super_shadow_frames: U and V must share one pitch"); return MVX_E_ARG; }
     void *dpl = nullptr;
     int rc;
     if ((rc = upload_ptrs(1, (const void *const *)planes, (size_t)nframes * 3, st, &dpl))) return rc;
     A.planes = (void *const *)dpl;
-    hipLaunchKernelGGL(super_shadow_kernel, dim3((unsigned)((maxsize / 16 + 255) / 256), nframes * 3), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(super_shadow_kernel, dim3((unsigned)((maxsize / 16 + 255) / 256), nframes * 2), dim3(256), 0, st, A);
     HIP_CHECK(hipGetLastError());
     return MVX_OK;
 }

@@ -130,6 +130,8 @@ def lib():
         L.mvx_super_frames_pelclip.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p), P(C.c_ssize_t), P(C.c_void_p), P(C.c_ssize_t), C.c_int, P(C.c_void_p),
                                                P(C.c_ssize_t), C.c_void_p]
         L.mvx_super_shadow_copies.argtypes = [C.c_void_p]
+        L.mvx_super_shadow_bytes.argtypes = [C.c_void_p, P(C.c_ssize_t), P(C.c_size_t)]
+        L.mvx_super_shadow_bytes.restype = None
         L.mvx_super_shadow_frames.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p), P(C.c_ssize_t), P(C.c_ssize_t), C.c_void_p]
         L.mvx_analyse_set_ref_shadow.argtypes = [C.c_void_p, P(C.c_ssize_t)]
         L.mvx_debug_option.argtypes = [C.c_char_p, C.c_int]
@@ -141,7 +143,6 @@ def lib():
         L.mvx_degrain_create.argtypes = [P(DegrainArgs), P(AnalysisData), C.c_void_p, P(C.c_ssize_t), P(C.c_ssize_t), P(C.c_ssize_t),
                                          P(C.c_void_p), C.c_char_p]
         L.mvx_degrain_destroy.argtypes = [C.c_void_p]
-        L.mvx_degrain_set_ref_shadow.argtypes = [C.c_void_p, P(C.c_ssize_t)]
         L.mvx_degrain_frames.argtypes = [C.c_void_p, C.c_int, P(DegrainJob), C.c_void_p]
         L.mvx_compensate_create.argtypes = [P(CompensateArgs), P(AnalysisData), C.c_void_p, P(C.c_ssize_t), P(C.c_ssize_t),
                                             P(C.c_void_p), C.c_char_p]
@@ -168,7 +169,7 @@ def lib():
         # developer / test switches: the library itself never reads the environment (mvx_debug_option is its one hook);
         # this TEST binding forwards the MVX_* variables the tools/ scripts use
         for env, opt in (("MVX_GENERAL", "general"), ("MVX_FAST_WPE", "fast_wpe"), ("MVX_WINDOW", "window"), ("MVX_TILE", "tile"), ("MVX_NO_WPE2", "no_wpe2"),
-                         ("MVX_NO_WPE3", "no_wpe3"), ("MVX_WPE3", "wpe3_u16"), ("MVX_FAST_CPW", "fast_cpw"), ("MVX_FAST_FLAGS", "fast_flags"), ("MVX_PAD_RUNS", "pad_runs"), ("MVX_SHADOW_PLANES", "shadow_planes"), ("MVX_CPW_SYNC", "cpw_sync"), ("MVX_LDS_MIN", "lds_min"), ("MVX_ABLATE", "ablate")):
+                         ("MVX_NO_WPE3", "no_wpe3"), ("MVX_WPE3", "wpe3_u16"), ("MVX_FAST_CPW", "fast_cpw"), ("MVX_FAST_FLAGS", "fast_flags"), ("MVX_PAD_RUNS", "pad_runs"), ("MVX_SHADOW_PLANES", "shadow_planes"), ("MVX_DEGRAIN_XCD", "degrain_xcd"), ("MVX_CPW_SYNC", "cpw_sync"), ("MVX_LDS_MIN", "lds_min"), ("MVX_ABLATE", "ablate")):
             if os.environ.get(env) is not None:
                 L.mvx_debug_option(opt.encode(), int(os.environ[env]))
         if os.environ.get("MVX_CPW") == "1":
@@ -198,12 +199,13 @@ def _torch():
     return torch
 
 
-def arena_frames(n, plane_shapes, device="cuda", zero=True, copies=1):
+def arena_frames(n, plane_shapes, device="cuda", zero=True, slots=None):
     """n frames x len(plane_shapes) planes (rows, pitch_bytes) carved out of ONE uint8 device allocation (see Super.alloc).
-    copies > 1: every plane is followed by copies - 1 further slots of the same (256-byte rounded) size: the shadow copies."""
+    slots[p] > 1: plane p is followed by slots[p] - 1 further areas of its (256-byte rounded) size: room for the shadow planes."""
     torch = _torch()
     sizes = [r * p for r, p in plane_shapes]
-    step = [(sz + 255) // 256 * 256 * copies for sz in sizes]
+    slots = slots or [1] * len(sizes)
+    step = [(sz + 255) // 256 * 256 * k for sz, k in zip(sizes, slots)]
     total = n * sum(step)
     big = torch.zeros(total, dtype=torch.uint8, device=device) if zero else torch.empty(total, dtype=torch.uint8, device=device)
     out, o = [], 0
@@ -267,13 +269,17 @@ class Super:
         self.bps = 1 if bits <= 8 else 2
         self.nplanes = self.info.num_planes
         self.pitch = [((self.info.plane_width[p] * self.bps + 255) // 256) * 256 for p in range(self.nplanes)]
-        # shadow copies (mvx_super_shadow_frames): every plane of a super frame is followed by its 4 / bps - 1 shifted copies, so
-        # that the search only issues dword-aligned loads.  On by default (MVX_SHADOW=0 / shadow=False: the plain layout).
+        # shadow planes (mvx_super_shadow_frames; clips of more than 8 bits): the luma plane is followed by its copy shifted by one
+        # sample, the U plane by the UV-interleaved plane, so that the search only issues dword-aligned loads.  On by default
+        # (MVX_SHADOW=0 / shadow=False: the plain layout).
         if shadow is None:
             shadow = os.environ.get("MVX_SHADOW", "1") != "0"
-        self.copies = 1 + (lib().mvx_super_shadow_copies(self.h) if shadow else 0)
-        self.shadow = self.copies > 1
         self.shadow_stride = [(self.info.plane_height[p] * self.pitch[p] + 255) // 256 * 256 for p in range(self.nplanes)]
+        extra = (C.c_size_t * 3)()
+        if shadow:
+            lib().mvx_super_shadow_bytes(self.h, (C.c_ssize_t * 3)(*(self.pitch + [0] * (3 - len(self.pitch)))), extra)
+        self.shadow = any(extra)
+        self.slots = [1 + (extra[p] + self.shadow_stride[p] - 1) // self.shadow_stride[p] for p in range(self.nplanes)]  # areas per plane: the plane + its shadow data
 
     def __del__(self):
         try:
@@ -290,9 +296,9 @@ class Super:
         # is mapped with large page fragments and keeps the TLBs effective).  MVX_ALLOC_ARENA=0 restores per-plane tensors.
         sizes = [self.info.plane_height[p] * self.pitch[p] for p in range(self.nplanes)]
         if os.environ.get("MVX_ALLOC_ARENA", "1") == "0":
-            return [[torch.zeros(self.shadow_stride[p] * self.copies, dtype=torch.uint8, device=device)[:self.info.plane_height[p] * self.pitch[p]].view(self.info.plane_height[p], self.pitch[p])
+            return [[torch.zeros(self.shadow_stride[p] * self.slots[p], dtype=torch.uint8, device=device)[:self.info.plane_height[p] * self.pitch[p]].view(self.info.plane_height[p], self.pitch[p])
                      for p in range(self.nplanes)] for _ in range(n)]
-        return arena_frames(n, [(self.info.plane_height[p], self.pitch[p]) for p in range(self.nplanes)], device, copies=self.copies)
+        return arena_frames(n, [(self.info.plane_height[p], self.pitch[p]) for p in range(self.nplanes)], device, slots=self.slots)
 
     def from_host(self, planes, device="cuda"):
         """a super frame given as host arrays (numpy planes of plane_height x >= plane_width samples, e.g. from another
@@ -445,8 +451,6 @@ class Degrain:
         err = C.create_string_buffer(ERRLEN)
         _check(lib().mvx_degrain_create(C.byref(a), C.byref(ad), sup.h, pad(src_pitch), pad(sup.pitch), pad(dst_pitch), C.byref(self.h), err), err)
         self.src_pitch, self.dst_pitch = list(src_pitch), list(dst_pitch)
-        if sup.shadow and os.environ.get("MVX_DEGRAIN_SHADOW", "1") != "0":
-            _check(lib().mvx_degrain_set_ref_shadow(self.h, pad(sup.shadow_stride)))
 
     def __del__(self):
         try:

@@ -64,13 +64,15 @@ static void super_geo(SuperGeo *g, const mvx_super *s) {
     mvx_super_get_info(s, &g->si);
     g->bps = (g->si.bits + 7) / 8;
     g->copies = 1 + mvx_super_shadow_copies(s);
+    for (int p = 0; p < 3; p++) g->pitch[p] = p < g->si.num_planes ? ((ptrdiff_t)g->si.plane_width[p] * g->bps + 255) / 256 * 256 : 0;
+    size_t extra[3];
+    mvx_super_shadow_bytes(s, g->pitch, extra); /* room behind each plane for its shadow data */
     size_t o = 0;
     for (int p = 0; p < 3; p++) {
-        g->pitch[p] = 0; g->off[p] = o; g->shadowStride[p] = 0;
+        g->off[p] = o; g->shadowStride[p] = 0;
         if (p < g->si.num_planes) {
-            g->pitch[p] = ((ptrdiff_t)g->si.plane_width[p] * g->bps + 255) / 256 * 256;
             g->shadowStride[p] = ((ptrdiff_t)g->pitch[p] * g->si.plane_height[p] + 255) / 256 * 256;
-            o += (size_t)g->shadowStride[p] * g->copies;
+            o += (size_t)g->shadowStride[p] + (extra[p] + 255) / 256 * 256;
         }
     }
     g->bytes = o;
