@@ -45,6 +45,12 @@ static inline bool mvx_fast_eligible(const AParams &P) {
     if (P.nLevels > 1 && !ok(cst, P.nSearchParam)) return false; // every coarser level
     for (int i = 0; i < P.nLevels; i++) {
         const ALevel &L = P.lv[i];
+        { // the level's lambda (doPobSearchMVs :1003-1009) must be a non-negative 32-bit value: the kernel multiplies it as one
+            long long v = P.lambda / (L.pel * L.pel);
+            const long long sc = 1LL << i;
+            if (P.plevel == 1) v *= sc; else if (P.plevel == 2) v *= sc * sc;
+            if (v < 0 || v > 0x7fffffffLL) return false;
+        }
         if ((long long)L.pel * L.pel * L.pstride[0] >= 0xffffffffLL || (long long)L.pel * L.pel * L.pstride[1] >= 0xffffffffLL) return false; // 32-bit plane offsets
         if ((long long)L.pel * L.pel * L.pstride[0] + P.shadow[0] >= 0xffffffffLL || 2 * (long long)L.pel * L.pel * L.pstride[1] + P.shadow[1] >= 0xffffffffLL) return false;
         if (P.shadow[0] && P.bps != 2) return false; // (shadow planes exist for 16-bit clips only)
@@ -78,7 +84,7 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
     int nDxMin, nDyMin, nDxMax, nDyMax;
     int predX, predY;          // predictor (:1100 / :449)
     int pX[4], pY[4];          // predictors[0..3]
-    long long nLambda;
+    int nLambda;               // (0 <= nLambda <= the level's lambda < 2^31: mvx_fast_eligible)
     int bestX, bestY, bestSad; // bestMV
     int nMinCost;              // 0x7fffffff = nothing accepted yet (every real cost is smaller: see cost32)
 
@@ -91,7 +97,7 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
     __device__ __forceinline__ int motion_distortion(int vx, int vy) const {
         const unsigned dx = (unsigned)(predX - vx), dy = (unsigned)(predY - vy);
         const int dist = (int)(dx * dx + dy * dy);
-        return (int)((nLambda * dist) >> 8);
+        return (int)(((long long)nLambda * dist) >> 8); // one signed 32 x 32 -> 64 multiply
     }
     __device__ __forceinline__ static int sat_add(int a, int b) { // b >= 0
         const long long r = (long long)a + b;
@@ -201,9 +207,26 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
     // Acceptance of a pass: every lane of a candidate's group holds the candidate's cost (0x7fffffff = not a candidate / not
     // better); groups are ordered by lane, so the lowest lane with the minimum is the FIRST minimal candidate -- the one the
     // reference's sequential strict `<` update ends on (PlaneOfBlocks.cpp:229,239,248).  Returns the winning lane or -1.
-    __device__ __forceinline__ int accept(int cost, int tot) {
-        int mc;
-        const int w = wave_argmin_i32(cost, &mc);
+    // wave minimum of values that are uniform inside aligned groups of 1 << LOGG lanes: the row_shr steps below the group size
+    // would compare a group with itself and are skipped (lane 15 of a row still meets one lane of every group of its row)
+    template <int LOGG> __device__ __forceinline__ static unsigned group_min_u32(unsigned v) {
+        if (LOGG <= 0) asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v));
+        if (LOGG <= 1) asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v));
+        if (LOGG <= 2) asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v));
+        asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                     "s_nop 1"
+                     : "+v"(v));
+        return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+    }
+    template <int LOGG> __device__ __forceinline__ int accept(int cost, int tot) {
+        int mc = 0, w = -1;
+        {
+            const unsigned u = (unsigned)cost ^ 0x80000000u;
+            const unsigned m = group_min_u32<LOGG>(u);
+            if (m != 0xffffffffu) { mc = (int)(m ^ 0x80000000u); w = __ffsll((long long)__ballot(u == m)) - 1; }
+        }
         if (w >= 0) { nMinCost = mc; bestSad = bcast_i(tot, w); }
         return w;
     }
@@ -245,13 +268,13 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
         const int tot = (int)aL + (chroma ? (int)aC : 0);
         const int cc = cost_new(vx, vy, aL, aC);
         const bool first = KIND != K_HEXSQ || g < 6;
-        int w = accept((ok && first && cc < nMinCost) ? cc : 0x7fffffff, tot);
+        int w = accept<LOGG>((ok && first && cc < nMinCost) ? cc : 0x7fffffff, tot);
         if (w >= 0) {
             if (KIND != K_HEXSQ) { bestX = bcast_i(vx, w); bestY = bcast_i(vy, w); } // (the hexagon is pobCheckMVdir: bestMV.x/y untouched)
             return w >> LOGG;
         }
         if (KIND == K_HEXSQ) {
-            w = accept((ok && !first && cc < nMinCost) ? cc : 0x7fffffff, tot);
+            w = accept<LOGG>((ok && !first && cc < nMinCost) ? cc : 0x7fffffff, tot);
             if (w >= 0) { bestX = bcast_i(vx, w); bestY = bcast_i(vy, w); }
         }
         return -1;
@@ -284,7 +307,7 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
             int cc = tot + (int)(((long long)pen * tot) >> 8);
             cc = sat_add(g >= 3 ? motion_distortion(vx, vy) : 0, cc);                       // pobCheckMV0: no new-vector penalty
             nMinCost = 0x7fffffff;
-            const int w = accept(ok ? cc : 0x7fffffff, tot); // (group 0 always has a finite cost)
+            const int w = accept<3>(ok ? cc : 0x7fffffff, tot); // (group 0 always has a finite cost)
             bestX = bcast_i(vx, w); bestY = bcast_i(vy, w);
         }
         // ---- pobRefine (:773-816)
@@ -348,7 +371,7 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
             aC = group_sum_c<3>(aC);
             const int tot = (int)aL + (chroma ? (int)aC : 0);
             const int cc = cost_new(vx, vy, aL, aC);
-            const int w = accept((ok && cc < nMinCost) ? cc : 0x7fffffff, tot);
+            const int w = accept<3>((ok && cc < nMinCost) ? cc : 0x7fffffff, tot);
             if (w >= 0) {
                 if (update) { bestX = bcast_i(vx, w); bestY = bcast_i(vy, w); }
                 winner = base + (w >> 3);
@@ -686,7 +709,7 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
             nLambda = 0;
             if (blky > 0) {
                 const double scale = (double)LSAD / (double)(LSAD + (long long)(predSad >> 1));
-                nLambda = uni((long long)((double)(long long)nLambdaLevel * scale * scale));
+                nLambda = uni((int)(long long)((double)(long long)nLambdaLevel * scale * scale));
             }
             __builtin_amdgcn_wave_barrier(); // single wave: DS ops are in order; keeps the compiler from moving LDS reads above the staging writes
             search_block();

@@ -258,28 +258,49 @@ __global__ __launch_bounds__(256) void degrain_kernel(const DGParams *Pp, const 
 // blocks, and inside one block they are contiguous, so every (block, reference) costs ONE unaligned vector load of
 // W = stepX samples instead of W scalar loads, and the plan record / window row are fetched once per W outputs.
 // Same arithmetic per sample as degrain_kernel (Degrain_C + overlaps_c + ToPixels + LimitChanges).
+// Pointers that come out of the job tables are generic ("flat") to the compiler; flat loads are slower and every one of them is waited
+// for with vmcnt(0) lgkmcnt(0).  The vector helpers therefore take global-address-space pointers (dg_gl casts).
+#define DG_GL __attribute__((address_space(1)))
+__device__ __forceinline__ DG_GL const unsigned char *dg_gl(const void *p) { return (DG_GL const unsigned char *)(unsigned long long)p; }
+__device__ __forceinline__ DG_GL unsigned char *dg_glw(void *p) { return (DG_GL unsigned char *)(unsigned long long)p; }
 typedef unsigned dg_uv4 __attribute__((ext_vector_type(4), aligned(1)));
 typedef unsigned dg_uv2 __attribute__((ext_vector_type(2), aligned(1)));
 typedef unsigned dg_uv1 __attribute__((aligned(1)));
 typedef unsigned short dg_uh1 __attribute__((aligned(1)));
 
 // W samples of type T from an arbitrarily aligned address, widened to int
-template <typename T, int W> __device__ __forceinline__ void dg_load(const unsigned char *p, int *o) {
+template <typename T, int W> __device__ __forceinline__ void dg_load(DG_GL const unsigned char *p, int *o) {
     constexpr int BYTES = W * (int)sizeof(T);
     unsigned d[(BYTES + 3) / 4];
     if (BYTES >= 16) {
 #pragma unroll
-        for (int k = 0; k < BYTES / 16; k++) { dg_uv4 t = *(const dg_uv4 *)(p + 16 * k); d[4 * k] = t[0]; d[4 * k + 1] = t[1]; d[4 * k + 2] = t[2]; d[4 * k + 3] = t[3]; }
-    } else if (BYTES == 8) { dg_uv2 t = *(const dg_uv2 *)p; d[0] = t[0]; d[1] = t[1]; }
-    else if (BYTES == 4) d[0] = *(const dg_uv1 *)p;
-    else d[0] = *(const dg_uh1 *)p;
+        for (int k = 0; k < BYTES / 16; k++) { dg_uv4 t = *(DG_GL const dg_uv4 *)(p + 16 * k); d[4 * k] = t[0]; d[4 * k + 1] = t[1]; d[4 * k + 2] = t[2]; d[4 * k + 3] = t[3]; }
+    } else if (BYTES == 8) { dg_uv2 t = *(DG_GL const dg_uv2 *)p; d[0] = t[0]; d[1] = t[1]; }
+    else if (BYTES == 4) d[0] = *(DG_GL const dg_uv1 *)p;
+    else d[0] = *(DG_GL const dg_uh1 *)p;
 #pragma unroll
     for (int i = 0; i < W; i++) {
         if (sizeof(T) == 2) o[i] = (int)((d[i >> 1] >> (16 * (i & 1))) & 0xffffu);
         else o[i] = (int)((d[i >> 2] >> (8 * (i & 3))) & 0xffu);
     }
 }
-template <typename T, int W> __device__ __forceinline__ void dg_store(unsigned char *p, const int *v) {
+// the same in two steps, so that several loads can be in flight before the first one is unpacked
+template <typename T, int W> struct DgRaw { unsigned d[(W * (int)sizeof(T) + 3) / 4]; };
+template <typename T, int W> __device__ __forceinline__ DgRaw<T, W> dg_load_raw(DG_GL const unsigned char *p) {
+    constexpr int BYTES = W * (int)sizeof(T);
+    DgRaw<T, W> r;
+    if (BYTES >= 16) {
+#pragma unroll
+        for (int k = 0; k < BYTES / 16; k++) { dg_uv4 t = *(DG_GL const dg_uv4 *)(p + 16 * k); r.d[4 * k] = t[0]; r.d[4 * k + 1] = t[1]; r.d[4 * k + 2] = t[2]; r.d[4 * k + 3] = t[3]; }
+    } else if (BYTES == 8) { dg_uv2 t = *(DG_GL const dg_uv2 *)p; r.d[0] = t[0]; r.d[1] = t[1]; }
+    else if (BYTES == 4) r.d[0] = *(DG_GL const dg_uv1 *)p;
+    else r.d[0] = *(DG_GL const dg_uh1 *)p;
+    return r;
+}
+template <typename T, int W> __device__ __forceinline__ int dg_sample(const DgRaw<T, W> &r, int i) {
+    return sizeof(T) == 2 ? (int)((r.d[i >> 1] >> (16 * (i & 1))) & 0xffffu) : (int)((r.d[i >> 2] >> (8 * (i & 3))) & 0xffu);
+}
+template <typename T, int W> __device__ __forceinline__ void dg_store(DG_GL unsigned char *p, const int *v) {
     constexpr int BYTES = W * (int)sizeof(T);
     unsigned d[(BYTES + 3) / 4];
 #pragma unroll
@@ -291,10 +312,10 @@ template <typename T, int W> __device__ __forceinline__ void dg_store(unsigned c
     }
     if (BYTES >= 16) {
 #pragma unroll
-        for (int k = 0; k < BYTES / 16; k++) { dg_uv4 t = { d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3] }; *(dg_uv4 *)(p + 16 * k) = t; }
-    } else if (BYTES == 8) { dg_uv2 t = { d[0], d[1] }; *(dg_uv2 *)p = t; }
-    else if (BYTES == 4) *(dg_uv1 *)p = d[0];
-    else *(dg_uh1 *)p = (unsigned short)d[0];
+        for (int k = 0; k < BYTES / 16; k++) { dg_uv4 t = { d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3] }; *(DG_GL dg_uv4 *)(p + 16 * k) = t; }
+    } else if (BYTES == 8) { dg_uv2 t = { d[0], d[1] }; *(DG_GL dg_uv2 *)p = t; }
+    else if (BYTES == 4) *(DG_GL dg_uv1 *)p = d[0];
+    else *(DG_GL dg_uh1 *)p = (unsigned short)d[0];
 }
 
 template <typename T, int NR, int W>
@@ -320,7 +341,7 @@ __global__ __launch_bounds__(256) void degrain_cell_kernel(const DGParams *Pp, c
     unsigned char *drow = J.dst[p] + (long long)y * g.dstPitch + (long long)x0 * sizeof(T);
     const bool fullW = x0 + W <= g.W;
     int s[W];
-    if (fullW) dg_load<T, W>(srow, s);
+    if (fullW) dg_load<T, W>(dg_gl(srow), s);
     else {
 #pragma unroll
         for (int i = 0; i < W; i++) s[i] = x0 + i < g.W ? (int)((const T *)srow)[i] : 0;
@@ -338,6 +359,9 @@ __global__ __launch_bounds__(256) void degrain_cell_kernel(const DGParams *Pp, c
 #pragma unroll
         for (int i = 0; i < W; i++) acc[i] = 0;
         const int16_t *win = P.win[p];
+        const unsigned char *refp[NR]; // a frame outside the clip has no super frame: point at the source plane (its weight is 0; any
+#pragma unroll                         // offset a plan record holds for an unusable reference is 0, so the address stays inside that plane)
+        for (int r = 0; r < NR; r++) refp[r] = J.refs[r][p] ? J.refs[r][p] : J.src[p];
         for (int by = by0; by <= by1; by++) {
             const int py = y - by * g.stepY;
             const int wby = by == 0 ? 0 : (by == P.nBlkY - 1 ? 6 : 3);
@@ -354,18 +378,19 @@ __global__ __launch_bounds__(256) void degrain_cell_kernel(const DGParams *Pp, c
                 const long long rowOff = (long long)py * g.supPitch + (long long)px * sizeof(T);
                 const int16_t *wrow = win + (wby + wbx) * g.blkW * g.blkH + py * g.blkW + px;
                 int wv[W];
-                if (nv >= W) { // whole cell inside the block: vector loads
+                if (nv >= W) { // whole cell inside the block: vector loads, ALL of the block's references requested before the first is used
+                    // (a reference with weight 0 is loaded too -- from a valid address: refp -- which costs bandwidth the kernel has to
+                    // spare; waiting for every load in turn, as a `if (w)` around each one makes the compiler do, cost 4x the round trips)
+                    DgRaw<T, W> raw[NR];
+#pragma unroll
+                    for (int r = 0; r < NR; r++) raw[r] = dg_load_raw<T, W>(dg_gl(refp[r] + R.off[r] + rowOff));
+                    dg_load<unsigned short, W>(dg_gl((const unsigned char *)wrow), wv);
 #pragma unroll
                     for (int r = 0; r < NR; r++) {
                         const int w = R.w[r];
-                        if (w) {
-                            int v[W];
-                            dg_load<T, W>(J.refs[r][p] + R.off[r] + rowOff, v);
 #pragma unroll
-                            for (int i = 0; i < W; i++) sum[i] += v[i] * w;
-                        }
+                        for (int i = 0; i < W; i++) sum[i] += dg_sample<T, W>(raw[r], i) * w;
                     }
-                    dg_load<unsigned short, W>((const unsigned char *)wrow, wv);
                 } else { // partially covered (overlap != block/2): per-sample loads of the covered samples only
 #pragma unroll
                     for (int r = 0; r < NR; r++) {
@@ -403,7 +428,7 @@ __global__ __launch_bounds__(256) void degrain_cell_kernel(const DGParams *Pp, c
             }
         }
     }
-    if (fullW) dg_store<T, W>(drow, out);
+    if (fullW) dg_store<T, W>(dg_glw(drow), out);
     else {
 #pragma unroll
         for (int i = 0; i < W; i++) if (x0 + i < g.W) ((T *)drow)[i] = (T)out[i];
@@ -518,8 +543,8 @@ __global__ __launch_bounds__(256) void compensate_rows_kernel(const DGParams *Pp
         sp = (R.fromRef ? refSup : srcSup) + R.off[p ? 1 : 0] + (long long)py * g.supPitch + (long long)px * (long long)sizeof(T);
     }
     int v[CW];
-    dg_load<T, CW>(sp, v);
-    dg_store<T, CW>(J.dst[p] + (long long)y * g.dstPitch + (long long)x * (long long)sizeof(T), v);
+    dg_load<T, CW>(dg_gl(sp), v);
+    dg_store<T, CW>(dg_glw(J.dst[p] + (long long)y * g.dstPitch + (long long)x * (long long)sizeof(T)), v);
 }
 
 // ------------------------------------------------------------------------------------------------ host objects
@@ -1066,24 +1091,24 @@ __global__ __launch_bounds__(256) void blockfps_rows_kernel(const DGParams *Pp, 
     int out[CW];
     if (!usable[f]) { // time256 0 / 256, vectors unusable or frames outside the clip (:285-288, :640-673)
         int l[CW];
-        dg_load<T, CW>(J.clipL[p] + (long long)y * B.clipPitch[p] + (long long)x * (long long)sizeof(T), l);
-        if (t <= 0 || (t < 256 && !B.blend)) { dg_store<T, CW>(dptr, l); return; }
+        dg_load<T, CW>(dg_gl(J.clipL[p] + (long long)y * B.clipPitch[p] + (long long)x * (long long)sizeof(T)), l);
+        if (t <= 0 || (t < 256 && !B.blend)) { dg_store<T, CW>(dg_glw(dptr), l); return; }
         int r[CW];
-        dg_load<T, CW>(J.clipR[p] + (long long)y * B.clipPitch[p] + (long long)x * (long long)sizeof(T), r);
+        dg_load<T, CW>(dg_gl(J.clipR[p] + (long long)y * B.clipPitch[p] + (long long)x * (long long)sizeof(T)), r);
 #pragma unroll
         for (int i = 0; i < CW; i++) out[i] = t >= 256 ? r[i] : (int)(T)((l[i] * (256 - t) + r[i] * t) >> 8);
-        dg_store<T, CW>(dptr, out);
+        dg_store<T, CW>(dg_glw(dptr), out);
         return;
     }
     int sVal[CW], rVal[CW];
     const long long inner = B.supInterior[p] + (long long)y * g.supPitch + (long long)x * (long long)sizeof(T);
-    dg_load<T, CW>(J.srcSup[p] + inner, sVal);
-    dg_load<T, CW>(J.refSup[p] + inner, rVal);
+    dg_load<T, CW>(dg_gl(J.srcSup[p] + inner), sVal);
+    dg_load<T, CW>(dg_gl(J.refSup[p] + inner), rVal);
     const int covW = g.blkW * P.nBlkX, covH = g.blkH * P.nBlkY;
     if (x >= covW || y >= covH) { // Blend of the uncovered strips
 #pragma unroll
         for (int i = 0; i < CW; i++) out[i] = (int)(T)((sVal[i] * (256 - t) + rVal[i] * t) >> 8);
-        dg_store<T, CW>(dptr, out);
+        dg_store<T, CW>(dg_glw(dptr), out);
         return;
     }
     const int mode = B.mode, c = p ? 1 : 0;
@@ -1115,8 +1140,8 @@ __global__ __launch_bounds__(256) void blockfps_rows_kernel(const DGParams *Pp, 
     const BFPlan R = plan[(size_t)f * P.nBlk + by * P.nBlkX + bx];
     int bv[CW], fv[CW];
     const long long bo = (long long)py * g.supPitch + (long long)px * (long long)sizeof(T);
-    dg_load<T, CW>(J.refSup[p] + R.offB[c] + bo, bv);
-    dg_load<T, CW>(J.srcSup[p] + R.offF[c] + bo, fv);
+    dg_load<T, CW>(dg_gl(J.refSup[p] + R.offB[c] + bo), bv);
+    dg_load<T, CW>(dg_gl(J.srcSup[p] + R.offF[c] + bo), fv);
 #pragma unroll
     for (int i = 0; i < CW; i++) { // RealResultBlock, MVBlockFPS.c:117-227
         const int b = bv[i], fw = fv[i];
@@ -1135,7 +1160,7 @@ __global__ __launch_bounds__(256) void blockfps_rows_kernel(const DGParams *Pp, 
         }
         out[i] = (int)(T)v;
     }
-    dg_store<T, CW>(dptr, out);
+    dg_store<T, CW>(dg_glw(dptr), out);
 }
 
 struct mvx_blockfps : DGCommon {
