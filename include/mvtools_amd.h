@@ -96,6 +96,11 @@ int mvx_super_shadow_copies(const mvx_super *s);   /* 1: shadow planes pay off f
 void mvx_super_shadow_bytes(const mvx_super *s, const ptrdiff_t pitch[3], size_t extra[3]);
 int mvx_super_shadow_frames(const mvx_super *s, int nframes, void *const *planes /* [f*3+p] */, const ptrdiff_t pitch[3],
                             const ptrdiff_t copy_stride[3] /* [2] unused */, void *stream);
+/* mvx_super_frames followed by mvx_super_shadow_frames, as one call: same results in the planes and in the shadow planes, but for
+ * pel 2 the level-0 kernels write their share of the shadow data while they have the samples in registers (about a third of a
+ * Super pass's HBM traffic saved).  shadow_stride as copy_stride above. */
+int mvx_super_frames_shadow(mvx_super *s, int nframes, const void *const *src, const ptrdiff_t src_pitch[3],
+                            void *const *dst, const ptrdiff_t dst_pitch[3], const ptrdiff_t shadow_stride[3], void *stream);
 
 /* mv.Super(pelclip=...): the sub-pel planes of level 0 are taken from the user's upsized clip instead of being interpolated.
  * replaces MVSuper.c:229-256 (mvx_super_pelclip_mode: 0 = ignored because pel is 1, 1 = pelclip is pel x the clip size,

@@ -42,6 +42,21 @@ SUPER_CASES = [
     (640, 360, 8, (1, 1), dict()),                    # BASELINE cfg1 size
     (128, 96, 8, (1, 1), dict(chroma=0)),
     (128, 96, 8, (1, 1), dict(levels=3)),
+    # the rows-in-registers level-0 kernel (pel 2): widths that are no multiple of a thread's span, narrow frames (no fast columns at
+    # all / a handful), paddings that keep or break the dword alignment it needs, every sharp mode, 4:4:4 / 4:2:2 / gray at 16 bits
+    (138, 70, 16, (1, 1), {}),
+    (138, 70, 16, (1, 1), dict(sharp=0)),
+    (150, 66, 12, (1, 1), dict(sharp=1, hpad=2, vpad=2)),
+    (40, 34, 16, (1, 1), dict(hpad=8, vpad=8)),
+    (72, 40, 16, (1, 1), dict(hpad=0, vpad=0)),
+    (150, 90, 16, (1, 1), dict(hpad=5, vpad=3)),      # chroma padding of 2 samples, luma of 5: alignment rule fails -> tile kernel
+    (150, 90, 8, (1, 1), dict(hpad=6, vpad=6)),       # 8 bit: 6 % 4 != 0 -> tile kernel
+    (150, 90, 8, (1, 1), dict(hpad=24, vpad=8, sharp=1)),
+    (134, 78, 16, (0, 0), dict(hpad=4, vpad=4)),
+    (160, 96, 16, (1, 0), dict()),
+    (1000, 48, 16, (1, 1), dict()),                   # several waves per row
+    (1000, 48, 8, (1, 1), dict()),
+    (128, 96, 16, (1, 1), dict(chroma=0)),
 ]
 
 
@@ -96,6 +111,52 @@ def test_super_pelclip_parity(oracle, mv, w, h, bits, sub, pel, padded, kw):
     ob = oracle.Analyse(osup, isb=1, **akw).frame(osf[0], osf[1])
     gb = mv.Analyse(gsup, isb=1, **akw).run([(gout[0], gout[1])])[0]
     assert np.array_equal(gb.cpu().numpy(), ob)
+
+
+def _behind(frame, p, offset, nbytes):
+    """nbytes of device memory `offset` bytes behind plane p of a frame (its shadow data lives there)"""
+    import torch
+    t = frame[p]
+    whole = torch.empty(0, dtype=torch.uint8, device=t.device).set_(t.untyped_storage())
+    o = t.storage_offset() + offset
+    return whole[o:o + nbytes].cpu().numpy()
+
+
+@pytest.mark.parametrize("w,h,bits,sub,kw", [c for c in SUPER_CASES if c[2] > 8 and c[4].get("pel", 2) == 2])
+def test_super_fused_shadow_planes(mv, w, h, bits, sub, kw):
+    """mvx_super_frames_shadow (level-0 kernels write the shadow data themselves) against mvx_super_shadow_frames (derives it from
+    the finished planes) on every shadow byte a search can read"""
+    frames = pl.moving_clip(w, h, bits, 2, seed=4, sub=sub)
+    gsup = mv.Super(w, h, bits, subsampling=sub, **kw)
+    if not gsup.shadow:
+        pytest.skip("no shadow planes for this format")
+    _, gout = _gpu_super(mv, gsup, frames)
+    i = gsup.info
+    geo = []  # per plane: rows of the four level-0 planes, padded width
+    for p in range(gsup.nplanes):
+        xr, yr = (1, 1) if p == 0 else (i.xRatioUV, i.yRatioUV)
+        geo.append((4 * (i.height // yr + 2 * (i.vpad // yr)), i.width // xr + 2 * (i.hpad // xr)))
+
+    def grab(fr):
+        size = [i.plane_height[p] * gsup.pitch[p] for p in range(gsup.nplanes)]
+        luma = _behind(fr, 0, gsup.shadow_stride[0], size[0]).view(np.uint16).reshape(i.plane_height[0], -1).copy()
+        uv = None
+        if gsup.nplanes >= 3:
+            uv = _behind(fr, 1, gsup.shadow_stride[1], 2 * size[1]).view(np.uint16).reshape(i.plane_height[1], -1).copy()
+        return luma, uv
+    fused = [grab(fr) for fr in gout]
+    gsup._shadows(gout)
+    import torch
+    torch.cuda.synchronize()
+    for f, fr in enumerate(gout):
+        luma, uv = grab(fr)
+        rows, pw = geo[0]
+        assert np.array_equal(fused[f][0][:rows, :pw - 1], luma[:rows, :pw - 1])  # the last sample of a row has no right neighbour
+        assert np.array_equal(fused[f][0][rows:], luma[rows:])
+        if uv is not None and (i.modeYUV & 2):
+            rows, pw = geo[1]
+            assert np.array_equal(fused[f][1][:rows, :2 * pw], uv[:rows, :2 * pw])
+            assert np.array_equal(fused[f][1][rows:], uv[rows:])
 
 
 def test_super_pelclip_errors(mv):

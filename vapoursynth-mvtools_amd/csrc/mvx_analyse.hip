@@ -36,12 +36,13 @@ struct MvxDebug {
     int degrain_xcd = -1;  // Degrain cell kernels: XCD-contiguous tile order (1 / 0), -1 = default
     int cpw_sync = -1; // barrier interval inside a workgroup (power of two, 0 = none)
     int lds_min = -1;  // LDS floor of the one-chain launches
+    int super_rows_off = 0; // 1: mv.Super level 0 / first reduction through the LDS-tile / per-sample kernels only
     int ablate = 0;
 };
 static MvxDebug g_dbg;
 extern "C" __attribute__((visibility("default"))) int mvx_debug_option(const char *name, int value) {
     struct { const char *n; int *p; } tab[] = { { "general", &g_dbg.general }, { "fast_wpe", &g_dbg.fast_wpe }, { "cpw1", &g_dbg.cpw1 }, { "window", &g_dbg.window },
-        { "tile", &g_dbg.tile }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "fast_cpw", &g_dbg.fast_cpw }, { "fast_flags", &g_dbg.fast_flags }, { "pad_runs", &g_dbg.pad_runs }, { "shadow_planes", &g_dbg.shadow_planes }, { "degrain_xcd", &g_dbg.degrain_xcd }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min },
+        { "tile", &g_dbg.tile }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "fast_cpw", &g_dbg.fast_cpw }, { "fast_flags", &g_dbg.fast_flags }, { "pad_runs", &g_dbg.pad_runs }, { "shadow_planes", &g_dbg.shadow_planes }, { "degrain_xcd", &g_dbg.degrain_xcd }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min }, { "super_rows_off", &g_dbg.super_rows_off },
 #ifdef MVX_LAB
         { "ablate", &g_dbg.ablate },
 #endif
@@ -53,6 +54,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_debug_option(const cha
 
 int mvx_debug_value(const char *name, int def) {
     if (!strcmp(name, "degrain_xcd")) return g_dbg.degrain_xcd >= 0 ? g_dbg.degrain_xcd : def;
+    if (!strcmp(name, "super_rows_off")) return g_dbg.super_rows_off;
     return def;
 }
 

@@ -118,6 +118,8 @@ struct SuperL0Args {
     void *const *dst;       // [nframes*3]
     SuperPlaneGeom g[3];
     int pel, bits, modeYUV, nplanes;
+    int XA[3], XB[3]; // columns [XA, XB) are produced by super_rows_kernel (multiples of 16; XA == XB: none)
+    int tcA[3], tcB[3]; // tile columns [tcA, tcB) lie entirely inside [XA, XB): no workgroups are launched for them
 };
 
 template <typename T> __device__ __forceinline__ int ldT(const void *p, long long i) { return ((const T *)p)[i]; }
@@ -153,7 +155,10 @@ __global__ __launch_bounds__(256) void super_level0_kernel(SuperL0Args A) {
     const int z = blockIdx.z, f = z / 3, p = z % 3;
     if (p >= A.nplanes || !(A.modeYUV & (1 << p))) return;
     const SuperPlaneGeom g = A.g[p];
-    const int X0 = blockIdx.x * L0_TW, Y0 = blockIdx.y * L0_TH;
+    // blockIdx.x counts the tile columns that have work left (empty workgroups are not free: ~0.5 ns of dispatch each, and a
+    // 1080p batch would launch millions of them)
+    const int tx = (int)blockIdx.x < A.tcA[p] ? (int)blockIdx.x : (int)blockIdx.x - A.tcA[p] + A.tcB[p];
+    const int X0 = tx * L0_TW, Y0 = blockIdx.y * L0_TH;
     if (X0 >= g.pw || Y0 >= g.ph) return;
     const unsigned char *src = (const unsigned char *)A.src[f * 3 + p];
     unsigned char *dst = (unsigned char *)A.dst[f * 3 + p];
@@ -182,6 +187,7 @@ __global__ __launch_bounds__(256) void super_level0_kernel(SuperL0Args A) {
     const int ty = tid >> 4, tx8 = (tid & 15) * 8;
     const int Y = Y0 + ty;
     if (Y >= g.ph) return;
+    if (X0 + tx8 >= A.XA[p] && X0 + tx8 < A.XB[p]) return;
     const long long planeStride = g.dst_pitch * g.ph;
     const int idxH = PEL == 2 ? 1 : 2, idxV = PEL == 2 ? 2 : 8, idxHV = PEL == 2 ? 3 : 10;
     T *r0 = (T *)(dst + (long long)Y * g.dst_pitch);
@@ -224,6 +230,8 @@ __global__ __launch_bounds__(256) void super_level0_kernel(SuperL0Args A) {
     }
 }
 
+#include "mvx_super_rows.h"
+
 // pel 4: the twelve averaged planes, MVFrame.cpp:1489-1524.  dst = (a[shifted by ax,ay] + b + 1) >> 1 over (pw-ax) x (ph-ay);
 // the untouched last column / row stays 0 as in the reference (frame memset, MVSuper.c:75).
 struct AvgOp { int d, a, b, ax, ay; };
@@ -265,6 +273,11 @@ struct SuperReduceArgs {
     int in_w[3], in_h[3], in_hpad[3], in_vpad[3];
     int out_w[3], out_h[3], out_hpad[3], out_vpad[3];
     int modeYUV, nplanes;
+    int XA[3], XB[3], YA[3], YB[3]; // interior outputs super_reduce_rows_kernel produces (XA == XB: none)
+    // blocks of 64 x 4 outputs: ncb x nrb of them; those with column block in [cbA, cbB) AND row block in [rbA, rbB) lie entirely
+    // inside the rows kernel's region and are not launched.  blockIdx.x enumerates the others: nfull blocks of the full-width
+    // row bands above and below, then the side blocks of the middle band.
+    int ncb[3], nrb[3], cbA[3], cbB[3], rbA[3], rbB[3], nfull[3], ntotal[3];
 };
 
 template <typename T, int RF, bool FROM_SRC>
@@ -272,8 +285,17 @@ __global__ __launch_bounds__(256) void super_reduce_kernel(SuperReduceArgs A) {
     const int z = blockIdx.z, f = z / 3, p = z % 3;
     if (p >= A.nplanes || !(A.modeYUV & (1 << p))) return;
     const int ow = A.out_w[p], oh = A.out_h[p], ohp = A.out_hpad[p], ovp = A.out_vpad[p];
-    const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    int idx = blockIdx.x, cb, rb;
+    if (idx >= A.ntotal[p]) return;
+    if (idx < A.nfull[p]) { const int r = idx / A.ncb[p]; cb = idx - r * A.ncb[p]; rb = r < A.rbA[p] ? r : r - A.rbA[p] + A.rbB[p]; }
+    else {
+        idx -= A.nfull[p];
+        const int ns = A.cbA[p] + A.ncb[p] - A.cbB[p], r = idx / ns, c = idx - r * ns;
+        rb = A.rbA[p] + r; cb = c < A.cbA[p] ? c : c - A.cbA[p] + A.cbB[p];
+    }
+    const int X = cb * 64 + (threadIdx.x & 63), Y = rb * 4 + (threadIdx.x >> 6);
     if (X >= ow + 2 * ohp || Y >= oh + 2 * ovp) return;
+    if (X - ohp >= A.XA[p] && X - ohp < A.XB[p] && Y - ovp >= A.YA[p] && Y - ovp < A.YB[p]) return;
     const int x = iclamp(X - ohp, 0, ow - 1), y = iclamp(Y - ovp, 0, oh - 1);
     unsigned char *dplane = (unsigned char *)A.dst[f * 3 + p];
     const unsigned char *sbase;
@@ -397,7 +419,8 @@ __global__ __launch_bounds__(256) void super_ext_kernel(SuperExtArgs A) {
 }
 
 static int super_frames_impl(mvx_super *s, int nframes, const void *const *src, const ptrdiff_t src_pitch[3], const void *const *pelclip,
-                             const ptrdiff_t pelclip_pitch[3], int pelMode, void *const *dst, const ptrdiff_t dst_pitch[3], void *stream);
+                             const ptrdiff_t pelclip_pitch[3], int pelMode, void *const *dst, const ptrdiff_t dst_pitch[3], const ptrdiff_t *shadow_stride,
+                             void *stream);
 
 // ---- shifted copies of a super frame's planes ("shadows") ---------------------------------------------------------------
 // The search reads reference blocks at arbitrary sample positions, i.e. at byte addresses that are mostly NOT multiples of
@@ -407,11 +430,11 @@ static int super_frames_impl(mvx_super *s, int nframes, const void *const *src, 
 // buffer shifted left by 1 .. n samples (copy k, byte i = plane byte i + k * bps).  A block at a sample position x with
 // x % (4 / bps) == k is then read from copy k at x - k: same samples, dword-aligned address.  mvx_analyse_set_ref_shadow tells
 // a search where the copies are.
-struct ShadowArgs { void *const *planes; long long size[3], stride[3]; int nplanes, bps; };
+struct ShadowArgs { void *const *planes; long long size[3], stride[3], begin[3]; int nplanes, bps; };
 // blockIdx.y = frame * 2 + kind; kind 0: the luma plane shifted left by one sample; kind 1: U and V interleaved sample by sample
 __global__ __launch_bounds__(256) void super_shadow_kernel(ShadowArgs A) {
     const int f = blockIdx.y >> 1, kind = blockIdx.y & 1;
-    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 16;
+    const long long i = A.begin[kind] + ((long long)blockIdx.x * 256 + threadIdx.x) * 16; // begin: bytes before it were written by the Super kernels themselves
     if (kind == 0) {
         if (i >= A.size[0]) return;
         unsigned char *base = (unsigned char *)A.planes[f * 3];
@@ -446,34 +469,53 @@ extern "C" __attribute__((visibility("default"))) void mvx_super_shadow_bytes(co
     extra[0] = (size_t)s->info.plane_height[0] * pitch[0];
     if (s->info.num_planes >= 3) extra[1] = 2 * (size_t)s->info.plane_height[1] * pitch[1];
 }
+static int shadow_check(const mvx_super_info &si, const ptrdiff_t pitch[3], const ptrdiff_t copy_stride[3]) {
+    for (int p = 0; p < si.num_planes && p < 2; p++) {
+        const long long size = (long long)si.plane_height[p] * pitch[p];
+        if (pitch[p] % 16 || copy_stride[p] % 16 || copy_stride[p] < size) { mvx_set_error("mvx_super_shadow_frames: pitch and shadow offset must be multiples of 16 bytes, the offset at least one plane"); return MVX_E_ARG; }
+    }
+    if (si.num_planes >= 3 && pitch[1] != pitch[2]) { mvx_set_error("mvx_super_shadow_frames: U and V must share one pitch"); return MVX_E_ARG; }
+    return MVX_OK;
+}
+// dplanes: the device copy of the plane-pointer table; begin[p]: first byte of plane p the linear kernel has to handle
+static int shadow_launch(const mvx_super_info &si, int nframes, void *const *dplanes, const ptrdiff_t pitch[3], const ptrdiff_t copy_stride[3],
+                         const long long begin[2], hipStream_t st) {
+    ShadowArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nplanes = si.num_planes; A.bps = 2; A.planes = dplanes;
+    long long maxsize = 0;
+    for (int p = 0; p < si.num_planes && p < 2; p++) {
+        A.size[p] = (long long)si.plane_height[p] * pitch[p]; A.stride[p] = copy_stride[p]; A.begin[p] = begin[p];
+        if (A.size[p] - begin[p] > maxsize) maxsize = A.size[p] - begin[p];
+    }
+    if (maxsize <= 0) return MVX_OK;
+    hipLaunchKernelGGL(super_shadow_kernel, dim3((unsigned)((maxsize / 16 + 255) / 256), nframes * 2), dim3(256), 0, st, A);
+    HIP_CHECK(hipGetLastError());
+    return MVX_OK;
+}
 extern "C" __attribute__((visibility("default"))) int mvx_super_shadow_frames(const mvx_super *s, int nframes, void *const *planes, const ptrdiff_t pitch[3],
                                                                               const ptrdiff_t copy_stride[3], void *stream) {
     if (nframes <= 0 || !mvx_super_shadow_copies(s)) return MVX_OK;
     const mvx_super_info &si = s->info;
     hipStream_t st = (hipStream_t)stream;
     CallGuard::Scope scope(g_scratch_guard, st);
-    ShadowArgs A;
-    memset(&A, 0, sizeof(A));
-    A.nplanes = si.num_planes; A.bps = 2;
-    long long maxsize = 0;
-    for (int p = 0; p < si.num_planes && p < 2; p++) {
-        A.size[p] = (long long)si.plane_height[p] * pitch[p]; A.stride[p] = copy_stride[p];
-        if (pitch[p] % 16 || copy_stride[p] % 16 || copy_stride[p] < A.size[p]) { mvx_set_error("mvx_super_shadow_frames: pitch and shadow offset must be multiples of 16 bytes, the offset at least one plane"); return MVX_E_ARG; }
-        if (A.size[p] > maxsize) maxsize = A.size[p];
-    }
-    if (si.num_planes >= 3 && pitch[1] != pitch[2]) { mvx_set_error("mvx_super_shadow_frames: U and V must share one pitch"); return MVX_E_ARG; }
-    void *dpl = nullptr;
     int rc;
+    if ((rc = shadow_check(si, pitch, copy_stride))) return rc;
+    void *dpl = nullptr;
     if ((rc = upload_ptrs(1, (const void *const *)planes, (size_t)nframes * 3, st, &dpl))) return rc;
-    A.planes = (void *const *)dpl;
-    hipLaunchKernelGGL(super_shadow_kernel, dim3((unsigned)((maxsize / 16 + 255) / 256), nframes * 2), dim3(256), 0, st, A);
-    HIP_CHECK(hipGetLastError());
-    return MVX_OK;
+    const long long begin[2] = { 0, 0 };
+    return shadow_launch(si, nframes, (void *const *)dpl, pitch, copy_stride, begin, st);
+}
+
+// mvx_super_frames + mvx_super_shadow_frames in one call; for pel 2 the level-0 kernels write the shadow data themselves
+extern "C" __attribute__((visibility("default"))) int mvx_super_frames_shadow(mvx_super *s, int nframes, const void *const *src, const ptrdiff_t src_pitch[3],
+                                void *const *dst, const ptrdiff_t dst_pitch[3], const ptrdiff_t shadow_stride[3], void *stream) {
+    return super_frames_impl(s, nframes, src, src_pitch, nullptr, nullptr, 0, dst, dst_pitch, shadow_stride, stream);
 }
 
 extern "C" __attribute__((visibility("default"))) int mvx_super_frames(mvx_super *s, int nframes, const void *const *src, const ptrdiff_t src_pitch[3],
                                 void *const *dst, const ptrdiff_t dst_pitch[3], void *stream) {
-    return super_frames_impl(s, nframes, src, src_pitch, nullptr, nullptr, 0, dst, dst_pitch, stream);
+    return super_frames_impl(s, nframes, src, src_pitch, nullptr, nullptr, 0, dst, dst_pitch, nullptr, stream);
 }
 
 // MVSuper.c:229-256
@@ -502,12 +544,15 @@ extern "C" __attribute__((visibility("default"))) int mvx_super_frames_pelclip(m
             for (int p = 0; p < s->info.num_planes; p++)
                 if (((uintptr_t)pelclip[f * 3 + p]) % align) { mvx_set_error("mvx_super_frames_pelclip: pelclip planes must be aligned to pel samples"); return MVX_E_ARG; }
     }
-    return super_frames_impl(s, nframes, src, src_pitch, pelclip, pelclip_pitch, pelclip_mode, dst, dst_pitch, stream);
+    return super_frames_impl(s, nframes, src, src_pitch, pelclip, pelclip_pitch, pelclip_mode, dst, dst_pitch, nullptr, stream);
 }
 
 static int super_frames_impl(mvx_super *s, int nframes, const void *const *src, const ptrdiff_t src_pitch[3], const void *const *pelclip,
-                             const ptrdiff_t pelclip_pitch[3], int pelMode, void *const *dst, const ptrdiff_t dst_pitch[3], void *stream) {
+                             const ptrdiff_t pelclip_pitch[3], int pelMode, void *const *dst, const ptrdiff_t dst_pitch[3], const ptrdiff_t *shadow_stride,
+                             void *stream) {
     if (nframes <= 0) return MVX_OK;
+    if (shadow_stride && !mvx_super_shadow_copies(s)) shadow_stride = nullptr;
+    if (shadow_stride) { int rc = shadow_check(s->info, dst_pitch, shadow_stride); if (rc) return rc; }
     const mvx_super_info &si = s->info;
     hipStream_t st = (hipStream_t)stream;
     CallGuard::Scope scope(g_scratch_guard, st);
@@ -531,10 +576,76 @@ static int super_frames_impl(mvx_super *s, int nframes, const void *const *src, 
         if (lp.pw > maxpw) maxpw = lp.pw;
         if (lp.ph > maxph) maxph = lp.ph;
     }
-    dim3 grid((maxpw + L0_TW - 1) / L0_TW, (maxph + L0_TH - 1) / L0_TH, nframes * 3);
     // with a pelclip only plane 0 comes from the source (PEL=1 instantiation); the sub-pel planes are taken from the pelclip
     const int l0pel = pelMode ? 1 : si.pel;
+    // pel 2: the columns whose filter window lies inside the source row go to super_rows_kernel (mvx_super_rows.h), which also writes
+    // the shadow data of level 0; it loads dword-aligned vectors, so the source rows and the left padding must keep that alignment
+    bool rows = l0pel == 2 && !mvx_debug_value("super_rows_off", 0);
+    const int bps = u8 ? 1 : 2, NS = 16 / bps;
+    for (int p = 0; rows && p < si.num_planes; p++) {
+        if ((A.g[p].hpad * bps) % 4 || src_pitch[p] % 4) rows = false;
+        for (int f = 0; rows && f < nframes; f++)
+            if (((uintptr_t)src[f * 3 + p] % 4) || ((uintptr_t)dst[f * 3 + p] % 16)) rows = false;
+    }
+    bool fusedShadow = false;
+    if (rows) {
+        SuperRowsArgs Q;
+        memset(&Q, 0, sizeof(Q));
+        Q.src = A.src; Q.dst = A.dst; Q.bits = si.bits; Q.modeYUV = si.modeYUV;
+        for (int p = 0; p < si.num_planes; p++) {
+            const SuperPlaneGeom &g = A.g[p];
+            Q.g[p] = g;
+            int xa = (g.hpad + 4 + NS - 1) / NS * NS, last = g.w + g.hpad - NS - 4; // last: the largest X whose window ends inside the row
+            int xb = last >= xa ? last / NS * NS + NS : xa;
+            Q.XA[p] = A.XA[p] = xa; Q.XB[p] = A.XB[p] = xb;
+            if (shadow_stride && p < 2) Q.shadow[p] = shadow_stride[p];
+        }
+        const bool chromaPair = si.num_planes >= 3 && A.g[1].w == A.g[2].w && A.g[1].h == A.g[2].h && src_pitch[1] == src_pitch[2] && dst_pitch[1] == dst_pitch[2];
+        fusedShadow = shadow_stride && !u8 && (si.num_planes < 3 || chromaPair);
+        auto launch = [&](int kind, int first, int nz) {
+            int mw = 0, mh = 0;
+            bool any = false;
+            for (int p = first; p < first + (kind == 2 ? 1 : nz); p++) { if (Q.XB[p] > Q.XA[p]) any = true; if (Q.XB[p] > mw) mw = Q.XB[p]; if (Q.g[p].ph > mh) mh = Q.g[p].ph; }
+            if (!any) return;
+            Q.firstPlane = first; Q.nz = nz;
+            dim3 gr((mw / NS + 63) / 64, (mh + 7) / 8, nframes * nz); // mw: the largest XB (threads start at column 0)
+#define RW(T, S, K) hipLaunchKernelGGL((super_rows_kernel<T, S, K, 2>), gr, dim3(256), 0, st, Q)
+#define RWS(T, K) do { if (si.sharp == 0) RW(T, 0, K); else if (si.sharp == 1) RW(T, 1, K); else RW(T, 2, K); } while (0)
+            if (u8) RWS(uint8_t, 0);
+            else if (kind == 0) RWS(uint16_t, 0);
+            else if (kind == 1) RWS(uint16_t, 1);
+            else RWS(uint16_t, 2);
+#undef RWS
+#undef RW
+        };
+        if (fusedShadow) {
+            launch(1, 0, 1);
+            if (si.num_planes >= 3) launch(2, 1, 1);
+        } else
+            launch(0, 0, si.num_planes);
+    }
+    int gx = 0;
+    for (int p = 0; p < si.num_planes; p++) {
+        const int ntx = (A.g[p].pw + L0_TW - 1) / L0_TW;
+        A.tcA[p] = (A.XA[p] + L0_TW - 1) / L0_TW; A.tcB[p] = A.XB[p] / L0_TW;
+        if (A.tcB[p] < A.tcA[p]) A.tcB[p] = A.tcA[p];
+        if (A.tcA[p] + ntx - A.tcB[p] > gx) gx = A.tcA[p] + ntx - A.tcB[p];
+    }
+    dim3 grid(gx, (maxph + L0_TH - 1) / L0_TH, nframes * 3);
     if (u8) launch_level0<uint8_t>(A, si.sharp, l0pel, grid, st); else launch_level0<uint16_t>(A, si.sharp, l0pel, grid, st);
+    if (fusedShadow) { // the two strips super_level0_kernel produced
+        ShadowStripArgs Z;
+        memset(&Z, 0, sizeof(Z));
+        Z.planes = A.dst; Z.nplanes = si.num_planes;
+        int mw = 0, mh = 0;
+        for (int p = 0; p < si.num_planes && p < 2; p++) {
+            Z.g[p] = A.g[p]; Z.XA[p] = A.XA[p]; Z.XB[p] = A.XB[p]; Z.shadow[p] = shadow_stride[p];
+            const int n = A.XA[p] + A.g[p].pw - A.XB[p];
+            if (n > mw) mw = n;
+            if (A.g[p].ph > mh) mh = A.g[p].ph;
+        }
+        hipLaunchKernelGGL(super_shadow_strip_kernel, dim3((mw + 63) / 64, mh, nframes * 2), dim3(256), 0, st, Z);
+    }
 
     if (pelMode) {
         void *dpel = nullptr;
@@ -579,11 +690,68 @@ static int super_frames_impl(mvx_super *s, int nframes, const void *const *src, 
             if (b.pw > mw) mw = b.pw;
             if (b.ph > mh) mh = b.ph;
         }
-        dim3 g3((mw + 63) / 64, (mh + 3) / 4, nframes * 3);
+        { // interior outputs whose filter window needs no edge rule: rows-in-registers kernel (mvx_super_rows.h)
+            SuperReduceRowsArgs Q;
+            memset(&Q, 0, sizeof(Q));
+            Q.src = R.src; Q.dst = R.dst; Q.modeYUV = R.modeYUV; Q.nplanes = R.nplanes;
+            bool ok = !mvx_debug_value("super_rows_off", 0);
+            int qw = 0, qh = 0;
+            for (int p = 0; ok && p < si.num_planes; p++) {
+                Q.src_pitch[p] = R.src_pitch[p]; Q.dst_pitch[p] = R.dst_pitch[p]; Q.in_off[p] = R.in_off[p]; Q.out_off[p] = R.out_off[p];
+                Q.in_hpad[p] = R.in_hpad[p]; Q.in_vpad[p] = R.in_vpad[p]; Q.out_hpad[p] = R.out_hpad[p]; Q.out_vpad[p] = R.out_vpad[p];
+                if ((R.in_hpad[p] * bps) % 4 || (R.out_hpad[p] * bps) % 4) ok = false;
+                if (L == 0) {
+                    if (src_pitch[p] % 4) ok = false;
+                    for (int f = 0; ok && f < nframes; f++) if ((uintptr_t)src[f * 3 + p] % 4) ok = false;
+                }
+                for (int f = 0; ok && f < nframes; f++) if ((uintptr_t)dst[f * 3 + p] % 16) ok = false;
+                const int iw = R.in_w[p], ih = R.in_h[p], ow = R.out_w[p], oh = R.out_h[p];
+                int last = (iw - 2 * NS - 4) / 2; // the window 2*x0 - 4 .. 2*x0 + 2*NS + 3 ends inside the input row
+                if (ow - NS - 1 < last) last = ow - NS - 1; // and the thread's last output is not the right edge
+                // threads sit at padded columns that are multiples of NS: x0 = k * NS - hpad; the first with x0 >= 2 (window inside the row, not the left edge)
+                const int hp = R.out_hpad[p], xa = (2 + hp + NS - 1) / NS * NS - hp;
+                Q.XA[p] = xa; Q.XB[p] = (iw >= 2 * NS + 4 && last >= xa) ? (last + hp) / NS * NS - hp + NS : xa;
+                int yb = oh - 1; // rows 1 .. oh - 2 whose taps 2y - 2 .. 2y + 3 exist
+                if ((ih - 4) / 2 + 1 < yb) yb = (ih - 4) / 2 + 1;
+                Q.YA[p] = 1; Q.YB[p] = (ih >= 4 && yb > 1) ? yb : 1;
+                if (Q.XB[p] <= Q.XA[p] || Q.YB[p] <= Q.YA[p]) { Q.XB[p] = Q.XA[p]; Q.YB[p] = Q.YA[p]; }
+                if (Q.XB[p] > Q.XA[p] && Q.XB[p] + hp > qw) qw = Q.XB[p] + hp;
+                if (Q.YB[p] - Q.YA[p] > qh) qh = Q.YB[p] - Q.YA[p];
+            }
+            if (ok && qw > 0 && qh > 0) {
+                for (int p = 0; p < si.num_planes; p++) { R.XA[p] = Q.XA[p]; R.XB[p] = Q.XB[p]; R.YA[p] = Q.YA[p]; R.YB[p] = Q.YB[p]; }
+                dim3 gq((qw / NS + 63) / 64, (qh + 3) / 4, nframes * 3);
+#define RR(T, F, FS) hipLaunchKernelGGL((super_reduce_rows_kernel<T, F, FS>), gq, dim3(256), 0, st, Q)
+#define RRF(T, FS) do { switch (si.rfilter) { case 0: RR(T, 0, FS); break; case 1: RR(T, 1, FS); break; case 2: RR(T, 2, FS); break; case 3: RR(T, 3, FS); break; default: RR(T, 4, FS); break; } } while (0)
+                if (L == 0) { if (u8) RRF(uint8_t, true); else RRF(uint16_t, true); }
+                else { if (u8) RRF(uint8_t, false); else RRF(uint16_t, false); }
+#undef RRF
+#undef RR
+            }
+        }
+        int gtot = 0;
+        for (int p = 0; p < si.num_planes; p++) {
+            const int pw = R.out_w[p] + 2 * R.out_hpad[p], ph = R.out_h[p] + 2 * R.out_vpad[p];
+            const int ncb = (pw + 63) / 64, nrb = (ph + 3) / 4;
+            int cbA = (R.out_hpad[p] + R.XA[p] + 63) / 64, cbB = (R.out_hpad[p] + R.XB[p]) / 64;
+            int rbA = (R.out_vpad[p] + R.YA[p] + 3) / 4, rbB = (R.out_vpad[p] + R.YB[p]) / 4;
+            if (R.XB[p] <= R.XA[p] || R.YB[p] <= R.YA[p] || cbB <= cbA || rbB <= rbA) { cbA = cbB = 0; rbA = rbB = nrb; } // no interior: every block is a band block
+            R.ncb[p] = ncb; R.nrb[p] = nrb; R.cbA[p] = cbA; R.cbB[p] = cbB; R.rbA[p] = rbA; R.rbB[p] = rbB;
+            R.nfull[p] = (rbA + nrb - rbB) * ncb;
+            R.ntotal[p] = R.nfull[p] + (rbB - rbA) * (cbA + ncb - cbB);
+            if (R.ntotal[p] > gtot) gtot = R.ntotal[p];
+        }
+        dim3 g3(gtot, 1, nframes * 3);
         if (L == 0) { if (u8) launch_reduce<uint8_t, true>(R, si.rfilter, g3, st); else launch_reduce<uint16_t, true>(R, si.rfilter, g3, st); }
         else { if (u8) launch_reduce<uint8_t, false>(R, si.rfilter, g3, st); else launch_reduce<uint16_t, false>(R, si.rfilter, g3, st); }
     }
     HIP_CHECK(hipGetLastError());
+    if (shadow_stride) { // what the level-0 kernels did not write themselves: the coarser levels, or everything
+        long long begin[2] = { 0, 0 };
+        if (fusedShadow)
+            for (int p = 0; p < si.num_planes && p < 2; p++) begin[p] = 4LL * A.g[p].ph * dst_pitch[p];
+        return shadow_launch(si, nframes, (void *const *)ddst, dst_pitch, shadow_stride, begin, st);
+    }
     return MVX_OK;
 }
 

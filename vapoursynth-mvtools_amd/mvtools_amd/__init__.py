@@ -134,6 +134,7 @@ def lib():
         L.mvx_super_shadow_bytes.restype = None
         L.mvx_super_shadow_frames.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p), P(C.c_ssize_t), P(C.c_ssize_t), C.c_void_p]
         L.mvx_analyse_set_ref_shadow.argtypes = [C.c_void_p, P(C.c_ssize_t)]
+        L.mvx_super_frames_shadow.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p), P(C.c_ssize_t), P(C.c_void_p), P(C.c_ssize_t), P(C.c_ssize_t), C.c_void_p]
         L.mvx_debug_option.argtypes = [C.c_char_p, C.c_int]
         L.mvx_analyse_create.argtypes = [P(AnalyseArgs), C.c_void_p, C.c_int, P(C.c_ssize_t), P(C.c_void_p), C.c_char_p]
         L.mvx_analyse_destroy.argtypes = [C.c_void_p]
@@ -169,7 +170,7 @@ def lib():
         # developer / test switches: the library itself never reads the environment (mvx_debug_option is its one hook);
         # this TEST binding forwards the MVX_* variables the tools/ scripts use
         for env, opt in (("MVX_GENERAL", "general"), ("MVX_FAST_WPE", "fast_wpe"), ("MVX_WINDOW", "window"), ("MVX_TILE", "tile"), ("MVX_NO_WPE2", "no_wpe2"),
-                         ("MVX_NO_WPE3", "no_wpe3"), ("MVX_WPE3", "wpe3_u16"), ("MVX_FAST_CPW", "fast_cpw"), ("MVX_FAST_FLAGS", "fast_flags"), ("MVX_PAD_RUNS", "pad_runs"), ("MVX_SHADOW_PLANES", "shadow_planes"), ("MVX_DEGRAIN_XCD", "degrain_xcd"), ("MVX_CPW_SYNC", "cpw_sync"), ("MVX_LDS_MIN", "lds_min"), ("MVX_ABLATE", "ablate")):
+                         ("MVX_NO_WPE3", "no_wpe3"), ("MVX_WPE3", "wpe3_u16"), ("MVX_FAST_CPW", "fast_cpw"), ("MVX_FAST_FLAGS", "fast_flags"), ("MVX_PAD_RUNS", "pad_runs"), ("MVX_SHADOW_PLANES", "shadow_planes"), ("MVX_DEGRAIN_XCD", "degrain_xcd"), ("MVX_CPW_SYNC", "cpw_sync"), ("MVX_LDS_MIN", "lds_min"), ("MVX_SUPER_ROWS_OFF", "super_rows_off"), ("MVX_ABLATE", "ablate")):
             if os.environ.get(env) is not None:
                 L.mvx_debug_option(opt.encode(), int(os.environ[env]))
         if os.environ.get("MVX_CPW") == "1":
@@ -379,8 +380,11 @@ class Super:
                 src[f * 3 + p] = frames[f][p].data_ptr()
                 dst[f * 3 + p] = out[f][p].data_ptr()
                 assert frames[f][p].stride(0) == frames[0][p].stride(0) and out[f][p].stride(0) == out[0][p].stride(0)
-        _check(lib().mvx_super_frames(self.h, n, src, _pitches(frames[0]), dst, _pitches(out[0]), _stream()))
-        self._shadows(out)
+        if self.shadow:  # one call: the level-0 kernels write the shadow data of level 0 themselves
+            pad = lambda l: (C.c_ssize_t * 3)(*(list(l) + [0] * (3 - len(l))))
+            _check(lib().mvx_super_frames_shadow(self.h, n, src, _pitches(frames[0]), dst, _pitches(out[0]), pad(self.shadow_stride), _stream()))
+        else:
+            _check(lib().mvx_super_frames(self.h, n, src, _pitches(frames[0]), dst, _pitches(out[0]), _stream()))
         return out
 
 
