@@ -305,10 +305,18 @@ void *mvx_dev_alloc_uninit(size_t bytes);     /* contents undefined (scratch, up
 void mvx_dev_free(void *p);                   /* goes to a size-keyed free list (no device synchronisation); wait for the work that uses p first */
 void mvx_dev_pool_limit(size_t bytes);        /* bytes the free list may hold (default 24 GiB) */
 void *mvx_stream_create(void);                /* a non-blocking stream for the `stream` arguments; NULL on failure */
+void *mvx_stream_create_priority(int level);  /* < 0 lowest, 0 default, > 0 highest priority; different priorities never share a hardware queue */
 void mvx_stream_destroy(void *stream);
 int mvx_copy_to_device(void *dst, ptrdiff_t dst_pitch, const void *src_host, ptrdiff_t src_pitch, size_t row_bytes, size_t rows, void *stream);
 int mvx_copy_to_host(void *dst_host, ptrdiff_t dst_pitch, const void *src, ptrdiff_t src_pitch, size_t row_bytes, size_t rows, void *stream);
 int mvx_stream_sync(void *stream);
+/* Synchronous 2-D transfers for hosts whose frames live in ordinary (pageable) memory: staged through a small set of pinned buffers
+ * inside the library (a linear PCIe copy + a row-by-row memcpy on the calling thread) -- several times faster than the pageable 2-D
+ * copies above for large planes, and safe to call from many threads.  Complete on return; work already enqueued on `stream` runs
+ * before the copy. */
+int mvx_upload_2d(void *dst, ptrdiff_t dst_pitch, const void *src_host, ptrdiff_t src_pitch, size_t row_bytes, size_t rows, void *stream);
+int mvx_download_2d(void *dst_host, ptrdiff_t dst_pitch, const void *src, ptrdiff_t src_pitch, size_t row_bytes, size_t rows, void *stream);
+int mvx_dev_memset(void *dst, int value, size_t bytes, void *stream); /* asynchronous on `stream` */
 int mvx_set_device(int ordinal);
 
 #ifdef __cplusplus

@@ -27,12 +27,12 @@ with open(src, "wb") as f:
 print("clip: %d frames %dx%d P%d written in %.1f s" % (N, w, h, bits, time.time() - t0), flush=True)
 
 host, plugin = os.path.join(ROOT, "vapoursynth-mvtools_amd", "mvx_vs_host"), os.path.join(ROOT, "vapoursynth-mvtools_amd", "libmvtools_vs.so")
-env = dict(os.environ, MVX_VS_STATS="1", MVX_VS_CACHE_FRAMES="64")
+env = dict(os.environ, MVX_VS_STATS="1", MVX_HOST_TIMES="1")
 t0 = time.time()
 r = subprocess.run([host, plugin, "run", "degrain3", src, str(w), str(h), str(bits), str(N), out, "a.blksize=16", "a.overlap=8", "x.threads=%d" % T],
                    capture_output=True, text=True, env=env)
 dt = time.time() - t0
-print(r.stdout.strip()[-200:], r.stderr.strip()[-400:], flush=True)
+print(r.stdout.strip()[-200:], r.stderr.strip()[-700:], flush=True)
 assert r.returncode == 0 and "DONE" in r.stdout
 print("shell: %d output frames, %d request threads: %.1f s wall = %.2f fps (reads the clip file, uploads, PCIe both ways, writes the result file)" % (N, T, dt, N / dt), flush=True)
 

@@ -90,6 +90,16 @@ extern "C" __attribute__((visibility("default"))) void *mvx_stream_create(void) 
     if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { mvx_set_error("hipStreamCreate failed"); return nullptr; }
     return (void *)s;
 }
+// level < 0: lowest priority, > 0: highest, 0: default.  Streams of different priorities do not share a hardware queue, so the short
+// per-frame kernels and copies of a frame server (high) are not stuck behind a search launch that runs for hundreds of milliseconds (low).
+extern "C" __attribute__((visibility("default"))) void *mvx_stream_create_priority(int level) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; }
+    hipStream_t s = nullptr;
+    const int prio = level < 0 ? least : (level > 0 ? greatest : (least + greatest) / 2);
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio) != hipSuccess) { mvx_set_error("hipStreamCreateWithPriority failed"); return nullptr; }
+    return (void *)s;
+}
 extern "C" __attribute__((visibility("default"))) void mvx_stream_destroy(void *s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }
 
 extern "C" __attribute__((visibility("default"))) int mvx_copy_to_device(void *dst, ptrdiff_t dp, const void *src, ptrdiff_t sp, size_t row_bytes, size_t rows, void *stream) {
@@ -100,4 +110,78 @@ extern "C" __attribute__((visibility("default"))) int mvx_copy_to_host(void *dst
     HIP_CHECK(hipMemcpy2DAsync(dst, dp, src, sp, row_bytes, rows, hipMemcpyDeviceToHost, (hipStream_t)stream));
     return MVX_OK;
 }
+// ---- synchronous 2-D transfers between PAGEABLE host memory (a frame server owns its frames) and the device, through pinned staging
+// buffers: hipMemcpy2D on pageable memory moves a 131 MB super frame at a few GB/s, a linear copy into pinned memory runs at PCIe
+// speed and the row-by-row repacking is an ordinary memcpy that the caller's threads do in parallel.  A fixed number of staging
+// buffers (they grow to the largest request) bounds the pinned memory; callers wait for a free one.
+#include <condition_variable>
+#include <cstring>
+namespace {
+struct Stage { void *p = nullptr; size_t cap = 0; bool busy = false; };
+constexpr int kStages = 16;
+Stage g_stage[kStages];
+std::mutex g_stage_mu;
+std::condition_variable g_stage_cv;
+Stage *stage_acquire(size_t bytes) {
+    std::unique_lock<std::mutex> lk(g_stage_mu);
+    Stage *s = nullptr;
+    g_stage_cv.wait(lk, [&] {
+        Stage *fit = nullptr, *any = nullptr;
+        for (auto &t : g_stage) if (!t.busy) { if (t.cap >= bytes && (!fit || t.cap < fit->cap)) fit = &t; if (!any || t.cap < any->cap) any = &t; }
+        s = fit ? fit : any;
+        return s != nullptr;
+    });
+    s->busy = true;
+    lk.unlock();
+    if (s->cap < bytes) {
+        if (s->p) (void)hipHostFree(s->p);
+        s->p = nullptr; s->cap = 0;
+        if (hipHostMalloc(&s->p, bytes, hipHostMallocDefault) != hipSuccess) {
+            mvx_set_error("hipHostMalloc(%zu) failed", bytes);
+            { std::lock_guard<std::mutex> g(g_stage_mu); s->busy = false; }
+            g_stage_cv.notify_one();
+            return nullptr;
+        }
+        s->cap = bytes;
+    }
+    return s;
+}
+void stage_release(Stage *s) {
+    { std::lock_guard<std::mutex> g(g_stage_mu); s->busy = false; }
+    g_stage_cv.notify_one();
+}
+}
+extern "C" __attribute__((visibility("default"))) int mvx_upload_2d(void *dev, ptrdiff_t dp, const void *host, ptrdiff_t hp, size_t row_bytes, size_t rows, void *stream) {
+    if (!rows || !row_bytes) return MVX_OK;
+    if (dp < (ptrdiff_t)row_bytes) { mvx_set_error("mvx_upload_2d: device pitch smaller than a row"); return MVX_E_ARG; }
+    const size_t bytes = (rows - 1) * (size_t)dp + row_bytes;
+    Stage *s = stage_acquire(bytes);
+    if (!s) return MVX_E_DEVICE;
+    for (size_t r = 0; r < rows; r++) memcpy((char *)s->p + r * (size_t)dp, (const char *)host + (ptrdiff_t)r * hp, row_bytes);
+    hipError_t e = hipMemcpyAsync(dev, s->p, bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    stage_release(s);
+    if (e != hipSuccess) { mvx_set_error("mvx_upload_2d: %s", hipGetErrorString(e)); return MVX_E_DEVICE; }
+    return MVX_OK;
+}
+// (work enqueued on `stream` before the call -- the kernels that produce the data -- is complete when the copy runs)
+extern "C" __attribute__((visibility("default"))) int mvx_download_2d(void *host, ptrdiff_t hp, const void *dev, ptrdiff_t dp, size_t row_bytes, size_t rows, void *stream) {
+    if (!rows || !row_bytes) return MVX_OK;
+    if (dp < (ptrdiff_t)row_bytes) { mvx_set_error("mvx_download_2d: device pitch smaller than a row"); return MVX_E_ARG; }
+    const size_t bytes = (rows - 1) * (size_t)dp + row_bytes;
+    Stage *s = stage_acquire(bytes);
+    if (!s) return MVX_E_DEVICE;
+    hipError_t e = hipMemcpyAsync(s->p, dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e == hipSuccess)
+        for (size_t r = 0; r < rows; r++) memcpy((char *)host + (ptrdiff_t)r * hp, (const char *)s->p + r * (size_t)dp, row_bytes);
+    stage_release(s);
+    if (e != hipSuccess) { mvx_set_error("mvx_download_2d: %s", hipGetErrorString(e)); return MVX_E_DEVICE; }
+    return MVX_OK;
+}
+extern "C" __attribute__((visibility("default"))) int mvx_dev_memset(void *dev, int value, size_t bytes, void *stream) {
+    HIP_CHECK(hipMemsetAsync(dev, value, bytes, (hipStream_t)stream));
+    return MVX_OK;
+}
+
 extern "C" __attribute__((visibility("default"))) int mvx_stream_sync(void *stream) { HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); return MVX_OK; }

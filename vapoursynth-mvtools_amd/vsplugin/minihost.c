@@ -22,6 +22,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <time.h>
 
 #include "vs4_api.h"
 
@@ -101,19 +103,33 @@ static void copy_map(VSMap *dst, const VSMap *src) {
 
 /* ---------------------------------------------------------------------------------------------------- frames */
 
-struct VSFrame { int refs; VSVideoFormat fmt; int w, h; uint8_t *data[3]; ptrdiff_t stride[3]; VSMap *props; };
+/* planes are reference-counted buffers shared between a frame and its copies, copied when somebody asks for a write pointer:
+ * VapourSynth's copy-on-write frames (mv.Analyse's copyFrame of a 131 MB super frame costs nothing there, and must not here) */
+struct VSFrame { int refs; VSVideoFormat fmt; int w, h; uint8_t *data[3]; int *planeRefs[3]; ptrdiff_t stride[3]; VSMap *props; };
 
 static int plane_w(const VSFrame *f, int p) { return p ? f->w >> f->fmt.subSamplingW : f->w; }
 static int plane_h(const VSFrame *f, int p) { return p ? f->h >> f->fmt.subSamplingH : f->h; }
 
+/* large planes on huge pages where the kernel offers them: a 131 MB super frame is 32 000 page faults otherwise, and the faults of
+ * 64 worker threads serialise on the process's memory map (VapourSynth recycles frame buffers instead) */
+static uint8_t *plane_alloc(size_t size) {
+    void *p = NULL;
+    const size_t big = (size_t)2 << 20;
+    if (size >= 2 * big) {
+        if (posix_memalign(&p, big, (size + big - 1) / big * big)) abort();
+        (void)madvise(p, (size + big - 1) / big * big, MADV_HUGEPAGE);
+    } else if (posix_memalign(&p, 64, size)) abort();
+    return (uint8_t *)p;
+}
 static VSFrame *VS_CC newVideoFrame(const VSVideoFormat *fmt, int w, int h, const VSFrame *propSrc, VSCore *core) {
     (void)core;
     VSFrame *f = (VSFrame *)calloc(1, sizeof(VSFrame));
     f->refs = 1; f->fmt = *fmt; f->w = w; f->h = h; f->props = createMap();
     for (int p = 0; p < fmt->numPlanes; p++) {
         f->stride[p] = ((ptrdiff_t)plane_w(f, p) * fmt->bytesPerSample + 63) / 64 * 64;
-        if (posix_memalign((void **)&f->data[p], 64, (size_t)f->stride[p] * plane_h(f, p))) abort();
+        f->data[p] = plane_alloc((size_t)f->stride[p] * plane_h(f, p));
         memset(f->data[p], 0xCD, (size_t)f->stride[p] * plane_h(f, p)); /* new frames are uninitialised in VapourSynth */
+        f->planeRefs[p] = (int *)malloc(sizeof(int)); *f->planeRefs[p] = 1;
     }
     if (propSrc) copy_map(f->props, propSrc->props);
     return f;
@@ -123,22 +139,45 @@ static void VS_CC freeFrame(const VSFrame *cf) {
     if (!f) return;
     pthread_mutex_lock(&g_host_mu);
     const int left = --f->refs;
+    int drop[3] = { 0, 0, 0 };
+    if (!left) for (int p = 0; p < 3; p++) if (f->planeRefs[p] && --*f->planeRefs[p] == 0) drop[p] = 1;
     pthread_mutex_unlock(&g_host_mu);
     if (left) return;
-    for (int p = 0; p < 3; p++) free(f->data[p]);
+    for (int p = 0; p < 3; p++) if (drop[p]) { free(f->data[p]); free(f->planeRefs[p]); }
     freeMap(f->props); free(f);
 }
 static const VSFrame *frame_addref(const VSFrame *f) { pthread_mutex_lock(&g_host_mu); ((VSFrame *)f)->refs++; pthread_mutex_unlock(&g_host_mu); return f; }
 static VSFrame *VS_CC copyFrame(const VSFrame *s, VSCore *core) {
-    VSFrame *f = newVideoFrame(&s->fmt, s->w, s->h, s, core);
-    for (int p = 0; p < s->fmt.numPlanes; p++) memcpy(f->data[p], s->data[p], (size_t)s->stride[p] * plane_h(s, p));
+    (void)core;
+    VSFrame *f = (VSFrame *)calloc(1, sizeof(VSFrame));
+    f->refs = 1; f->fmt = s->fmt; f->w = s->w; f->h = s->h; f->props = createMap();
+    pthread_mutex_lock(&g_host_mu);
+    for (int p = 0; p < s->fmt.numPlanes; p++) { f->data[p] = s->data[p]; f->stride[p] = s->stride[p]; f->planeRefs[p] = s->planeRefs[p]; ++*f->planeRefs[p]; }
+    pthread_mutex_unlock(&g_host_mu);
+    copy_map(f->props, s->props);
     return f;
 }
 static const VSMap *VS_CC getFramePropertiesRO(const VSFrame *f) { return f->props; }
 static VSMap *VS_CC getFramePropertiesRW(VSFrame *f) { return f->props; }
 static ptrdiff_t VS_CC getStride(const VSFrame *f, int p) { return f->stride[p]; }
 static const uint8_t *VS_CC getReadPtr(const VSFrame *f, int p) { return f->data[p]; }
-static uint8_t *VS_CC getWritePtr(VSFrame *f, int p) { return f->data[p]; }
+static uint8_t *VS_CC getWritePtr(VSFrame *f, int p) {
+    pthread_mutex_lock(&g_host_mu);
+    const int shared = *f->planeRefs[p] > 1;
+    pthread_mutex_unlock(&g_host_mu);
+    if (shared) { /* copy on write */
+        const size_t size = (size_t)f->stride[p] * plane_h(f, p);
+        uint8_t *d;
+        d = plane_alloc(size);
+        memcpy(d, f->data[p], size);
+        int *rc = (int *)malloc(sizeof(int)); *rc = 1;
+        pthread_mutex_lock(&g_host_mu);
+        --*f->planeRefs[p]; /* (cannot reach 0: it was > 1 and this frame held one of the references) */
+        pthread_mutex_unlock(&g_host_mu);
+        f->data[p] = d; f->planeRefs[p] = rc;
+    }
+    return f->data[p];
+}
 static const VSVideoFormat *VS_CC getVideoFrameFormat(const VSFrame *f) { return &f->fmt; }
 static int VS_CC getFrameWidth(const VSFrame *f, int p) { return plane_w(f, p); }
 static int VS_CC getFrameHeight(const VSFrame *f, int p) { return plane_h(f, p); }
@@ -394,8 +433,12 @@ static void prefetch_parallel(int threads, int count, VSNode **nodes, int nnodes
     if (w.err[0]) die("parallel request", w.err);
 }
 
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+static double g_start;
+
 int main(int argc, char **argv) {
     if (argc < 3) { fprintf(stderr, "usage: see minihost.c\n"); return 2; }
+    g_start = now_s();
     init_api();
     void *h = dlopen(argv[1], RTLD_NOW | RTLD_GLOBAL);
     if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
@@ -569,11 +612,16 @@ int main(int argc, char **argv) {
         out = invoke(fn, m, err, sizeof(err));
     }
     if (!out) die(pipeline, err);
+    const int times = getenv("MVX_HOST_TIMES") != NULL;
+    double t0 = now_s();
+    if (times) fprintf(stderr, "minihost: graph built at %.2f s after start\n", t0 - g_start);
     if (threads > 1) { /* the vector clips first (all threads inside one Analyse instance at a time), then the output */
         prefetch_parallel(threads, nframes, vec, 2 * R < 4 ? 2 * R : 4);
         if (2 * R > 4) prefetch_parallel(threads, nframes, vec + 4, 2 * R - 4 < 4 ? 2 * R - 4 : 4);
         if (2 * R > 8) prefetch_parallel(threads, nframes, vec + 8, 2 * R - 8);
+        if (times) { fprintf(stderr, "minihost: vector clips %.2f s\n", now_s() - t0); t0 = now_s(); }
         prefetch_parallel(threads, nframes, &out, 1);
+        if (times) { fprintf(stderr, "minihost: output clip %.2f s\n", now_s() - t0); t0 = now_s(); }
     }
     for (int n = 0; n < nframes; n++) {
         const VSFrame *f = eval_frame(n, out, err, sizeof(err));
@@ -581,6 +629,7 @@ int main(int argc, char **argv) {
         dump_frame(fo, f); freeFrame(f);
     }
     fclose(fo);
+    if (times) fprintf(stderr, "minihost: result file written in %.2f s\n", now_s() - t0);
     printf("DONE\n");
     return 0;
 }

@@ -38,17 +38,66 @@
 /* ------------------------------------------------------------------------------------------------ device frame cache */
 
 typedef struct DevFrame { int64_t id; void *arena; void *plane[3]; size_t bytes; int pins; uint64_t stamp; uint64_t print; } DevFrame;
-#define CACHE_MAX 64
+#define CACHE_MAX 1024
 static DevFrame g_cache[CACHE_MAX];
 static int g_cache_cap = -1;
+static size_t g_cache_frame_bytes; /* size of the first super frame seen: the default capacity is a byte budget */
 static uint64_t g_stamp = 1;
 static int64_t g_next_instance = 1;
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 
+/* ONE high-priority non-blocking stream carries every thread's uploads, per-frame kernels (Super, Degrain, ...) and downloads: that
+ * work is short and PCIe is serial anyway; the searches run on low-priority streams of their own (one per Analyse instance) and a
+ * different priority means a different hardware queue, so a frame's copies never wait behind a 0.3 s search launch.  (A stream per
+ * worker thread was measured and is worse: 40 ms to create each, and they share hardware queues with the searches.) */
+static void *g_frame_stream;
+static int g_frame_stream_tried;
+/* MVX_VS_STATS=1: thread-seconds by category, printed with the launch statistics when the plugin is unloaded */
+enum { PF_STREAM, PF_UPLOAD, PF_DOWNLOAD, PF_SUPER, PF_SEARCH_WAIT, PF_DEGRAIN, PF_ALLOC, PF_N };
+static double g_prof[PF_N];
+static long g_prof_n[PF_N];
+static int g_prof_on = -1;
+static double prof_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+static void prof_add(int k, double t0) {
+    if (g_prof_on < 0) g_prof_on = getenv("MVX_VS_STATS") != NULL;
+    if (!g_prof_on) return;
+    const double dt = prof_now() - t0;
+    pthread_mutex_lock(&g_lock); g_prof[k] += dt; g_prof_n[k]++; pthread_mutex_unlock(&g_lock);
+}
+static void *thread_stream(void) {
+    if (!__atomic_load_n(&g_frame_stream_tried, __ATOMIC_ACQUIRE)) {
+        pthread_mutex_lock(&g_lock);
+        if (!g_frame_stream_tried) { g_frame_stream = mvx_stream_create_priority(1); __atomic_store_n(&g_frame_stream_tried, 1, __ATOMIC_RELEASE); }
+        pthread_mutex_unlock(&g_lock);
+    }
+    return g_frame_stream;
+}
+static int timed_upload(void *dst, ptrdiff_t dp, const void *src, ptrdiff_t sp, size_t rb, size_t rows) {
+    const double t0 = prof_now();
+    const int rc = mvx_upload_2d(dst, dp, src, sp, rb, rows, thread_stream());
+    prof_add(PF_UPLOAD, t0);
+    return rc;
+}
+static int timed_download(void *dst, ptrdiff_t dp, const void *src, ptrdiff_t sp, size_t rb, size_t rows) {
+    const double t0 = prof_now();
+    const int rc = mvx_download_2d(dst, dp, src, sp, rb, rows, thread_stream());
+    prof_add(PF_DOWNLOAD, t0);
+    return rc;
+}
+
+/* capacity in frames: MVX_VS_CACHE_FRAMES, or MVX_VS_CACHE_BYTES (default 48 GiB of the 288) / the size of a super frame.  It must
+ * cover the frames a host has in flight (its thread count + twice the temporal radius): a frame that falls out is uploaded again,
+ * 131 MB for 4K16, and a search that waits for uploads runs at PCIe speed. */
 static int cache_cap(void) {
     if (g_cache_cap < 0) {
-        const char *e = getenv("MVX_VS_CACHE_FRAMES");
-        g_cache_cap = e ? atoi(e) : 16;
+        const char *e = getenv("MVX_VS_CACHE_FRAMES"), *b = getenv("MVX_VS_CACHE_BYTES");
+        if (e) g_cache_cap = atoi(e);
+        else {
+            if (!g_cache_frame_bytes) return 16; /* (not fixed yet: no frame seen) */
+            const double budget = b ? atof(b) : 48.0 * 1024 * 1024 * 1024;
+            g_cache_cap = (int)(budget / (double)g_cache_frame_bytes);
+            if (g_cache_cap < 16) g_cache_cap = 16;
+        }
         if (g_cache_cap > CACHE_MAX) g_cache_cap = CACHE_MAX;
         if (g_cache_cap < 0) g_cache_cap = 0;
     }
@@ -122,6 +171,7 @@ static DevFrame *cache_insert(int64_t id, uint64_t print, void *arena, const Sup
     DevFrame *slot = NULL;
     void *victim = NULL;
     pthread_mutex_lock(&g_lock);
+    if (!g_cache_frame_bytes) g_cache_frame_bytes = g->bytes;
     for (int i = 0; i < cache_cap(); i++) {
         DevFrame *e = &g_cache[i];
         if (!e->arena) { slot = e; break; }
@@ -155,16 +205,17 @@ static int super_to_device(DevRef *r, const VSFrame *f, const SuperGeo *g, const
         for (int p = 0; p < 3; p++) r->plane[p] = r->cached->plane[p];
         return 0;
     }
-    void *arena = mvx_dev_alloc(g->bytes); /* zero-filled like the frames mv.Super builds */
+    void *arena = mvx_dev_alloc_uninit(g->bytes);
     if (!arena) return MVX_E_NOMEM;
-    int rc = 0;
+    void *st = thread_stream();
+    int rc = mvx_dev_memset(arena, 0, g->bytes, st); /* zero-filled like the frames mv.Super builds (pitch padding) */
     for (int p = 0; p < g->si.num_planes && !rc; p++) {
         void *d = (char *)arena + g->off[p];
-        rc = mvx_copy_to_device(d, g->pitch[p], vs->getReadPtr(f, p), vs->getStride(f, p), (size_t)g->si.plane_width[p] * g->bps, (size_t)g->si.plane_height[p], NULL);
+        rc = timed_upload(d, g->pitch[p], vs->getReadPtr(f, p), vs->getStride(f, p), (size_t)g->si.plane_width[p] * g->bps, (size_t)g->si.plane_height[p]);
         r->plane[p] = d;
     }
-    if (!rc) rc = super_shadows(g, r->plane, NULL);
-    if (!rc) rc = mvx_stream_sync(NULL); /* the host frame may be released, and consumers launch on their own streams */
+    if (!rc) rc = super_shadows(g, r->plane, st);
+    if (!rc) rc = mvx_stream_sync(st); /* consumers launch on their own streams */
     if (rc) { mvx_dev_free(arena); memset(r, 0, sizeof(*r)); return rc; }
     if (!err && (r->cached = cache_insert(id, print, arena, g)) != NULL) return 0; /* keep it for the next consumer */
     r->temp = arena;
@@ -311,7 +362,7 @@ static int blob_to_device(void **dblob, int *size, const mvx_analysis_data *ad, 
     }
     *dblob = mvx_dev_alloc_uninit((size_t)n);
     if (!*dblob) return MVX_E_NOMEM;
-    if (mvx_copy_to_device(*dblob, n, blob, n, (size_t)n, 1, NULL) || mvx_stream_sync(NULL)) return MVX_E_DEVICE; /* the prop memory goes away with the frame */
+    if (timed_upload(*dblob, n, blob, n, (size_t)n, 1)) return MVX_E_DEVICE; /* complete on return: the prop memory goes away with the frame */
     if (size) *size = n;
     return 0;
 }
@@ -327,9 +378,8 @@ static int upload_plane_set(void *dst[3], void **arena, const VSFrame *f, const 
     int rc = 0;
     for (int p = 0; p < nplanes && !rc; p++) {
         dst[p] = (char *)*arena + off[p];
-        rc = mvx_copy_to_device(dst[p], pitch[p], vs->getReadPtr(f, p), vs->getStride(f, p), (size_t)vs->getFrameWidth(f, p) * bps, (size_t)vs->getFrameHeight(f, p), NULL);
+        rc = timed_upload(dst[p], pitch[p], vs->getReadPtr(f, p), vs->getStride(f, p), (size_t)vs->getFrameWidth(f, p) * bps, (size_t)vs->getFrameHeight(f, p));
     }
-    if (!rc) rc = mvx_stream_sync(NULL);
     return rc;
 }
 
@@ -352,19 +402,30 @@ static const VSFrame *VS_CC superGetFrame(int n, int reason, void *inst, void **
     int rc = upload_plane_set(dsrc, &srcArena, src, d->srcPitch, g->si.num_planes, g->bps, vs);
     const VSFrame *pf = d->pelMode ? vs->getFrameFilter(n, d->pelclip, ctx) : NULL; /* src/MVSuper.c:62-64 */
     if (pf && !rc) rc = upload_plane_set(dpel, &pelArena, pf, d->pelPitch, g->si.num_planes, g->bps, vs);
-    void *arena = rc ? NULL : mvx_dev_alloc(g->bytes); /* zero-filled: only the defined rectangles are written (MVSuper.c:73 memsets too) */
+    void *st = thread_stream();
+    double tp = prof_now();
+    void *arena = rc ? NULL : mvx_dev_alloc_uninit(g->bytes);
+    prof_add(PF_ALLOC, tp);
+    tp = prof_now();
     if (!rc && !arena) rc = MVX_E_NOMEM;
+    if (!rc) rc = mvx_dev_memset(arena, 0, g->bytes, st); /* zero-filled: only the defined rectangles are written (MVSuper.c:73 memsets too) */
     if (!rc) {
         for (int p = 0; p < g->si.num_planes; p++) ddst[p] = (char *)arena + g->off[p];
-        rc = mvx_super_frames_pelclip(d->sup, 1, (const void *const *)dsrc, d->srcPitch, (const void *const *)dpel, d->pelPitch, d->pelMode, (void *const *)ddst, g->pitch, NULL);
-        if (!rc) rc = super_shadows(g, ddst, NULL);
+        if (!d->pelMode && g->copies > 1) /* the level-0 kernels write their share of the shadow planes themselves */
+            rc = mvx_super_frames_shadow(d->sup, 1, (const void *const *)dsrc, d->srcPitch, (void *const *)ddst, g->pitch, g->shadowStride, st);
+        else {
+            rc = mvx_super_frames_pelclip(d->sup, 1, (const void *const *)dsrc, d->srcPitch, (const void *const *)dpel, d->pelPitch, d->pelMode, (void *const *)ddst, g->pitch, st);
+            if (!rc) rc = super_shadows(g, ddst, st);
+        }
     }
+    if (!rc) rc = mvx_stream_sync(st);
+    prof_add(PF_SUPER, tp);
     VSFrame *dst = NULL;
     if (!rc) {
         dst = vs->newVideoFrame(&d->vi.format, d->vi.width, d->vi.height, src, core);
         for (int p = 0; p < g->si.num_planes && !rc; p++)
-            rc = mvx_copy_to_host(vs->getWritePtr(dst, p), vs->getStride(dst, p), ddst[p], g->pitch[p], (size_t)g->si.plane_width[p] * g->bps, (size_t)g->si.plane_height[p], NULL);
-        if (!rc) rc = mvx_stream_sync(NULL);
+            rc = timed_download(vs->getWritePtr(dst, p), vs->getStride(dst, p), ddst[p], g->pitch[p], (size_t)g->si.plane_width[p] * g->bps, (size_t)g->si.plane_height[p]);
+        if (!rc) rc = mvx_stream_sync(st);
     }
     if (srcArena) mvx_dev_free(srcArena);
     if (pelArena) mvx_dev_free(pelArena);
@@ -464,13 +525,17 @@ static void VS_CC superCreate(const VSMap *in, VSMap *out, void *user, VSCore *c
 /* ------------------------------------------------------------------------------------------------ mv.Analyse */
 
 /* Combining queue: the getFrame calls of concurrent worker threads become ONE mvx_analyse_frames launch.  The first thread to
- * arrive leads: it waits a moment for others (until `maxBatch` requests or `waitUs` microseconds), takes the whole queue, launches
- * it on the instance's stream, waits for it and wakes the others up.  Requests arriving meanwhile form the next batch. */
+ * arrive leads: it waits for others -- until `maxBatch` requests are queued, or no new request has arrived for a quiet period, or a
+ * total budget is used up -- takes the whole queue, launches it on the instance's stream, waits for it and wakes the others up.
+ * Requests arriving meanwhile form the next batch.  Quiet period and budget follow the duration of the previous launch (1/8 and
+ * 1/2 of it, at least MVX_VS_BATCH_WAIT_US, the quiet period at most MVX_VS_BATCH_QUIET_MAX_US): a 4K search takes ~0.3 s whether it
+ * carries one chain or five hundred, so the frames a host delivers a few milliseconds apart are worth waiting for. */
 typedef struct AnReq { mvx_analyse_job job; int rc, done; struct AnReq *next; } AnReq;
 typedef struct Combiner {
     pthread_mutex_t mu; pthread_cond_t done, more;
     AnReq *head, *tail; int n, leader;
-    void *stream; int maxBatch; long waitUs;
+    void *stream; int maxBatch; long waitUs, quietMaxUs;
+    long lastUs; /* duration of the previous launch: a search of few chains takes as long as one of hundreds, so waiting a fraction of it for more requests is cheap */
     long batches, jobs, largest; /* statistics (MVX_VS_STATS=1 prints them when the filter is freed) */
 } Combiner;
 
@@ -482,16 +547,23 @@ static long env_long(const char *name, long def) { const char *e = getenv(name);
 static long g_stat_launches, g_stat_jobs, g_stat_largest, g_stat_instances;
 __attribute__((destructor)) static void print_stats(void) {
     if (env_long("MVX_VS_STATS", 0) && g_stat_instances)
+    {
         fprintf(stderr, "mvtools_vs: Analyse instances=%ld launches=%ld jobs=%ld largest_batch=%ld\n", g_stat_instances, g_stat_launches, g_stat_jobs, g_stat_largest);
+        static const char *nm[PF_N] = { "stream_create", "upload", "download", "super_kernels", "search_wait", "degrain", "dev_alloc" };
+        fprintf(stderr, "mvtools_vs: thread-seconds");
+        for (int k = 0; k < PF_N; k++) fprintf(stderr, " %s=%.2f/%ld", nm[k], g_prof[k], g_prof_n[k]);
+        fprintf(stderr, "\n");
+    }
 }
 
 static void combiner_init(Combiner *c) {
     memset(c, 0, sizeof(*c));
     pthread_mutex_init(&c->mu, NULL); pthread_cond_init(&c->done, NULL); pthread_cond_init(&c->more, NULL);
-    c->stream = mvx_stream_create(); /* NULL (the default stream) still works, it only serialises the instances */
+    c->stream = mvx_stream_create_priority(-1); /* NULL (the default stream) still works, it only serialises the instances */
     pthread_mutex_lock(&g_lock); g_stat_instances++; pthread_mutex_unlock(&g_lock);
     c->maxBatch = (int)env_long("MVX_VS_BATCH_MAX", 1024);
     c->waitUs = env_long("MVX_VS_BATCH_WAIT_US", 2000);
+    c->quietMaxUs = env_long("MVX_VS_BATCH_QUIET_MAX_US", 30000);
     if (c->maxBatch < 1) c->maxBatch = 1;
 }
 static void combiner_free(Combiner *c, const char *what) {
@@ -506,17 +578,29 @@ static int combiner_submit(Combiner *c, mvx_analyse *an, AnReq *r) {
     if (c->tail) c->tail->next = r; else c->head = r;
     c->tail = r; c->n++;
     if (c->leader) { /* follower */
-        if (c->n >= c->maxBatch) pthread_cond_signal(&c->more);
+        pthread_cond_signal(&c->more); /* the leader restarts its quiet period */
         while (!r->done) pthread_cond_wait(&c->done, &c->mu);
         pthread_mutex_unlock(&c->mu);
         return r->rc;
     }
     c->leader = 1;
     if (c->waitUs > 0 && c->n < c->maxBatch) {
-        struct timespec ts;
-        clock_gettime(CLOCK_REALTIME, &ts);
-        ts.tv_nsec += (c->waitUs % 1000000) * 1000; ts.tv_sec += c->waitUs / 1000000 + ts.tv_nsec / 1000000000; ts.tv_nsec %= 1000000000;
-        while (c->n < c->maxBatch) if (pthread_cond_timedwait(&c->more, &c->mu, &ts) == ETIMEDOUT) break;
+        long quiet = c->lastUs / 8, budget = c->lastUs / 2;
+        if (quiet > c->quietMaxUs) quiet = c->quietMaxUs;
+        if (quiet < c->waitUs) quiet = c->waitUs;
+        if (budget < c->waitUs) budget = c->waitUs;
+        struct timespec t0, now, ts;
+        clock_gettime(CLOCK_REALTIME, &t0);
+        while (c->n < c->maxBatch) {
+            clock_gettime(CLOCK_REALTIME, &now);
+            const long used = (now.tv_sec - t0.tv_sec) * 1000000L + (now.tv_nsec - t0.tv_nsec) / 1000;
+            if (used >= budget) break;
+            const long w = quiet < budget - used ? quiet : budget - used;
+            ts = now;
+            ts.tv_nsec += (w % 1000000) * 1000; ts.tv_sec += w / 1000000 + ts.tv_nsec / 1000000000; ts.tv_nsec %= 1000000000;
+            const int n0 = c->n;
+            if (pthread_cond_timedwait(&c->more, &c->mu, &ts) == ETIMEDOUT && c->n == n0) break; /* quiet: nobody else is about to arrive */
+        }
     }
     AnReq *list = c->head;
     const int n = c->n;
@@ -532,9 +616,15 @@ static int combiner_submit(Combiner *c, mvx_analyse *an, AnReq *r) {
     else {
         int i = 0;
         for (AnReq *q = list; q; q = q->next) jobs[i++] = q->job;
+        struct timespec a, b;
+        clock_gettime(CLOCK_MONOTONIC, &a);
         rc = mvx_analyse_frames(an, n, jobs, c->stream);
         if (!rc) rc = mvx_stream_sync(c->stream);
+        clock_gettime(CLOCK_MONOTONIC, &b);
         free(jobs);
+        pthread_mutex_lock(&c->mu);
+        c->lastUs = (b.tv_sec - a.tv_sec) * 1000000L + (b.tv_nsec - a.tv_nsec) / 1000;
+        pthread_mutex_unlock(&c->mu);
     }
     pthread_mutex_lock(&c->mu);
     for (AnReq *q = list; q;) { AnReq *nx = q->next; q->rc = rc; q->done = 1; q = nx; } /* (q may be freed by its owner once done) */
@@ -588,9 +678,11 @@ static const VSFrame *VS_CC analyseGetFrame(int n, int reason, void *inst, void 
         for (int p = 0; p < 3; p++) { req.job.src[p] = ds.plane[p]; req.job.ref[p] = ref ? dr.plane[p] : NULL; }
         req.job.blob = dblob;
         req.job.field_shift = fieldShift;
+        const double t0 = prof_now();
         rc = combiner_submit(&d->cb, d->an, &req); /* one launch for all the frames requested right now */
-        if (!rc) rc = mvx_copy_to_host(blob, d->blobSize, dblob, d->blobSize, (size_t)d->blobSize, 1, NULL);
-        if (!rc) rc = mvx_stream_sync(NULL);
+        prof_add(PF_SEARCH_WAIT, t0);
+        if (!rc) rc = timed_download(blob, d->blobSize, dblob, d->blobSize, (size_t)d->blobSize, 1);
+        if (!rc) rc = mvx_stream_sync(thread_stream());
     }
     dev_release(&ds); dev_release(&dr);
     if (dblob) mvx_dev_free(dblob);
@@ -651,6 +743,8 @@ static void VS_CC analyseCreate(const VSMap *in, VSMap *out, void *user, VSCore 
     d->blobSize = mvx_analyse_blob_size(d->an);
     if (d->geo.copies > 1) mvx_analyse_set_ref_shadow(d->an, d->geo.shadowStride); /* every device super frame of this shell carries its copies */
     combiner_init(&d->cb);
+    /* before the first launch has been timed: a chain walks every block of every level, a few microseconds each */
+    d->cb.lastUs = (long)((double)d->ad.nBlkX * d->ad.nBlkY * 4.0 / 3.0 * 2.5);
     VSFilterDependency deps[1] = { { node, rpGeneral } };
     vs->createVideoFilter(out, "Analyse", vi, analyseGetFrame, analyseFree, fmParallel, deps, 1, d, core);
 }
@@ -676,10 +770,10 @@ static const VSFrame *VS_CC finestGetFrame(int n, int reason, void *inst, void *
     if (!rc) {
         const void *src3[3]; void *dst3[3];
         for (int p = 0; p < 3; p++) { src3[p] = ds.plane[p]; dst3[p] = p < np ? (char *)arena + off[p] : NULL; }
-        rc = mvx_finest_frames(d->sup, 1, src3, d->geo.pitch, dst3, d->pitch, NULL);
+        rc = mvx_finest_frames(d->sup, 1, src3, d->geo.pitch, dst3, d->pitch, thread_stream());
         for (int p = 0; p < np && !rc; p++)
-            rc = mvx_copy_to_host(vs->getWritePtr(dst, p), vs->getStride(dst, p), dst3[p], d->pitch[p], (size_t)vs->getFrameWidth(dst, p) * bps, (size_t)vs->getFrameHeight(dst, p), NULL);
-        if (!rc) rc = mvx_stream_sync(NULL);
+            rc = timed_download(vs->getWritePtr(dst, p), vs->getStride(dst, p), dst3[p], d->pitch[p], (size_t)vs->getFrameWidth(dst, p) * bps, (size_t)vs->getFrameHeight(dst, p));
+        if (!rc) rc = mvx_stream_sync(thread_stream());
     }
     dev_release(&ds);
     if (arena) mvx_dev_free(arena);
@@ -737,7 +831,7 @@ static const VSFrame *VS_CC scdGetFrame(int n, int reason, void *inst, void **fd
     vs->freeFrame(mvn);
     int32_t sc = 0;
     char lerr[MVX_ERRLEN];
-    if (!rc) { const void *b1[1] = { dblob }; rc = mvx_scdetect(&d->ad, d->thscd1, d->thscd2, 1, b1, &sc, NULL, lerr); }
+    if (!rc) { const void *b1[1] = { dblob }; rc = mvx_scdetect(&d->ad, d->thscd1, d->thscd2, 1, b1, &sc, thread_stream(), lerr); }
     if (dblob) mvx_dev_free(dblob);
     if (rc) { vs->freeFrame(dst); vs->setFilterError(rc == MVX_E_ARG ? "SCDetection: vector clip frame without a valid MVTools_vectors property." : mvx_last_error(), ctx); return NULL; }
     vs->mapSetInt(vs->getFramePropertiesRW(dst), d->ad.isBackward ? "_SceneChangeNext" : "_SceneChangePrev", sc, maReplace); /* :62-64 */
@@ -815,9 +909,9 @@ static const VSFrame *VS_CC recalcGetFrame(int n, int reason, void *inst, void *
         memset(&job, 0, sizeof(job));
         for (int p = 0; p < 3; p++) { job.src[p] = ds.plane[p]; job.ref[p] = ref ? dr.plane[p] : NULL; }
         job.old_blob = oldBlob; job.blob = dblob;
-        rc = mvx_recalculate_frames(d->rc, 1, &job, NULL);
-        if (!rc) rc = mvx_copy_to_host(blob, d->blobSize, dblob, d->blobSize, (size_t)d->blobSize, 1, NULL);
-        if (!rc) rc = mvx_stream_sync(NULL);
+        rc = mvx_recalculate_frames(d->rc, 1, &job, thread_stream());
+        if (!rc) rc = timed_download(blob, d->blobSize, dblob, d->blobSize, (size_t)d->blobSize, 1);
+        if (!rc) rc = mvx_stream_sync(thread_stream());
     }
     dev_release(&ds); dev_release(&dr);
     if (dblob) mvx_dev_free(dblob);
@@ -936,13 +1030,16 @@ static const VSFrame *VS_CC degrainGetFrame(int n, int reason, void *inst, void 
             for (int p = 0; p < 3; p++) job.refs[r][p] = refs[r].plane[p];
         }
     }
-    if (!rc) rc = mvx_degrain_frames(d->dg, 1, &job, NULL);
+    const double tdg = prof_now();
+    if (!rc) rc = mvx_degrain_frames(d->dg, 1, &job, thread_stream());
+    if (!rc) rc = mvx_stream_sync(thread_stream());
+    prof_add(PF_DEGRAIN, tdg);
     VSFrame *dst = NULL;
     if (!rc) {
         dst = vs->newVideoFrame(&d->vi->format, d->vi->width, d->vi->height, src, core);
         for (int p = 0; p < np && !rc; p++)
-            rc = mvx_copy_to_host(vs->getWritePtr(dst, p), vs->getStride(dst, p), job.dst[p], d->pitch[p], (size_t)vs->getFrameWidth(dst, p) * bps, (size_t)vs->getFrameHeight(dst, p), NULL);
-        if (!rc) rc = mvx_stream_sync(NULL);
+            rc = timed_download(vs->getWritePtr(dst, p), vs->getStride(dst, p), job.dst[p], d->pitch[p], (size_t)vs->getFrameWidth(dst, p) * bps, (size_t)vs->getFrameHeight(dst, p));
+        if (!rc) rc = mvx_stream_sync(thread_stream());
     }
     for (int r = 0; r < nr; r++) { dev_release(&refs[r]); if (blobArena[r]) mvx_dev_free(blobArena[r]); }
     if (srcArena) mvx_dev_free(srcArena);
@@ -1100,14 +1197,14 @@ static const VSFrame *VS_CC compGetFrame(int n, int reason, void *inst, void **f
         for (int p = 0; p < np; p++) job.dst[p] = (char *)dstArena + dstOff[p];
         job.blob = dblob;
         job.field_shift = fieldShift;
-        if (!rc) rc = mvx_compensate_frames(d->cp, 1, &job, NULL);
+        if (!rc) rc = mvx_compensate_frames(d->cp, 1, &job, thread_stream());
     }
     VSFrame *dst = NULL;
     if (!rc) {
         dst = vs->newVideoFrame(&d->vi->format, d->vi->width, d->vi->height, src, core);
         for (int p = 0; p < np && !rc; p++)
-            rc = mvx_copy_to_host(vs->getWritePtr(dst, p), vs->getStride(dst, p), job.dst[p], d->pitch[p], (size_t)vs->getFrameWidth(dst, p) * bps, (size_t)vs->getFrameHeight(dst, p), NULL);
-        if (!rc) rc = mvx_stream_sync(NULL);
+            rc = timed_download(vs->getWritePtr(dst, p), vs->getStride(dst, p), job.dst[p], d->pitch[p], (size_t)vs->getFrameWidth(dst, p) * bps, (size_t)vs->getFrameHeight(dst, p));
+        if (!rc) rc = mvx_stream_sync(thread_stream());
     }
     dev_release(&ds); dev_release(&dr);
     if (dblob) mvx_dev_free(dblob);
@@ -1239,13 +1336,13 @@ static const VSFrame *VS_CC fpsGetFrame(int n, int reason, void *inst, void **fd
         job.blob_fw = blobF; job.blob_bw = blobB;
         vs->freeFrame(sl); vs->freeFrame(sr); vs->freeFrame(vf); vs->freeFrame(vb);
     }
-    if (!rc) rc = mvx_blockfps_frames(d->bf, 1, &job, NULL);
+    if (!rc) rc = mvx_blockfps_frames(d->bf, 1, &job, thread_stream());
     VSFrame *dst = NULL;
     if (!rc) {
         dst = vs->newVideoFrame(&d->vi.format, d->vi.width, d->vi.height, cl, core);
         for (int p = 0; p < np && !rc; p++)
-            rc = mvx_copy_to_host(vs->getWritePtr(dst, p), vs->getStride(dst, p), job.dst[p], d->pitch[p], (size_t)vs->getFrameWidth(dst, p) * bps, (size_t)vs->getFrameHeight(dst, p), NULL);
-        if (!rc) rc = mvx_stream_sync(NULL);
+            rc = timed_download(vs->getWritePtr(dst, p), vs->getStride(dst, p), job.dst[p], d->pitch[p], (size_t)vs->getFrameWidth(dst, p) * bps, (size_t)vs->getFrameHeight(dst, p));
+        if (!rc) rc = mvx_stream_sync(thread_stream());
     }
     dev_release(&ds); dev_release(&dr2);
     if (blobF) mvx_dev_free(blobF);
