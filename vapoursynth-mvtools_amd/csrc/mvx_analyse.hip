@@ -260,7 +260,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_create(const m
 extern "C" __attribute__((visibility("default"))) void mvx_analyse_destroy(mvx_analyse *a) {
     if (!a) return;
     if (a->dP) (void)hipFree(a->dP);
-    if (a->dJobs) (void)hipFree(a->dJobs);
+    for (auto &sl : a->slot) if (sl.d) (void)hipFree(sl.d);
     delete a;
 }
 extern "C" __attribute__((visibility("default"))) int mvx_analyse_set_ref_shadow(mvx_analyse *a, const ptrdiff_t copy_stride[3]) {
@@ -279,17 +279,21 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_blob_size(cons
 extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_analyse *a, int njobs, const mvx_analyse_job *jobs, void *stream) {
     if (njobs <= 0) return MVX_OK;
     hipStream_t st = (hipStream_t)stream;
-    CallGuard::Scope scope(a->guard, st);
     const AParams &P = a->P;
-    if (!a->dP) {
-        HIP_CHECK(hipGetDevice(&a->device));
-        HIP_CHECK(hipMalloc((void **)&a->dP, sizeof(AParams)));
-        HIP_CHECK(hipMemcpy(a->dP, &P, sizeof(AParams), hipMemcpyHostToDevice));
+    {
+        std::lock_guard<std::mutex> lk(a->guard.mu);
+        if (!a->dP) {
+            HIP_CHECK(hipGetDevice(&a->device));
+            HIP_CHECK(hipMalloc((void **)&a->dP, sizeof(AParams)));
+            HIP_CHECK(hipMemcpy(a->dP, &P, sizeof(AParams), hipMemcpyHostToDevice));
+        }
     }
-    if ((size_t)njobs > a->jobsCap) {
-        if (a->dJobs) (void)hipFree(a->dJobs);
-        a->jobsCap = (size_t)njobs * 2;
-        HIP_CHECK(hipMalloc((void **)&a->dJobs, a->jobsCap * sizeof(AJob)));
+    mvx_analyse::JobSlot &S = a->slot[a->nextSlot.fetch_add(1) % mvx_analyse::kSlots];
+    CallGuard::Scope scope(S.guard, st);
+    if ((size_t)njobs > S.cap) {
+        if (S.d) (void)hipFree(S.d);
+        S.cap = (size_t)njobs * 2;
+        HIP_CHECK(hipMalloc((void **)&S.d, S.cap * sizeof(AJob)));
     }
     std::vector<AJob> hj(njobs);
     for (int i = 0; i < njobs; i++) {
@@ -360,12 +364,12 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
                 table = &padded;
             }
             const int ntab = (int)table->size();
-            if ((size_t)ntab > a->jobsCap) {
-                if (a->dJobs) (void)hipFree(a->dJobs);
-                a->jobsCap = (size_t)ntab * 2;
-                HIP_CHECK(hipMalloc((void **)&a->dJobs, a->jobsCap * sizeof(AJob)));
+            if ((size_t)ntab > S.cap) {
+                if (S.d) (void)hipFree(S.d);
+                S.cap = (size_t)ntab * 2;
+                HIP_CHECK(hipMalloc((void **)&S.d, S.cap * sizeof(AJob)));
             }
-            HIP_CHECK(hipMemcpyAsync(a->dJobs, table->data(), sizeof(AJob) * ntab, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(S.d, table->data(), sizeof(AJob) * ntab, hipMemcpyHostToDevice, st));
             // Barrier between the chains of a workgroup every that many blocks of a row.  16-bit clips (shadow layout: the kernel is
             // bound by what the XCD's L2 must re-fetch): the chains that share a reference frame have to stay within a few blocks of
             // each other to share its lines -- measured r2 at three chains per SIMD (4K16): 256 blocks 337 fps, 128: 378, 16-64: 389-390,
@@ -375,10 +379,10 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
             if (g_dbg.cpw_sync >= 0 && (g_dbg.cpw_sync & (g_dbg.cpw_sync - 1)) == 0) syncEvery = g_dbg.cpw_sync;
             // XCD-contiguous workgroup order: neighbours in the (reference-sorted) job table share an L2 (+0.5 %, 4K16)
             const int flags = (g_dbg.fast_flags >= 0 ? g_dbg.fast_flags : MVX_FAST_XCD_REMAP) | ((P.shadow[1] != 0 && P.chroma) ? MVX_FAST_UV : 0);
-            ALaunch L = { 0, ntab, fNeed, fRow, fRow, fBins, -1, 0, fNeed, simds, cpw, k, syncEvery, k, flags, st, a->dP, a->dJobs };
+            ALaunch L = { 0, ntab, fNeed, fRow, fRow, fBins, -1, 0, fNeed, simds, cpw, k, syncEvery, k, flags, st, a->dP, S.d };
             int rc = P.bps == 1 ? mvx_analyse_launch_fast_u8(P, L) : mvx_analyse_launch_fast_u16(P, L);
             if (rc == MVX_OK) {
-                if (P.divide) hipLaunchKernelGGL(analyse_divide_kernel, dim3((P.lv[0].nBlkX * P.lv[0].nBlkY + 255) / 256, ntab), dim3(256), 0, st, a->dP, a->dJobs);
+                if (P.divide) hipLaunchKernelGGL(analyse_divide_kernel, dim3((P.lv[0].nBlkX * P.lv[0].nBlkY + 255) / 256, ntab), dim3(256), 0, st, a->dP, S.d);
                 HIP_CHECK(hipGetLastError());
                 return MVX_OK;
             }
@@ -395,7 +399,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         if (P.bps == 2 && P.blkX == 16 && njobs > 2 * simds && g_dbg.wpe3_u16) { wpe = 3; cpw = 12; }
     }
     if (cpw > 1) std::stable_sort(hj.begin(), hj.end(), [](const AJob &x, const AJob &y) { return (uintptr_t)x.ref[0] > (uintptr_t)y.ref[0]; }); // (no reference: last)
-    HIP_CHECK(hipMemcpyAsync(a->dJobs, hj.data(), sizeof(AJob) * njobs, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(S.d, hj.data(), sizeof(AJob) * njobs, hipMemcpyHostToDevice, st));
     // LDS: [source block (Y,U,V) | previous-row vectors | predictor rows (this, below) | histogram]
     int srcBytes = P.blkX * P.blkY * P.bps;
     if (P.chroma) srcBytes += 2 * (P.blkX / P.xr) * (P.blkY / P.yr) * P.bps;
@@ -465,7 +469,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
     // 8-bit); with one chain per SIMD it costs 1 %
     int syncEvery = wpe >= 2 ? 256 : 0;
     if (g_dbg.cpw_sync >= 0 && (g_dbg.cpw_sync & (g_dbg.cpw_sync - 1)) == 0) syncEvery = g_dbg.cpw_sync;
-    ALaunch L = { mode, njobs, ldsBytes, ldsRow, ldsHist, histBins, ldsWin, winCap, ldsNeed, simds, cpw, wpe, syncEvery, 0, 0, st, a->dP, a->dJobs };
+    ALaunch L = { mode, njobs, ldsBytes, ldsRow, ldsHist, histBins, ldsWin, winCap, ldsNeed, simds, cpw, wpe, syncEvery, 0, 0, st, a->dP, S.d };
     // the specialised kernels address the reference as "64-bit base + 32-bit offset inside the level's plane set" (all sub-pel planes)
     bool off32 = true;
     for (int i = 0; i < P.nLevels; i++)
@@ -473,7 +477,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
     int rc = (P.dctmode != 0 || !off32) ? 1 : P.bps == 1 ? mvx_analyse_launch_u8(P, L) : mvx_analyse_launch_u16(P, L); // specialised 4:2:0 geometries (SAD cost only)
     if (rc == 1) rc = mvx_analyse_launch_any(P, L);                                     // everything else
     if (rc) return rc;
-    if (P.divide) hipLaunchKernelGGL(analyse_divide_kernel, dim3((P.lv[0].nBlkX * P.lv[0].nBlkY + 255) / 256, njobs), dim3(256), 0, st, a->dP, a->dJobs);
+    if (P.divide) hipLaunchKernelGGL(analyse_divide_kernel, dim3((P.lv[0].nBlkX * P.lv[0].nBlkY + 255) / 256, njobs), dim3(256), 0, st, a->dP, S.d);
     HIP_CHECK(hipGetLastError());
     return MVX_OK;
 }

@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #pragma once
+#include <atomic>
 #include "mvx_common.h"
 
 enum { SearchOnetime, SearchNstep, SearchLogarithmic, SearchExhaustive, SearchHex2, SearchUMH, SearchHorizontal, SearchVertical };
@@ -73,11 +74,16 @@ struct mvx_analyse {
     mvx_analysis_data ad;
     AParams P;
     AParams *dP = nullptr;
-    AJob *dJobs = nullptr;
-    size_t jobsCap = 0;
+    // The job table is the only device state a launch rewrites.  A small ring of tables (each with its own guard) lets consecutive
+    // calls on one handle -- from different threads, on different streams -- overlap on the device: a launch of a few chains
+    // leaves most of the chip idle and takes as long as a full one.
+    struct JobSlot { AJob *d = nullptr; size_t cap = 0; CallGuard guard; };
+    static constexpr int kSlots = 4;
+    JobSlot slot[kSlots];
+    std::atomic<unsigned> nextSlot{0};
     int ldsBytes = 0;
     int device = 0;
-    CallGuard guard;
+    CallGuard guard; // creation of dP, mvx_analyse_set_ref_shadow
 };
 
 // ------------------------------------------------------------------------------------------------ device

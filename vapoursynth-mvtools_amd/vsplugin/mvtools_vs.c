@@ -534,7 +534,7 @@ typedef struct AnReq { mvx_analyse_job job; int rc, done; struct AnReq *next; } 
 typedef struct Combiner {
     pthread_mutex_t mu; pthread_cond_t done, more;
     AnReq *head, *tail; int n, leader;
-    void *stream; int maxBatch; long waitUs, quietMaxUs;
+    void *stream[4]; unsigned nextStream; int maxBatch; long waitUs, quietMaxUs; /* a few streams: the next batch may start while the previous one runs */
     long lastUs; /* duration of the previous launch: a search of few chains takes as long as one of hundreds, so waiting a fraction of it for more requests is cheap */
     long batches, jobs, largest; /* statistics (MVX_VS_STATS=1 prints them when the filter is freed) */
 } Combiner;
@@ -559,7 +559,7 @@ __attribute__((destructor)) static void print_stats(void) {
 static void combiner_init(Combiner *c) {
     memset(c, 0, sizeof(*c));
     pthread_mutex_init(&c->mu, NULL); pthread_cond_init(&c->done, NULL); pthread_cond_init(&c->more, NULL);
-    c->stream = mvx_stream_create_priority(-1); /* NULL (the default stream) still works, it only serialises the instances */
+    for (int i = 0; i < 4; i++) c->stream[i] = mvx_stream_create_priority(-1); /* NULL (the default stream) still works, it only serialises the launches */
     pthread_mutex_lock(&g_lock); g_stat_instances++; pthread_mutex_unlock(&g_lock);
     c->maxBatch = (int)env_long("MVX_VS_BATCH_MAX", 1024);
     c->waitUs = env_long("MVX_VS_BATCH_WAIT_US", 2000);
@@ -568,7 +568,7 @@ static void combiner_init(Combiner *c) {
 }
 static void combiner_free(Combiner *c, const char *what) {
     (void)what;
-    mvx_stream_destroy(c->stream);
+    for (int i = 0; i < 4; i++) mvx_stream_destroy(c->stream[i]);
     pthread_mutex_destroy(&c->mu); pthread_cond_destroy(&c->done); pthread_cond_destroy(&c->more);
 }
 /* blocks until the request's blob is computed; returns its MVX_* code */
@@ -605,6 +605,7 @@ static int combiner_submit(Combiner *c, mvx_analyse *an, AnReq *r) {
     AnReq *list = c->head;
     const int n = c->n;
     c->head = c->tail = NULL; c->n = 0; c->leader = 0; /* the next arrival leads the next batch while this one runs */
+    void *stream = c->stream[c->nextStream++ % 4];
     c->batches++; c->jobs += n; if (n > c->largest) c->largest = n;
     pthread_mutex_unlock(&c->mu);
     pthread_mutex_lock(&g_lock);
@@ -618,8 +619,8 @@ static int combiner_submit(Combiner *c, mvx_analyse *an, AnReq *r) {
         for (AnReq *q = list; q; q = q->next) jobs[i++] = q->job;
         struct timespec a, b;
         clock_gettime(CLOCK_MONOTONIC, &a);
-        rc = mvx_analyse_frames(an, n, jobs, c->stream);
-        if (!rc) rc = mvx_stream_sync(c->stream);
+        rc = mvx_analyse_frames(an, n, jobs, stream);
+        if (!rc) rc = mvx_stream_sync(stream);
         clock_gettime(CLOCK_MONOTONIC, &b);
         free(jobs);
         pthread_mutex_lock(&c->mu);
