@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 2, GPU call 31: candidate loads as one rolling stream (luma + UV), loads kept in program order
+export TMPDIR=/tmp
+out=$PWD/gpurun_out; mkdir -p $out
+timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "analyse or degrain or full_size" 2>&1 | tail -4 | tee $out/c31_tests.txt
+r() { name=$1; shift; envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
+  env "${envs[@]}" timeout 300 python bench.py --no-cpu --steps 2 --warmup 1 "$@" 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(\"$name\", round(d[\"value\"],1), \"fps\", round(d[\"roofline\"][\"avg_launch_ms\"],1), \"ms/launch\", round(d[\"ms_per_step\"]-d[\"roofline\"][\"avg_launch_ms\"],1), \"ms other\")" || echo "$name FAILED"; }
+{
+r cfg3 X=1 --
+r cfg5 X=1 -- --config cfg5
+r cfg2 X=1 -- --config cfg2
+r cfg3-small X=1 -- --batch 22
+} 2>&1 | tee $out/c31_variants.txt

@@ -20,6 +20,9 @@
 //     32-bit (block SADs are < 2^27, the motion term saturates);
 //   * the rescue is a loop over passes of eight candidates (eight lanes each) around one evaluation site.
 #pragma once
+#ifndef MVX_ROLL_LOADS
+#define MVX_ROLL_LOADS 1 // rolling load windows in the candidate evaluation (0: batches of four, the first form)
+#endif
 #include "mvx_analyse_kernel.h"
 
 template <int BPS, int BW> struct FGeo {
@@ -161,6 +164,21 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
             const lds_u8 *sp = src + row0 * ROWB + xb;
             const unsigned step = (unsigned)(GG >> LOGC) * refPitch;
             constexpr int lstep = (GG >> LOGC) * ROWB;
+            // rolling window: NB loads in flight, the register of a consumed piece is reloaded at once (issuing NB, consuming NB,
+            // issuing the next NB costs one memory round trip per batch)
+            constexpr bool ROLL = MVX_ROLL_LOADS && N > NB && N <= 8;
+            if (ROLL) {
+                v4u r[NB];
+                auto issue = [&]() { const v4u v = ld_ref<CB>(base + po); po += step; asm("" : "+v"(po)); return v; };
+#pragma unroll
+                for (int k = 0; k < NB; k++) r[k] = issue();
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    acc = sad_piece<CB>(sp + k * lstep, r[k % NB], acc);
+                    if (k + NB < N) r[k % NB] = issue();
+                }
+                return acc;
+            }
 #pragma unroll 2
             for (int k0 = 0; k0 < N; k0 += NB) {
                 v4u r[NB];
@@ -191,8 +209,41 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
         }
         return acc;
     }
+    // two regions (luma, then the UV plane) as ONE stream of loads with a rolling window of W in flight: the chroma loads are
+    // requested while the luma pieces are still being consumed.  Both regions must be of the "piece column fixed per lane" kind.
+    template <int LOGG, int TA, int LOGCA, int CBA, int ROWBA, int TB, int LOGCB, int CBB, int ROWBB>
+    __device__ __forceinline__ void region2(int s, const lds_u8 *srcA, gl_u8 *baseA, unsigned offA, unsigned pitchA, unsigned &accA,
+                                            const lds_u8 *srcB, gl_u8 *baseB, unsigned offB, unsigned pitchB, unsigned &accB) const {
+        constexpr int GG = 1 << LOGG, CA = 1 << LOGCA, CB_ = 1 << LOGCB;
+        constexpr int NA = TA / GG, NBB = TB / GG, NT = NA + NBB, W = NT < 6 ? NT : 6;
+        const int rowA = s >> LOGCA, xbA = (s & (CA - 1)) * CBA, rowB = s >> LOGCB, xbB = (s & (CB_ - 1)) * CBB;
+        unsigned poA = offA + (unsigned)rowA * pitchA + (unsigned)xbA, poB = offB + (unsigned)rowB * pitchB + (unsigned)xbB;
+        const lds_u8 *spA = srcA + rowA * ROWBA + xbA, *spB = srcB + rowB * ROWBB + xbB;
+        const unsigned stepA = (unsigned)(GG >> LOGCA) * pitchA, stepB = (unsigned)(GG >> LOGCB) * pitchB;
+        constexpr int lstepA = (GG >> LOGCA) * ROWBA, lstepB = (GG >> LOGCB) * ROWBB;
+        v4u r[W];
+        // (the memory clobber keeps the loads in program order: the scheduler otherwise likes to issue the FIRST piece's load last,
+        // and the first use then waits for all of them)
+        auto issueA = [&]() { const v4u v = ld_ref<CBA>(baseA + poA); poA += stepA; asm volatile("" : "+v"(poA) : : "memory"); return v; };
+        auto issueB = [&]() { const v4u v = ld_ref<CBB>(baseB + poB); poB += stepB; asm volatile("" : "+v"(poB) : : "memory"); return v; };
+#pragma unroll
+        for (int k = 0; k < W; k++) r[k] = k < NA ? issueA() : issueB();
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            if (k < NA) accA = sad_piece<CBA>(spA + k * lstepA, r[k % W], accA);
+            else accB = sad_piece<CBB>(spB + (k - NA) * lstepB, r[k % W], accB);
+            if (k + W < NT) r[k % W] = (k + W) < NA ? issueA() : issueB();
+        }
+    }
     // partial SADs (this lane's share) of candidate (vx, vy); vyc = the vertical component the chroma planes use (:836-839)
     template <int LOGG> __device__ __forceinline__ void eval(int s, int vx, int vy, int vyc, unsigned &aL, unsigned &aC) const {
+        constexpr int GG = 1 << LOGG;
+        constexpr bool STREAM = MVX_ROLL_LOADS && UV && G::LT >= GG && G::UVT >= GG && GG >= (1 << G::LLOGC) && GG >= (1 << G::UVLOGC) && (G::LT + G::UVT) / GG >= 2 && (G::LT + G::UVT) / GG <= 12;
+        if (STREAM && chroma) {
+            const unsigned co = ref_chroma_off(vx, vyc);
+            region2<LOGG, G::LT, G::LLOGC, G::LCB, G::LROWB, G::UVT, G::UVLOGC, G::UVCB, G::UVROWB>(s, lds, refY, ref_luma_off(vx, vy), pitchY, aL, lds + G::UOFF, refUV, 2 * co, 2 * pitchC, aC);
+            return;
+        }
         aL = region<LOGG, G::LT, G::LLOGC, G::LCB, G::LROWB>(s, lds, refY, ref_luma_off(vx, vy), pitchY, aL);
         if (chroma) {
             const unsigned co = ref_chroma_off(vx, vyc);
