@@ -960,3 +960,42 @@ def test_scdetect_matches_oracle(oracle, mv):
     assert mv.scdetect(gan.ad, gb)[2] == 1  # invalid vectors count as a scene change
     with pytest.raises(mv.MvtoolsError):
         mv.scdetect(gan.ad, gb, thscd1=8 * 8 * 255 + 1)
+
+
+def test_staged_copies_round_trip(mv):
+    """mvx_upload_2d / mvx_download_2d (pinned staging inside the library) from several threads at once: rows of odd lengths, host and
+    device pitches that differ, more concurrent callers than staging buffers"""
+    import threading
+    L = mv.lib()
+    L.mvx_upload_2d.argtypes = L.mvx_download_2d.argtypes = [C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_size_t, C.c_size_t, C.c_void_p]
+    L.mvx_dev_alloc_uninit.restype = C.c_void_p
+    L.mvx_dev_alloc_uninit.argtypes = [C.c_size_t]
+    L.mvx_dev_free.argtypes = [C.c_void_p]
+    L.mvx_stream_create_priority.restype = C.c_void_p
+    L.mvx_stream_create_priority.argtypes = [C.c_int]
+    L.mvx_stream_destroy.argtypes = [C.c_void_p]
+    stream = L.mvx_stream_create_priority(1)
+    assert stream
+    errors = []
+
+    def work(i):
+        rng = np.random.default_rng(100 + i)
+        rows, rb = 37 + 11 * i, 1001 + 333 * i
+        hp, dp, hp2 = rb + 7, (rb + 255) // 256 * 256, rb + 64
+        src = rng.integers(0, 256, (rows, hp), dtype=np.uint8)
+        dst = np.zeros((rows, hp2), dtype=np.uint8)
+        dev = L.mvx_dev_alloc_uninit(rows * dp)
+        try:
+            if L.mvx_upload_2d(dev, dp, src.ctypes.data, hp, rb, rows, stream) or L.mvx_download_2d(dst.ctypes.data, hp2, dev, dp, rb, rows, stream):
+                errors.append("call %d failed" % i)
+            elif not np.array_equal(dst[:, :rb], src[:, :rb]) or dst[:, rb:].any():
+                errors.append("data %d differs" % i)
+        finally:
+            L.mvx_dev_free(dev)
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(24)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    L.mvx_stream_destroy(stream)
+    assert not errors, errors
