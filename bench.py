@@ -36,7 +36,8 @@ CONFIGS = {
     # BASELINE config 4: frame-rate conversion instead of denoising (radius field = 0 selects PipelineFPS)
     "cfg4": (1920, 1080, 8, 0, dict(blksize=8), dict(pel=2), 2047, "1080p YUV420P8 Compensate + BlockFPS 24->60 blksize=8 pel=2"),
 }
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_MEASURED_GBS = 6290.0  # the same guide's measured copy ceiling
 
 
 def synth_clip_device(torch, width, height, bits, nframes, seed, device):
@@ -143,6 +144,13 @@ class Pipeline:
             djobs.append((self.src[n], [self.supers[r] if r is not None else None for r in refs], [self.blobs[key][i] for key in self.plan.clips]))
         self.dg.run(djobs, out=self.out)
 
+    def level_grids(self):
+        """[(nBlkX, nBlkY)] of every level of the search, finest first (GroupOfPlanes.c:25-56)"""
+        ad = self.an[(1, 1)].ad
+        wb = (ad.nBlkSizeX - ad.nOverlapX) * ad.nBlkX + ad.nOverlapX
+        hb = (ad.nBlkSizeY - ad.nOverlapY) * ad.nBlkY + ad.nOverlapY
+        return [(((wb >> i) - ad.nOverlapX) // (ad.nBlkSizeX - ad.nOverlapX), ((hb >> i) - ad.nOverlapY) // (ad.nBlkSizeY - ad.nOverlapY)) for i in range(ad.nLvCount)]
+
     def algorithmic_bytes_per_chain(self):
         """one chain reads the current frame's pyramid (sub-pel plane 0 of every level), the whole
         reference super frame once, and writes the vector blob."""
@@ -210,41 +218,151 @@ class PipelineFPS:
             self.fps.run(list(range(self.nout)), self.src, self.supers, self.blobs[(1, 1)], self.blobs[(1, 0)], out=self.fps_out)
 
     algorithmic_bytes_per_chain = Pipeline.algorithmic_bytes_per_chain
+    level_grids = Pipeline.level_grids
 
 
-def cpu_baseline(cfg, threads):
-    """The oracle (CPU restatement, kind 'port') on a bounded sample of the same workload: F output frames, F = worker
-    threads, each thread owning whole frames (VapourSynth fmParallel style); supers are shared."""
+def _frame_to_numpy(mv, frame, w, h, bits):
+    import numpy as np
+    dt = np.uint16 if bits > 8 else np.uint8
+    return [mv.plane_to_numpy(frame[p], w >> (1 if p else 0), dt) for p in range(3)]
+
+
+def oracle_leg(mv, torch, cfg, pipe, threads, F):
+    """The CPU oracle (scalar C restatement of the reference, kind 'port') on F output frames OF THE TIMED STEP: the clip
+    frames they need are downloaded from the device clip, the oracle runs Super / Analyse x 2tr / DegrainN on them with
+    `threads` worker threads each owning whole frames (VapourSynth fmParallel style; the wall time of this part is the CPU
+    baseline), and every vector blob and every output plane of those frames is compared byte for byte with what the GPU
+    left in HBM after the last timed step.  Returns (seconds, parity dict)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
     import mvoracle as mo
-    import pipeline as pl
     (w, h, bits, tr, akw, skw, _, label) = cfg
-    F = threads
-    n = F + 2 * tr
-    frames = pl.moving_clip(w, h, bits, n, seed=5, noise=2)
+    B = pipe.B
+    F = max(1, min(F, B))
+    i0 = max(0, B // 2 - F // 2)                       # F consecutive output frames from the middle of the batch
+    dgs = pipe.plan.degrains()[i0:i0 + F]              # (local frame, local refs per vector clip, blob index)
+    need = sorted({n for n, refs, _ in dgs} | {r for _, refs, _ in dgs for r in refs if r is not None})
+    torch.cuda.synchronize()
+    host = {n: _frame_to_numpy(mv, pipe.src[n], w, h, bits) for n in need}
     sup = mo.Super(w, h, bits, **skw)
-    ans = {(d, isb): mo.Analyse(sup, isb=isb, delta=d, **akw) for d in range(1, tr + 1) for isb in (1, 0)}
-    dg = mo.Degrain(tr, sup, ans[(1, 1)].ad)
+    ans = {(d, isb): mo.Analyse(sup, isb=isb, delta=d, **akw) for d, isb in pipe.plan.clips}
+    dg = mo.Degrain(tr, sup, ans[pipe.plan.clips[0]].ad)
+    t0 = time.time()
+    with ThreadPoolExecutor(threads) as ex:
+        supers = dict(zip(need, ex.map(lambda n: sup.frame(host[n]), need)))
+
+        def one(job):
+            n, refs, _ = job
+            blobs = [ans[key].frame(supers[n], supers[r] if r is not None else None) for key, r in zip(pipe.plan.clips, refs)]
+            return blobs, dg.frame(host[n], [supers[r] if r is not None else None for r in refs], blobs)
+        res = list(ex.map(one, dgs))
+    dt = time.time() - t0
+    bad = []
+    for (n, refs, i), (blobs, out) in zip(dgs, res):
+        for key, ob in zip(pipe.plan.clips, blobs):
+            if not np.array_equal(pipe.blobs[key][i].cpu().numpy(), ob):
+                bad.append("vectors frame %d clip delta=%d isb=%d" % (n, key[0], key[1]))
+        for p in range(3):
+            if not np.array_equal(mv.plane_to_numpy(pipe.out[i][p], out[p].shape[1], out[p].dtype), out[p]):
+                bad.append("Degrain%d output frame %d plane %d" % (tr, n, p))
+    parity = {"frames": len(dgs), "vector_blobs": len(dgs) * 2 * tr, "output_planes": 3 * len(dgs), "identical": not bad,
+              "against": "oracle/ (CPU restatement) on the same clip frames, downloaded from the device clip of the timed step",
+              "first_output_frame_in_batch": i0}
+    if bad:
+        parity["mismatches"] = bad[:8]
+    sample = "%d output frames of %s taken from the timed step's own clip (%d Super + %d Analyse + %d Degrain%d), %d threads each owning whole frames, %.1f s wall; scalar C oracle (-O2 -mavx2), not the reference's SIMD build (BASELINE.md 4)" % (
+        len(dgs), label, len(need), 2 * tr * len(dgs), len(dgs), tr, threads, dt)
+    return {"value": len(dgs) / dt, "unit": "fps", "cores": threads, "kind": "port", "sample": sample}, parity
+
+
+def oracle_leg_fps(mv, torch, cfg, pipe, threads, F):
+    """cfg4 on the host cores: the oracle's Super / Analyse x2 / Compensate / BlockFPS 24 -> 60 on the first F + 1 input frames of
+    the timed step's own clip; blobs, compensated and interpolated frames that do not depend on frames beyond the sample are
+    compared byte for byte with the GPU's."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    import mvoracle as mo
+    (w, h, bits, _, akw, skw, _, label) = cfg
+    F = max(2, min(F, pipe.B))
+    n = F + 1
+    torch.cuda.synchronize()
+    frames = [_frame_to_numpy(mv, pipe.src[i], w, h, bits) for i in range(n)]
+    sup = mo.Super(w, h, bits, **skw)
+    abw, afw = mo.Analyse(sup, num_frames=n, isb=1, **akw), mo.Analyse(sup, num_frames=n, isb=0, **akw)
+    comp = mo.Compensate(sup, abw.ad)
+    fps = mo.BlockFPS(sup, abw.ad, afw.ad, n, 24, 1, num=60, den=1)
     t0 = time.time()
     with ThreadPoolExecutor(threads) as ex:
         supers = list(ex.map(sup.frame, frames))
-
-        def one(i):
-            nn = tr + i
-            refs, blobs = [], []
-            for d in range(1, tr + 1):
-                for isb in (1, 0):
-                    r = supers[nn + d if isb else nn - d]
-                    refs.append(r)
-                    blobs.append(ans[(d, isb)].frame(supers[nn], r))
-            return dg.frame(frames[nn], refs, blobs)
-        list(ex.map(one, range(F)))
+        bbw = list(ex.map(lambda i: abw.frame(supers[i], supers[i + 1] if i + 1 < n else None), range(n)))
+        bfw = list(ex.map(lambda i: afw.frame(supers[i], supers[i - 1] if i >= 1 else None), range(n)))
+        oc = list(ex.map(lambda i: comp.frame(supers[i], supers[i + 1], bbw[i]), range(F)))
+        of = list(ex.map(lambda k: fps.frame(k, frames, supers, bbw, bfw), range(fps.num_frames)))
     dt = time.time() - t0
-    return {"value": F / dt, "unit": "fps", "cores": threads, "kind": "port",
-            "sample": "%d output frames of %s (%d Super + %d Analyse + %d Degrain%d), %d threads each owning whole frames, %.1f s wall; scalar C oracle (-O2 -mavx2), not the reference's SIMD build (BASELINE.md 4)" % (
-                F, label, n, 2 * tr * F, F, tr, threads, dt)}
+    bad = []
+    for i in range(F):
+        if not np.array_equal(pipe.blobs[(1, 1)][i].cpu().numpy(), bbw[i]):
+            bad.append("backward vectors frame %d" % i)
+        if not np.array_equal(pipe.blobs[(1, 0)][i].cpu().numpy(), bfw[i]):
+            bad.append("forward vectors frame %d" % i)
+        for p in range(3):
+            if not np.array_equal(mv.plane_to_numpy(pipe.comp_out[i][p], oc[i][p].shape[1], oc[i][p].dtype), oc[i][p]):
+                bad.append("Compensate frame %d plane %d" % (i, p))
+    checked = 0
+    for k in range(fps.num_frames):
+        nl, nr, _ = fps.map(k)
+        if nr > F or nl >= F:  # (the sample clip ends there: its last backward vectors are invalid, the bench clip's are not)
+            continue
+        checked += 1
+        for p in range(3):
+            if not np.array_equal(mv.plane_to_numpy(pipe.fps_out[k][p], of[k][p].shape[1], of[k][p].dtype), of[k][p]):
+                bad.append("BlockFPS output frame %d plane %d" % (k, p))
+    parity = {"frames": checked, "vector_blobs": 2 * F, "output_planes": 3 * (F + checked), "identical": not bad,
+              "against": "oracle/ (CPU restatement) on the same clip frames, downloaded from the device clip of the timed step"}
+    if bad:
+        parity["mismatches"] = bad[:8]
+    sample = "%d input frames of %s taken from the timed step's own clip -> %d interpolated + %d compensated frames, %d threads each owning whole frames, %.1f s wall; scalar C oracle (-O2 -mavx2), not the reference's SIMD build (BASELINE.md 4)" % (
+        n, label, fps.num_frames, F, threads, dt)
+    return {"value": fps.num_frames / dt, "unit": "fps", "cores": threads, "kind": "port", "sample": sample}, parity
+
+
+def measure_traffic(args, B):
+    """HBM bytes of ONE launch of the search kernel, measured now: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; kernel-trace
+    only, one counter per pass) over `bench.py --steps 1 --warmup 0` of the same configuration, corrected as MI355X_MICROARCH.md
+    prescribes for gfx950 (FETCH_SIZE counts 64 B per 128-byte request of 16-byte-per-lane reads: bytes = 2 * FETCH_SIZE KB + WRITE_SIZE
+    KB).  The caller must have released its device memory.  Returns (bytes or None, how it was obtained)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "not measured: rocprofv3 not found"
+    vals = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="mvx_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+               "--no-cpu", "--no-parity", "--no-traffic", "--steps", "1", "--warmup", "0", "--config", args.config, "--batch", str(B), "--slots", str(args.slots)]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+            tot, n = 0.0, 0
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if r["Counter_Name"] == c and "analyse" in r["Kernel_Name"] and "divide" not in r["Kernel_Name"]:
+                            tot += float(r["Counter_Value"])
+                            n += 1
+            if n == 0:
+                return None, "not measured: no %s rows for the search kernel" % c
+            vals[c] = tot / n
+        except Exception as e:  # (a profiler failure must not cost the bench line)
+            return None, "not measured: rocprofv3 --pmc %s pass failed (%s)" % (c, type(e).__name__)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return 2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each, in this run; 2 * FETCH_SIZE KB + WRITE_SIZE KB (gfx950 correction)"
 
 
 def spawn_ranks(n, argv):
@@ -274,34 +392,6 @@ def world_from_env(gpus, env=None):
     return int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0")), world
 
 
-def cpu_baseline_fps(cfg, threads):
-    """cfg4 on the host cores: the oracle's Super / Analyse x2 / Compensate / BlockFPS 24 -> 60 on a bounded sample (F input frames,
-    F = worker threads; every thread owns whole frames)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from concurrent.futures import ThreadPoolExecutor
-    import mvoracle as mo
-    import pipeline as pl
-    (w, h, bits, _, akw, skw, _, label) = cfg
-    F = 8 * threads  # (1080p 8-bit frames are cheap: eight per thread keep the sample in the 10-30 s range)
-    n = F + 1
-    frames = pl.moving_clip(w, h, bits, n, seed=5, noise=2)
-    sup = mo.Super(w, h, bits, **skw)
-    abw, afw = mo.Analyse(sup, num_frames=n, isb=1, **akw), mo.Analyse(sup, num_frames=n, isb=0, **akw)
-    comp = mo.Compensate(sup, abw.ad)
-    fps = mo.BlockFPS(sup, abw.ad, afw.ad, n, 24, 1, num=60, den=1)
-    t0 = time.time()
-    with ThreadPoolExecutor(threads) as ex:
-        supers = list(ex.map(sup.frame, frames))
-        bbw = list(ex.map(lambda i: abw.frame(supers[i], supers[i + 1] if i + 1 < n else None), range(n)))
-        bfw = list(ex.map(lambda i: afw.frame(supers[i], supers[i - 1] if i >= 1 else None), range(n)))
-        list(ex.map(lambda i: comp.frame(supers[i], supers[i + 1], bbw[i]), range(F)))
-        list(ex.map(lambda k: fps.frame(k, frames, supers, bbw, bfw), range(fps.num_frames)))
-    dt = time.time() - t0
-    return {"value": fps.num_frames / dt, "unit": "fps", "cores": threads, "kind": "port",
-            "sample": "%d input frames of %s -> %d interpolated + %d compensated frames, %d threads each owning whole frames, %.1f s wall; scalar C oracle (-O2 -mavx2), not the reference's SIMD build (BASELINE.md 4)" % (
-                n, label, fps.num_frames, F, threads, dt)}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -311,7 +401,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--slots", type=int, default=1, help="batches in flight: slot i owns its buffers and HIP stream, so the Super / "
                     "Degrain kernels of one batch run under the (latency-bound) search kernel of the other")
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline (a two-frame parity check of the timed step still runs)")
+    ap.add_argument("--no-parity", action="store_true", help="with --no-cpu: skip the oracle comparison of the timed step too")
+    ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure the search launch's HBM traffic")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
@@ -364,20 +456,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    rc = 0
     if rank == 0:
         search_ms = [a.elapsed_time(b) for pp in pipes for a, b in pp.ev]
         avg_launch_ms = sum(search_ms) / len(search_ms)
         bytes_chain, full = pipe.algorithmic_bytes_per_chain()
         chains = 2 * (B + 1) if fpsconv else 2 * cfg[3] * B
         achieved = bytes_chain * chains / (avg_launch_ms * 1e-3) / 1e9
-        traffic = None  # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (same command)
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as f:
-                t = json.load(f)
-            if t.get("config") == "%s batch %d" % (args.config, B):
-                traffic = [v["hbm_bytes_per_dispatch_corrected"] for k, v in t["kernels"].items() if "analyse" in k and "divide" not in k][0]
-        except Exception:
-            traffic = None
+        nblk = sum(lv[0] * lv[1] for lv in pipe.level_grids())   # blocks one chain walks (all levels)
         out = {
             "metric": ("Compensate+BlockFPS 24->60 %s output fps (Super+Analyse+Compensate+BlockFPS end-to-end)" % args.config) if fpsconv else
                       ("MDegrain%d %s fps (Super+Analyse+Degrain end-to-end)" % (cfg[3], args.config)),
@@ -388,16 +474,40 @@ def main():
                        "sharding": "frame ranges, no collective", "batches_in_flight": len(pipes),
                        "rank0_output_frames": list(plan.out), "rank0_held_frames": list(plan.held)},
             "roofline": {"bound": "hbm", "kernel": "analyse_fast_kernel (the motion search; one launch = %d chains)" % chains, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                         "peak_measured": HBM_MEASURED_GBS, "frac_of_measured_peak": achieved / HBM_MEASURED_GBS,
                          "algorithmic_bytes_per_launch": bytes_chain * chains, "avg_launch_ms": avg_launch_ms,
-                         "search_share_of_step": sum(search_ms) / (dt * 1e3)},
+                         "search_share_of_step": sum(search_ms) / (dt * 1e3),
+                         # the search is a serial chain per (frame, direction) -- its own yardstick is block steps per second
+                         "blocks_per_chain": nblk, "chain_steps_per_s": chains * nblk / (avg_launch_ms * 1e-3)},
         }
-        if not args.no_cpu and world == 1:
-            th = args.cpu_threads or min(os.cpu_count() or 1, 32)
-            out["cpu_baseline"] = cpu_baseline_fps(cfg, th) if fpsconv else cpu_baseline(cfg, th)
+        if world == 1 and not (args.no_cpu and args.no_parity):
+            # the CPU leg doubles as the parity check of the timed step: the oracle runs on frames of the SAME clip
+            th = args.cpu_threads or min(os.cpu_count() or 1, 64)   # min(host cores, 64)
+            F = (8 * th if fpsconv else th) if not args.no_cpu else 2
+            base, parity = (oracle_leg_fps if fpsconv else oracle_leg)(mv, torch, cfg, pipes[(args.steps - 1) % len(pipes)] if args.steps else pipe, th, F)
+            if not args.no_cpu:
+                out["cpu_baseline"] = base
+            out["parity_check"] = parity
+            if not parity["identical"]:
+                rc = 3
+        traffic, traffic_note = None, "not measured (--no-traffic)" if args.no_traffic else "not measured at more than one rank"
+        if world == 1 and not args.no_traffic:
+            for pp in pipes:  # the profiled child needs the HBM this process holds
+                pp.__dict__.clear()
+            del pipe, pipes
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            traffic, traffic_note = measure_traffic(args, B)
+        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = traffic, traffic_note
         print(json.dumps(out))
+        if rc:
+            sys.stderr.write("bench.py: the timed step's results differ from the oracle: %s\n" % out["parity_check"].get("mismatches"))
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0 and rc:
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -722,6 +722,63 @@ def _fullsize_props(mv, w, h, bits, blk, ov, tr, label):
         assert (d == 0).mean() > 0.5, label + ": %.3f exact" % (d == 0).mean()
 
 
+def _fullsize_parity(mv, oracle, w, h, bits, tr, akw, nout, replicas, want_k, label):
+    """BASELINE configuration at FULL size against the oracle, byte for byte: `nout` consecutive output frames -- all 2*tr vector
+    blobs and the three DegrainN planes of each -- with the searches launched inside a batch large enough to take the build the
+    benchmark times (want_k chains per SIMD, a workgroup barrier every few blocks, shadow planes for 16-bit clips).  The batch is
+    made of `replicas` copies of the distinct chains, each writing its own blob: every copy must equal the oracle's blob, so the
+    test also covers what a chain's neighbours in the launch do to it.  MVAnalyse.c:189-239, MVDegrains.cpp:210-306."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    n = nout + 2 * tr
+    frames = pl.moving_clip(w, h, bits, n, seed=21, noise=2)
+    osup, gsup = oracle.Super(w, h, bits), mv.Super(w, h, bits)
+    clips = [(d, isb) for d in range(1, tr + 1) for isb in (1, 0)]
+    oan = {k: oracle.Analyse(osup, isb=k[1], delta=k[0], **akw) for k in clips}
+    gan = mv.Analyse(gsup, **akw)  # (delta / isb only pick the reference frame: one parameter block, one launch, as bench.py does)
+    gsrc = [mv.frame_to_device(f) for f in frames]
+    gsf = gsup.build(gsrc)
+    chains = [(f, f + d if isb else f - d) for f in range(tr, tr + nout) for d, isb in clips]
+    jobs = [(gsf[a], gsf[b]) for a, b in chains] * replicas
+    blobs = gan.run(jobs)
+    torch.cuda.synchronize()
+    info = (C.c_int * 4)()
+    mv.lib().mvx_debug_last_launch(info)
+    assert info[0] == want_k and info[2] > 0 and info[3] == len(jobs), label + ": the batch did not take the %d-per-SIMD build with a barrier interval (%s)" % (want_k, list(info))
+    with ThreadPoolExecutor(16) as ex:
+        osf = list(ex.map(osup.frame, frames))
+        oblobs = list(ex.map(lambda c: oan[(abs(c[1] - c[0]), 1 if c[1] > c[0] else 0)].frame(osf[c[0]], osf[c[1]]), chains))
+    nc = len(chains)
+    want = [torch.from_numpy(b).to(blobs[0].device) for b in oblobs]
+    for i, b in enumerate(blobs):
+        assert torch.equal(b, want[i % nc]), label + ": vectors of chain %s differ from the oracle (copy %d of %d)" % (chains[i % nc], i // nc, replicas)
+    gdg = mv.Degrain(tr, gsup, gan.ad, [p.stride(0) for p in gsrc[0]])
+    odg = oracle.Degrain(tr, osup, oan[clips[0]].ad)
+    for k, f in enumerate(range(tr, tr + nout)):
+        refs = [f + d if isb else f - d for d, isb in clips]
+        fb = blobs[k * len(clips):(k + 1) * len(clips)]
+        got = gdg.run([(gsrc[f], [gsf[r] for r in refs], fb)])[0]
+        exp = odg.frame(frames[f], [osf[r] for r in refs], oblobs[k * len(clips):(k + 1) * len(clips)])
+        for p in range(3):
+            assert np.array_equal(mv.plane_to_numpy(got[p], exp[p].shape[1], exp[p].dtype), exp[p]), label + ": Degrain%d output frame %d plane %d" % (tr, f, p)
+
+
+def test_full_size_parity_cfg3(mv, oracle):
+    """BASELINE cfg3 (4K YUV420P16 Degrain3 blk 16 ov 8 pel 2), full size, byte for byte, inside a 2 052-chain launch = the three
+    chains per SIMD build bench.py times"""
+    _fullsize_parity(mv, oracle, 3840, 2160, 16, 3, dict(blksize=16, overlap=8), nout=2, replicas=171, want_k=3, label="cfg3")
+
+
+def test_full_size_parity_cfg2(mv, oracle):
+    """BASELINE cfg2 (1080p YUV420P8 Degrain1 blk 8 ov 4 pel 2 search 4), full size, inside a 3 078-chain launch (four per SIMD)"""
+    _fullsize_parity(mv, oracle, 1920, 1080, 8, 1, dict(blksize=8, overlap=4, search=4), nout=3, replicas=513, want_k=4, label="cfg2")
+
+
+def test_full_size_parity_cfg5(mv, oracle):
+    """BASELINE cfg5 (8K YUV420P16 Degrain6 blk 32 ov 16 pel 2), full size, inside a 1 032-chain launch (two per SIMD)"""
+    _fullsize_parity(mv, oracle, 7680, 4320, 16, 6, dict(blksize=32, overlap=16), nout=1, replicas=86, want_k=2, label="cfg5")
+
+
 @pytest.mark.gpu
 def test_full_size_properties_cfg3(mv):
     """BASELINE cfg3: 4K YUV420P16, blk 16, overlap 8, pel 2, Degrain3."""

@@ -52,6 +52,14 @@ extern "C" __attribute__((visibility("default"))) int mvx_debug_option(const cha
     return MVX_E_ARG;
 }
 
+// what the last search launch of this process looked like (tests assert that a batch really took the build they mean to cover):
+// out[0] = chains per SIMD of the lean kernel (0: the general kernel ran), out[1] = chains per workgroup, out[2] = barrier interval in
+// blocks, out[3] = entries of the job table
+static std::atomic<int> g_lastLaunch[4];
+extern "C" __attribute__((visibility("default"))) void mvx_debug_last_launch(int out[4]) {
+    for (int i = 0; i < 4; i++) out[i] = g_lastLaunch[i].load();
+}
+
 int mvx_debug_value(const char *name, int def) {
     if (!strcmp(name, "degrain_xcd")) return g_dbg.degrain_xcd >= 0 ? g_dbg.degrain_xcd : def;
     if (!strcmp(name, "super_rows_off")) return g_dbg.super_rows_off;
@@ -382,6 +390,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
             ALaunch L = { 0, ntab, fNeed, fRow, fRow, fBins, -1, 0, fNeed, simds, cpw, k, syncEvery, k, flags, st, a->dP, S.d };
             int rc = P.bps == 1 ? mvx_analyse_launch_fast_u8(P, L) : mvx_analyse_launch_fast_u16(P, L);
             if (rc == MVX_OK) {
+                g_lastLaunch[0] = k; g_lastLaunch[1] = cpw; g_lastLaunch[2] = syncEvery; g_lastLaunch[3] = ntab;
                 if (P.divide) hipLaunchKernelGGL(analyse_divide_kernel, dim3((P.lv[0].nBlkX * P.lv[0].nBlkY + 255) / 256, ntab), dim3(256), 0, st, a->dP, S.d);
                 HIP_CHECK(hipGetLastError());
                 return MVX_OK;
@@ -477,6 +486,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
     int rc = (P.dctmode != 0 || !off32) ? 1 : P.bps == 1 ? mvx_analyse_launch_u8(P, L) : mvx_analyse_launch_u16(P, L); // specialised 4:2:0 geometries (SAD cost only)
     if (rc == 1) rc = mvx_analyse_launch_any(P, L);                                     // everything else
     if (rc) return rc;
+    g_lastLaunch[0] = 0; g_lastLaunch[1] = cpw; g_lastLaunch[2] = syncEvery; g_lastLaunch[3] = njobs;
     if (P.divide) hipLaunchKernelGGL(analyse_divide_kernel, dim3((P.lv[0].nBlkX * P.lv[0].nBlkY + 255) / 256, njobs), dim3(256), 0, st, a->dP, S.d);
     HIP_CHECK(hipGetLastError());
     return MVX_OK;
