@@ -535,6 +535,46 @@ def test_analyse_default_search_other_kernels(oracle, mv, dbg, variant, w, h, bi
         assert np.array_equal(gan.run([(gsf[1], gsf[ref])])[0].cpu().numpy(), oan.frame(osf[1], osf[ref]))
 
 
+@pytest.mark.parametrize("w,h,skw,akw", [
+    (384, 224, {}, dict(blksize=16, overlap=8)),                                  # cfg3 shape
+    (320, 192, {}, dict(blksize=16, overlap=8, _noise=14)),                       # many bad blocks: the rescue (global path) between window blocks
+    (320, 192, {}, dict(blksize=16, overlap=8, _noise=14, badsad=400, badrange=-3)),
+    (256, 144, {}, dict(blksize=16, overlap=0)),
+    (256, 144, {}, dict(blksize=16, overlap=8, chroma=0)),
+    (256, 144, dict(pel=1), dict(blksize=16, overlap=8)),
+    (256, 144, {}, dict(blksize=16, overlap=4, search=3, searchparam=2, pelsearch=2)),   # exhaustive radius 2 at the finest level too
+    (256, 144, {}, dict(blksize=16, overlap=8, pelsearch=1)),                        # Hex2 with range 1: the square only
+    (256, 144, {}, dict(blksize=16, overlap=8, global_=0, pglobal=30, pzero=90)),
+    (256, 144, {}, dict(blksize=16, overlap=8, meander=0, levels=2)),
+    (200, 120, dict(hpad=8, vpad=8), dict(blksize=16, overlap=8)),               # small padding: windows clamp at the plane edges
+    (1000, 64, {}, dict(blksize=16, overlap=8)),                                  # several 64-block groups per row
+])
+def test_analyse_window_kernel(oracle, mv, dbg, w, h, skw, akw):
+    """The LDS-window kernel of the default search (mvx_analyse_win.h; opt-in, "win" = 1): candidates served from LDS windows that
+    LDS-DMA fills once per block.  Same blobs as the oracle -- forward, backward, with a field shift, with a missing reference."""
+    akw = dict(akw)
+    noise = akw.pop("_noise", 3)
+    dbg("win", 1)
+    frames = pl.moving_clip(w, h, 16, 3, seed=17, noise=noise, motion=(5, -2))
+    osup = oracle.Super(w, h, 16, **skw)
+    gsup = mv.Super(w, h, 16, **skw)
+    osf = [osup.frame(f) for f in frames]
+    gsf = gsup.build([mv.frame_to_device(f) for f in frames])
+    info = (C.c_int * 5)()
+    for isb in (1, 0):
+        oan = oracle.Analyse(osup, isb=isb, **akw)
+        gan = mv.Analyse(gsup, isb=isb, **akw)
+        ref = 2 if isb else 0
+        got = gan.run([(gsf[1], gsf[ref]), (gsf[1], None)])
+        mv.lib().mvx_debug_last_launch(info)
+        assert info[4] == 1, "the window kernel did not run (%s)" % list(info)
+        assert np.array_equal(got[0].cpu().numpy(), oan.frame(osf[1], osf[ref]))
+        assert np.array_equal(got[1].cpu().numpy(), oan.frame(osf[1], None))
+        if skw.get("pel", 2) == 2:
+            for fs in (1, -1):  # fields: the zero candidate's luma is shifted, its chroma is not (PlaneOfBlocks.cpp:836-839)
+                assert np.array_equal(gan.run([(gsf[1], gsf[ref])], field_shift=fs)[0].cpu().numpy(), oan.frame(osf[1], osf[ref], field_shift=fs))
+
+
 @pytest.mark.parametrize("bits,akw,per_simd", [(8, dict(blksize=8, overlap=4), 3), (8, dict(blksize=8, overlap=4), 4), (16, dict(blksize=16, overlap=8), 3),
                                                (16, dict(blksize=16, overlap=8), 4), (8, dict(blksize=16, overlap=8), 4), (16, dict(blksize=32, overlap=16), 3),
                                                (16, dict(blksize=8, overlap=4), 4)])
@@ -742,7 +782,7 @@ def _fullsize_parity(mv, oracle, w, h, bits, tr, akw, nout, replicas, want_k, la
     jobs = [(gsf[a], gsf[b]) for a, b in chains] * replicas
     blobs = gan.run(jobs)
     torch.cuda.synchronize()
-    info = (C.c_int * 4)()
+    info = (C.c_int * 5)()
     mv.lib().mvx_debug_last_launch(info)
     assert info[0] == want_k and info[2] > 0 and info[3] == len(jobs), label + ": the batch did not take the %d-per-SIMD build with a barrier interval (%s)" % (want_k, list(info))
     with ThreadPoolExecutor(16) as ex:

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include "mvx_analyse_kernel.h"
 #include "mvx_analyse_fast.h"
+#include "mvx_analyse_win.h"
 
 // ------------------------------------------------------------------------------------------------ host
 
@@ -36,13 +37,14 @@ struct MvxDebug {
     int degrain_xcd = -1;  // Degrain cell kernels: XCD-contiguous tile order (1 / 0), -1 = default
     int cpw_sync = -1; // barrier interval inside a workgroup (power of two, 0 = none)
     int lds_min = -1;  // LDS floor of the one-chain launches
+    int win = 0;       // 1: the LDS-window kernel of the default search (mvx_analyse_win.h) where it applies: bit-exact, measured slower
     int super_rows_off = 0; // 1: mv.Super level 0 / first reduction through the LDS-tile / per-sample kernels only
     int ablate = 0;
 };
 static MvxDebug g_dbg;
 extern "C" __attribute__((visibility("default"))) int mvx_debug_option(const char *name, int value) {
     struct { const char *n; int *p; } tab[] = { { "general", &g_dbg.general }, { "fast_wpe", &g_dbg.fast_wpe }, { "cpw1", &g_dbg.cpw1 }, { "window", &g_dbg.window },
-        { "tile", &g_dbg.tile }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "fast_cpw", &g_dbg.fast_cpw }, { "fast_flags", &g_dbg.fast_flags }, { "pad_runs", &g_dbg.pad_runs }, { "shadow_planes", &g_dbg.shadow_planes }, { "degrain_xcd", &g_dbg.degrain_xcd }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min }, { "super_rows_off", &g_dbg.super_rows_off },
+        { "tile", &g_dbg.tile }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "fast_cpw", &g_dbg.fast_cpw }, { "fast_flags", &g_dbg.fast_flags }, { "pad_runs", &g_dbg.pad_runs }, { "shadow_planes", &g_dbg.shadow_planes }, { "degrain_xcd", &g_dbg.degrain_xcd }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min }, { "super_rows_off", &g_dbg.super_rows_off }, { "win", &g_dbg.win },
 #ifdef MVX_LAB
         { "ablate", &g_dbg.ablate },
 #endif
@@ -54,10 +56,10 @@ extern "C" __attribute__((visibility("default"))) int mvx_debug_option(const cha
 
 // what the last search launch of this process looked like (tests assert that a batch really took the build they mean to cover):
 // out[0] = chains per SIMD of the lean kernel (0: the general kernel ran), out[1] = chains per workgroup, out[2] = barrier interval in
-// blocks, out[3] = entries of the job table
-static std::atomic<int> g_lastLaunch[4];
-extern "C" __attribute__((visibility("default"))) void mvx_debug_last_launch(int out[4]) {
-    for (int i = 0; i < 4; i++) out[i] = g_lastLaunch[i].load();
+// blocks, out[3] = entries of the job table, out[4] = 1 when the LDS-window kernel ran
+static std::atomic<int> g_lastLaunch[5];
+extern "C" __attribute__((visibility("default"))) void mvx_debug_last_launch(int out[5]) {
+    for (int i = 0; i < 5; i++) out[i] = g_lastLaunch[i].load();
 }
 
 int mvx_debug_value(const char *name, int def) {
@@ -340,9 +342,12 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         const int fBins = 1024;
         int fNeed = fRow + fMaxBlkX * 16;
         if (fNeed < fRow + fBins * 4) fNeed = fRow + fBins * 4;
-        const int perChain = (fNeed + 255) & ~255;
+        // 16-bit 16x16 blocks: the LDS-window kernel (mvx_analyse_win.h) -- its own LDS layout, builds for one to three chains per SIMD
+        const bool useWin = g_dbg.win && mvx_win_eligible(P);
+        const int perChain = useWin ? WG16::TOTAL : (fNeed + 255) & ~255;
         // builds per (sample size, block size): chains per SIMD that exist (mvx_analyse_u8.hip / _u16.hip)
         auto have = [&](int k) {
+            if (useWin) return k >= 1 && k <= 3;
             if (P.bps == 2 && P.blkX == 8) return k == 1 || k == 2 || k == 4;
             if (P.bps == 2 && P.blkX == 32) return k >= 1 && k <= 3;
             return k >= 1 && k <= 4;
@@ -388,9 +393,9 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
             // XCD-contiguous workgroup order: neighbours in the (reference-sorted) job table share an L2 (+0.5 %, 4K16)
             const int flags = (g_dbg.fast_flags >= 0 ? g_dbg.fast_flags : MVX_FAST_XCD_REMAP) | ((P.shadow[1] != 0 && P.chroma) ? MVX_FAST_UV : 0);
             ALaunch L = { 0, ntab, fNeed, fRow, fRow, fBins, -1, 0, fNeed, simds, cpw, k, syncEvery, k, flags, st, a->dP, S.d };
-            int rc = P.bps == 1 ? mvx_analyse_launch_fast_u8(P, L) : mvx_analyse_launch_fast_u16(P, L);
+            int rc = useWin ? mvx_analyse_launch_win(P, L) : P.bps == 1 ? mvx_analyse_launch_fast_u8(P, L) : mvx_analyse_launch_fast_u16(P, L);
             if (rc == MVX_OK) {
-                g_lastLaunch[0] = k; g_lastLaunch[1] = cpw; g_lastLaunch[2] = syncEvery; g_lastLaunch[3] = ntab;
+                g_lastLaunch[0] = k; g_lastLaunch[1] = cpw; g_lastLaunch[2] = syncEvery; g_lastLaunch[3] = ntab; g_lastLaunch[4] = useWin;
                 if (P.divide) hipLaunchKernelGGL(analyse_divide_kernel, dim3((P.lv[0].nBlkX * P.lv[0].nBlkY + 255) / 256, ntab), dim3(256), 0, st, a->dP, S.d);
                 HIP_CHECK(hipGetLastError());
                 return MVX_OK;
@@ -486,7 +491,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
     int rc = (P.dctmode != 0 || !off32) ? 1 : P.bps == 1 ? mvx_analyse_launch_u8(P, L) : mvx_analyse_launch_u16(P, L); // specialised 4:2:0 geometries (SAD cost only)
     if (rc == 1) rc = mvx_analyse_launch_any(P, L);                                     // everything else
     if (rc) return rc;
-    g_lastLaunch[0] = 0; g_lastLaunch[1] = cpw; g_lastLaunch[2] = syncEvery; g_lastLaunch[3] = njobs;
+    g_lastLaunch[0] = 0; g_lastLaunch[1] = cpw; g_lastLaunch[2] = syncEvery; g_lastLaunch[3] = njobs; g_lastLaunch[4] = 0;
     if (P.divide) hipLaunchKernelGGL(analyse_divide_kernel, dim3((P.lv[0].nBlkX * P.lv[0].nBlkY + 255) / 256, njobs), dim3(256), 0, st, a->dP, S.d);
     HIP_CHECK(hipGetLastError());
     return MVX_OK;

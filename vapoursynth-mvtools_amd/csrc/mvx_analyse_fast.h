@@ -690,6 +690,11 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
         // 64 blocks at a time: bSelf / bBelow = the interpolated predictors of this row's group and of the blocks "below-ahead"
         // of it (lane i <-> column 64 * grp + i of the current row; bBelow holds column + dir of the next row), bUp = the previous
         // row's results for the group (LDS), bOut = this group's results.
+        // lambda of a block whose predictor SAD is predSad (:456-462), fp64 as the reference
+        auto lambda_of = [&](int predSad) {
+            const double scale = (double)LSAD / (double)(LSAD + (long long)(predSad >> 1));
+            return (int)(long long)((double)(long long)nLambdaLevel * scale * scale);
+        };
         v4u bSelf = {0, 0, 0, 0}, bBelow = {0, 0, 0, 0}, bUp = {0, 0, 0, 0}, bOut = {0, 0, 0, 0};
         int prevX = 0, prevY = 0, prevSad = 0;
         A4x32 pf[G::NPF];
@@ -710,7 +715,12 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
             if (rowStart || col == (fwd ? 0 : 63)) {
                 const int c0 = blkx & ~63, c = c0 + l;
                 const bool in = c < nBlkX;
-                if (in) bSelf = ld_batch(&vectors[blky * nBlkX + c]);
+                if (in) {
+                    bSelf = ld_batch(&vectors[blky * nBlkX + c]);
+                    // :456-462 lane-parallel: every level but the coarsest scales lambda by its block's OWN interpolated SAD, which this lane
+                    // just fetched -- 64 fp64 divisions at once instead of one per block in uniform code (the 4th dword of a batch is free)
+                    if (!smallestPlane) bSelf[3] = (unsigned)lambda_of((int)bSelf[2]);
+                }
                 const int cb = c + dir; // "below-ahead" of column c
                 bBelow = v4u{0, 0, 0, 0};
                 if (in && blky < nBlkY - 1 && cb >= 0 && cb < nBlkX) bBelow = ld_batch(&vectors[(blky + 1) * nBlkX + cb]);
@@ -758,10 +768,7 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
             else { predX = clipx(sfx); predY = clipy(sfy); predSad = sfs; }
             // :456-462: lambda shrinks with the predictor's SAD (row 0 searches without the motion term, :1081-1084)
             nLambda = 0;
-            if (blky > 0) {
-                const double scale = (double)LSAD / (double)(LSAD + (long long)(predSad >> 1));
-                nLambda = uni((int)(long long)((double)(long long)nLambdaLevel * scale * scale));
-            }
+            if (blky > 0) nLambda = smallestPlane ? uni(lambda_of(predSad)) : __builtin_amdgcn_readlane((int)bSelf[3], col);
             __builtin_amdgcn_wave_barrier(); // single wave: DS ops are in order; keeps the compiler from moving LDS reads above the staging writes
             search_block();
             __builtin_amdgcn_wave_barrier();
