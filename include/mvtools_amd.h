@@ -308,6 +308,8 @@ void *mvx_dev_alloc(size_t bytes);            /* zero-filled */
 void *mvx_dev_alloc_uninit(size_t bytes);     /* contents undefined (scratch, upload targets) */
 void mvx_dev_free(void *p);                   /* goes to a size-keyed free list (no device synchronisation); wait for the work that uses p first */
 void mvx_dev_pool_limit(size_t bytes);        /* bytes the free list may hold (default 24 GiB) */
+void mvx_dev_pool_trim(void);                 /* returns the whole free list to the driver */
+int mvx_dev_mem_info(size_t *free_bytes, size_t *total_bytes); /* of the current device; the free list counts as free */
 void *mvx_stream_create(void);                /* a non-blocking stream for the `stream` arguments; NULL on failure */
 void *mvx_stream_create_priority(int level);  /* < 0 lowest, 0 default, > 0 highest priority; different priorities never share a hardware queue */
 void mvx_stream_destroy(void *stream);

@@ -119,3 +119,48 @@ def test_bench_rank_plumbing(monkeypatch, capsys):
         env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=240)
         assert r.returncode != 0 and "--gpus 2" in r.stderr and not r.stdout.strip()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_rank_plans_on_one_gpu_match_the_single_rank_run(world):
+    """The N>1 path on the GPU as far as one GPU allows: the ranks of a world of 2 (3) run one after the other on the same device
+    -- each with bench.py's own Pipeline, its RankPlan share of ONE clip and the tr-frame halo it runs mv.Super on itself -- and the
+    union of their outputs (vector blobs of every clip and the Degrain planes) must equal the world-1 run frame for frame.  No
+    collective is involved: SURVEY.md 8(e)."""
+    import torch
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "vapoursynth-mvtools_amd")]
+    import bench
+    import mvtools_amd as mv
+    from mvtools_amd import shard
+    w, h, bits, tr, total = 320, 192, 16, 2, 11
+    cfg = (w, h, bits, tr, dict(blksize=16, overlap=8), dict(pel=2), 0, "sharding test clip")
+    N = total + 2 * tr
+    dev = torch.device("cuda", 0)
+    clip = bench.synth_clip_device(torch, w, h, bits, N, seed=5, device=dev)
+
+    def run(rank, nranks):
+        plan = shard.RankPlan(N, rank, nranks, tr, first_out=tr, last_out=N - tr)
+        outs = list(plan.outputs())
+        p = bench.Pipeline(mv, torch, cfg, len(outs), dev, seed=0, src=clip[plan.held[0]:plan.held[1]], plan=plan)
+        p.step()
+        torch.cuda.synchronize()
+        res = {}
+        for i, n in enumerate(outs):
+            res[n] = ([pl_.clone() for pl_ in p.out[i]], {k: p.blobs[k][i].clone() for k in plan.clips})
+        return res, plan
+
+    whole, _ = run(0, 1)
+    union = {}
+    for r in range(world):
+        part, plan = run(r, world)
+        assert plan.held[0] == max(0, plan.out[0] - tr) and plan.held[1] == min(N, plan.out[1] + tr)
+        assert not (set(part) & set(union)), "ranks must own disjoint frame ranges"
+        union.update(part)
+    assert sorted(union) == sorted(whole) == list(range(tr, N - tr))
+    for n in whole:
+        for pi, (a, b) in enumerate(zip(whole[n][0], union[n][0])):
+            rb = (w >> (1 if pi else 0)) * 2  # (the pitch padding of the output planes is never written)
+            assert torch.equal(a[:, :rb], b[:, :rb]), "Degrain output of frame %d differs between the world-1 and the world-%d run" % (n, world)
+        for k in whole[n][1]:
+            assert torch.equal(whole[n][1][k], union[n][1][k]), "vectors of frame %d, clip %s differ" % (n, k)

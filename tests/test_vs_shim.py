@@ -396,3 +396,27 @@ def test_concurrent_requests_are_batched_and_bit_identical(tmp_path, bits, pipel
     kv = {k: int(v) for k, v in (t.split("=") for t in stats[0].split()[2:])}
     # every Analyse instance served its 70 frames in a handful of launches, the largest with most of the 64 concurrent requests
     assert kv["jobs"] == n * kv["instances"] and kv["launches"] <= 8 * kv["instances"] and kv["largest_batch"] >= 32, stats[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits,pipeline,extra,threads", [(16, "degrain3", ("a.blksize=16", "a.overlap=8"), 32), (8, "degrain1", ("a.blksize=8", "a.overlap=4"), 1),
+                                                          (8, "analyse", ("a.blksize=8", "a.overlap=4", "a.delta=2"), 8)])
+def test_lookahead_serves_windows_and_is_bit_identical(tmp_path, bits, pipeline, extra, threads):
+    """mv.Analyse on this plugin's own mv.Super node computes its vector clip a window of 64 frames at a time (one search launch per
+    window, super frames built on the device from the SOURCE frames; the request protocol stays MVAnalyse.c:84-113's arInitial /
+    arAllFramesReady).  The clip must be the one the per-frame path gives (MVX_VS_LOOKAHEAD=0, which the other tests tie to the oracle),
+    with at least ten times fewer launches than frames."""
+    w, h, n = 192, 112, 150
+    frames = pl.moving_clip(w, h, bits, n, seed=19, noise=3)
+    src, ref, la = str(tmp_path / "in.raw"), str(tmp_path / "ref.raw"), str(tmp_path / "la.raw")
+    _write_clip(src, frames)
+    args = [str(a) for a in ("run", pipeline, src, w, h, bits, n)]
+    r0 = subprocess.run([HOST, PLUGIN] + args + [ref] + list(extra) + ["x.threads=16"], capture_output=True, text=True, timeout=900, env=dict(os.environ, MVX_VS_LOOKAHEAD="0"))
+    assert r0.returncode == 0 and "DONE" in r0.stdout, r0.stdout + r0.stderr
+    r1 = subprocess.run([HOST, PLUGIN] + args + [la] + list(extra) + ["x.threads=%d" % threads], capture_output=True, text=True, timeout=900, env=dict(os.environ, MVX_VS_STATS="1"))
+    assert r1.returncode == 0 and "DONE" in r1.stdout, r1.stdout + r1.stderr
+    assert open(ref, "rb").read() == open(la, "rb").read()
+    stats = [l for l in r1.stderr.splitlines() if l.startswith("mvtools_vs: Analyse")]
+    assert len(stats) == 1, r1.stderr
+    kv = {k: int(v) for k, v in (t.split("=") for t in stats[0].split()[2:])}
+    assert kv["jobs"] == n * kv["instances"] and kv["launches"] * 10 <= kv["jobs"] and kv["largest_batch"] == 64, stats[0]

@@ -1,4 +1,4 @@
-"""Round-2 measurement of the drop-in path: the VapourSynth filter shell (libmvtools_vs.so) driven by the mini host with 64
+"""Measurement of the drop-in path: the VapourSynth filter shell (libmvtools_vs.so) driven by the mini host with T
 request threads on a 4K YUV420P16 clip -- mv.Super -> mv.Analyse x 6 -> mv.Degrain3 -- timed wall-clock (host copies, PCIe and
 the per-frame shell work included), and compared bit for bit with the same graph evaluated through the batched C ABI (the
 Python binding), which the parity suite ties to the oracle.   usage (GPU box):  python tools/vs_4k_run.py [frames] [threads]"""
@@ -29,7 +29,7 @@ print("clip: %d frames %dx%d P%d written in %.1f s" % (N, w, h, bits, time.time(
 host, plugin = os.path.join(ROOT, "vapoursynth-mvtools_amd", "mvx_vs_host"), os.path.join(ROOT, "vapoursynth-mvtools_amd", "libmvtools_vs.so")
 env = dict(os.environ, MVX_VS_STATS="1", MVX_HOST_TIMES="1")
 t0 = time.time()
-r = subprocess.run([host, plugin, "run", "degrain3", src, str(w), str(h), str(bits), str(N), out, "a.blksize=16", "a.overlap=8", "x.threads=%d" % T],
+r = subprocess.run([host, plugin, "run", "degrain3", src, str(w), str(h), str(bits), str(N), out, "a.blksize=16", "a.overlap=8", "x.threads=%d" % T] + (["x.order=frame"] if os.environ.get("VS_ORDER", "frame") == "frame" else []),
                    capture_output=True, text=True, env=env)
 dt = time.time() - t0
 print(r.stdout.strip()[-200:], r.stderr.strip()[-700:], flush=True)

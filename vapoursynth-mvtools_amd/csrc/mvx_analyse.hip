@@ -31,6 +31,7 @@ struct MvxDebug {
     int tile = 0;      // refinement-tile kernel
     int no_wpe2 = 0, no_wpe3 = 0, wpe3_u16 = 0;
     int fast_cpw = 0;  // lean kernel: chains per workgroup (<= 4 * chains per SIMD)
+    int fast_k = 0;    // lean kernel: build for exactly that many chains per SIMD whatever the launch carries (several launches sharing the GPU)
     int fast_flags = -1; // lean kernel: MVX_FAST_* bits, -1 = default
     int pad_runs = -1;   // lean kernel: 1 = pad the job table so that the chains of one reference frame never straddle two workgroups
     int shadow_planes = 3; // 1 = luma only, 2 = chroma only uses the shadow copies
@@ -44,7 +45,7 @@ struct MvxDebug {
 static MvxDebug g_dbg;
 extern "C" __attribute__((visibility("default"))) int mvx_debug_option(const char *name, int value) {
     struct { const char *n; int *p; } tab[] = { { "general", &g_dbg.general }, { "fast_wpe", &g_dbg.fast_wpe }, { "cpw1", &g_dbg.cpw1 }, { "window", &g_dbg.window },
-        { "tile", &g_dbg.tile }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "fast_cpw", &g_dbg.fast_cpw }, { "fast_flags", &g_dbg.fast_flags }, { "pad_runs", &g_dbg.pad_runs }, { "shadow_planes", &g_dbg.shadow_planes }, { "degrain_xcd", &g_dbg.degrain_xcd }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min }, { "super_rows_off", &g_dbg.super_rows_off }, { "win", &g_dbg.win },
+        { "tile", &g_dbg.tile }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "fast_cpw", &g_dbg.fast_cpw }, { "fast_k", &g_dbg.fast_k }, { "fast_flags", &g_dbg.fast_flags }, { "pad_runs", &g_dbg.pad_runs }, { "shadow_planes", &g_dbg.shadow_planes }, { "degrain_xcd", &g_dbg.degrain_xcd }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min }, { "super_rows_off", &g_dbg.super_rows_off }, { "win", &g_dbg.win },
 #ifdef MVX_LAB
         { "ablate", &g_dbg.ablate },
 #endif
@@ -354,6 +355,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         };
         int k = njobs > 3 * simds ? 4 : njobs > 2 * simds ? 3 : njobs > simds ? 2 : 1;
         if (g_dbg.fast_wpe > 0 && g_dbg.fast_wpe < k) k = g_dbg.fast_wpe;
+        if (g_dbg.fast_k > 0) k = g_dbg.fast_k;
         while (k > 1 && (!have(k) || (long long)perChain * 4 * k > 160 * 1024)) k--;
         if ((long long)perChain * 4 * k <= 160 * 1024) {
             std::stable_sort(hj.begin(), hj.end(), [](const AJob &x, const AJob &y) { return (uintptr_t)x.ref[0] > (uintptr_t)y.ref[0]; }); // (no reference: last)

@@ -19,13 +19,16 @@ extern "C" __attribute__((visibility("default"))) int mvx_set_device(int ordinal
 #include <map>
 #include <unordered_map>
 static std::mutex g_pool_mu;
-static std::multimap<size_t, void *> g_pool_free;
-static std::unordered_map<void *, size_t> g_pool_size;
+typedef std::pair<int, size_t> PoolKey; // (device ordinal, bytes): a host that switches devices (mvx_set_device) never gets another GPU's buffer
+static std::multimap<PoolKey, void *> g_pool_free;
+static std::unordered_map<void *, PoolKey> g_pool_size;
 static size_t g_pool_held = 0, g_pool_limit = (size_t)24 << 30;
+static int pool_device() { int d = 0; (void)hipGetDevice(&d); return d; }
 
 static void *pool_take(size_t bytes) {
+    const PoolKey key(pool_device(), bytes);
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    auto it = g_pool_free.find(bytes);
+    auto it = g_pool_free.find(key);
     if (it == g_pool_free.end()) return nullptr;
     void *p = it->second;
     g_pool_free.erase(it);
@@ -45,14 +48,14 @@ extern "C" __attribute__((visibility("default"))) void *mvx_dev_alloc_uninit(siz
         if (hipMalloc(&p, bytes) != hipSuccess) { mvx_set_error("hipMalloc(%zu) failed", bytes); return nullptr; }
     }
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    g_pool_size[p] = bytes;
+    g_pool_size[p] = PoolKey(pool_device(), bytes);
     return p;
 }
 extern "C" __attribute__((visibility("default"))) void *mvx_dev_alloc(size_t bytes) { // zero-filled
     void *p = mvx_dev_alloc_uninit(bytes);
     if (!p) return nullptr;
     // (on the legacy default stream and waited for: the caller may touch the buffer from any stream next)
-    if (hipMemsetAsync(p, 0, bytes ? bytes : 1, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { mvx_set_error("hipMemset failed"); return nullptr; }
+    if (hipMemsetAsync(p, 0, bytes ? bytes : 1, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { mvx_set_error("hipMemset failed"); mvx_dev_free(p); return nullptr; }
     return p;
 }
 // The caller must have waited for the work that uses the buffer (every host in this repository synchronises its stream before it
@@ -62,21 +65,36 @@ extern "C" __attribute__((visibility("default"))) void mvx_dev_free(void *p) {
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         auto it = g_pool_size.find(p);
-        if (it != g_pool_size.end() && g_pool_held + it->second <= g_pool_limit) {
+        if (it != g_pool_size.end() && g_pool_held + it->second.second <= g_pool_limit) {
             g_pool_free.emplace(it->second, p);
-            g_pool_held += it->second;
+            g_pool_held += it->second.second;
             return;
         }
         if (it != g_pool_size.end()) g_pool_size.erase(it);
     }
     (void)hipFree(p);
 }
+// free / total bytes of the current device, the free list counted as free (a host sizes its caches from this)
+extern "C" __attribute__((visibility("default"))) int mvx_dev_mem_info(size_t *free_bytes, size_t *total_bytes) {
+    size_t f = 0, t = 0;
+    HIP_CHECK(hipMemGetInfo(&f, &t));
+    { std::lock_guard<std::mutex> lk(g_pool_mu); f += g_pool_held; }
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return MVX_OK;
+}
+// gives every buffer of the free list back to the driver (a host calls this before it retries a failed allocation of another size)
+extern "C" __attribute__((visibility("default"))) void mvx_dev_pool_trim(void) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto &e : g_pool_free) { (void)hipFree(e.second); g_pool_size.erase(e.second); }
+    g_pool_free.clear(); g_pool_held = 0;
+}
 extern "C" __attribute__((visibility("default"))) void mvx_dev_pool_limit(size_t bytes) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     g_pool_limit = bytes;
     while (g_pool_held > g_pool_limit && !g_pool_free.empty()) {
         auto it = std::prev(g_pool_free.end());
-        g_pool_held -= it->first;
+        g_pool_held -= it->first.second;
         g_pool_size.erase(it->second);
         (void)hipFree(it->second);
         g_pool_free.erase(it);
@@ -157,7 +175,11 @@ extern "C" __attribute__((visibility("default"))) int mvx_upload_2d(void *dev, p
     const size_t bytes = (rows - 1) * (size_t)dp + row_bytes;
     Stage *s = stage_acquire(bytes);
     if (!s) return MVX_E_DEVICE;
-    for (size_t r = 0; r < rows; r++) memcpy((char *)s->p + r * (size_t)dp, (const char *)host + (ptrdiff_t)r * hp, row_bytes);
+    for (size_t r = 0; r < rows; r++) {
+        memcpy((char *)s->p + r * (size_t)dp, (const char *)host + (ptrdiff_t)r * hp, row_bytes);
+        // the pitch padding travels with the linear copy: zero it (a staging buffer holds whatever an earlier transfer left)
+        if (r + 1 < rows && (size_t)dp > row_bytes) memset((char *)s->p + r * (size_t)dp + row_bytes, 0, (size_t)dp - row_bytes);
+    }
     hipError_t e = hipMemcpyAsync(dev, s->p, bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     stage_release(s);

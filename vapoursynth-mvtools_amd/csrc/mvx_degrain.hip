@@ -106,13 +106,16 @@ struct DGJob {
     int fieldShift;          // compensate only (MVCompensate.c:188-225)
 };
 
-// plan record: one per (frame, plane class luma/chroma, block)
-struct PlanRec {
-    unsigned off[12];  // byte offset of the compensated block's first sample inside the reference super plane
-    short w[12];
+// plan record: one per (frame, plane class luma/chroma, block), sized for the filter's 2 * radius references (Degrain3: 40 bytes; a fixed
+// 12-reference record was 76 -- at 4K16 the plan of a 512-frame batch was 10 GB written and read back, more than the vector blobs it digests)
+template <int NR> struct PlanRecT {
+    unsigned off[NR];  // byte offset of the compensated block's first sample inside the reference super plane
+    short w[NR];
     short wsrc;
     short pad;
 };
+static size_t plan_rec_bytes(int nrefs) { return (size_t)6 * nrefs + 4; }
+static_assert(sizeof(PlanRecT<6>) == 40 && sizeof(PlanRecT<12>) == 76 && sizeof(PlanRecT<2>) == 16, "plan record layout");
 
 // ------------------------------------------------------------------------------------------------ kernels
 
@@ -150,15 +153,17 @@ __device__ __forceinline__ unsigned sup_offset(const PlaneG &g, int pel, int log
     return (unsigned)(idx * g.supPlaneStride + (long long)(nY >> logPel) * g.supPitch + (long long)(nX >> logPel) * bps);
 }
 
-__global__ __launch_bounds__(256) void degrain_plan_kernel(const DGParams *Pp, const DGJob *jobs, const int *usable, PlanRec *plan) {
+template <int NR>
+__global__ __launch_bounds__(256) void degrain_plan_kernel(const DGParams *Pp, const DGJob *jobs, const int *usable, PlanRecT<NR> *plan) {
+    typedef PlanRecT<NR> PlanRec;
     const DGParams &P = *Pp;
     const int f = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P.nBlk) return;
     const int by = i / P.nBlkX, bx = i - by * P.nBlkX;
     const DGJob &J = jobs[f];
-    const int n = P.nRefs;
-    int vx[12], vy[12]; long long sad[12]; int us[12];
+    constexpr int n = NR; // (= P.nRefs)
+    int vx[NR], vy[NR]; long long sad[NR]; int us[NR];
     for (int r = 0; r < n; r++) {
         us[r] = usable[f * 12 + r];
         if (us[r]) {
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(256) void degrain_plan_kernel(const DGParams *Pp, c
     for (int c = 0; c < ncls; c++) {
         const PlaneG &g = P.pl[c];
         PlanRec rec;
-        int W[12], WSum = 256 + 1;
+        int W[NR], WSum = 256 + 1;
         for (int r = 0; r < n; r++) {
             W[r] = 0; rec.off[r] = 0;
             if (us[r]) { // MVDegrains.h:192-200 useBlock; block origin Fakery.c:31-32
@@ -183,14 +188,14 @@ __global__ __launch_bounds__(256) void degrain_plan_kernel(const DGParams *Pp, c
         const double scale = 256.0 / WSum; // MVDegrains.h:208-223 normaliseWeights
         int WSrc = 256;
         for (int r = 0; r < n; r++) { W[r] = (int)(W[r] * scale); WSrc -= W[r]; rec.w[r] = (short)W[r]; }
-        for (int r = n; r < 12; r++) { rec.w[r] = 0; rec.off[r] = 0; }
         rec.wsrc = (short)WSrc; rec.pad = 0;
         plan[((size_t)f * 2 + c) * P.nBlk + i] = rec;
     }
 }
 
 template <typename T, int NR>
-__global__ __launch_bounds__(256) void degrain_kernel(const DGParams *Pp, const DGJob *jobs, const PlanRec *plan) {
+__global__ __launch_bounds__(256) void degrain_kernel(const DGParams *Pp, const DGJob *jobs, const PlanRecT<NR> *plan) {
+    typedef PlanRecT<NR> PlanRec;
     const DGParams &P = *Pp;
     const int z = blockIdx.z, f = z / 3, p = z % 3;
     if (p >= P.nplanes) return;
@@ -319,7 +324,8 @@ template <typename T, int W> __device__ __forceinline__ void dg_store(DG_GL unsi
 }
 
 template <typename T, int NR, int W>
-__global__ __launch_bounds__(256) void degrain_cell_kernel(const DGParams *Pp, const DGJob *jobs, const PlanRec *plan, int planeFirst, int planesPerFrame, int xcdOrder) {
+__global__ __launch_bounds__(256) void degrain_cell_kernel(const DGParams *Pp, const DGJob *jobs, const PlanRecT<NR> *plan, int planeFirst, int planesPerFrame, int xcdOrder) {
+    typedef PlanRecT<NR> PlanRec;
     const DGParams &P = *Pp;
     int bxi = blockIdx.x, byi = blockIdx.y, z = blockIdx.z;
     if (xcdOrder) { // workgroup w runs on XCD w % 8: give every XCD a contiguous range of tiles, so that vertically adjacent tiles (which
@@ -359,9 +365,13 @@ __global__ __launch_bounds__(256) void degrain_cell_kernel(const DGParams *Pp, c
 #pragma unroll
         for (int i = 0; i < W; i++) acc[i] = 0;
         const int16_t *win = P.win[p];
-        const unsigned char *refp[NR]; // a frame outside the clip has no super frame: point at the source plane (its weight is 0; any
-#pragma unroll                         // offset a plan record holds for an unusable reference is 0, so the address stays inside that plane)
-        for (int r = 0; r < NR; r++) refp[r] = J.refs[r][p] ? J.refs[r][p] : J.src[p];
+        // a frame outside the clip has no super frame: its loads (weight 0, plan offset 0) go to a super plane the job does have, so that
+        // the row offset (super pitch) stays inside the buffer; a job without any reference reads the source plane at offset 0
+        const unsigned char *refp[NR], *safe = nullptr;
+#pragma unroll
+        for (int r = 0; r < NR; r++) if (J.refs[r][p]) safe = J.refs[r][p];
+#pragma unroll
+        for (int r = 0; r < NR; r++) refp[r] = J.refs[r][p] ? J.refs[r][p] : (safe ? safe : J.src[p]);
         for (int by = by0; by <= by1; by++) {
             const int py = y - by * g.stepY;
             const int wby = by == 0 ? 0 : (by == P.nBlkY - 1 ? 6 : 3);
@@ -375,7 +385,7 @@ __global__ __launch_bounds__(256) void degrain_cell_kernel(const DGParams *Pp, c
                 int sum[W];
 #pragma unroll
                 for (int i = 0; i < W; i++) sum[i] = 128 + s[i] * wsrc;
-                const long long rowOff = (long long)py * g.supPitch + (long long)px * sizeof(T);
+                const long long rowOff = safe ? (long long)py * g.supPitch + (long long)px * sizeof(T) : 0;
                 const int16_t *wrow = win + (wby + wbx) * g.blkW * g.blkH + py * g.blkW + px;
                 int wv[W];
                 if (nv >= W) { // whole cell inside the block: vector loads, ALL of the block's references requested before the first is used
@@ -699,21 +709,21 @@ extern "C" __attribute__((visibility("default"))) int mvx_degrain_create(const m
 
 extern "C" __attribute__((visibility("default"))) void mvx_degrain_destroy(mvx_degrain *d) { delete d; }
 
-template <typename T> static void launch_degrain(int nr, dim3 grid, hipStream_t st, const DGParams *dP, const DGJob *dJ, const PlanRec *plan) {
-#define DG(N) hipLaunchKernelGGL((degrain_kernel<T, N>), grid, dim3(256), 0, st, dP, dJ, plan)
+template <typename T> static void launch_degrain(int nr, dim3 grid, hipStream_t st, const DGParams *dP, const DGJob *dJ, const void *plan) {
+#define DG(N) hipLaunchKernelGGL((degrain_kernel<T, N>), grid, dim3(256), 0, st, dP, dJ, (const PlanRecT<N> *)plan)
     switch (nr) { case 2: DG(2); break; case 4: DG(4); break; case 6: DG(6); break; case 8: DG(8); break; case 10: DG(10); break; default: DG(12); break; }
 #undef DG
 }
 
-template <typename T, int W> static void launch_degrain_cells_w(int nr, dim3 grid, hipStream_t st, const DGParams *dP, const DGJob *dJ, const PlanRec *plan, int p0, int npl) {
+template <typename T, int W> static void launch_degrain_cells_w(int nr, dim3 grid, hipStream_t st, const DGParams *dP, const DGJob *dJ, const void *plan, int p0, int npl) {
     // XCD-contiguous tile order: measured r2 (4K16 Degrain3, 512 frames): HBM fetch 124 -> 88 GB (luma) and 75 -> 34 GB (chroma), but the
     // launch gets 8 ms SLOWER (189 against 181 ms for everything but the search) -- the kernel is not HBM-bound.  Off.
     const int xo = mvx_debug_value("degrain_xcd", 0);
-#define DGC(N) hipLaunchKernelGGL((degrain_cell_kernel<T, N, W>), grid, dim3(256), 0, st, dP, dJ, plan, p0, npl, xo)
+#define DGC(N) hipLaunchKernelGGL((degrain_cell_kernel<T, N, W>), grid, dim3(256), 0, st, dP, dJ, (const PlanRecT<N> *)plan, p0, npl, xo)
     switch (nr) { case 2: DGC(2); break; case 4: DGC(4); break; case 6: DGC(6); break; case 8: DGC(8); break; case 10: DGC(10); break; default: DGC(12); break; }
 #undef DGC
 }
-template <typename T> static void launch_degrain_cells(int nr, int W, dim3 grid, hipStream_t st, const DGParams *dP, const DGJob *dJ, const PlanRec *plan, int p0, int npl) {
+template <typename T> static void launch_degrain_cells(int nr, int W, dim3 grid, hipStream_t st, const DGParams *dP, const DGJob *dJ, const void *plan, int p0, int npl) {
     switch (W) {
     case 2: launch_degrain_cells_w<T, 2>(nr, grid, st, dP, dJ, plan, p0, npl); break;
     case 4: launch_degrain_cells_w<T, 4>(nr, grid, st, dP, dJ, plan, p0, npl); break;
@@ -729,7 +739,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_degrain_frames(mvx_deg
     int rc = finish_common(d);
     if (rc) return rc;
     const DGParams &P = d->P;
-    if ((rc = ensure_jobs(d, nframes, sizeof(PlanRec) * 2 * (size_t)P.nBlk))) return rc;
+    if ((rc = ensure_jobs(d, nframes, plan_rec_bytes(P.nRefs) * 2 * (size_t)P.nBlk))) return rc;
     std::vector<DGJob> hj(nframes);
     for (int f = 0; f < nframes; f++) {
         memset(&hj[f], 0, sizeof(DGJob));
@@ -741,7 +751,12 @@ extern "C" __attribute__((visibility("default"))) int mvx_degrain_frames(mvx_deg
     }
     HIP_CHECK(hipMemcpyAsync(d->dJobs, hj.data(), sizeof(DGJob) * nframes, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(usable_kernel, dim3(P.nRefs, nframes), dim3(256), 0, st, d->dP, d->dJobs, d->dUsable, 0);
-    hipLaunchKernelGGL(degrain_plan_kernel, dim3((P.nBlk + 255) / 256, nframes), dim3(256), 0, st, d->dP, d->dJobs, d->dUsable, (PlanRec *)d->dPlan);
+    {
+        const dim3 pg((P.nBlk + 255) / 256, nframes);
+#define DGP(N) hipLaunchKernelGGL(degrain_plan_kernel<N>, pg, dim3(256), 0, st, d->dP, d->dJobs, d->dUsable, (PlanRecT<N> *)d->dPlan)
+        switch (P.nRefs) { case 2: DGP(2); break; case 4: DGP(4); break; case 6: DGP(6); break; case 8: DGP(8); break; case 10: DGP(10); break; default: DGP(12); break; }
+#undef DGP
+    }
     // overlapped blocks with a power-of-two step: vectorised cell kernel, one launch per plane class; otherwise the
     // per-sample gather
     auto cellW = [&](int p) { const int w = P.pl[p].stepX; return (P.overlap && (w == 2 || w == 4 || w == 8 || w == 16)) ? w : 0; };
@@ -750,13 +765,13 @@ extern "C" __attribute__((visibility("default"))) int mvx_degrain_frames(mvx_deg
         for (int cls = 0; cls < (P.nplanes > 1 ? 2 : 1); cls++) {
             const int p0 = cls, npl = cls ? 2 : 1, W = cellW(p0);
             dim3 grid(((P.pl[p0].W + W - 1) / W + 31) / 32, (P.pl[p0].H + 7) / 8, nframes * npl);
-            if (P.bps == 1) launch_degrain_cells<uint8_t>(P.nRefs, W, grid, st, d->dP, d->dJobs, (const PlanRec *)d->dPlan, p0, npl);
-            else launch_degrain_cells<uint16_t>(P.nRefs, W, grid, st, d->dP, d->dJobs, (const PlanRec *)d->dPlan, p0, npl);
+            if (P.bps == 1) launch_degrain_cells<uint8_t>(P.nRefs, W, grid, st, d->dP, d->dJobs, d->dPlan, p0, npl);
+            else launch_degrain_cells<uint16_t>(P.nRefs, W, grid, st, d->dP, d->dJobs, d->dPlan, p0, npl);
         }
     } else {
         dim3 grid((P.pl[0].W + 63) / 64, (P.pl[0].H + 3) / 4, nframes * 3);
-        if (P.bps == 1) launch_degrain<uint8_t>(P.nRefs, grid, st, d->dP, d->dJobs, (const PlanRec *)d->dPlan);
-        else launch_degrain<uint16_t>(P.nRefs, grid, st, d->dP, d->dJobs, (const PlanRec *)d->dPlan);
+        if (P.bps == 1) launch_degrain<uint8_t>(P.nRefs, grid, st, d->dP, d->dJobs, d->dPlan);
+        else launch_degrain<uint16_t>(P.nRefs, grid, st, d->dP, d->dJobs, d->dPlan);
     }
     HIP_CHECK(hipGetLastError());
     return MVX_OK;
@@ -1123,7 +1138,8 @@ __global__ __launch_bounds__(256) void blockfps_rows_kernel(const DGParams *Pp, 
         // vertically interpolated values of up to three mask columns; columns further right (upsizing by less than CW) are done on demand
         auto vcol = [&](const unsigned char *mm, int o) { return (int)(unsigned char)((mm[rowOff + o] * wt + mm[rowOff + B.XP + o] * wb + 8192) >> 14); };
         auto upsize = [&](const unsigned char *mm, int *dst) {
-            const int a0 = vcol(mm, o0), a1 = vcol(mm, o0 + 1), a2 = vcol(mm, o0 + 2);
+            // (the third column is only used when a sample's left neighbour is o0 + 1; at the plane's right edge it does not exist: read o0 + 1 again)
+            const int a0 = vcol(mm, o0), a1 = vcol(mm, o0 + 1), a2 = vcol(mm, o0 + 2 < B.XP ? o0 + 2 : o0 + 1);
 #pragma unroll
             for (int i = 0; i < CW; i++) {
                 const int o = B.hOff[c][x + i], wr = B.hW[c][x + i], wl = 16384 - wr, k = o - o0;

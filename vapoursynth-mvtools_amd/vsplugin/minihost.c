@@ -185,7 +185,7 @@ static int VS_CC getFrameHeight(const VSFrame *f, int p) { return plane_h(f, p);
 /* ---------------------------------------------------------------------------------------------------- nodes */
 
 struct VSNode { int refs; VSVideoInfo vi; VSFilterGetFrame getFrame; VSFilterFree freeFn; void *inst; const VSFrame **cache; unsigned char *busy; char name[32]; };
-struct VSFrameContext { int n; struct { int n; VSNode *node; const VSFrame *f; } req[64]; int nreq; char error[1024]; };
+struct VSFrameContext { int n; struct { int n; VSNode *node; const VSFrame *f; } req[1024]; int nreq; char error[1024]; };
 
 static VSAPI g_api;
 static VSNode *node_addref(VSNode *n) { pthread_mutex_lock(&g_host_mu); n->refs++; pthread_mutex_unlock(&g_host_mu); return n; }
@@ -236,7 +236,7 @@ static const VSFrame *eval_frame(int n, VSNode *node, char *err, int errsz) {
 static const VSFrame *VS_CC getFrame(int n, VSNode *node, char *err, int sz) { return eval_frame(n, node, err, sz); }
 static void VS_CC requestFrameFilter(int n, VSNode *node, VSFrameContext *ctx) {
     for (int i = 0; i < ctx->nreq; i++) if (ctx->req[i].n == n && ctx->req[i].node == node) return;
-    if (ctx->nreq >= 64) { fprintf(stderr, "minihost: too many frame requests\n"); abort(); }
+    if (ctx->nreq >= 1024) { fprintf(stderr, "minihost: too many frame requests\n"); abort(); }
     ctx->req[ctx->nreq].n = n; ctx->req[ctx->nreq].node = node; ctx->req[ctx->nreq].f = NULL; ctx->nreq++;
 }
 static const VSFrame *VS_CC getFrameFilter(int n, VSNode *node, VSFrameContext *ctx) {
@@ -615,7 +615,12 @@ int main(int argc, char **argv) {
     const int times = getenv("MVX_HOST_TIMES") != NULL;
     double t0 = now_s();
     if (times) fprintf(stderr, "minihost: graph built at %.2f s after start\n", t0 - g_start);
-    if (threads > 1) { /* the vector clips first (all threads inside one Analyse instance at a time), then the output */
+    int frameOrder = 0; /* x.order=frame: the threads ask for OUTPUT frames only, as a client of a real core does (every upstream request is then made by the filters) */
+    for (int i = 0; i < nextra; i++) if (!strcmp(extra[i], "x.order=frame")) frameOrder = 1;
+    if (threads > 1 && frameOrder) {
+        prefetch_parallel(threads, nframes, &out, 1);
+        if (times) { fprintf(stderr, "minihost: output clip (frame order) %.2f s\n", now_s() - t0); t0 = now_s(); }
+    } else if (threads > 1) { /* the vector clips first (all threads inside one Analyse instance at a time), then the output */
         prefetch_parallel(threads, nframes, vec, 2 * R < 4 ? 2 * R : 4);
         if (2 * R > 4) prefetch_parallel(threads, nframes, vec + 4, 2 * R - 4 < 4 ? 2 * R - 4 : 4);
         if (2 * R > 8) prefetch_parallel(threads, nframes, vec + 8, 2 * R - 8);

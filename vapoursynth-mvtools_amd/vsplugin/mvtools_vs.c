@@ -38,10 +38,11 @@
 /* ------------------------------------------------------------------------------------------------ device frame cache */
 
 typedef struct DevFrame { int64_t id; void *arena; void *plane[3]; size_t bytes; int pins; uint64_t stamp; uint64_t print; } DevFrame;
-#define CACHE_MAX 1024
+#define CACHE_MAX 2048
 static DevFrame g_cache[CACHE_MAX];
-static int g_cache_cap = -1;
-static size_t g_cache_frame_bytes; /* size of the first super frame seen: the default capacity is a byte budget */
+static int g_cache_cap = -1;       /* entries (MVX_VS_CACHE_FRAMES), at most CACHE_MAX */
+static size_t g_cache_budget;      /* bytes the cached frames may hold together; 0 = not fixed yet */
+static size_t g_cache_bytes;       /* bytes they hold now */
 static uint64_t g_stamp = 1;
 static int64_t g_next_instance = 1;
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
@@ -85,23 +86,57 @@ static int timed_download(void *dst, ptrdiff_t dp, const void *src, ptrdiff_t sp
     return rc;
 }
 
-/* capacity in frames: MVX_VS_CACHE_FRAMES, or MVX_VS_CACHE_BYTES (default 48 GiB of the 288) / the size of a super frame.  It must
- * cover the frames a host has in flight (its thread count + twice the temporal radius): a frame that falls out is uploaded again,
- * 131 MB for 4K16, and a search that waits for uploads runs at PCIe speed. */
+/* The device cache is bounded in BYTES: MVX_VS_CACHE_BYTES, else 40 % of what the device has free when the first frame arrives (115 GB
+ * of an idle MI355X; less on a smaller or shared GPU) -- and in entries (MVX_VS_CACHE_FRAMES, CACHE_MAX).  The budget limits what is
+ * KEPT for later: frames somebody has pinned (a getFrame in progress, the windows of a look-ahead search) are held whatever it says,
+ * and unpinned ones are evicted least recently used first to make room.  It should cover the frames a host has in flight (its thread
+ * count + twice the temporal radius; with look-ahead two windows per vector clip): a frame that falls out is built or uploaded again.
+ * Super clips of different sizes share the budget; when a device allocation fails, unpinned entries are evicted before the shell gives
+ * up (shell_alloc). */
 static int cache_cap(void) {
     if (g_cache_cap < 0) {
-        const char *e = getenv("MVX_VS_CACHE_FRAMES"), *b = getenv("MVX_VS_CACHE_BYTES");
-        if (e) g_cache_cap = atoi(e);
-        else {
-            if (!g_cache_frame_bytes) return 16; /* (not fixed yet: no frame seen) */
-            const double budget = b ? atof(b) : 48.0 * 1024 * 1024 * 1024;
-            g_cache_cap = (int)(budget / (double)g_cache_frame_bytes);
-            if (g_cache_cap < 16) g_cache_cap = 16;
-        }
+        const char *e = getenv("MVX_VS_CACHE_FRAMES");
+        g_cache_cap = e ? atoi(e) : CACHE_MAX;
         if (g_cache_cap > CACHE_MAX) g_cache_cap = CACHE_MAX;
         if (g_cache_cap < 0) g_cache_cap = 0;
     }
     return g_cache_cap;
+}
+static size_t cache_budget(void) { /* g_lock held */
+    if (!g_cache_budget) {
+        const char *b = getenv("MVX_VS_CACHE_BYTES");
+        double budget = b ? atof(b) : 48.0 * 1024 * 1024 * 1024;
+        size_t fr = 0, tot = 0;
+        if (!b && mvx_dev_mem_info(&fr, &tot) == 0) budget = 0.4 * (double)fr;
+        g_cache_budget = budget < 1.0 ? 1 : (size_t)budget;
+    }
+    return g_cache_budget;
+}
+/* drops the least recently used unpinned entry; returns its arena (the caller frees it outside the lock) or NULL.  g_lock held. */
+static void *cache_evict_lru_locked(void) {
+    DevFrame *v = NULL;
+    for (int i = 0; i < cache_cap(); i++) {
+        DevFrame *e = &g_cache[i];
+        if (e->arena && e->pins == 0 && (!v || e->stamp < v->stamp)) v = e;
+    }
+    if (!v) return NULL;
+    void *a = v->arena;
+    v->arena = NULL; g_cache_bytes -= v->bytes; v->bytes = 0;
+    return a;
+}
+/* device memory for the shell: on failure the free list of the pool and then unpinned cache entries make room */
+static void *shell_alloc(size_t bytes) {
+    void *p = mvx_dev_alloc_uninit(bytes);
+    while (!p) {
+        pthread_mutex_lock(&g_lock);
+        void *victim = cache_evict_lru_locked();
+        pthread_mutex_unlock(&g_lock);
+        if (!victim) break;
+        mvx_dev_free(victim);
+        mvx_dev_pool_trim(); /* the victim has another size: give it back to the driver */
+        p = mvx_dev_alloc_uninit(bytes);
+    }
+    return p;
 }
 
 /* geometry of a super frame on the device: one arena per frame, planes at 256-byte pitches */
@@ -147,43 +182,57 @@ static uint64_t frame_print(const VSFrame *f, const SuperGeo *g, const VSAPI *vs
     return h;
 }
 
-/* returns a pinned cache entry holding frame `id` with that fingerprint, or NULL */
-static DevFrame *cache_find(int64_t id, uint64_t print) {
+/* returns a pinned cache entry holding frame `id` with that fingerprint, or NULL.  any_print: entries are trusted by id alone
+ * (the caller knows that the frames of this id range come straight from this plugin's mv.Super: look-ahead, superGetFrame) */
+static DevFrame *cache_find_ex(int64_t id, uint64_t print, int any_print) {
     DevFrame *r = NULL;
     pthread_mutex_lock(&g_lock);
     for (int i = 0; i < cache_cap(); i++)
-        if (g_cache[i].arena && g_cache[i].id == id && g_cache[i].print == print) { r = &g_cache[i]; r->pins++; r->stamp = g_stamp++; break; }
+        if (g_cache[i].arena && g_cache[i].id == id && (any_print || g_cache[i].print == print)) { r = &g_cache[i]; r->pins++; r->stamp = g_stamp++; break; }
     pthread_mutex_unlock(&g_lock);
     return r;
 }
+static DevFrame *cache_find(int64_t id, uint64_t print) { return cache_find_ex(id, print, 0); }
 /* drops the unpinned entries of one mv.Super instance (its free callback) */
 static void cache_evict_instance(int64_t instance) {
     void *victims[CACHE_MAX];
     int nv = 0;
     pthread_mutex_lock(&g_lock);
     for (int i = 0; i < cache_cap(); i++)
-        if (g_cache[i].arena && (g_cache[i].id >> 32) == instance && g_cache[i].pins == 0) { victims[nv++] = g_cache[i].arena; g_cache[i].arena = NULL; }
+        if (g_cache[i].arena && (g_cache[i].id >> 32) == instance && g_cache[i].pins == 0) { victims[nv++] = g_cache[i].arena; g_cache[i].arena = NULL; g_cache_bytes -= g_cache[i].bytes; g_cache[i].bytes = 0; }
     pthread_mutex_unlock(&g_lock);
     for (int i = 0; i < nv; i++) mvx_dev_free(victims[i]);
 }
-/* hands a freshly filled arena to the cache (pinned); returns NULL if the cache is full of pinned frames / disabled */
+/* hands a freshly filled arena to the cache (pinned); returns NULL if the cache is full of pinned frames / disabled.  Entries are
+ * evicted least recently used first until the new frame fits the byte budget. */
 static DevFrame *cache_insert(int64_t id, uint64_t print, void *arena, const SuperGeo *g) {
     DevFrame *slot = NULL;
-    void *victim = NULL;
+    void *victims[CACHE_MAX];
+    int nv = 0;
     pthread_mutex_lock(&g_lock);
-    if (!g_cache_frame_bytes) g_cache_frame_bytes = g->bytes;
-    for (int i = 0; i < cache_cap(); i++) {
+    const size_t budget = cache_budget();
+    for (int i = 0; i < cache_cap(); i++) { /* a stale unpinned copy of the same frame goes first */
         DevFrame *e = &g_cache[i];
-        if (!e->arena) { slot = e; break; }
-        if (e->pins == 0 && (e->id == id || !slot || e->stamp < slot->stamp)) { slot = e; if (e->id == id) break; } /* (a stale copy of the same frame goes first) */
+        if (e->arena && e->id == id && e->pins == 0) { victims[nv++] = e->arena; e->arena = NULL; g_cache_bytes -= e->bytes; e->bytes = 0; }
+    }
+    while (g_cache_bytes + g->bytes > budget) {
+        void *v = cache_evict_lru_locked();
+        if (!v) break;
+        victims[nv++] = v;
+    }
+    /* (still over the budget: everything left is pinned, i.e. needed right now -- the new frame is kept all the same) */
+    for (int i = 0; i < cache_cap(); i++) if (!g_cache[i].arena) { slot = &g_cache[i]; break; }
+    if (!slot && cache_cap() > 0) { /* every entry in use: recycle the least recently used unpinned one */
+        void *v = cache_evict_lru_locked();
+        if (v) { victims[nv++] = v; for (int i = 0; i < cache_cap(); i++) if (!g_cache[i].arena) { slot = &g_cache[i]; break; } }
     }
     if (slot) {
-        victim = slot->arena;
         slot->id = id; slot->print = print; slot->arena = arena; slot->bytes = g->bytes; slot->pins = 1; slot->stamp = g_stamp++;
+        g_cache_bytes += g->bytes;
         for (int p = 0; p < 3; p++) slot->plane[p] = p < g->si.num_planes ? (char *)arena + g->off[p] : NULL;
     }
     pthread_mutex_unlock(&g_lock);
-    if (victim) mvx_dev_free(victim);
+    for (int i = 0; i < nv; i++) mvx_dev_free(victims[i]);
     return slot;
 }
 static void cache_unpin(DevFrame *e) {
@@ -205,7 +254,7 @@ static int super_to_device(DevRef *r, const VSFrame *f, const SuperGeo *g, const
         for (int p = 0; p < 3; p++) r->plane[p] = r->cached->plane[p];
         return 0;
     }
-    void *arena = mvx_dev_alloc_uninit(g->bytes);
+    void *arena = shell_alloc(g->bytes);
     if (!arena) return MVX_E_NOMEM;
     void *st = thread_stream();
     int rc = mvx_dev_memset(arena, 0, g->bytes, st); /* zero-filled like the frames mv.Super builds (pitch padding) */
@@ -360,7 +409,7 @@ static int blob_to_device(void **dblob, int *size, const mvx_analysis_data *ad, 
         for (int i = ad->nLvCount - 1; i >= 1 && off < n; i--) { int psz; memcpy(&psz, blob + off, sizeof(psz)); off += psz; }
         if (planes < ad->nLvCount || off > lastOff || n - off < 4 + ad->nBlkX * ad->nBlkY * 16) return MVX_E_ARG;
     }
-    *dblob = mvx_dev_alloc_uninit((size_t)n);
+    *dblob = shell_alloc((size_t)n);
     if (!*dblob) return MVX_E_NOMEM;
     if (timed_upload(*dblob, n, blob, n, (size_t)n, 1)) return MVX_E_DEVICE; /* complete on return: the prop memory goes away with the frame */
     if (size) *size = n;
@@ -372,7 +421,7 @@ static int blob_to_device(void **dblob, int *size, const mvx_analysis_data *ad, 
 static int upload_plane_set(void *dst[3], void **arena, const VSFrame *f, const ptrdiff_t pitch[3], int nplanes, int bps, const VSAPI *vs) {
     size_t off[3], total = 0;
     for (int p = 0; p < nplanes; p++) { off[p] = total; total += (size_t)pitch[p] * vs->getFrameHeight(f, p); }
-    *arena = mvx_dev_alloc_uninit(total);
+    *arena = shell_alloc(total);
     for (int p = 0; p < 3; p++) dst[p] = NULL;
     if (!*arena) return MVX_E_NOMEM;
     int rc = 0;
@@ -387,6 +436,90 @@ static int upload_plane_set(void *dst[3], void **arena, const VSFrame *f, const 
 
 typedef struct SuperData { VSNode *node, *pelclip; VSVideoInfo vi; mvx_super *sup; SuperGeo geo; ptrdiff_t srcPitch[3], pelPitch[3]; int32_t pelMode; int64_t instance; } SuperData;
 
+/* The output nodes of this plugin's own mv.Super filters.  A consumer whose `super` argument IS one of them (pointer identity: no
+ * filter in between that could have changed pixels while copying the props) may build the super frames it needs on the device itself
+ * from the 5x smaller SOURCE frames -- what mv.Analyse's look-ahead does -- and trust cached device frames by their id alone. */
+#define SUPER_REG_MAX 64
+static struct { VSNode *out; struct SuperData *d; } g_supers[SUPER_REG_MAX];
+static void super_register(VSNode *out, SuperData *d) {
+    pthread_mutex_lock(&g_lock);
+    for (int i = 0; i < SUPER_REG_MAX; i++) if (!g_supers[i].out) { g_supers[i].out = out; g_supers[i].d = d; break; }
+    pthread_mutex_unlock(&g_lock);
+}
+static void super_unregister(SuperData *d) {
+    pthread_mutex_lock(&g_lock);
+    for (int i = 0; i < SUPER_REG_MAX; i++) if (g_supers[i].d == d) { g_supers[i].out = NULL; g_supers[i].d = NULL; }
+    pthread_mutex_unlock(&g_lock);
+}
+static SuperData *super_lookup(VSNode *out) {
+    SuperData *d = NULL;
+    pthread_mutex_lock(&g_lock);
+    for (int i = 0; i < SUPER_REG_MAX; i++) if (g_supers[i].out == out) d = g_supers[i].d;
+    pthread_mutex_unlock(&g_lock);
+    return d;
+}
+/* builds the device super frames of `n` SOURCE frames in one batch (uploads, then one mvx_super_frames_shadow call) and hands them
+ * to the cache, pinned; frames that are cached already are only pinned.  out[i] = the pinned entry of frame nums[i].  One builder at a
+ * time: six vector clips ask for the same frames.  Returns 0 or an MVX_E_* code (entries pinned so far are released on failure). */
+static pthread_mutex_t g_build_mu = PTHREAD_MUTEX_INITIALIZER;
+static int super_build_device(SuperData *sd, int n, const int *nums, const VSFrame *const *srcs, DevFrame **out, const VSAPI *vs) {
+    const SuperGeo *g = &sd->geo;
+    int rc = 0, nmiss = 0;
+    pthread_mutex_lock(&g_build_mu);
+    int *miss = (int *)malloc(sizeof(int) * (size_t)n);
+    void **srcArena = (void **)calloc((size_t)n, sizeof(void *)), **arena = (void **)calloc((size_t)n, sizeof(void *));
+    const void **sp = (const void **)calloc((size_t)n * 3, sizeof(void *));
+    void **dp = (void **)calloc((size_t)n * 3, sizeof(void *));
+    if (!miss || !srcArena || !arena || !sp || !dp) rc = MVX_E_NOMEM;
+    for (int i = 0; i < n; i++) out[i] = NULL;
+    for (int i = 0; i < n && !rc; i++) {
+        out[i] = cache_find_ex((sd->instance << 32) | (uint32_t)nums[i], 0, 1);
+        if (!out[i]) miss[nmiss++] = i;
+    }
+    void *st = thread_stream();
+    const double tp = prof_now();
+    for (int k = 0; k < nmiss && !rc; k++) {
+        const int i = miss[k];
+        void *d3[3];
+        rc = upload_plane_set(d3, &srcArena[k], srcs[i], sd->srcPitch, g->si.num_planes, g->bps, vs);
+        for (int p = 0; p < 3; p++) sp[k * 3 + p] = d3[p];
+        if (!rc && !(arena[k] = shell_alloc(g->bytes))) rc = MVX_E_NOMEM;
+        if (!rc) rc = mvx_dev_memset(arena[k], 0, g->bytes, st);
+        for (int p = 0; p < g->si.num_planes && !rc; p++) dp[k * 3 + p] = (char *)arena[k] + g->off[p];
+    }
+    if (!rc && nmiss) {
+        if (g->copies > 1) rc = mvx_super_frames_shadow(sd->sup, nmiss, sp, sd->srcPitch, dp, g->pitch, g->shadowStride, st);
+        else rc = mvx_super_frames(sd->sup, nmiss, sp, sd->srcPitch, dp, g->pitch, st);
+    }
+    if (!rc && nmiss) rc = mvx_stream_sync(st);
+    prof_add(PF_SUPER, tp);
+    for (int k = 0; k < nmiss; k++) {
+        if (srcArena && srcArena[k]) mvx_dev_free(srcArena[k]);
+        if (!rc) {
+            const int i = miss[k];
+            out[i] = cache_insert((sd->instance << 32) | (uint32_t)nums[i], 0, arena[k], g); /* (print 0: superGetFrame fills it in when it hands the host frame out) */
+            if (!out[i]) { rc = MVX_E_NOMEM; mvx_dev_free(arena[k]); }
+        } else if (arena && arena[k]) mvx_dev_free(arena[k]);
+    }
+    if (rc) for (int i = 0; i < n; i++) if (out[i]) { cache_unpin(out[i]); out[i] = NULL; }
+    free(miss); free(srcArena); free(arena); free(sp); free(dp);
+    pthread_mutex_unlock(&g_build_mu);
+    return rc;
+}
+
+static void super_frame_props(VSFrame *dst, int n, int64_t id, const SuperGeo *g, const VSAPI *vs) {
+    VSMap *props = vs->getFramePropertiesRW(dst);
+    if (n == 0) { /* src/MVSuper.c:111-120 */
+        vs->mapSetInt(props, "Super_height", g->si.height, maReplace);
+        vs->mapSetInt(props, "Super_hpad", g->si.hpad, maReplace);
+        vs->mapSetInt(props, "Super_vpad", g->si.vpad, maReplace);
+        vs->mapSetInt(props, "Super_pel", g->si.pel, maReplace);
+        vs->mapSetInt(props, "Super_modeyuv", g->si.modeYUV, maReplace);
+        vs->mapSetInt(props, "Super_levels", g->si.levels, maReplace);
+    }
+    vs->mapSetInt(props, PROP_SUPER_ID, id, maReplace); /* (harmless extra prop; frames without it are uploaded by the consumers) */
+}
+
 static const VSFrame *VS_CC superGetFrame(int n, int reason, void *inst, void **fd, VSFrameContext *ctx, VSCore *core, const VSAPI *vs) {
     (void)fd;
     SuperData *d = (SuperData *)inst;
@@ -398,13 +531,28 @@ static const VSFrame *VS_CC superGetFrame(int n, int reason, void *inst, void **
     if (reason != arAllFramesReady) return NULL;
     const VSFrame *src = vs->getFrameFilter(n, d->node, ctx);
     const SuperGeo *g = &d->geo;
+    const int64_t id = (d->instance << 32) | (uint32_t)n;
+    DevFrame *have = d->pelMode ? NULL : cache_find_ex(id, 0, 1); /* built on the device already (a vector clip's look-ahead): only the download is left */
+    if (have) {
+        int rc2 = 0;
+        VSFrame *dst2 = vs->newVideoFrame(&d->vi.format, d->vi.width, d->vi.height, src, core);
+        for (int p = 0; p < g->si.num_planes && !rc2; p++)
+            rc2 = timed_download(vs->getWritePtr(dst2, p), vs->getStride(dst2, p), have->plane[p], g->pitch[p], (size_t)g->si.plane_width[p] * g->bps, (size_t)g->si.plane_height[p]);
+        vs->freeFrame(src);
+        if (rc2) { cache_unpin(have); vs->freeFrame(dst2); vs->setFilterError(mvx_last_error(), ctx); return NULL; }
+        super_frame_props(dst2, n, id, g, vs);
+        const uint64_t pr = frame_print(dst2, g, vs);
+        pthread_mutex_lock(&g_lock); have->print = pr; pthread_mutex_unlock(&g_lock);
+        cache_unpin(have);
+        return dst2;
+    }
     void *srcArena = NULL, *pelArena = NULL, *dsrc[3], *dpel[3] = { NULL, NULL, NULL }, *ddst[3] = { NULL, NULL, NULL };
     int rc = upload_plane_set(dsrc, &srcArena, src, d->srcPitch, g->si.num_planes, g->bps, vs);
     const VSFrame *pf = d->pelMode ? vs->getFrameFilter(n, d->pelclip, ctx) : NULL; /* src/MVSuper.c:62-64 */
     if (pf && !rc) rc = upload_plane_set(dpel, &pelArena, pf, d->pelPitch, g->si.num_planes, g->bps, vs);
     void *st = thread_stream();
     double tp = prof_now();
-    void *arena = rc ? NULL : mvx_dev_alloc_uninit(g->bytes);
+    void *arena = rc ? NULL : shell_alloc(g->bytes);
     prof_add(PF_ALLOC, tp);
     tp = prof_now();
     if (!rc && !arena) rc = MVX_E_NOMEM;
@@ -437,18 +585,8 @@ static const VSFrame *VS_CC superGetFrame(int n, int reason, void *inst, void **
         vs->setFilterError(mvx_last_error(), ctx);
         return NULL;
     }
-    VSMap *props = vs->getFramePropertiesRW(dst);
-    if (n == 0) { /* src/MVSuper.c:111-120 */
-        vs->mapSetInt(props, "Super_height", g->si.height, maReplace);
-        vs->mapSetInt(props, "Super_hpad", g->si.hpad, maReplace);
-        vs->mapSetInt(props, "Super_vpad", g->si.vpad, maReplace);
-        vs->mapSetInt(props, "Super_pel", g->si.pel, maReplace);
-        vs->mapSetInt(props, "Super_modeyuv", g->si.modeYUV, maReplace);
-        vs->mapSetInt(props, "Super_levels", g->si.levels, maReplace);
-    }
-    /* the device copy stays resident for the consumers (harmless extra prop; frames without it are uploaded) */
-    const int64_t id = (d->instance << 32) | (uint32_t)n;
-    vs->mapSetInt(props, PROP_SUPER_ID, id, maReplace);
+    super_frame_props(dst, n, id, g, vs);
+    /* the device copy stays resident for the consumers */
     DevFrame *e = cache_insert(id, frame_print(dst, g, vs), arena, g);
     if (e) cache_unpin(e); else mvx_dev_free(arena);
     return dst;
@@ -459,6 +597,7 @@ static void VS_CC superFree(void *inst, VSCore *core, const VSAPI *vs) {
     SuperData *d = (SuperData *)inst;
     vs->freeNode(d->node);
     if (d->pelclip) vs->freeNode(d->pelclip);
+    super_unregister(d);
     cache_evict_instance(d->instance); /* its device-resident frames are of no use to anybody now */
     mvx_super_destroy(d->sup);
     free(d);
@@ -520,6 +659,11 @@ static void VS_CC superCreate(const VSMap *in, VSMap *out, void *user, VSCore *c
     pthread_mutex_unlock(&g_lock);
     VSFilterDependency deps[2] = { { node, rpStrictSpatial }, { pelclip, rpStrictSpatial } };
     vs->createVideoFilter(out, "Super", &d->vi, superGetFrame, superFree, fmParallel, deps, pelMode ? 2 : 1, d, core);
+    { /* remember the node the core made for this instance (identity only: no reference is kept) */
+        int e = 0;
+        VSNode *o = vs->mapGetNode(out, "clip", 0, &e);
+        if (o && !e) { super_register(o, d); vs->freeNode(o); }
+    }
 }
 
 /* ------------------------------------------------------------------------------------------------ mv.Analyse */
@@ -539,7 +683,21 @@ typedef struct Combiner {
     long batches, jobs, largest; /* statistics (MVX_VS_STATS=1 prints them when the filter is freed) */
 } Combiner;
 
-typedef struct AnalyseData { VSNode *node; const VSVideoInfo *vi; mvx_super *sup; SuperGeo geo; mvx_analyse *an; mvx_analysis_data ad; int blobSize; FieldOpt fo; Combiner cb; } AnalyseData;
+/* Look-ahead (mv.Analyse whose `super` argument is this plugin's own mv.Super node).  A search is a serial chain per frame that
+ * takes ~0.45 s at 4K however few chains a launch carries, so a vector clip is computed a WINDOW of B consecutive
+ * frames at a time: the first request that touches window w also asks for the SOURCE frames (25 MB each at 4K16, not the 131 MB
+ * super frames) of w and of w + 1, builds their super frames on the device only, and launches one search per window on the instance's
+ * low-priority streams; window w + 1 runs while the frames of w are being consumed.  Every other request of the window just waits
+ * for the launch that is already running (GPU work only: nothing it waits for needs a host worker thread) and copies its blob out
+ * of the window's host array.  The request protocol stays the reference's (MVAnalyse.c:84-113: everything a frame needs is asked
+ * for at arInitial and fetched at arAllFramesReady); the extra requests go to the source clip, declared as a second dependency. */
+#define LA_SLOTS 4
+enum { LW_EMPTY, LW_BUILDING, LW_LAUNCHED, LW_SYNCING, LW_READY, LW_FAILED };
+typedef struct LaWindow { int w, state, first, count, users, rc; char *blobs; void *dblobs; size_t dstride; DevFrame **pins; int npins; void *stream; } LaWindow;
+typedef struct LookAhead { int on, B; VSNode *srcNode; SuperData *sd; pthread_mutex_t mu; pthread_cond_t cv; LaWindow win[LA_SLOTS]; } LookAhead;
+typedef struct LaReq { int legacy, w, hold[2], want[2]; } LaReq;
+
+typedef struct AnalyseData { VSNode *node; const VSVideoInfo *vi; mvx_super *sup; SuperGeo geo; mvx_analyse *an; mvx_analysis_data ad; int blobSize; FieldOpt fo; Combiner cb; LookAhead la; } AnalyseData;
 
 static long env_long(const char *name, long def) { const char *e = getenv(name); return e ? atol(e) : def; }
 
@@ -639,11 +797,188 @@ static int analyse_nref(const AnalyseData *d, int n) { /* src/MVAnalyse.c:84-104
     return -d->ad.nDeltaFrame;
 }
 
+/* ---- look-ahead helpers (d->la.mu held where noted) */
+static void la_window_release(LaWindow *s) { /* frees what a finished / failed window holds; the slot becomes EMPTY */
+    for (int i = 0; i < s->npins; i++) cache_unpin(s->pins[i]);
+    free(s->pins); s->pins = NULL; s->npins = 0;
+    if (s->dblobs) { mvx_dev_free(s->dblobs); s->dblobs = NULL; }
+    free(s->blobs); s->blobs = NULL;
+    s->state = LW_EMPTY; s->count = 0; s->rc = 0;
+}
+/* the slot of window w, recycled from an older finished window if nobody uses it; NULL if it is taken.  mu held. */
+static LaWindow *la_slot(AnalyseData *d, int w) {
+    LaWindow *s = &d->la.win[w % LA_SLOTS];
+    if (s->w == w) return s;
+    if (s->users || s->state == LW_BUILDING || s->state == LW_LAUNCHED || s->state == LW_SYNCING) return NULL;
+    la_window_release(s);
+    s->w = w;
+    return s;
+}
+/* source frames window v needs: [*lo, *hi] and, for a static reference (delta <= 0), the frame *fixed (else -1) */
+static void la_inputs(const AnalyseData *d, int v, int *lo, int *hi, int *fixed) {
+    const int first = v * d->la.B, last = (first + d->la.B < d->vi->numFrames ? first + d->la.B : d->vi->numFrames) - 1;
+    *lo = first; *hi = last; *fixed = -1;
+    if (d->ad.nDeltaFrame > 0) {
+        if (d->ad.isBackward) { const int h = last + d->ad.nDeltaFrame; *hi = h < d->vi->numFrames ? h : d->vi->numFrames - 1; }
+        else { const int l = first - d->ad.nDeltaFrame; *lo = l > 0 ? l : 0; }
+    } else if (-d->ad.nDeltaFrame < d->vi->numFrames) *fixed = -d->ad.nDeltaFrame;
+}
+static void la_request_inputs(const AnalyseData *d, int v, VSFrameContext *ctx, const VSAPI *vs) {
+    int lo, hi, fixed;
+    la_inputs(d, v, &lo, &hi, &fixed);
+    for (int k = lo; k <= hi; k++) vs->requestFrameFilter(k, d->la.srcNode, ctx);
+    if (fixed >= 0 && (fixed < lo || fixed > hi)) vs->requestFrameFilter(fixed, d->la.srcNode, ctx);
+}
+static int analyse_nref(const AnalyseData *d, int n);
+/* builds the super frames of window v on the device and enqueues its search (does not wait for it) */
+static int la_launch(AnalyseData *d, LaWindow *s, int v, VSFrameContext *ctx, const VSAPI *vs) {
+    int lo, hi, fixed;
+    la_inputs(d, v, &lo, &hi, &fixed);
+    const int first = v * d->la.B, count = (first + d->la.B < d->vi->numFrames ? first + d->la.B : d->vi->numFrames) - first;
+    const int extra = fixed >= 0 && (fixed < lo || fixed > hi);
+    const int nn = hi - lo + 1 + extra;
+    int *nums = (int *)malloc(sizeof(int) * (size_t)nn), *top = (int *)calloc((size_t)nn, sizeof(int));
+    const VSFrame **srcs = (const VSFrame **)calloc((size_t)nn, sizeof(VSFrame *));
+    DevFrame **pins = (DevFrame **)calloc((size_t)nn, sizeof(DevFrame *));
+    mvx_analyse_job *jobs = (mvx_analyse_job *)calloc((size_t)count, sizeof(mvx_analyse_job));
+    int rc = (!nums || !top || !srcs || !pins || !jobs) ? MVX_E_NOMEM : 0, missing = 0;
+    for (int i = 0; i < nn && !rc; i++) {
+        nums[i] = i < hi - lo + 1 ? lo + i : fixed;
+        srcs[i] = vs->getFrameFilter(nums[i], d->la.srcNode, ctx);
+        if (!srcs[i]) { rc = MVX_E_ARG; break; }
+        top[i] = frame_top_field(&d->fo, srcs[i], nums[i], &missing, vs); /* mv.Super copies the props of its source frame (MVSuper.c:104) */
+    }
+    if (!rc && missing && d->fo.fields) rc = -1000; /* reported by the caller with the reference's message */
+    if (!rc) rc = super_build_device(d->la.sd, nn, nums, srcs, pins, vs);
+    for (int i = 0; i < nn; i++) if (srcs && srcs[i]) vs->freeFrame(srcs[i]);
+    const size_t stride = ((size_t)d->blobSize + 255) / 256 * 256;
+    void *dblobs = rc ? NULL : shell_alloc(stride * (size_t)count);
+    char *blobs = rc ? NULL : (char *)malloc((size_t)d->blobSize * (size_t)count);
+    if (!rc && (!dblobs || !blobs)) rc = MVX_E_NOMEM;
+    if (!rc) {
+        for (int i = 0; i < count; i++) {
+            const int k = first + i, nref = analyse_nref(d, k);
+            const int haveRef = nref >= 0 && nref < d->vi->numFrames;
+            const int is = k - lo, ir = !haveRef ? -1 : (nref >= lo && nref <= hi) ? nref - lo : nn - 1;
+            for (int p = 0; p < 3; p++) { jobs[i].src[p] = pins[is]->plane[p]; jobs[i].ref[p] = haveRef ? pins[ir]->plane[p] : NULL; }
+            jobs[i].blob = (char *)dblobs + stride * (size_t)i;
+            jobs[i].field_shift = (haveRef && d->fo.fields && d->ad.nPel > 1 && (d->ad.nDeltaFrame % 2)) ? field_shift_of(top[is], top[ir], d->ad.nPel) : 0;
+        }
+        s->stream = d->cb.stream[v & 3];
+        rc = mvx_analyse_frames(d->an, count, jobs, s->stream);
+        pthread_mutex_lock(&g_lock);
+        g_stat_launches++; g_stat_jobs += count; if (count > g_stat_largest) g_stat_largest = count;
+        pthread_mutex_unlock(&g_lock);
+    }
+    if (rc) {
+        for (int i = 0; i < nn; i++) if (pins && pins[i]) cache_unpin(pins[i]);
+        free(pins); free(blobs);
+        if (dblobs) mvx_dev_free(dblobs);
+    } else { s->pins = pins; s->npins = nn; s->dblobs = dblobs; s->dstride = stride; s->blobs = blobs; s->first = first; s->count = count; }
+    free(nums); free(top); free(srcs); free(jobs);
+    return rc;
+}
+/* waits until window s is READY (or FAILED): the first waiter synchronises the window's stream and brings its blobs to the host */
+static int la_wait(AnalyseData *d, LaWindow *s) {
+    pthread_mutex_lock(&d->la.mu);
+    for (;;) {
+        if (s->state == LW_READY || s->state == LW_FAILED || s->state == LW_EMPTY) break;
+        if (s->state == LW_LAUNCHED) {
+            s->state = LW_SYNCING;
+            pthread_mutex_unlock(&d->la.mu);
+            const double t0 = prof_now();
+            int rc = mvx_stream_sync(s->stream);
+            prof_add(PF_SEARCH_WAIT, t0);
+            if (!rc) rc = timed_download(s->blobs, d->blobSize, s->dblobs, (ptrdiff_t)s->dstride, (size_t)d->blobSize, (size_t)s->count);
+            pthread_mutex_lock(&d->la.mu);
+            for (int i = 0; i < s->npins; i++) cache_unpin(s->pins[i]);
+            free(s->pins); s->pins = NULL; s->npins = 0;
+            mvx_dev_free(s->dblobs); s->dblobs = NULL;
+            s->rc = rc; s->state = rc ? LW_FAILED : LW_READY;
+            pthread_cond_broadcast(&d->la.cv);
+            continue;
+        }
+        pthread_cond_wait(&d->la.cv, &d->la.mu); /* BUILDING / SYNCING: somebody is on it */
+    }
+    const int rc = s->state == LW_READY ? 0 : (s->rc ? s->rc : MVX_E_DEVICE);
+    pthread_mutex_unlock(&d->la.mu);
+    return rc;
+}
+static void la_release_req(AnalyseData *d, LaReq *r) {
+    if (!r) return;
+    if (!r->legacy) {
+        pthread_mutex_lock(&d->la.mu);
+        for (int i = 0; i < 2; i++) if (r->hold[i]) d->la.win[(r->w + i) % LA_SLOTS].users--;
+        pthread_mutex_unlock(&d->la.mu);
+    }
+    free(r);
+}
+
 static const VSFrame *VS_CC analyseGetFrame(int n, int reason, void *inst, void **fd, VSFrameContext *ctx, VSCore *core, const VSAPI *vs) {
-    (void)fd;
     AnalyseData *d = (AnalyseData *)inst;
     const int nref = analyse_nref(d, n);
     const int haveRef = nref >= 0 && nref < d->vi->numFrames;
+    if (d->la.on) {
+        if (reason == arInitial) {
+            LaReq *r = (LaReq *)calloc(1, sizeof(LaReq));
+            *fd = r;
+            if (r) {
+                r->w = n / d->la.B;
+                pthread_mutex_lock(&d->la.mu);
+                LaWindow *s0 = la_slot(d, r->w);
+                if (!s0) r->legacy = 1;
+                else {
+                    s0->users++; r->hold[0] = 1; r->want[0] = s0->state == LW_EMPTY;
+                    if ((r->w + 1) * d->la.B < d->vi->numFrames) {
+                        LaWindow *s1 = la_slot(d, r->w + 1);
+                        if (s1 && s1->state == LW_EMPTY) { s1->users++; r->hold[1] = 1; r->want[1] = 1; }
+                    }
+                }
+                pthread_mutex_unlock(&d->la.mu);
+                if (!r->legacy) {
+                    vs->requestFrameFilter(n, d->node, ctx); /* the vector clip's frame is a copy of the super frame (MVAnalyse.c:224) */
+                    for (int i = 0; i < 2; i++) if (r->want[i]) la_request_inputs(d, r->w + i, ctx, vs);
+                    return NULL;
+                }
+            }
+            /* (no slot / no memory: this request takes the per-frame path below) */
+        } else if (*fd && !((LaReq *)*fd)->legacy) {
+            LaReq *r = (LaReq *)*fd;
+            *fd = NULL;
+            if (reason != arAllFramesReady) { la_release_req(d, r); return NULL; } /* arError */
+            int rc = 0;
+            for (int i = 0; i < 2 && !rc; i++) {
+                if (!r->want[i]) continue;
+                LaWindow *s = &d->la.win[(r->w + i) % LA_SLOTS];
+                int mine = 0;
+                pthread_mutex_lock(&d->la.mu);
+                if (s->state == LW_EMPTY) { s->state = LW_BUILDING; mine = 1; }
+                pthread_mutex_unlock(&d->la.mu);
+                if (!mine) continue;
+                const int lrc = la_launch(d, s, r->w + i, ctx, vs);
+                pthread_mutex_lock(&d->la.mu);
+                s->rc = lrc; s->state = lrc ? LW_FAILED : LW_LAUNCHED;
+                pthread_cond_broadcast(&d->la.cv);
+                pthread_mutex_unlock(&d->la.mu);
+                if (lrc && i == 0) rc = lrc;
+            }
+            LaWindow *s = &d->la.win[r->w % LA_SLOTS];
+            if (!rc) rc = la_wait(d, s);
+            const VSFrame *src = vs->getFrameFilter(n, d->node, ctx);
+            VSFrame *dst = NULL;
+            if (!rc && src) { /* src/MVAnalyse.c:224-239 */
+                dst = vs->copyFrame(src, core);
+                VSMap *props = vs->getFramePropertiesRW(dst);
+                vs->mapSetData(props, PROP_ADATA, (const char *)&d->ad, sizeof(d->ad), dtBinary, maReplace);
+                vs->mapSetData(props, PROP_VECTORS, s->blobs + (size_t)(n - s->first) * (size_t)d->blobSize, d->blobSize, dtBinary, maReplace);
+            } else
+                vs->setFilterError(rc == -1000 ? "Analyse: _Field property not found in input frame. Therefore, you must pass tff argument." :
+                                   rc == MVX_E_NOMEM ? "Analyse: out of memory." : mvx_last_error(), ctx);
+            if (src) vs->freeFrame(src);
+            la_release_req(d, r);
+            return dst;
+        } else if (*fd) { free(*fd); *fd = NULL; }
+    }
     if (reason == arInitial) {
         if (haveRef && nref < n) vs->requestFrameFilter(nref, d->node, ctx);
         vs->requestFrameFilter(n, d->node, ctx);
@@ -670,7 +1005,7 @@ static const VSFrame *VS_CC analyseGetFrame(int n, int reason, void *inst, void 
     memset(&dr, 0, sizeof(dr));
     int rc = super_to_device(&ds, src, &d->geo, vs);
     if (!rc && ref) rc = super_to_device(&dr, ref, &d->geo, vs);
-    void *dblob = rc ? NULL : mvx_dev_alloc_uninit((size_t)d->blobSize);
+    void *dblob = rc ? NULL : shell_alloc((size_t)d->blobSize);
     char *blob = (char *)malloc((size_t)d->blobSize);
     if (!rc && (!dblob || !blob)) rc = MVX_E_NOMEM;
     if (!rc) {
@@ -705,6 +1040,15 @@ static void VS_CC analyseFree(void *inst, VSCore *core, const VSAPI *vs) {
     (void)core;
     AnalyseData *d = (AnalyseData *)inst;
     vs->freeNode(d->node);
+    if (d->la.on) {
+        for (int i = 0; i < LA_SLOTS; i++) {
+            LaWindow *s = &d->la.win[i];
+            if (s->state == LW_LAUNCHED) (void)mvx_stream_sync(s->stream); /* nobody came for it */
+            la_window_release(s);
+        }
+        vs->freeNode(d->la.srcNode);
+        pthread_mutex_destroy(&d->la.mu); pthread_cond_destroy(&d->la.cv);
+    }
     combiner_free(&d->cb, "Analyse");
     mvx_analyse_destroy(d->an);
     mvx_super_destroy(d->sup);
@@ -746,8 +1090,20 @@ static void VS_CC analyseCreate(const VSMap *in, VSMap *out, void *user, VSCore 
     combiner_init(&d->cb);
     /* before the first launch has been timed: a chain walks every block of every level, a few microseconds each */
     d->cb.lastUs = (long)((double)d->ad.nBlkX * d->ad.nBlkY * 4.0 / 3.0 * 2.5);
-    VSFilterDependency deps[1] = { { node, rpGeneral } };
-    vs->createVideoFilter(out, "Analyse", vi, analyseGetFrame, analyseFree, fmParallel, deps, 1, d, core);
+    VSFilterDependency deps[2] = { { node, rpGeneral }, { NULL, rpGeneral } };
+    int ndeps = 1;
+    { /* look-ahead when `super` is this plugin's own mv.Super node (MVX_VS_LOOKAHEAD = window length in frames, 0 = off; default 64) */
+        SuperData *sd = super_lookup(node);
+        const long B = env_long("MVX_VS_LOOKAHEAD", 64);
+        if (sd && !sd->pelMode && B > 0 && vi->numFrames > 1) {
+            d->la.on = 1; d->la.B = (int)(B > 512 ? 512 : B); d->la.sd = sd;
+            d->la.srcNode = vs->addNodeRef(sd->node);
+            pthread_mutex_init(&d->la.mu, NULL); pthread_cond_init(&d->la.cv, NULL);
+            for (int i = 0; i < LA_SLOTS; i++) d->la.win[i].w = -1;
+            deps[1].source = d->la.srcNode; ndeps = 2;
+        }
+    }
+    vs->createVideoFilter(out, "Analyse", vi, analyseGetFrame, analyseFree, fmParallel, deps, ndeps, d, core);
 }
 
 /* ------------------------------------------------------------------------------------------------ mv.Finest */
@@ -1015,7 +1371,7 @@ static const VSFrame *VS_CC degrainGetFrame(int n, int reason, void *inst, void 
     rc = upload_plane_set(dsrc, &srcArena, src, d->pitch, np, bps, vs);
     size_t dstOff[3], dstBytes = 0;
     for (int p = 0; p < np; p++) { dstOff[p] = dstBytes; dstBytes += (size_t)d->pitch[p] * vs->getFrameHeight(src, p); }
-    void *dstArena = mvx_dev_alloc_uninit(dstBytes);
+    void *dstArena = shell_alloc(dstBytes);
     if (!rc && (!srcArena || !dstArena)) rc = MVX_E_NOMEM;
     for (int p = 0; p < np && !rc; p++) { job.src[p] = dsrc[p]; job.dst[p] = (char *)dstArena + dstOff[p]; }
     for (int r = 0; r < nr && !rc; r++) {
@@ -1321,7 +1677,7 @@ static const VSFrame *VS_CC fpsGetFrame(int n, int reason, void *inst, void **fd
     if (!rc) rc = upload_plane_set(dr, &arenaR, cr, d->pitch, np, bps, vs);
     size_t dstOff[3], dstBytes = 0;
     for (int p = 0; p < np; p++) { dstOff[p] = dstBytes; dstBytes += (size_t)d->pitch[p] * vs->getFrameHeight(cl, p); }
-    void *dstArena = mvx_dev_alloc_uninit(dstBytes);
+    void *dstArena = shell_alloc(dstBytes);
     if (!rc && (!arenaL || !arenaR || !dstArena)) rc = MVX_E_NOMEM;
     for (int p = 0; p < np && !rc; p++) { job.clip_left[p] = dl[p]; job.clip_right[p] = dr[p]; job.dst[p] = (char *)dstArena + dstOff[p]; }
     DevRef ds, dr2;
