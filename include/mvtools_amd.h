@@ -316,6 +316,8 @@ void mvx_stream_destroy(void *stream);
 int mvx_copy_to_device(void *dst, ptrdiff_t dst_pitch, const void *src_host, ptrdiff_t src_pitch, size_t row_bytes, size_t rows, void *stream);
 int mvx_copy_to_host(void *dst_host, ptrdiff_t dst_pitch, const void *src, ptrdiff_t src_pitch, size_t row_bytes, size_t rows, void *stream);
 int mvx_stream_sync(void *stream);
+void *mvx_host_alloc_pinned(size_t bytes);    /* page-locked host memory for asynchronous mvx_copy_to_host targets; NULL on failure */
+void mvx_host_free_pinned(void *p);
 /* Synchronous 2-D transfers for hosts whose frames live in ordinary (pageable) memory: staged through a small set of pinned buffers
  * inside the library (a linear PCIe copy + a row-by-row memcpy on the calling thread) -- several times faster than the pageable 2-D
  * copies above for large planes, and safe to call from many threads.  Complete on return; work already enqueued on `stream` runs

@@ -423,53 +423,9 @@ def test_fields_shift_parity(oracle, mv, w, h, bits, pel, akw, shift):
     assert not all(np.array_equal(a, b) for a, b in zip(want, oc.frame(osf[0], osf[1], ob)))
 
 
-@pytest.mark.parametrize("w,h,bits,skw,akw", [
-    (384, 224, 16, {}, dict(blksize=16, overlap=8)),
-    (384, 224, 16, dict(pel=4), dict(blksize=16, overlap=8)),
-    (320, 180, 16, {}, dict(blksize=8, overlap=4)),
-    (320, 180, 8, {}, dict(blksize=8, overlap=4)),
-    (384, 224, 8, dict(pel=1), dict(blksize=16, overlap=8, search=3, searchparam=2)),
-    (320, 180, 16, {}, dict(blksize=16, overlap=8, chroma=0)),
-])
-def test_analyse_window_kernels(oracle, mv, dbg, w, h, bits, skw, akw):
-    """the opt-in LDS search-window kernels (MVX_WINDOW=1): candidates inside the window are compared from LDS
-    (aligned dword reads + v_alignbit), the others from global memory -- the vectors must not depend on which"""
-    dbg("window", 1)
-    frames, osup, gsup, osf, gsrc, gsf = _pipeline(oracle, mv, w, h, bits, 1, skw, akw, nframes=3, seed=5)
-    for isb in (1, 0):
-        oan = oracle.Analyse(osup, isb=isb, **akw)
-        gan = mv.Analyse(gsup, isb=isb, **akw)
-        ref = 2 if isb else 0
-        ob = oan.frame(osf[1], osf[ref])
-        gb = gan.run([(gsf[1], gsf[ref])])[0]
-        assert np.array_equal(gb.cpu().numpy(), ob)
-
-
-@pytest.mark.parametrize("w,h,skw,akw", [
-    (384, 224, {}, dict(blksize=16, overlap=8)),
-    (384, 224, dict(pel=1), dict(blksize=16, overlap=8)),
-    (200, 120, {}, dict(blksize=16, overlap=8, search=3, searchparam=2)),
-    (384, 224, {}, dict(blksize=16, overlap=0, chroma=0)),
-    (384, 224, dict(pel=4), dict(blksize=16, overlap=8)),   # pel 4: the host keeps the plain kernel
-])
-def test_analyse_refinement_tile_kernel(oracle, mv, dbg, w, h, skw, akw):
-    """the opt-in refinement-tile kernel (MVX_TILE=1): hexagon / square / exhaustive rounds read the reference
-    from an LDS tile around the predictor round's winner; same samples, same vectors (plane borders included: small frames)"""
-    dbg("tile", 1)
-    frames, osup, gsup, osf, gsrc, gsf = _pipeline(oracle, mv, w, h, 16, 1, skw, akw, nframes=3, seed=6)
-    for isb in (1, 0):
-        oan = oracle.Analyse(osup, isb=isb, **akw)
-        gan = mv.Analyse(gsup, isb=isb, **akw)
-        ref = 2 if isb else 0
-        ob = oan.frame(osf[1], osf[ref])
-        gb = gan.run([(gsf[1], gsf[ref])])[0]
-        assert np.array_equal(gb.cpu().numpy(), ob)
-
-
 @pytest.mark.parametrize("bits,akw", [(8, dict(blksize=8, overlap=4)), (16, dict(blksize=16, overlap=8)), (16, dict(blksize=32, overlap=16))])
 def test_analyse_one_chain_per_workgroup(oracle, mv, dbg, bits, akw):
-    """MVX_CPW=1 keeps the one-chain-per-workgroup builds of the specialised kernels reachable (they are also what the opt-in
-    window / tile modes and A/B timing use): same vectors"""
+    """MVX_CPW=1 keeps the one-chain-per-workgroup builds of the specialised kernels reachable (A/B timing uses them): same vectors"""
     dbg("cpw1", 1)
     frames, osup, gsup, osf, gsrc, gsf = _pipeline(oracle, mv, 256, 160, bits, 1, {}, akw, nframes=2, seed=9)
     ob = oracle.Analyse(osup, isb=1, **akw).frame(osf[0], osf[1])

@@ -27,8 +27,6 @@ struct MvxDebug {
     int general = 0;   // 1: never use the lean kernel of the default search (mvx_analyse_fast.h)
     int fast_wpe = 0;  // > 0: chains per SIMD the lean kernel is launched at (when such a build exists)
     int cpw1 = 0;      // one chain per workgroup (general kernels)
-    int window = 0;    // LDS search-window kernels
-    int tile = 0;      // refinement-tile kernel
     int no_wpe2 = 0, no_wpe3 = 0, wpe3_u16 = 0;
     int fast_cpw = 0;  // lean kernel: chains per workgroup (<= 4 * chains per SIMD)
     int fast_k = 0;    // lean kernel: build for exactly that many chains per SIMD whatever the launch carries (several launches sharing the GPU)
@@ -44,8 +42,7 @@ struct MvxDebug {
 };
 static MvxDebug g_dbg;
 extern "C" __attribute__((visibility("default"))) int mvx_debug_option(const char *name, int value) {
-    struct { const char *n; int *p; } tab[] = { { "general", &g_dbg.general }, { "fast_wpe", &g_dbg.fast_wpe }, { "cpw1", &g_dbg.cpw1 }, { "window", &g_dbg.window },
-        { "tile", &g_dbg.tile }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "fast_cpw", &g_dbg.fast_cpw }, { "fast_k", &g_dbg.fast_k }, { "fast_flags", &g_dbg.fast_flags }, { "pad_runs", &g_dbg.pad_runs }, { "shadow_planes", &g_dbg.shadow_planes }, { "degrain_xcd", &g_dbg.degrain_xcd }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min }, { "super_rows_off", &g_dbg.super_rows_off }, { "win", &g_dbg.win },
+    struct { const char *n; int *p; } tab[] = { { "general", &g_dbg.general }, { "fast_wpe", &g_dbg.fast_wpe }, { "cpw1", &g_dbg.cpw1 }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "fast_cpw", &g_dbg.fast_cpw }, { "fast_k", &g_dbg.fast_k }, { "fast_flags", &g_dbg.fast_flags }, { "pad_runs", &g_dbg.pad_runs }, { "shadow_planes", &g_dbg.shadow_planes }, { "degrain_xcd", &g_dbg.degrain_xcd }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min }, { "super_rows_off", &g_dbg.super_rows_off }, { "win", &g_dbg.win },
 #ifdef MVX_LAB
         { "ablate", &g_dbg.ablate },
 #endif
@@ -279,6 +276,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_set_ref_shadow
         const long long v = copy_stride ? (long long)copy_stride[p] : 0;
         if (v < 0 || v % 16) { mvx_set_error("mvx_analyse_set_ref_shadow: copy strides must be non-negative multiples of 16 bytes"); return MVX_E_ARG; }
         a->P.shadow[p] = ((p == 0 && !(g_dbg.shadow_planes & 1)) || (p > 0 && !(g_dbg.shadow_planes & 2))) ? 0 : v;
+        if (p == 0 && a->P.bps == 1) a->P.shadow[0] = 0; // (8-bit super frames carry the UV plane only)
     }
     std::lock_guard<std::mutex> lk(a->guard.mu);
     if (a->dP) HIP_CHECK(hipMemcpy(a->dP, &a->P, sizeof(AParams), hipMemcpyHostToDevice)); // (synchronous: no launch of this handle is reading it concurrently unless the caller races)
@@ -320,7 +318,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
     // lines in the CU's L1 (+4.7 % at 4K16; measured r1: a barrier between them only costs -- per block -13 %, per 16 blocks 0 %,
     // per row +3.7 % -- and dealing the groups out so that each XCD gets a contiguous range of frames changes nothing).
     const bool spec = P.dctmode == 0 && P.xr == 2 && P.yr == 2 && P.blkX == P.blkY && (P.blkX == 16 || P.blkX == 8 || (P.blkX == 32 && P.bps == 2)) &&
-                      !g_dbg.cpw1 && !g_dbg.tile && !g_dbg.window;
+                      !g_dbg.cpw1;
     int simds = 0; // of the device this call runs on
     {
         int dev = 0, cus = 0;
@@ -333,7 +331,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
     // that share a reference frame -- eight unrelated chains per CU thrash its L1 / the XCD's L2 and lose.
     // ---- the default search runs in the lean kernel (mvx_analyse_fast.h): workgroups of 4 * k chains that share a reference
     // frame, k = 1..4 chains per SIMD depending on how many chains the launch carries and which builds exist / pay off.
-    if (mvx_fast_eligible(P) && !g_dbg.general && !g_dbg.cpw1 && !g_dbg.tile && !g_dbg.window) {
+    if (mvx_fast_eligible(P) && !g_dbg.general && !g_dbg.cpw1) {
         int srcB = P.blkX * P.blkY * P.bps + 2 * (P.blkX / 2) * (P.blkY / 2) * P.bps;
         const int fRow = (srcB + 15) & ~15;
         int fMaxBlkX = 0;
@@ -394,7 +392,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
             if (g_dbg.cpw_sync >= 0 && (g_dbg.cpw_sync & (g_dbg.cpw_sync - 1)) == 0) syncEvery = g_dbg.cpw_sync;
             // XCD-contiguous workgroup order: neighbours in the (reference-sorted) job table share an L2 (+0.5 %, 4K16)
             const int flags = (g_dbg.fast_flags >= 0 ? g_dbg.fast_flags : MVX_FAST_XCD_REMAP) | ((P.shadow[1] != 0 && P.chroma) ? MVX_FAST_UV : 0);
-            ALaunch L = { 0, ntab, fNeed, fRow, fRow, fBins, -1, 0, fNeed, simds, cpw, k, syncEvery, k, flags, st, a->dP, S.d };
+            ALaunch L = { ntab, fNeed, fRow, fRow, fBins, fNeed, simds, cpw, k, syncEvery, k, flags, st, a->dP, S.d };
             int rc = useWin ? mvx_analyse_launch_win(P, L) : P.bps == 1 ? mvx_analyse_launch_fast_u8(P, L) : mvx_analyse_launch_fast_u16(P, L);
             if (rc == MVX_OK) {
                 g_lastLaunch[0] = k; g_lastLaunch[1] = cpw; g_lastLaunch[2] = syncEvery; g_lastLaunch[3] = ntab; g_lastLaunch[4] = useWin;
@@ -405,7 +403,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
             if (rc != 1) return rc;
         }
     }
-    const bool oneChain = g_dbg.cpw1 || g_dbg.tile || g_dbg.window;
+    const bool oneChain = g_dbg.cpw1 != 0;
     int cpw = oneChain ? 1 : 4, wpe = 1; // (the generic kernels have four-chain builds too)
     if (spec && njobs > simds && !g_dbg.no_wpe2) {
         if (P.bps == 1 && (P.blkX == 8 || P.blkX == 16)) wpe = 2;
@@ -424,45 +422,8 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
     for (int i = 0; i < P.nLevels; i++) if (P.lv[i].nBlkX > maxBlkX) maxBlkX = P.lv[i].nBlkX;
     const int histBins = 1024;
     // LDS of a chain: [source block | previous block row's results, 16 B per block | histogram of the global-motion estimate]
-    // Search-window kernels (Geo<..., scan step>, 4:2:0 16x16 / 8x8 blocks with half-block overlap, SAD cost): the window follows
-    // the row buffer and the histogram aliases its start (it is only used between levels); everything must fit a quarter of
-    // the CU's 160 KiB so that four chains still share a CU.
-    int ldsHist = ldsRow + maxBlkX * 16;
+    const int ldsHist = ldsRow + maxBlkX * 16;
     int ldsBytes = ldsHist + histBins * 4;
-    int ldsWin = -1, winCap = 0, mode = 0;
-    {
-        auto p2 = [](int v) { int r = 1; while (r < v) r <<= 1; return r; };
-        const int S = P.blkX - P.ovX, npp = P.lv[0].pel * P.lv[0].pel;
-        const bool sq420 = P.dctmode == 0 && P.xr == 2 && P.yr == 2 && P.blkX == P.blkY;
-        const bool winGeom = sq420 && ((P.blkX == 16 && S == 8) || (P.blkX == 8 && S == 4));
-        const bool wantWin = g_dbg.window != 0;
-        const int histW = ldsRow + maxBlkX * 16; // window / tile kernels keep the predictors in registers
-        if (winGeom && wantWin) {
-            const int MX = ((8 + S - 1) / S) * S, MY = MVX_WIN_MY;
-            const int lumaB = npp * (P.blkY + 2 * MY) * (p2(P.blkX + 2 * MX + 2 * S) * P.bps + MVX_WIN_MIRROR);
-            const int chromaB = P.chroma ? 2 * npp * (P.blkY / P.yr + 2 * (MY / P.yr)) * (p2(P.blkX / P.xr + 2 * (MX / P.xr) + 2 * (S / P.xr)) * P.bps + MVX_WIN_MIRROR) : 0;
-            int total = histW + lumaB + chromaB;
-            if (total < histW + histBins * 4) total = histW + histBins * 4;
-            if (total <= 40 * 1024) { mode = 1; ldsHist = histW; ldsWin = histW; winCap = lumaB + chromaB; ldsBytes = total; }
-        }
-        // refinement tile (16-bit 16x16 4:2:0): opt-in (MVX_TILE=1), no faster than the plain kernels yet
-        const bool wantTile = g_dbg.tile != 0;
-        if (mode == 0 && wantTile && sq420 && P.bps == 2 && P.blkX == 16) {
-            int tb = mvx_tile_lds_bytes(P.blkX, P.blkY, P.xr, P.yr, P.bps, P.lv[0].pel, P.chroma);
-            const int tb1 = mvx_tile_lds_bytes(P.blkX, P.blkY, P.xr, P.yr, P.bps, 1, P.chroma);
-            bool fits = tb > 0 && tb1 > 0 && P.lv[0].pel <= 2;
-            for (int i = 0; i < P.nLevels && fits; i++) { // what Searcher::tile_setup_level insists on
-                const ALevel &lv = P.lv[i];
-                if (lv.pw < 24 || lv.ph < 24 || (lv.pw >> 1) < 16 || (lv.ph >> 1) < 16 || (long long)lv.pel * lv.pel * lv.pstride[0] >= 0x7fffffffLL) fits = false;
-            }
-            if (fits) {
-                if (tb1 > tb) tb = tb1;
-                int total = histW + tb;
-                if (total < histW + histBins * 4) total = histW + histBins * 4;
-                mode = 2; ldsHist = histW; ldsWin = histW; winCap = tb; ldsBytes = total;
-            }
-        }
-    }
     if (ldsBytes > 160 * 1024) { mvx_set_error("mvx_analyse_frames: frame too wide for the LDS row buffer"); return MVX_E_ARG; }
     // One-chain-per-workgroup launches (generic kernels, MVX_CPW=1, window / tile modes): asking for a little more than a fifth of
     // the CU's 160 KiB of LDS makes the dispatcher spread the chains four per CU instead of stacking some CUs (+5 % at 1008 chains).
@@ -473,7 +434,6 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         if (g_dbg.lds_min >= 0) v = g_dbg.lds_min; // developer override
         if (v > ldsBytes && v <= 160 * 1024) ldsBytes = v;
     }
-    if (mode != 0) { cpw = 1; wpe = 1; }
     // a workgroup's chains share the CU's 160 KiB of LDS: very wide frames (long row buffers) get fewer chains per workgroup
     while (cpw > 1 && (long long)((ldsNeed + 255) & ~255) * cpw > 160 * 1024) {
         cpw = cpw == 12 ? 8 : cpw == 8 ? 4 : 1;
@@ -485,7 +445,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
     // 8-bit); with one chain per SIMD it costs 1 %
     int syncEvery = wpe >= 2 ? 256 : 0;
     if (g_dbg.cpw_sync >= 0 && (g_dbg.cpw_sync & (g_dbg.cpw_sync - 1)) == 0) syncEvery = g_dbg.cpw_sync;
-    ALaunch L = { mode, njobs, ldsBytes, ldsRow, ldsHist, histBins, ldsWin, winCap, ldsNeed, simds, cpw, wpe, syncEvery, 0, 0, st, a->dP, S.d };
+    ALaunch L = { njobs, ldsBytes, ldsRow, ldsHist, histBins, ldsNeed, simds, cpw, wpe, syncEvery, 0, 0, st, a->dP, S.d };
     // the specialised kernels address the reference as "64-bit base + 32-bit offset inside the level's plane set" (all sub-pel planes)
     bool off32 = true;
     for (int i = 0; i < P.nLevels; i++)

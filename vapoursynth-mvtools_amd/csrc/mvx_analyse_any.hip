@@ -1,7 +1,7 @@
 // generic search kernels (block geometry only known at run time)
 #include "mvx_analyse_kernel.h"
 int mvx_analyse_launch_any(const AParams &P, const ALaunch &L) {
-    if (L.mode == 0 && L.cpw == 4) { // four chains per workgroup (mvx_analyse_frames sorted the job table by reference frame)
+    if (L.cpw == 4) { // four chains per workgroup (mvx_analyse_frames sorted the job table by reference frame)
         if (P.dctmode != 0) return P.bps == 1 ? launch_analyse_kernel<1, GeoAnyDct, 1, 4>(L) : launch_analyse_kernel<2, GeoAnyDct, 1, 4>(L); // SATD cost modes
         return P.bps == 1 ? launch_analyse_kernel<1, GeoAny, 1, 4>(L) : launch_analyse_kernel<2, GeoAny, 1, 4>(L);
     }

@@ -851,8 +851,7 @@ template <int BPS, int BW, int WPE, int MAXCPW, bool UV> static int launch_analy
                        L.njobs, perChain, L.syncEvery, L.ldsRow, L.ldsHist, L.histBins, L.flags);
     return MVX_OK;
 }
-// (8-bit clips have no shadow planes: only the plain chroma path is built for them)
 template <int BPS, int BW, int WPE, int MAXCPW> static int launch_analyse_fast(const ALaunch &L) {
-    if (BPS == 2 && (L.flags & MVX_FAST_UV)) return launch_analyse_fast_uv<BPS, BW, WPE, MAXCPW, BPS == 2>(L);
+    if (L.flags & MVX_FAST_UV) return launch_analyse_fast_uv<BPS, BW, WPE, MAXCPW, true>(L);
     return launch_analyse_fast_uv<BPS, BW, WPE, MAXCPW, false>(L);
 }

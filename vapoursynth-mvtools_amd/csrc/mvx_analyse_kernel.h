@@ -322,33 +322,15 @@ __device__ unsigned long long g_prof[32];
 #define PROF_ADD(i, v) ((void)0)
 #endif
 #define PF_MAX 4 // source-block prefetch registers per lane (16 B each)
-// LDS search window (host layout and kernel agree through these): rows above / below the block at the row's expected motion,
-// and the bytes after each ring row that mirror its start.  The reads are aligned dwords, so a chunk that starts in the last
-// bytes of the ring reads up to 20 bytes past its end; 48 makes the row stride an odd multiple of 16 bytes (176 / 112), which
-// spreads the rows of a candidate over all LDS banks.
-#define MVX_WIN_MY 6
-#define MVX_WIN_MIRROR 48
-// LDS bytes of the refinement tile (Searcher::tile_setup_level computes the same numbers); 0: geometry not supported
-static inline int mvx_tile_lds_bytes(int bw, int bh, int xr, int yr, int bps, int pel, int chroma) {
-    const int R = 3, m = pel - 1, lp = pel == 4 ? 2 : pel == 2 ? 1 : 0, npp = pel * pel;
-    const int pw = ((bw + 2 * R + 1) * bps + 15) / 16, pwc = ((bw / xr + (2 * R) / xr + 2) * bps + 15) / 16;
-    const int th = bh + ((2 * R + m) >> lp), thc = bh / yr + (((2 * R) / yr + m) >> lp);
-    if ((npp * th * pw + 63) / 64 > 4 || (npp * thc * pwc + 63) / 64 > 2) return 0; // TQL / TQC item slots per lane
-    return npp * th * (pw | 1) * 16 + (chroma ? 2 * npp * thc * (pwc | 1) * 16 : 0);
-}
-
 // Compile-time block geometry for the specialised kernels (BW == 0: geometry only known at run time -> generic loops).
 constexpr int pow2c(int v, int r = 1) { return r >= v ? r : pow2c(v, r * 2); }
-// SX = blkW - overlapX (the scan step) enables the LDS search window (0: no window).
 // DCT: the SATD cost modes (dct 5..10) are compiled into their own generic kernel only -- their code costs the default
 // kernels 5-7 % through register allocation even when it never runs (measured)
-// TILE: the refinement rounds of the default search (hexagon / square at level 0, the exhaustive rings above) read the
-// reference from a small LDS tile around the predictor round's winner instead of from global memory (see "refinement tile").
-template <int BW_, int BH_, int XR_, int YR_, int SX_ = 0, bool DCT_ = false, bool TILE_ = false> struct Geo {
-    static constexpr int BW = BW_, BH = BH_, XR = XR_, YR = YR_, SX = SX_; static constexpr bool DCT = DCT_, TILE = TILE_;
+template <int BW_, int BH_, int XR_, int YR_, bool DCT_ = false> struct Geo {
+    static constexpr int BW = BW_, BH = BH_, XR = XR_, YR = YR_; static constexpr bool DCT = DCT_;
 };
-typedef Geo<0, 0, 0, 0, 0> GeoAny;
-typedef Geo<0, 0, 0, 0, 0, true> GeoAnyDct;
+typedef Geo<0, 0, 0, 0> GeoAny;
+typedef Geo<0, 0, 0, 0, true> GeoAnyDct;
 
 // WPE: chains per SIMD the enclosing kernel is built for (register budget; picks register-saving variants below)
 template <int BPS, typename GEO, int WPE = 1> struct Searcher {
@@ -909,14 +891,7 @@ template <int BPS, typename GEO, int WPE = 1> struct Searcher {
             }
             unsigned aL = 0, aC = 0;
             const long long pt0 = PROF_T();
-            if (ok && ablate != 3) {
-                bool done = false;
-                if (W_ON) { // the general rounds use the window for the two common group sizes
-                    if (winOn && logG == 3) done = eval_win<3>(s, vx, vy, vyc, aL, aC);
-                    else if (winOn && logG == 1) done = eval_win<1>(s, vx, vy, vyc, aL, aC);
-                }
-                if (!done) eval_cand(s, logG, vx, vy, vyc, aL, aC);
-            }
+            if (ok && ablate != 3) eval_cand(s, logG, vx, vy, vyc, aL, aC);
             const long long pt1 = PROF_T();
             aL = group_sum(aL, logG);
             aC = group_sum(aC, logG);
@@ -974,363 +949,8 @@ template <int BPS, typename GEO, int WPE = 1> struct Searcher {
         nLambda = uni((long long)((double)nLambda * scale * scale));
     }
 
-    // ---- LDS search window (specialised kernels with a compile-time scan step) -------------------------------------
-    // Per chain, the reference rows around the expected motion-compensated position of the current block live in LDS:
-    // for every sub-pel plane a band of BH + 2*MY rows and a ring of WW columns that slides with the scan.  One strip of
-    // SX columns is requested per block, a whole block before it is stored and two before its first use, so its HBM
-    // latency is never exposed.  Candidates whose block lies inside the band are evaluated from LDS (aligned dword reads
-    // realigned with v_alignbit); all others (large deviation from the row's expected motion, plane borders) take the
-    // global-memory path, so results never depend on the window.  This is the north star's "search window staged in
-    // LDS", adapted to the serial-chain design: the window follows the chain instead of being loaded per macroblock.
-    // Status (r1, 4K16): bit-exact; vector-memory instructions per block drop from 22 to 7 and the time a chain waits from
-    // 54 % to 44 %, but the block needs 1200 instead of 1020 instructions and a single chain per SIMD issues one instruction
-    // every four cycles -- 204 fps against 214 without the window.  Opt-in (MVX_WINDOW=1) until its bookkeeping is cheaper.
-    static constexpr bool W_ON = GEO::SX != 0 && GEO::BW != 0;
-    static constexpr int W_S = W_ON ? GEO::SX : 8, W_SC = W_S / G_XR;
-    static constexpr int W_MX = ((8 + W_S - 1) / W_S) * W_S, W_MY = MVX_WIN_MY, W_MXC = W_MX / G_XR, W_MYC = W_MY / G_YR;
-    static constexpr int W_NS = (G_BW + 2 * W_MX) / W_S;
-    static constexpr int W_WW = pow2c(G_BW + 2 * W_MX + 2 * W_S), W_WH = G_BH + 2 * W_MY;
-    static constexpr int W_WWC = pow2c(G_BW / G_XR + 2 * W_MXC + 2 * W_SC), W_WHC = G_BH / G_YR + 2 * W_MYC;
-    static constexpr int W_RB = W_WW * BPS, W_RBC = W_WWC * BPS;       // ring bytes per row
-    static constexpr int W_RS = W_RB + MVX_WIN_MIRROR, W_RSC = W_RBC + MVX_WIN_MIRROR; // row stride: ring + mirror of its start (reads never wrap)
-    static constexpr int W_CBS = W_S * BPS < 16 ? W_S * BPS : 16, W_SCL = W_S * BPS / W_CBS;
-    static constexpr int W_CBSC = W_SC * BPS < 16 ? W_SC * BPS : 16, W_SCC = W_SC * BPS / W_CBSC;
-    // Strip items (one CBS-byte piece of one window row of one sub-pel plane) are dealt to per-plane slots: slots
-    // 0..WQY-1 hold luma items, slot WQY the U items, slot WQY+1 the V items (same geometry as U).  Within a slot every
-    // lane owns item min(lane + 64*q, last): surplus lanes duplicate the last item (same address, same data, same LDS
-    // target), which keeps the per-block code free of branches and per-lane predicates.
-#define WQY 2
-#define WQ_MAX (WQY + 2)
-    int ablate;                                        // developer switch (MVX_ABLATE), copied once: never re-read from memory inside the block loop
-    int blockSync;                                     // four chains per workgroup: barrier per block (analyse_kernel, CPW)
-    int winOn, ldsWin, winCap;
-    int wLdsC;                                         // LDS offset of the chroma windows (U planes then V planes)
-    int wQY;                                           // luma slots in use (1 or 2)
-    int wcx, wcy, wccx, wccy;                          // expected motion of this block row (full-pel), luma / chroma
-    int worg, worgC, wrow0, wrow0C;                    // ring origin columns, absolute row of window row 0
-    int wgoodL, wgoodR, wgoodLC, wgoodRC;              // strip-aligned column range whose strips lie fully inside the plane
-    int wvalL, wvalR, wvalLC, wvalRC;                  // columns valid for the current block
-    int wPend;                                         // strip index pending in registers
-    int gmvx0, gmvy0;                                  // the level's global motion predictor before the cumulative clipping
-    int wPP[WQY], wRowL[WQY], wChL[WQY], wLdsL[WQY];   // per lane luma items: sub-pel plane, window row, piece, LDS offset
-    int wPPC, wRowC, wChC, wLdsU;                      // per lane chroma item (U; V = + wVstep in LDS)
-    unsigned wOffL[WQY], wOffC;                        // per block row: byte offset of (plane, clamped row, piece) in the plane set
-    int wVstep;
-
-    __device__ __forceinline__ void win_setup_level() {
-        winOn = 0;
-        if (!W_ON || ldsWin < 0 || ablate == 6) return;
-        const int npp = pel * pel;
-        const int NIL = npp * W_WH * W_SCL, NIC = chroma ? npp * W_WHC * W_SCC : 0;
-        wQY = (NIL + WAVE - 1) / WAVE;
-        const int lumaBytes = npp * W_WH * W_RS, chromaBytes = chroma ? 2 * npp * W_WHC * W_RSC : 0;
-        if (wQY > WQY || NIC > WAVE || lumaBytes + chromaBytes > winCap) return;
-        if ((long long)npp * pstrideY >= 0x7fffffffLL) return; // 32-bit plane offsets
-        wLdsC = ldsWin + lumaBytes;
-        wVstep = npp * W_WHC * W_RSC;
-        const int l = lane_id();
-#pragma unroll
-        for (int q = 0; q < WQY; q++) {
-            const int i = min(l + q * WAVE, NIL - 1);
-            const int pp = i / (W_WH * W_SCL), rem = i - pp * (W_WH * W_SCL), row = rem / W_SCL, ch = rem % W_SCL;
-            wPP[q] = pp; wRowL[q] = row; wChL[q] = ch;
-            wLdsL[q] = ldsWin + (pp * W_WH + row) * W_RS + ch * W_CBS;
-        }
-        {
-            const int i = min(l, max(NIC - 1, 0));
-            const int pp = i / (W_WHC * W_SCC), rem = i - pp * (W_WHC * W_SCC), row = rem / W_SCC, ch = rem % W_SCC;
-            wPPC = pp; wRowC = row; wChC = ch;
-            wLdsU = wLdsC + (pp * W_WHC + row) * W_RSC + ch * W_CBSC;
-        }
-        winOn = 1;
-    }
-    // per block row: plane offsets of this lane's items with the window rows clamped into the plane
-    __device__ __forceinline__ void win_row_offsets() {
-#pragma unroll
-        for (int q = 0; q < WQY; q++) {
-            const int ar = min(max(wrow0 + wRowL[q], 0), ph - 1);
-            wOffL[q] = (unsigned)(wPP[q] * (int)pstrideY) + (unsigned)ar * (unsigned)pitchY + (unsigned)(wChL[q] * W_CBS);
-        }
-        const int arc = min(max(wrow0C + wRowC, 0), (ph >> logyr) - 1);
-        wOffC = (unsigned)(wPPC * (int)pstrideC) + (unsigned)arc * (unsigned)pitchC + (unsigned)(wChC * W_CBSC);
-    }
-
-    // request strip k (SX columns, k-th from the row origin in scan direction) into registers
-    __device__ __forceinline__ void win_issue(int k, A4x32 *wpf) const {
-        const int c0 = blkScanDir == 1 ? worg + k * W_S : worg - (k + 1) * W_S;
-        const int c0c = blkScanDir == 1 ? worgC + k * W_SC : worgC - (k + 1) * W_SC;
-        const unsigned cb = (unsigned)(min(max(c0, 0), pw - W_S) * BPS), cbc = (unsigned)(min(max(c0c, 0), (pw >> logxr) - W_SC) * BPS); // inside the plane
-        wpf[0] = ld_chunk_g(refY + (wOffL[0] + cb), W_CBS);
-        if (wQY > 1) wpf[1] = ld_chunk_g(refY + (wOffL[1] + cb), W_CBS);
-        if (chroma) {
-            wpf[WQY] = ld_chunk_g(refU + (wOffC + cbc), W_CBSC);
-            wpf[WQY + 1] = ld_chunk_g(refV + (wOffC + cbc), W_CBSC);
-        }
-    }
-    __device__ __forceinline__ void win_store(int k, const A4x32 *wpf) const {
-        const int rc = ((blkScanDir == 1 ? k * W_S : -(k + 1) * W_S) & (W_WW - 1)) * BPS;
-        const int rcc = ((blkScanDir == 1 ? k * W_SC : -(k + 1) * W_SC) & (W_WWC - 1)) * BPS;
-        st_chunk_l(lds + wLdsL[0] + rc, wpf[0], W_CBS);
-        if (wQY > 1) st_chunk_l(lds + wLdsL[1] + rc, wpf[1], W_CBS);
-        if (rc < 32) { // mirror of the ring start
-            st_chunk_l(lds + wLdsL[0] + rc + W_RB, wpf[0], W_CBS);
-            if (wQY > 1) st_chunk_l(lds + wLdsL[1] + rc + W_RB, wpf[1], W_CBS);
-        }
-        if (chroma) {
-            st_chunk_l(lds + wLdsU + rcc, wpf[WQY], W_CBSC);
-            st_chunk_l(lds + wLdsU + wVstep + rcc, wpf[WQY + 1], W_CBSC);
-            if (rcc < 32) {
-                st_chunk_l(lds + wLdsU + rcc + W_RBC, wpf[WQY], W_CBSC);
-                st_chunk_l(lds + wLdsU + wVstep + rcc + W_RBC, wpf[WQY + 1], W_CBSC);
-            }
-        }
-    }
-
-    // first block of a block row: choose the expected motion, fill the strips the first block needs, start the pipeline
-    __device__ __forceinline__ void win_row_init(A4x32 *wpf) {
-        wcx = gmvx0 >> logPel; wcy = gmvy0 >> logPel;
-        {   // chroma position of the centre vector, same arithmetic as ref_chroma_off
-            const int vx = wcx << logPel, vy = wcy << logPel;
-            const int xb = (vx < 0) ? ((1 << logxr) - 1) : 0, yb = (vy < 0) ? ((1 << logyr) - 1) : 0;
-            wccx = ((vx + xb) >> logxr) >> logPel; wccy = ((vy + yb) >> logyr) >> logPel;
-        }
-        wrow0 = y0 + wcy - W_MY; wrow0C = cy0 + wccy - W_MYC;
-        if (blkScanDir == 1) { worg = x0 + wcx - W_MX; worgC = cx0 + wccx - W_MXC; }
-        else { worg = x0 + wcx + G_BW + W_MX; worgC = cx0 + wccx + G_BW / G_XR + W_MXC; }
-        // strip boundaries are worg + m*S: the reliable range is the largest strip-aligned sub-range of [0, pw)
-        auto cdiv = [](int a, int b) { return (a >= 0) ? (a + b - 1) / b : -((-a) / b); }; // ceil(a / b), b > 0
-        auto fdiv = [](int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); };    // floor(a / b), b > 0
-        wgoodL = worg + cdiv(-worg, W_S) * W_S;
-        wgoodR = worg + fdiv(pw - worg, W_S) * W_S;
-        const int pwc = pw >> logxr;
-        wgoodLC = worgC + cdiv(-worgC, W_SC) * W_SC;
-        wgoodRC = worgC + fdiv(pwc - worgC, W_SC) * W_SC;
-        win_row_offsets();
-        for (int k = 0; k < W_NS; k++) { win_issue(k, wpf); win_store(k, wpf); }
-        win_issue(W_NS, wpf);
-        wPend = W_NS;
-    }
-    // every later block of the row: the strip requested during the previous block goes to LDS (win_consume, BEFORE this
-    // block issues any new global load, so that its wait only covers loads that are a whole block old), then the next
-    // strip is requested (win_request)
-    __device__ __forceinline__ void win_consume(A4x32 *wpf) { win_store(wPend, wpf); wPend++; }
-    __device__ __forceinline__ void win_request(A4x32 *wpf) { win_issue(wPend, wpf); }
-    __device__ __forceinline__ void win_block_range() {
-        wvalL = max(x0 + wcx - W_MX, wgoodL); wvalR = min(x0 + wcx + G_BW + W_MX, wgoodR);
-        wvalLC = max(cx0 + wccx - W_MXC, wgoodLC); wvalRC = min(cx0 + wccx + G_BW / G_XR + W_MXC, wgoodRC);
-    }
-
-    // SAD of this lane's items of one plane region against the LDS window; winRow = LDS offset of the window row holding
-    // the candidate's first row, b0 = byte offset of its first column relative to the ring origin (any sign).
-    // A reference chunk sits at sample alignment in the window.  gfx950 executes an under-aligned ds_read_b64/b128 at one lane
-    // per cycle (64 cycles of the CU's LDS pipe per wave instruction; four chains per CU saturate it: tools/micro/lds_read2.hip),
-    // so the chunk is read as CB/4 + 1 ALIGNED dwords (ds_read2_b32) from rp4 = its address rounded down to 4 and shifted into
-    // place with v_alignbit (sh = 8 * (address & 3)); the source chunk is naturally aligned.
-    typedef unsigned w2a4 __attribute__((ext_vector_type(2), aligned(4)));
-    template <int CB> __device__ __forceinline__ unsigned win_chunk(const lds_u8 *sp, const lds_u8 *rp4, unsigned sh, unsigned acc) const {
-        if (CB == 16) {
-            const v4u a = *(const LDS_AS v4u *)sp;
-            const w2a4 d01 = *(const LDS_AS w2a4 *)rp4, d23 = *(const LDS_AS w2a4 *)(rp4 + 8);
-            const unsigned d4 = *(const LDS_AS unsigned *)(rp4 + 16);
-            acc = sad32<BPS>(a[0], __builtin_amdgcn_alignbit(d01[1], d01[0], sh), acc);
-            acc = sad32<BPS>(a[1], __builtin_amdgcn_alignbit(d23[0], d01[1], sh), acc);
-            acc = sad32<BPS>(a[2], __builtin_amdgcn_alignbit(d23[1], d23[0], sh), acc);
-            acc = sad32<BPS>(a[3], __builtin_amdgcn_alignbit(d4, d23[1], sh), acc);
-        } else if (CB == 8) {
-            const v2u a = *(const LDS_AS v2u *)sp;
-            const w2a4 d01 = *(const LDS_AS w2a4 *)rp4;
-            const unsigned d2 = *(const LDS_AS unsigned *)(rp4 + 8);
-            acc = sad32<BPS>(a[0], __builtin_amdgcn_alignbit(d01[1], d01[0], sh), acc);
-            acc = sad32<BPS>(a[1], __builtin_amdgcn_alignbit(d2, d01[1], sh), acc);
-        } else if (CB == 4) {
-            const w2a4 d01 = *(const LDS_AS w2a4 *)rp4;
-            acc = sad32<BPS>(*(const LDS_AS unsigned *)sp, __builtin_amdgcn_alignbit(d01[1], d01[0], sh), acc);
-        } else {
-            const w2a4 d01 = *(const LDS_AS w2a4 *)rp4;
-            acc = sad32<BPS>(*(const LDS_AS unsigned short *)sp, __builtin_amdgcn_alignbit(d01[1], d01[0], sh) & 0xffffu, acc);
-        }
-        return acc;
-    }
-    template <int LOGG, int T, int LOGC, int CB, int ROWB, int RB, int RS>
-    __device__ __forceinline__ unsigned win_region(int s, const lds_u8 *src, int winRow, int b0, unsigned acc) const {
-        constexpr int G = 1 << LOGG, C = 1 << LOGC;
-        constexpr int N = T >= G ? T / G : 1;
-        if (T < G && s >= T) return acc;
-        if (G >= C) { // chunk column fixed per lane; rows advance by G / C per item -> one base address, immediate offsets
-            const int row0 = s >> LOGC, xb = (s & (C - 1)) * CB;
-            const int bo = (b0 + xb) & (RB - 1);
-            const lds_u8 *rp4 = lds + winRow + row0 * RS + (bo & ~3); // rows and the ring start are 16-byte aligned
-            const unsigned sh = (unsigned)(bo & 3) * 8;
-            const lds_u8 *sp = src + row0 * ROWB + xb;
-            constexpr int rstep = (G >> LOGC) * RS, sstep = (G >> LOGC) * ROWB;
-#pragma unroll
-            for (int k = 0; k < N; k++) acc = win_chunk<CB>(sp + k * sstep, rp4 + k * rstep, sh, acc);
-        } else {
-#pragma unroll
-            for (int k = 0; k < N; k++) {
-                const int t = s + k * G, row = t >> LOGC, xb = (t & (C - 1)) * CB;
-                const int bo = (b0 + xb) & (RB - 1);
-                acc = win_chunk<CB>(src + row * ROWB + xb, lds + winRow + row * RS + (bo & ~3), (unsigned)(bo & 3) * 8, acc);
-            }
-        }
-        return acc;
-    }
-
-    // candidate inside the window?  If so evaluate it from LDS and return true.
-    template <int LOGG> __device__ __forceinline__ bool eval_win(int s, int vx, int vy, int vyc, unsigned &aL, unsigned &aC) const {
-        const int m = pel - 1, npp = pel * pel;
-        const int ax = (x0 << logPel) + vx, ay = (y0 << logPel) + vy;
-        const int fx = ax >> logPel, fy = ay >> logPel;
-        bool in = fx >= wvalL && fx + G_BW <= wvalR && fy >= wrow0 && fy + G_BH <= wrow0 + W_WH;
-        int cax = 0, cay = 0, fcx = 0, fcy = 0;
-        if (chroma) {
-            const int xb = (vx < 0) ? ((1 << logxr) - 1) : 0, yb = (vyc < 0) ? ((1 << logyr) - 1) : 0;
-            cax = (cx0 << logPel) + ((vx + xb) >> logxr); cay = (cy0 << logPel) + ((vyc + yb) >> logyr);
-            fcx = cax >> logPel; fcy = cay >> logPel;
-            in = in && fcx >= wvalLC && fcx + G_BW / G_XR <= wvalRC && fcy >= wrow0C && fcy + G_BH / G_YR <= wrow0C + W_WHC;
-        }
-        if (!in) return false;
-        {
-            const int pp = (ax & m) | ((ay & m) << logPel);
-            aL = win_region<LOGG, G_LT, ilog2c(G_LC), G_LCB, G_LROWB, W_RB, W_RS>(s, lds, ldsWin + (pp * W_WH + (fy - wrow0)) * W_RS, (fx - worg) * BPS, aL);
-        }
-        if (chroma) {
-            const int pp = (cax & m) | ((cay & m) << logPel);
-            const int rowU = wLdsC + (pp * W_WHC + (fcy - wrow0C)) * W_RSC, rowV = rowU + npp * W_WHC * W_RSC;
-            const int b0 = (fcx - worgC) * BPS;
-            aC = win_region<LOGG, G_CT, ilog2c(G_CC), G_CCB, G_CROWB, W_RBC, W_RSC>(s, lds + G_UOFF, rowU, b0, aC);
-            aC = win_region<LOGG, G_CT, ilog2c(G_CC), G_CCB, G_CROWB, W_RBC, W_RSC>(s, lds + G_VOFF, rowV, b0, aC);
-        }
-        return true;
-    }
-
-    // ---- refinement tile ------------------------------------------------------------------------------------------
-    // After the predictor round the default search only looks at most T_R = 3 vector units around its winner (hexagon +-2,
-    // then the square +-1 around the moved centre; the exhaustive rings of the coarse levels +-2).  Those rounds re-read nearly
-    // the same reference samples 14 + 8 (or 24) times, and every 16-byte-per-lane load of such a round touches up to 64
-    // different cache lines -- the CU's texture path is what keeps a second chain per SIMD from paying off on 16-bit clips.
-    // Here the (block + 2*T_R) neighbourhood of every sub-pel plane is fetched ONCE per block (three 16-byte pieces per row,
-    // adjacent lanes on one line) into LDS, and the refinement rounds compare from there: aligned dword reads shifted into
-    // place (win_chunk), no validity test -- every admissible candidate (vector_ok) of those rounds lies inside the tile by
-    // construction, the tile origin being clamped into the padded plane.  Results cannot differ: same samples, same sums.
-    static constexpr bool T_ON = GEO::TILE && GEO::BW != 0;
-    static constexpr int T_R = 3;
-    static constexpr int T_PW = ((G_BW + 2 * T_R + 1) * BPS + 15) / 16;                     // 16-byte pieces per luma tile row (pel 1 is the widest)
-    static constexpr int T_PWC = ((G_BW / G_XR + (2 * T_R) / G_XR + 2) * BPS + 15) / 16;    // chroma
-    static constexpr int T_RS = (T_PW | 1) * 16, T_RSC = (T_PWC | 1) * 16;                   // row strides: odd multiples of 16 bytes (bank spread)
-    static constexpr int T_TWB = T_PW * 16 / BPS, T_TWBC = T_PWC * 16 / BPS;                 // columns a tile row loads
-#define TQL 4
-#define TQC 2
-    int tileOn, tTH, tTHC, tNQL, tNQC, tVstep;
-    int tfx0, tfy0, tfcx0, tfcy0;                      // tile origins (full-pel, clamped into the padded plane)
-    unsigned tOffL[TQL], tOffC[TQC];                   // per lane: byte offset of the item inside the plane set, relative to the tile origin
-    int tLdsL[TQL], tLdsC[TQC];                        // per lane: LDS offset of the item
-
-    __device__ __forceinline__ static int t_extent(int r2, int m, int lp) { return (r2 + m) >> lp; } // full-pel positions spanned by r2 + 1 vector units
-    __device__ __forceinline__ void tile_setup_level() {
-        tileOn = 0;
-        if (!T_ON) return;
-        const int npp = pel * pel, m = pel - 1;
-        tTH = G_BH + t_extent(2 * T_R, m, logPel);
-        tTHC = G_BH / G_YR + t_extent((2 * T_R) / G_YR, m, logPel);
-        const int tw = G_BW + t_extent(2 * T_R, m, logPel), twc = G_BW / G_XR + t_extent((2 * T_R) / G_XR, m, logPel);
-        const int NIL = npp * tTH * T_PW, NIC = chroma ? npp * tTHC * T_PWC : 0;
-        tNQL = (NIL + WAVE - 1) / WAVE; tNQC = (NIC + WAVE - 1) / WAVE;
-        const int lumaBytes = npp * tTH * T_RS, chromaBytes = chroma ? 2 * npp * tTHC * T_RSC : 0;
-        // the host (mvx_analyse_frames) only launches a tile kernel when all of this holds for every level
-        if (ldsWin < 0 || tNQL > TQL || tNQC > TQC || lumaBytes + chromaBytes > winCap || tw > T_TWB || twc > T_TWBC || pw < T_TWB || ph < tTH ||
-            (pw >> logxr) < T_TWBC || (ph >> logyr) < tTHC || (long long)npp * pstrideY >= 0x7fffffffLL) __builtin_trap();
-        tVstep = npp * tTHC * T_RSC;
-        const int l = lane_id();
-#pragma unroll
-        for (int q = 0; q < TQL; q++) {
-            const int i = min(l + q * WAVE, NIL - 1); // surplus lanes repeat the last item: same address, same data, same LDS target
-            const int pp = i / (tTH * T_PW), rem = i - pp * (tTH * T_PW), row = rem / T_PW, pc = rem - row * T_PW;
-            tOffL[q] = (unsigned)(pp * (int)pstrideY) + (unsigned)row * (unsigned)pitchY + (unsigned)(pc * 16);
-            tLdsL[q] = ldsWin + (pp * tTH + row) * T_RS + pc * 16;
-        }
-#pragma unroll
-        for (int q = 0; q < TQC; q++) {
-            const int i = min(l + q * WAVE, max(NIC - 1, 0));
-            const int pp = i / (tTHC * T_PWC), rem = i - pp * (tTHC * T_PWC), row = rem / T_PWC, pc = rem - row * T_PWC;
-            tOffC[q] = (unsigned)(pp * (int)pstrideC) + (unsigned)row * (unsigned)pitchC + (unsigned)(pc * 16);
-            tLdsC[q] = ldsWin + lumaBytes + (pp * tTHC + row) * T_RSC + pc * 16;
-        }
-        tileOn = 1;
-    }
-    // fetch the tile around vector (cx, cy) of the current block and put it into LDS
-    __device__ __forceinline__ void tile_load(int cx, int cy) {
-        {
-            const int ax = (x0 << logPel) + cx - T_R, ay = (y0 << logPel) + cy - T_R;
-            tfx0 = min(max(ax >> logPel, 0), pw - T_TWB); tfy0 = min(max(ay >> logPel, 0), ph - tTH);
-        }
-        gl_u8 *bL = refY + (long long)tfy0 * pitchY + (long long)tfx0 * BPS;
-        A4x32 tl[TQL], tu[TQC], tv[TQC];
-#pragma unroll
-        for (int q = 0; q < TQL; q++) if (q < tNQL) tl[q] = ld_chunk_g(bL + tOffL[q], 16);
-        if (chroma) {
-            const int vx = cx - T_R, vy = cy - T_R; // same arithmetic as ref_chroma_off; monotonic in the vector, so this is the smallest position
-            const int xb = (vx < 0) ? ((1 << logxr) - 1) : 0, yb = (vy < 0) ? ((1 << logyr) - 1) : 0;
-            const int cax = (cx0 << logPel) + ((vx + xb) >> logxr), cay = (cy0 << logPel) + ((vy + yb) >> logyr);
-            tfcx0 = min(max(cax >> logPel, 0), (pw >> logxr) - T_TWBC); tfcy0 = min(max(cay >> logPel, 0), (ph >> logyr) - tTHC);
-            const long long co = (long long)tfcy0 * pitchC + (long long)tfcx0 * BPS;
-#pragma unroll
-            for (int q = 0; q < TQC; q++) if (q < tNQC) { tu[q] = ld_chunk_g(refU + co + tOffC[q], 16); tv[q] = ld_chunk_g(refV + co + tOffC[q], 16); }
-        }
-#pragma unroll
-        for (int q = 0; q < TQL; q++) if (q < tNQL) st_chunk_l(lds + tLdsL[q], tl[q], 16);
-        if (chroma) {
-#pragma unroll
-            for (int q = 0; q < TQC; q++) if (q < tNQC) { st_chunk_l(lds + tLdsC[q], tu[q], 16); st_chunk_l(lds + tLdsC[q] + tVstep, tv[q], 16); }
-        }
-        __builtin_amdgcn_wave_barrier(); // single wave, DS ops execute in order: only keeps the compiler from hoisting tile reads above the stores
-    }
-    template <int LOGG, int T, int LOGC, int CB, int ROWB, int RS>
-    __device__ __forceinline__ unsigned tile_region(int s, const lds_u8 *src, int tileRow, int b0, unsigned acc) const {
-        constexpr int G = 1 << LOGG, C = 1 << LOGC;
-        constexpr int N = T >= G ? T / G : 1;
-        if (T < G && s >= T) return acc;
-        if (G >= C) {
-            const int row0 = s >> LOGC, xb = (s & (C - 1)) * CB;
-            const int a = tileRow + row0 * RS + b0 + xb;
-            const lds_u8 *rp4 = lds + (a & ~3);
-            const unsigned sh = (unsigned)(a & 3) * 8;
-            const lds_u8 *sp = src + row0 * ROWB + xb;
-            constexpr int rstep = (G >> LOGC) * RS, sstep = (G >> LOGC) * ROWB;
-#pragma unroll
-            for (int k = 0; k < N; k++) {
-#ifdef MVX_TILE_NB
-                if (k && k % MVX_TILE_NB == 0) __builtin_amdgcn_sched_barrier(0); // bounds the LDS reads in flight (registers)
-#endif
-                acc = win_chunk<CB>(sp + k * sstep, rp4 + k * rstep, sh, acc);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < N; k++) {
-                const int t = s + k * G, row = t >> LOGC, xb = (t & (C - 1)) * CB;
-                const int a = tileRow + row * RS + b0 + xb;
-                acc = win_chunk<CB>(src + row * ROWB + xb, lds + (a & ~3), (unsigned)(a & 3) * 8, acc);
-            }
-        }
-        return acc;
-    }
-    template <int LOGG> __device__ __forceinline__ void eval_tile(int s, int vx, int vy, unsigned &aL, unsigned &aC) const {
-        const int m = pel - 1, npp = pel * pel;
-        {
-            const int ax = (x0 << logPel) + vx, ay = (y0 << logPel) + vy;
-            const int pp = (ax & m) | ((ay & m) << logPel);
-            aL = tile_region<LOGG, G_LT, ilog2c(G_LC), G_LCB, G_LROWB, T_RS>(s, lds, ldsWin + (pp * tTH + ((ay >> logPel) - tfy0)) * T_RS, ((ax >> logPel) - tfx0) * BPS, aL);
-        }
-        if (chroma) {
-            const int xb = (vx < 0) ? ((1 << logxr) - 1) : 0, yb = (vy < 0) ? ((1 << logyr) - 1) : 0;
-            const int cax = (cx0 << logPel) + ((vx + xb) >> logxr), cay = (cy0 << logPel) + ((vy + yb) >> logyr);
-            const int pp = (cax & m) | ((cay & m) << logPel);
-            const int rowU = ldsWin + npp * tTH * T_RS + (pp * tTHC + ((cay >> logPel) - tfcy0)) * T_RSC;
-            const int b0 = ((cax >> logPel) - tfcx0) * BPS;
-            aC = tile_region<LOGG, G_CT, ilog2c(G_CC), G_CCB, G_CROWB, T_RSC>(s, lds + G_UOFF, rowU, b0, aC);
-            aC = tile_region<LOGG, G_CT, ilog2c(G_CC), G_CCB, G_CROWB, T_RSC>(s, lds + G_VOFF, rowU + tVstep, b0, aC);
-        }
-    }
+    int ablate;                                        // developer switch ("ablate" debug option, LAB builds), copied once: never re-read from memory inside the block loop
+    int blockSync;                                     // several chains per workgroup: barrier interval in blocks (analyse_kernel, CPW)
 
     // ---- fast path -----------------------------------------------------------------------------------------------
     // The default search (predictor set, then Hex2 hexagon + square at level 0 or the 24-point exhaustive rings at the
@@ -1395,30 +1015,15 @@ template <int BPS, typename GEO, int WPE = 1> struct Searcher {
             ok = ok && vector_ok(vx, vy);
         }
         unsigned aL = 0, aC = 0;
-#ifdef MVX_PROFILE
-        bool wmiss = false;
-#endif
         const long long ft0 = PROF_T();
         if (PRE) {
             if (ok) pre_sad(s, *pre, aL, aC);
-        } else if (T_ON && KIND != FR_A) { // tile kernels: always (the host only picks them when every level can have its tile)
-            if (ok) eval_tile<LOGG>(s, vx, vy, aL, aC);
         } else if (ok) {
-            bool done = false;
-            if (W_ON) { if (winOn) done = eval_win<LOGG>(s, vx, vy, vyc, aL, aC); }
-#ifdef MVX_PROFILE
-            wmiss = !done;
-#endif
-            if (!done) {
-                if (GEO::BW != 0) eval_fixed<LOGG>(s, vx, vy, vyc, aL, aC);
-                else eval_cand(s, LOGG, vx, vy, vyc, aL, aC);
-            }
+            if (GEO::BW != 0) eval_fixed<LOGG>(s, vx, vy, vyc, aL, aC);
+            else eval_cand(s, LOGG, vx, vy, vyc, aL, aC);
         }
         const long long ft1 = PROF_T();
         PROF_ADD(4, ft1 - ft0); PROF_ADD(8, 1);
-#ifdef MVX_PROFILE
-        if (__builtin_amdgcn_ballot_w64(wmiss)) prof[5] += 1; // passes with at least one candidate outside the LDS window
-#endif
         aL = group_sum_c<LOGG>(aL);
         aC = group_sum_c<LOGG>(aC);
         int w;
@@ -1486,22 +1091,15 @@ template <int BPS, typename GEO, int WPE = 1> struct Searcher {
         if (!PRE) globalMVPredictor = clip_mv(globalMVPredictor); // cumulative clip (:859); done before the early request otherwise
         nMinCost = BIG64;
         round_fast<FR_A, PRE>(0, 0, pre);
-        if (T_ON) tile_load(bestMV.x, bestMV.y);
         if (searchType == SearchHex2) { // pobHex2Search :667-724 with i_me_range <= 3: no half-hexagon iterations
             int bmx = bestMV.x, bmy = bestMV.y;
             if (nSearchParam > 1) {
-#ifdef MVX_NO_HEXSQ // developer experiment: hexagon, then square, as two passes (no speculative square)
-                const int dir = round_fast<FR_HEX6>(bmx, bmy);
-                if (dir >= 0) { bmx += tab8(HEX2X, dir + 1); bmy += tab8(HEX2Y, dir + 1); bestMV.x = bmx; bestMV.y = bmy; }
-                round_fast<FR_SQUARE>(bmx, bmy);
-#else
                 const int dir = round_fast<FR_HEXSQ>(bmx, bmy); // >= 0: a hexagon point won; < 0: the square around (bmx, bmy) is done too
                 if (dir >= 0) {
                     bmx += tab8(HEX2X, dir + 1); bmy += tab8(HEX2Y, dir + 1);
                     bestMV.x = bmx; bestMV.y = bmy;
                     round_fast<FR_SQUARE>(bmx, bmy);
                 }
-#endif
             } else
                 round_fast<FR_SQUARE>(bmx, bmy);
         } else
@@ -1879,7 +1477,6 @@ template <int BPS, typename GEO, int WPE = 1> struct Searcher {
         globalMVPredictor.x = pel * globalMV->x;
         globalMVPredictor.y = pel * globalMV->y + fieldShift;
         globalMVPredictor.sad = globalMV->sad;
-        gmvx0 = globalMVPredictor.x; gmvy0 = globalMVPredictor.y;
         int nLambdaLevel = P.lambda / (pel * pel);
         const int nScale = 1 << lvl;
         if (P.plevel == 1) nLambdaLevel = nLambdaLevel * nScale;
@@ -1952,20 +1549,11 @@ template <int BPS, typename GEO, int WPE = 1> struct Searcher {
         };
         prefetch();
         int curIb = 0, curBy = 0;
-        win_setup_level();
-        tile_setup_level();
-        A4x32 wpf[WQ_MAX];
         const bool fast = !tryMany && dctmode == 0 && ((searchType == SearchHex2 && nSearchParam <= 3) || (searchType == SearchExhaustive && nSearchParam == 2));
-        // early request of the predictor round (specialised kernels, reference samples from global memory)
-        // compile-time: one variant of the fast path per kernel.  Measured (r1, A/B in one session): at one chain per SIMD +1.7 % on
-        // 1080p 8-bit and -11 % on 4K 16-bit (more loads in flight per CU when the texture path is already the bottleneck); at two
-        // chains per SIMD -4 % on 1080p 8-bit (1573 against 1639 fps) and 0 % on 4K 16-bit: the other chain hides that latency
-        // already.  Off; MVX_FORCE_EARLY builds it for experiments.
-#ifdef MVX_FORCE_EARLY
-        constexpr bool EARLY_K = GEO::BW != 0 && G_PF && !W_ON;
-#else
+        // early request of the predictor round (specialised kernels, reference samples from global memory): compile-time, one variant of
+        // the fast path per kernel.  Measured (r1): at one chain per SIMD +1.7 % on 1080p 8-bit and -11 % on 4K 16-bit, at two chains per
+        // SIMD -4 % / 0 %: the other chain hides that latency already.  Off.
         constexpr bool EARLY_K = false;
-#endif
         const bool early = EARLY_K && fast;
         PreA preA;
         for (int n = 0; n < nBlk; n++) {
@@ -2009,23 +1597,10 @@ template <int BPS, typename GEO, int WPE = 1> struct Searcher {
                     st_chunk_l(lds + loff, a, cb);
                 }
             }
-            bool winRowStart = false;
-            if (W_ON) {
-                if (winOn) { // slide the LDS search window: the strip requested a block ago goes to LDS
-                    winRowStart = (blkScanDir == 1) ? blkx == 0 : blkx == nBlkX - 1;
-                    if (!winRowStart) win_consume(wpf);
-                }
-            }
             const long long btA = PROF_T();
             if (!early && n + 1 < nBlk) prefetch();
             const long long btW = PROF_T();
-            if (W_ON) {
-                if (winOn) {
-                    if (winRowStart) win_row_init(wpf); else win_request(wpf);
-                    win_block_range();
-                }
-            }
-            const long long btB = PROF_T();
+            const long long btB = btW;
             PROF_ADD(13, btA - bt0); PROF_ADD(14, btW - btA); PROF_ADD(15, btB - btW);
 
             nDxMax = (pw - x0 - blkW - hpad + hps) << logPel; // :1094-1097
@@ -2054,12 +1629,8 @@ template <int BPS, typename GEO, int WPE = 1> struct Searcher {
             if (ablate == 1) { bestMV = predictor; bestMV.sad = 0; }
             // (the hints matter: the general state machine is an inner loop, which the register allocator would otherwise favour
             // over the straight-line path that actually runs; measured +2 % at 4K16)
-#ifdef MVX_X1 // developer experiment: no general state machine at all (WRONG results for bad blocks / other searches)
-            else if (fast) search_block_fast<EARLY_K>(&preA);
-#else
             else if (__builtin_expect(fast, 1)) { if (__builtin_expect(!search_block_fast<EARLY_K>(&preA), 0)) search_block(1); }
             else search_block(0);
-#endif
             const long long bt2 = PROF_T();
             __builtin_amdgcn_wave_barrier();
 
@@ -2136,7 +1707,7 @@ template <int BPS, typename GEO, int WPE = 1> struct Searcher {
 // the SAME reference frame (different current frames); a workgroup barrier per block keeps them on the same block, so the
 // reference lines one of them pulls into the CU's L1 (and the XCD's L2) serve the others.
 template <int BPS, typename GEO, int WPE = 1, int CPW = 1>
-__global__ __launch_bounds__(64 * CPW, WPE) void analyse_kernel(const AParams *Pp, const AJob *jobs, int njobs, int ldsChain, int syncEvery, int ldsRow, int ldsHist, int histBins, int ldsWin, int winCap) {
+__global__ __launch_bounds__(64 * CPW, WPE) void analyse_kernel(const AParams *Pp, const AJob *jobs, int njobs, int ldsChain, int syncEvery, int ldsRow, int ldsHist, int histBins) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // WPE == 1 is for launches with at most one chain per SIMD.  The host's LDS request limits a CU to four chains, but a
     // kernel that fits 256 VGPRs would let the dispatcher stack two of them on one SIMD while another SIMD idles (measured:
@@ -2167,7 +1738,6 @@ __global__ __launch_bounds__(64 * CPW, WPE) void analyse_kernel(const AParams *P
     Searcher<BPS, GEO, WPE> S(P, J);
     S.lds = (lds_u8 *)smem + (CPW == 1 ? 0 : uni((int)(threadIdx.x >> 6)) * ldsChain);
     S.ldsRow = ldsRow; S.ldsHist = ldsHist; S.histBins = histBins;
-    S.ldsWin = ldsWin; S.winCap = winCap; S.winOn = 0;
     S.blockSync = CPW > 1 ? syncEvery : 0;
     S.ablate = uni(P.ablate) & 0xff;
 #ifdef MVX_PROFILE
@@ -2211,7 +1781,7 @@ __global__ __launch_bounds__(64, 1) void recalc_kernel(const AParams *Pp, const 
     typedef Searcher<BPS, GeoAnyDct> S_t;
     S_t S(P, J);
     S.lds = (lds_u8 *)smem; S.ldsRow = ldsRow; S.ldsHist = ldsHist; S.histBins = histBins;
-    S.ldsWin = -1; S.winCap = 0; S.winOn = 0; S.ablate = 0; S.blockSync = 0;
+    S.ablate = 0; S.blockSync = 0;
     for (int i = 0; i < 16; i++) S.prof[i] = 0;
     const int l = lane_id();
     S.setup_geometry(0);
@@ -2290,8 +1860,7 @@ struct RLaunch { int njobs, nBlk, ldsBytes, ldsRow, ldsHist, histBins; hipStream
 int mvx_recalc_launch(const AParams &P, const RLaunch &L);
 
 struct ALaunch {
-    int mode; // 0 plain kernels, 1 LDS search window (Geo<..., scan step>), 2 refinement tile (Geo<..., TILE>): decides the LDS layout
-    int njobs, ldsBytes, ldsRow, ldsHist, histBins, ldsWin, winCap;
+    int njobs, ldsBytes, ldsRow, ldsHist, histBins;
     int ldsNeed; // what the kernel really uses (ldsBytes may carry the one-chain-per-SIMD floor)
     int simds;   // SIMDs of the device (4 per CU)
     int cpw;     // chains per workgroup the host ordered the jobs for (1, 4 or 8)
@@ -2304,13 +1873,12 @@ struct ALaunch {
     const AJob *dJobs;
 };
 template <int BPS_, typename GEO_, int WPE_ = 1, int CPW_ = 1> static int launch_analyse_kernel(const ALaunch &L) {
-    const bool win = (GEO_::SX != 0 || GEO_::TILE) && L.ldsWin >= 0;
-    const int perChain = CPW_ > 1 ? ((L.ldsNeed + 255) & ~255) : (win ? L.ldsBytes : L.ldsWin >= 0 ? L.ldsWin + L.histBins * 4 : L.ldsBytes);
+    const int perChain = CPW_ > 1 ? ((L.ldsNeed + 255) & ~255) : L.ldsBytes;
     const int lds = perChain * CPW_;
     if (lds > 64 * 1024)
         HIP_CHECK(hipFuncSetAttribute((const void *)analyse_kernel<BPS_, GEO_, WPE_, CPW_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL((analyse_kernel<BPS_, GEO_, WPE_, CPW_>), dim3((L.njobs + CPW_ - 1) / CPW_), dim3(64 * CPW_), lds, L.st, L.dP, L.dJobs,
-                       L.njobs, perChain, L.syncEvery, L.ldsRow, L.ldsHist, L.histBins, win ? L.ldsWin : -1, win ? L.winCap : 0);
+                       L.njobs, perChain, L.syncEvery, L.ldsRow, L.ldsHist, L.histBins);
     return MVX_OK;
 }
 // returns MVX_OK after launching, or 1 when this translation unit has no kernel for the geometry

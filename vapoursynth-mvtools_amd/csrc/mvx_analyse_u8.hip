@@ -1,4 +1,4 @@
-// 8-bit search kernels specialised for the common 4:2:0 block geometries (Geo<BW, BH, XR, YR, scan step>)
+// 8-bit search kernels specialised for the common 4:2:0 block geometries (Geo<BW, BH, XR, YR>)
 #include "mvx_analyse_kernel.h"
 #include "mvx_analyse_fast.h"
 // the lean kernel of the default search (mvx_analyse_fast.h): L.fast = chains per SIMD it is launched at, L.cpw chains per workgroup
@@ -20,22 +20,19 @@ int mvx_analyse_launch_fast_u8(const AParams &P, const ALaunch &L) {
 
 int mvx_analyse_launch_u8(const AParams &P, const ALaunch &L) {
     if (P.xr != 2 || P.yr != 2) return 1;
-    // The LDS search-window kernels (Geo<..., scan step>) are bit-exact but measured SLOWER than the plain ones in round 1
-    // (DESIGN.md 4.2): opt-in via MVX_WINDOW=1 until the window path is cheaper in instructions.
-    const int S = L.mode == 1 ? P.blkX - P.ovX : 0;
     // More chains than SIMDs: the 8-bit kernels have a 256-register build so that two chains share a SIMD (+53 % at 1080p,
     // DESIGN.md 4.2).  It drops the LDS floor that spreads a small launch one chain per SIMD.
-    if (L.mode == 0 && L.cpw == 4) { // four chains per workgroup (mvx_analyse_frames sorted the job table by reference frame)
+    if (L.cpw == 4) { // four chains per workgroup (mvx_analyse_frames sorted the job table by reference frame)
         if (P.blkX == 8 && P.blkY == 8 && L.wpe == 3) return launch_analyse_kernel<1, Geo<8, 8, 2, 2>, 3, 4>(L); // three chains per SIMD (launches with more than two chains per SIMD)
         if (P.blkX == 8 && P.blkY == 8) return L.wpe == 2 ? launch_analyse_kernel<1, Geo<8, 8, 2, 2>, 2, 4>(L) : launch_analyse_kernel<1, Geo<8, 8, 2, 2>, 1, 4>(L);
         if (P.blkX == 16 && P.blkY == 16) return L.wpe == 2 ? launch_analyse_kernel<1, Geo<16, 16, 2, 2>, 2, 4>(L) : launch_analyse_kernel<1, Geo<16, 16, 2, 2>, 1, 4>(L);
     }
-    if (S == 0 && L.njobs > L.simds) {
+    if (L.njobs > L.simds) {
         ALaunch L2 = L;
         L2.ldsBytes = L.ldsNeed;
         if (P.blkX == 8 && P.blkY == 8) return launch_analyse_kernel<1, Geo<8, 8, 2, 2>, 2>(L2); // (the 16x16 kernel would spill at 256 registers)
     }
-    if (P.blkX == 8 && P.blkY == 8) return S == 4 ? launch_analyse_kernel<1, Geo<8, 8, 2, 2, 4>>(L) : launch_analyse_kernel<1, Geo<8, 8, 2, 2>>(L);
-    if (P.blkX == 16 && P.blkY == 16) return S == 8 ? launch_analyse_kernel<1, Geo<16, 16, 2, 2, 8>>(L) : launch_analyse_kernel<1, Geo<16, 16, 2, 2>>(L);
+    if (P.blkX == 8 && P.blkY == 8) return launch_analyse_kernel<1, Geo<8, 8, 2, 2>>(L);
+    if (P.blkX == 16 && P.blkY == 16) return launch_analyse_kernel<1, Geo<16, 16, 2, 2>>(L);
     return 1;
 }

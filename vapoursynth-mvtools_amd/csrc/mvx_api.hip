@@ -120,6 +120,14 @@ extern "C" __attribute__((visibility("default"))) void *mvx_stream_create_priori
 }
 extern "C" __attribute__((visibility("default"))) void mvx_stream_destroy(void *s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }
 
+// page-locked host memory: the target of asynchronous device-to-host copies (mvx_copy_to_host) that must not stall the caller
+extern "C" __attribute__((visibility("default"))) void *mvx_host_alloc_pinned(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { mvx_set_error("hipHostMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+extern "C" __attribute__((visibility("default"))) void mvx_host_free_pinned(void *p) { if (p) (void)hipHostFree(p); }
+
 extern "C" __attribute__((visibility("default"))) int mvx_copy_to_device(void *dst, ptrdiff_t dp, const void *src, ptrdiff_t sp, size_t row_bytes, size_t rows, void *stream) {
     HIP_CHECK(hipMemcpy2DAsync(dst, dp, src, sp, row_bytes, rows, hipMemcpyHostToDevice, (hipStream_t)stream));
     return MVX_OK;

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void super_shadow_kernel(ShadowArgs A) {
     const int f = blockIdx.y >> 1, kind = blockIdx.y & 1;
     const long long i = A.begin[kind] + ((long long)blockIdx.x * 256 + threadIdx.x) * 16; // begin: bytes before it were written by the Super kernels themselves
     if (kind == 0) {
-        if (i >= A.size[0]) return;
+        if (A.bps == 1 || i >= A.size[0]) return; // (8-bit clips keep no shifted luma copy)
         unsigned char *base = (unsigned char *)A.planes[f * 3];
         const uint4 a = *(const uint4 *)(base + i);
         const unsigned b = i + 16 < A.size[0] ? *(const unsigned *)(base + i + 16) : 0u;
@@ -449,6 +449,14 @@ __global__ __launch_bounds__(256) void super_shadow_kernel(ShadowArgs A) {
         if (A.nplanes < 3 || i >= A.size[1]) return;
         const unsigned char *pu = (const unsigned char *)A.planes[f * 3 + 1], *pv = (const unsigned char *)A.planes[f * 3 + 2];
         const uint4 u = *(const uint4 *)(pu + i), v = *(const uint4 *)(pv + i);
+        if (A.bps == 1) { // 8-bit samples: dword k of u holds samples 4k .. 4k+3 -> (U V U V) twice
+            auto lo8 = [](unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x05010400u); };
+            auto hi8 = [](unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07030602u); };
+            const uint4 o0 = { lo8(u.x, v.x), hi8(u.x, v.x), lo8(u.y, v.y), hi8(u.y, v.y) }, o1 = { lo8(u.z, v.z), hi8(u.z, v.z), lo8(u.w, v.w), hi8(u.w, v.w) };
+            unsigned char *d8 = (unsigned char *)A.planes[f * 3 + 1] + A.stride[1] + 2 * i;
+            *(uint4 *)d8 = o0; *(uint4 *)(d8 + 16) = o1;
+            return;
+        }
         // 16-bit samples: dword k of u holds samples 2k, 2k+1 -> (U 2k | V 2k), (U 2k+1 | V 2k+1)
         auto lo = [](unsigned a, unsigned b) { return (a & 0xffffu) | (b << 16); };
         auto hi = [](unsigned a, unsigned b) { return (a >> 16) | (b & 0xffff0000u); };
@@ -460,17 +468,19 @@ __global__ __launch_bounds__(256) void super_shadow_kernel(ShadowArgs A) {
 // 16-bit clips: shadows exist (1).  8-bit clips: none (0) -- measured (r2, 1080p Degrain1): shifted copies of an 8-bit plane (three are
 // needed) quadruple the cache footprint of every chain and cost more than the aligned loads save (1250-1340 fps with copies, 2005
 // without); the search then simply loads from the planes themselves.
-extern "C" __attribute__((visibility("default"))) int mvx_super_shadow_copies(const mvx_super *s) { return s->info.bits <= 8 ? 0 : 1; }
+// r3: 8-bit 4:2:x clips get the UV-interleaved plane too (U and V of a chroma block in ONE row of twice the width: half the load
+// instructions and cache lines per candidate), still no luma copy.
+extern "C" __attribute__((visibility("default"))) int mvx_super_shadow_copies(const mvx_super *s) { return s->info.bits <= 8 ? (s->info.num_planes >= 3 ? 1 : 0) : 1; }
 // bytes of shadow data a caller must provide behind plane p: the luma plane's shifted copy, and -- behind the U plane -- ONE plane
 // of twice the chroma size holding U and V interleaved (every chroma position is dword-aligned there, no shifted copy needed)
 extern "C" __attribute__((visibility("default"))) void mvx_super_shadow_bytes(const mvx_super *s, const ptrdiff_t pitch[3], size_t extra[3]) {
     extra[0] = extra[1] = extra[2] = 0;
     if (!mvx_super_shadow_copies(s)) return;
-    extra[0] = (size_t)s->info.plane_height[0] * pitch[0];
+    if (s->info.bits > 8) extra[0] = (size_t)s->info.plane_height[0] * pitch[0];
     if (s->info.num_planes >= 3) extra[1] = 2 * (size_t)s->info.plane_height[1] * pitch[1];
 }
 static int shadow_check(const mvx_super_info &si, const ptrdiff_t pitch[3], const ptrdiff_t copy_stride[3]) {
-    for (int p = 0; p < si.num_planes && p < 2; p++) {
+    for (int p = si.bits > 8 ? 0 : 1; p < si.num_planes && p < 2; p++) {
         const long long size = (long long)si.plane_height[p] * pitch[p];
         if (pitch[p] % 16 || copy_stride[p] % 16 || copy_stride[p] < size) { mvx_set_error("mvx_super_shadow_frames: pitch and shadow offset must be multiples of 16 bytes, the offset at least one plane"); return MVX_E_ARG; }
     }
@@ -482,9 +492,9 @@ static int shadow_launch(const mvx_super_info &si, int nframes, void *const *dpl
                          const long long begin[2], hipStream_t st) {
     ShadowArgs A;
     memset(&A, 0, sizeof(A));
-    A.nplanes = si.num_planes; A.bps = 2; A.planes = dplanes;
+    A.nplanes = si.num_planes; A.bps = si.bits > 8 ? 2 : 1; A.planes = dplanes;
     long long maxsize = 0;
-    for (int p = 0; p < si.num_planes && p < 2; p++) {
+    for (int p = A.bps == 1 ? 1 : 0; p < si.num_planes && p < 2; p++) {
         A.size[p] = (long long)si.plane_height[p] * pitch[p]; A.stride[p] = copy_stride[p]; A.begin[p] = begin[p];
         if (A.size[p] - begin[p] > maxsize) maxsize = A.size[p] - begin[p];
     }

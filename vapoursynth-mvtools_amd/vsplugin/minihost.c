@@ -203,11 +203,17 @@ static void VS_CC freeNode(VSNode *n) { node_free(n); }
 static VSNode *VS_CC addNodeRef(VSNode *n) { return node_addref(n); }
 static const VSVideoInfo *VS_CC getVideoInfo(VSNode *n) { return &n->vi; }
 
+static double g_wait_s; /* thread-seconds spent waiting for a frame another thread is producing (MVX_HOST_TIMES) */
+static double mono_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 static const VSFrame *eval_frame(int n, VSNode *node, char *err, int errsz) {
     if (n < 0) n = 0;
     if (n >= node->vi.numFrames) n = node->vi.numFrames - 1;
     pthread_mutex_lock(&g_host_mu); /* one producer per frame; the others wait for it (a real core would park the request) */
-    while (node->busy && node->busy[n] && !node->cache[n]) pthread_cond_wait(&g_host_cv, &g_host_mu);
+    if (node->busy && node->busy[n] && !node->cache[n]) {
+        const double t0 = mono_s();
+        while (node->busy[n] && !node->cache[n]) pthread_cond_wait(&g_host_cv, &g_host_mu);
+        g_wait_s += mono_s() - t0;
+    }
     if (node->cache[n]) { ((VSFrame *)node->cache[n])->refs++; const VSFrame *hit = node->cache[n]; pthread_mutex_unlock(&g_host_mu); return hit; }
     if (node->busy) node->busy[n] = 1;
     pthread_mutex_unlock(&g_host_mu);
@@ -634,7 +640,7 @@ int main(int argc, char **argv) {
         dump_frame(fo, f); freeFrame(f);
     }
     fclose(fo);
-    if (times) fprintf(stderr, "minihost: result file written in %.2f s\n", now_s() - t0);
+    if (times) fprintf(stderr, "minihost: result file written in %.2f s; threads waited %.2f thread-seconds for frames other threads were producing\n", now_s() - t0, g_wait_s);
     printf("DONE\n");
     return 0;
 }

@@ -29,6 +29,7 @@
 #include <time.h>
 
 #include "vs4_api.h"
+#include "vs4_api_check.h"
 #include "../../include/mvtools_amd.h"
 
 #define PROP_ADATA "MVTools_MVAnalysisData"
@@ -54,7 +55,7 @@ static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 static void *g_frame_stream;
 static int g_frame_stream_tried;
 /* MVX_VS_STATS=1: thread-seconds by category, printed with the launch statistics when the plugin is unloaded */
-enum { PF_STREAM, PF_UPLOAD, PF_DOWNLOAD, PF_SUPER, PF_SEARCH_WAIT, PF_DEGRAIN, PF_ALLOC, PF_N };
+enum { PF_STREAM, PF_UPLOAD, PF_DOWNLOAD, PF_SUPER, PF_SEARCH_WAIT, PF_DEGRAIN, PF_ALLOC, PF_LA_BLOCKED, PF_BUILD_LOCK, PF_GF_SUPER, PF_GF_ANALYSE, PF_GF_DEGRAIN, PF_N };
 static double g_prof[PF_N];
 static long g_prof_n[PF_N];
 static int g_prof_on = -1;
@@ -65,6 +66,7 @@ static void prof_add(int k, double t0) {
     const double dt = prof_now() - t0;
     pthread_mutex_lock(&g_lock); g_prof[k] += dt; g_prof_n[k]++; pthread_mutex_unlock(&g_lock);
 }
+static void prof_add_locked_ok(int k, double t0) { prof_add(k, t0); } /* (g_lock is a different mutex than the callers hold) */
 static void *thread_stream(void) {
     if (!__atomic_load_n(&g_frame_stream_tried, __ATOMIC_ACQUIRE)) {
         pthread_mutex_lock(&g_lock);
@@ -72,6 +74,25 @@ static void *thread_stream(void) {
         pthread_mutex_unlock(&g_lock);
     }
     return g_frame_stream;
+}
+/* the 131 MB downloads of finished super frames (mv.Super's host frames) run on a stream of their own: they only depend on kernels that
+ * were waited for already, and on their own stream they overlap the other threads' uploads (PCIe is full duplex) instead of queueing
+ * in front of them */
+static void *g_dl_stream;
+static int g_dl_stream_tried;
+static void *download_stream(void) {
+    if (!__atomic_load_n(&g_dl_stream_tried, __ATOMIC_ACQUIRE)) {
+        pthread_mutex_lock(&g_lock);
+        if (!g_dl_stream_tried) { g_dl_stream = mvx_stream_create_priority(1); __atomic_store_n(&g_dl_stream_tried, 1, __ATOMIC_RELEASE); }
+        pthread_mutex_unlock(&g_lock);
+    }
+    return g_dl_stream ? g_dl_stream : thread_stream();
+}
+static int timed_download_on(void *stream, void *dst, ptrdiff_t dp, const void *src, ptrdiff_t sp, size_t rb, size_t rows) {
+    const double t0 = prof_now();
+    const int rc = mvx_download_2d(dst, dp, src, sp, rb, rows, stream);
+    prof_add(PF_DOWNLOAD, t0);
+    return rc;
 }
 static int timed_upload(void *dst, ptrdiff_t dp, const void *src, ptrdiff_t sp, size_t rb, size_t rows) {
     const double t0 = prof_now();
@@ -462,10 +483,33 @@ static SuperData *super_lookup(VSNode *out) {
  * to the cache, pinned; frames that are cached already are only pinned.  out[i] = the pinned entry of frame nums[i].  One builder at a
  * time: six vector clips ask for the same frames.  Returns 0 or an MVX_E_* code (entries pinned so far are released on failure). */
 static pthread_mutex_t g_build_mu = PTHREAD_MUTEX_INITIALIZER;
+#define BUILD_THREADS 8
+typedef struct BuildJob { SuperData *sd; const VSAPI *vs; const int *miss; int nmiss; const VSFrame *const *srcs; void **srcArena, **arena; const void **sp; void **dp; int next, rc; pthread_mutex_t mu; } BuildJob;
+static void *build_worker(void *arg) { /* uploads source frames and prepares their (zero-filled) super arenas, one frame at a time */
+    BuildJob *j = (BuildJob *)arg;
+    const SuperGeo *g = &j->sd->geo;
+    void *st = thread_stream();
+    for (;;) {
+        pthread_mutex_lock(&j->mu);
+        const int k = (j->rc || j->next >= j->nmiss) ? -1 : j->next++;
+        pthread_mutex_unlock(&j->mu);
+        if (k < 0) return NULL;
+        const int i = j->miss[k];
+        void *d3[3];
+        int rc = upload_plane_set(d3, &j->srcArena[k], j->srcs[i], j->sd->srcPitch, g->si.num_planes, g->bps, j->vs);
+        for (int p = 0; p < 3; p++) j->sp[k * 3 + p] = d3[p];
+        if (!rc && !(j->arena[k] = shell_alloc(g->bytes))) rc = MVX_E_NOMEM;
+        if (!rc) rc = mvx_dev_memset(j->arena[k], 0, g->bytes, st);
+        for (int p = 0; p < g->si.num_planes && !rc; p++) j->dp[k * 3 + p] = (char *)j->arena[k] + g->off[p];
+        if (rc) { pthread_mutex_lock(&j->mu); if (!j->rc) j->rc = rc; pthread_mutex_unlock(&j->mu); }
+    }
+}
 static int super_build_device(SuperData *sd, int n, const int *nums, const VSFrame *const *srcs, DevFrame **out, const VSAPI *vs) {
     const SuperGeo *g = &sd->geo;
     int rc = 0, nmiss = 0;
+    const double tl = prof_now();
     pthread_mutex_lock(&g_build_mu);
+    prof_add(PF_BUILD_LOCK, tl);
     int *miss = (int *)malloc(sizeof(int) * (size_t)n);
     void **srcArena = (void **)calloc((size_t)n, sizeof(void *)), **arena = (void **)calloc((size_t)n, sizeof(void *));
     const void **sp = (const void **)calloc((size_t)n * 3, sizeof(void *));
@@ -478,14 +522,15 @@ static int super_build_device(SuperData *sd, int n, const int *nums, const VSFra
     }
     void *st = thread_stream();
     const double tp = prof_now();
-    for (int k = 0; k < nmiss && !rc; k++) {
-        const int i = miss[k];
-        void *d3[3];
-        rc = upload_plane_set(d3, &srcArena[k], srcs[i], sd->srcPitch, g->si.num_planes, g->bps, vs);
-        for (int p = 0; p < 3; p++) sp[k * 3 + p] = d3[p];
-        if (!rc && !(arena[k] = shell_alloc(g->bytes))) rc = MVX_E_NOMEM;
-        if (!rc) rc = mvx_dev_memset(arena[k], 0, g->bytes, st);
-        for (int p = 0; p < g->si.num_planes && !rc; p++) dp[k * 3 + p] = (char *)arena[k] + g->off[p];
+    if (!rc && nmiss) { /* the uploads (a host memcpy into pinned staging + a DMA each) are spread over a few helper threads: a window of 64 4K16
+                         * frames is 1.6 GB, which one thread moves in ~0.4 s -- as long as it takes to consume the window */
+        BuildJob job = { sd, vs, miss, nmiss, srcs, srcArena, arena, sp, dp, 0, 0, PTHREAD_MUTEX_INITIALIZER };
+        pthread_t th[BUILD_THREADS];
+        int nth = nmiss >= 2 * BUILD_THREADS ? BUILD_THREADS : (nmiss > 1 ? 2 : 1), started = 0;
+        for (int t = 1; t < nth; t++) if (pthread_create(&th[started], NULL, build_worker, &job) == 0) started++;
+        build_worker(&job);
+        for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+        rc = job.rc;
     }
     if (!rc && nmiss) {
         if (g->copies > 1) rc = mvx_super_frames_shadow(sd->sup, nmiss, sp, sd->srcPitch, dp, g->pitch, g->shadowStride, st);
@@ -529,6 +574,7 @@ static const VSFrame *VS_CC superGetFrame(int n, int reason, void *inst, void **
         return NULL;
     }
     if (reason != arAllFramesReady) return NULL;
+    const double tgf = prof_now();
     const VSFrame *src = vs->getFrameFilter(n, d->node, ctx);
     const SuperGeo *g = &d->geo;
     const int64_t id = (d->instance << 32) | (uint32_t)n;
@@ -537,13 +583,14 @@ static const VSFrame *VS_CC superGetFrame(int n, int reason, void *inst, void **
         int rc2 = 0;
         VSFrame *dst2 = vs->newVideoFrame(&d->vi.format, d->vi.width, d->vi.height, src, core);
         for (int p = 0; p < g->si.num_planes && !rc2; p++)
-            rc2 = timed_download(vs->getWritePtr(dst2, p), vs->getStride(dst2, p), have->plane[p], g->pitch[p], (size_t)g->si.plane_width[p] * g->bps, (size_t)g->si.plane_height[p]);
+            rc2 = timed_download_on(download_stream(), vs->getWritePtr(dst2, p), vs->getStride(dst2, p), have->plane[p], g->pitch[p], (size_t)g->si.plane_width[p] * g->bps, (size_t)g->si.plane_height[p]);
         vs->freeFrame(src);
         if (rc2) { cache_unpin(have); vs->freeFrame(dst2); vs->setFilterError(mvx_last_error(), ctx); return NULL; }
         super_frame_props(dst2, n, id, g, vs);
         const uint64_t pr = frame_print(dst2, g, vs);
         pthread_mutex_lock(&g_lock); have->print = pr; pthread_mutex_unlock(&g_lock);
         cache_unpin(have);
+        prof_add(PF_GF_SUPER, tgf);
         return dst2;
     }
     void *srcArena = NULL, *pelArena = NULL, *dsrc[3], *dpel[3] = { NULL, NULL, NULL }, *ddst[3] = { NULL, NULL, NULL };
@@ -589,6 +636,7 @@ static const VSFrame *VS_CC superGetFrame(int n, int reason, void *inst, void **
     /* the device copy stays resident for the consumers */
     DevFrame *e = cache_insert(id, frame_print(dst, g, vs), arena, g);
     if (e) cache_unpin(e); else mvx_dev_free(arena);
+    prof_add(PF_GF_SUPER, tgf);
     return dst;
 }
 
@@ -686,16 +734,17 @@ typedef struct Combiner {
 /* Look-ahead (mv.Analyse whose `super` argument is this plugin's own mv.Super node).  A search is a serial chain per frame that
  * takes ~0.45 s at 4K however few chains a launch carries, so a vector clip is computed a WINDOW of B consecutive
  * frames at a time: the first request that touches window w also asks for the SOURCE frames (25 MB each at 4K16, not the 131 MB
- * super frames) of w and of w + 1, builds their super frames on the device only, and launches one search per window on the instance's
- * low-priority streams; window w + 1 runs while the frames of w are being consumed.  Every other request of the window just waits
+ * super frames) of w and of the next two windows, builds their super frames on the device only, and launches one search per window on
+ * the instance's low-priority streams; the windows ahead are gathered, built and searched while the frames of w are being consumed.  Every other request of the window just waits
  * for the launch that is already running (GPU work only: nothing it waits for needs a host worker thread) and copies its blob out
  * of the window's host array.  The request protocol stays the reference's (MVAnalyse.c:84-113: everything a frame needs is asked
  * for at arInitial and fetched at arAllFramesReady); the extra requests go to the source clip, declared as a second dependency. */
-#define LA_SLOTS 4
+#define LA_SLOTS 6
 enum { LW_EMPTY, LW_BUILDING, LW_LAUNCHED, LW_SYNCING, LW_READY, LW_FAILED };
-typedef struct LaWindow { int w, state, first, count, users, rc; char *blobs; void *dblobs; size_t dstride; DevFrame **pins; int npins; void *stream; } LaWindow;
-typedef struct LookAhead { int on, B; VSNode *srcNode; SuperData *sd; pthread_mutex_t mu; pthread_cond_t cv; LaWindow win[LA_SLOTS]; } LookAhead;
-typedef struct LaReq { int legacy, w, hold[2], want[2]; } LaReq;
+typedef struct LaWindow { int w, state, first, count, users, rc; char *blobs; size_t blobsCap; void *dblobs; size_t dstride; DevFrame **pins; int npins; void *stream; } LaWindow; /* blobs: pinned host memory, kept with the slot */
+typedef struct LookAhead { int on, B, depth; VSNode *srcNode; SuperData *sd; pthread_mutex_t mu; pthread_cond_t cv; LaWindow win[LA_SLOTS]; } LookAhead;
+#define LA_DEPTH_MAX 3
+typedef struct LaReq { int legacy, w, hold[1 + LA_DEPTH_MAX], want[1 + LA_DEPTH_MAX]; } LaReq;
 
 typedef struct AnalyseData { VSNode *node; const VSVideoInfo *vi; mvx_super *sup; SuperGeo geo; mvx_analyse *an; mvx_analysis_data ad; int blobSize; FieldOpt fo; Combiner cb; LookAhead la; } AnalyseData;
 
@@ -707,7 +756,8 @@ __attribute__((destructor)) static void print_stats(void) {
     if (env_long("MVX_VS_STATS", 0) && g_stat_instances)
     {
         fprintf(stderr, "mvtools_vs: Analyse instances=%ld launches=%ld jobs=%ld largest_batch=%ld\n", g_stat_instances, g_stat_launches, g_stat_jobs, g_stat_largest);
-        static const char *nm[PF_N] = { "stream_create", "upload", "download", "super_kernels", "search_wait", "degrain", "dev_alloc" };
+        static const char *nm[PF_N] = { "stream_create", "upload", "download", "super_kernels", "search_wait", "degrain", "dev_alloc", "lookahead_blocked", "build_lock",
+                                        "getframe_super", "getframe_analyse", "getframe_degrain" };
         fprintf(stderr, "mvtools_vs: thread-seconds");
         for (int k = 0; k < PF_N; k++) fprintf(stderr, " %s=%.2f/%ld", nm[k], g_prof[k], g_prof_n[k]);
         fprintf(stderr, "\n");
@@ -802,8 +852,7 @@ static void la_window_release(LaWindow *s) { /* frees what a finished / failed w
     for (int i = 0; i < s->npins; i++) cache_unpin(s->pins[i]);
     free(s->pins); s->pins = NULL; s->npins = 0;
     if (s->dblobs) { mvx_dev_free(s->dblobs); s->dblobs = NULL; }
-    free(s->blobs); s->blobs = NULL;
-    s->state = LW_EMPTY; s->count = 0; s->rc = 0;
+    s->state = LW_EMPTY; s->count = 0; s->rc = 0; /* (the pinned host array stays with the slot for its next window) */
 }
 /* the slot of window w, recycled from an older finished window if nobody uses it; NULL if it is taken.  mu held. */
 static LaWindow *la_slot(AnalyseData *d, int w) {
@@ -853,7 +902,17 @@ static int la_launch(AnalyseData *d, LaWindow *s, int v, VSFrameContext *ctx, co
     for (int i = 0; i < nn; i++) if (srcs && srcs[i]) vs->freeFrame(srcs[i]);
     const size_t stride = ((size_t)d->blobSize + 255) / 256 * 256;
     void *dblobs = rc ? NULL : shell_alloc(stride * (size_t)count);
-    char *blobs = rc ? NULL : (char *)malloc((size_t)d->blobSize * (size_t)count);
+    /* the vectors come back by an asynchronous copy queued behind the search on the window's stream, into page-locked memory that
+     * belongs to the slot: whoever needs the window first only waits for the stream (a synchronous 175 MB download at that point
+     * stalled every request thread of the window, six vector clips in turn) */
+    const size_t hostBytes = (size_t)d->blobSize * (size_t)count;
+    if (!rc && s->blobsCap < hostBytes) {
+        mvx_host_free_pinned(s->blobs);
+        s->blobsCap = (size_t)d->blobSize * (size_t)d->la.B;
+        s->blobs = (char *)mvx_host_alloc_pinned(s->blobsCap);
+        if (!s->blobs) s->blobsCap = 0;
+    }
+    char *blobs = s->blobs;
     if (!rc && (!dblobs || !blobs)) rc = MVX_E_NOMEM;
     if (!rc) {
         for (int i = 0; i < count; i++) {
@@ -866,15 +925,16 @@ static int la_launch(AnalyseData *d, LaWindow *s, int v, VSFrameContext *ctx, co
         }
         s->stream = d->cb.stream[v & 3];
         rc = mvx_analyse_frames(d->an, count, jobs, s->stream);
+        if (!rc) rc = mvx_copy_to_host(blobs, d->blobSize, dblobs, (ptrdiff_t)stride, (size_t)d->blobSize, (size_t)count, s->stream);
         pthread_mutex_lock(&g_lock);
         g_stat_launches++; g_stat_jobs += count; if (count > g_stat_largest) g_stat_largest = count;
         pthread_mutex_unlock(&g_lock);
     }
     if (rc) {
         for (int i = 0; i < nn; i++) if (pins && pins[i]) cache_unpin(pins[i]);
-        free(pins); free(blobs);
+        free(pins);
         if (dblobs) mvx_dev_free(dblobs);
-    } else { s->pins = pins; s->npins = nn; s->dblobs = dblobs; s->dstride = stride; s->blobs = blobs; s->first = first; s->count = count; }
+    } else { s->pins = pins; s->npins = nn; s->dblobs = dblobs; s->dstride = stride; s->first = first; s->count = count; }
     free(nums); free(top); free(srcs); free(jobs);
     return rc;
 }
@@ -887,9 +947,8 @@ static int la_wait(AnalyseData *d, LaWindow *s) {
             s->state = LW_SYNCING;
             pthread_mutex_unlock(&d->la.mu);
             const double t0 = prof_now();
-            int rc = mvx_stream_sync(s->stream);
+            const int rc = mvx_stream_sync(s->stream); /* the search and the copy of its vectors into s->blobs */
             prof_add(PF_SEARCH_WAIT, t0);
-            if (!rc) rc = timed_download(s->blobs, d->blobSize, s->dblobs, (ptrdiff_t)s->dstride, (size_t)d->blobSize, (size_t)s->count);
             pthread_mutex_lock(&d->la.mu);
             for (int i = 0; i < s->npins; i++) cache_unpin(s->pins[i]);
             free(s->pins); s->pins = NULL; s->npins = 0;
@@ -898,7 +957,7 @@ static int la_wait(AnalyseData *d, LaWindow *s) {
             pthread_cond_broadcast(&d->la.cv);
             continue;
         }
-        pthread_cond_wait(&d->la.cv, &d->la.mu); /* BUILDING / SYNCING: somebody is on it */
+        { const double tb = prof_now(); pthread_cond_wait(&d->la.cv, &d->la.mu); prof_add_locked_ok(PF_LA_BLOCKED, tb); } /* BUILDING / SYNCING: somebody is on it */
     }
     const int rc = s->state == LW_READY ? 0 : (s->rc ? s->rc : MVX_E_DEVICE);
     pthread_mutex_unlock(&d->la.mu);
@@ -908,7 +967,7 @@ static void la_release_req(AnalyseData *d, LaReq *r) {
     if (!r) return;
     if (!r->legacy) {
         pthread_mutex_lock(&d->la.mu);
-        for (int i = 0; i < 2; i++) if (r->hold[i]) d->la.win[(r->w + i) % LA_SLOTS].users--;
+        for (int i = 0; i <= LA_DEPTH_MAX; i++) if (r->hold[i]) d->la.win[(r->w + i) % LA_SLOTS].users--;
         pthread_mutex_unlock(&d->la.mu);
     }
     free(r);
@@ -929,15 +988,18 @@ static const VSFrame *VS_CC analyseGetFrame(int n, int reason, void *inst, void 
                 if (!s0) r->legacy = 1;
                 else {
                     s0->users++; r->hold[0] = 1; r->want[0] = s0->state == LW_EMPTY;
-                    if ((r->w + 1) * d->la.B < d->vi->numFrames) {
-                        LaWindow *s1 = la_slot(d, r->w + 1);
-                        if (s1 && s1->state == LW_EMPTY) { s1->users++; r->hold[1] = 1; r->want[1] = 1; }
+                    for (int i = 1; i <= d->la.depth && (r->w + i) * d->la.B < d->vi->numFrames; i++) { /* the windows ahead: whoever sees them empty first starts them */
+                        LaWindow *s1 = la_slot(d, r->w + i);
+                        if (s1 && s1->state == LW_EMPTY) { s1->users++; r->hold[i] = 1; r->want[i] = 1; }
                     }
                 }
                 pthread_mutex_unlock(&d->la.mu);
                 if (!r->legacy) {
                     vs->requestFrameFilter(n, d->node, ctx); /* the vector clip's frame is a copy of the super frame (MVAnalyse.c:224) */
-                    for (int i = 0; i < 2; i++) if (r->want[i]) la_request_inputs(d, r->w + i, ctx, vs);
+                    /* one source frame of the window that will be started next: by the time some request sees that window empty and asks
+                     * for all of its frames, the requests of this window have had the host produce them, in parallel */
+                    { const int ahead = n + (d->la.depth + 1) * d->la.B; if (ahead < d->vi->numFrames) vs->requestFrameFilter(ahead, d->la.srcNode, ctx); }
+                    for (int i = 0; i <= LA_DEPTH_MAX; i++) if (r->want[i]) la_request_inputs(d, r->w + i, ctx, vs);
                     return NULL;
                 }
             }
@@ -946,8 +1008,9 @@ static const VSFrame *VS_CC analyseGetFrame(int n, int reason, void *inst, void 
             LaReq *r = (LaReq *)*fd;
             *fd = NULL;
             if (reason != arAllFramesReady) { la_release_req(d, r); return NULL; } /* arError */
+            const double tgf = prof_now();
             int rc = 0;
-            for (int i = 0; i < 2 && !rc; i++) {
+            for (int i = 0; i <= LA_DEPTH_MAX && !rc; i++) {
                 if (!r->want[i]) continue;
                 LaWindow *s = &d->la.win[(r->w + i) % LA_SLOTS];
                 int mine = 0;
@@ -976,6 +1039,7 @@ static const VSFrame *VS_CC analyseGetFrame(int n, int reason, void *inst, void 
                                    rc == MVX_E_NOMEM ? "Analyse: out of memory." : mvx_last_error(), ctx);
             if (src) vs->freeFrame(src);
             la_release_req(d, r);
+            prof_add(PF_GF_ANALYSE, tgf);
             return dst;
         } else if (*fd) { free(*fd); *fd = NULL; }
     }
@@ -1045,6 +1109,7 @@ static void VS_CC analyseFree(void *inst, VSCore *core, const VSAPI *vs) {
             LaWindow *s = &d->la.win[i];
             if (s->state == LW_LAUNCHED) (void)mvx_stream_sync(s->stream); /* nobody came for it */
             la_window_release(s);
+            mvx_host_free_pinned(s->blobs); s->blobs = NULL; s->blobsCap = 0;
         }
         vs->freeNode(d->la.srcNode);
         pthread_mutex_destroy(&d->la.mu); pthread_cond_destroy(&d->la.cv);
@@ -1097,6 +1162,11 @@ static void VS_CC analyseCreate(const VSMap *in, VSMap *out, void *user, VSCore 
         const long B = env_long("MVX_VS_LOOKAHEAD", 64);
         if (sd && !sd->pelMode && B > 0 && vi->numFrames > 1) {
             d->la.on = 1; d->la.B = (int)(B > 512 ? 512 : B); d->la.sd = sd;
+            /* windows started ahead of the one being consumed.  Two: gathering a window's source frames and building its super frames
+             * takes a host about as long as consuming a window does, and the search itself another ~0.5 s */
+            d->la.depth = (int)env_long("MVX_VS_LOOKAHEAD_DEPTH", 2);
+            if (d->la.depth < 0) d->la.depth = 0;
+            if (d->la.depth > LA_DEPTH_MAX) d->la.depth = LA_DEPTH_MAX;
             d->la.srcNode = vs->addNodeRef(sd->node);
             pthread_mutex_init(&d->la.mu, NULL); pthread_cond_init(&d->la.cv, NULL);
             for (int i = 0; i < LA_SLOTS; i++) d->la.win[i].w = -1;
@@ -1359,6 +1429,7 @@ static const VSFrame *VS_CC degrainGetFrame(int n, int reason, void *inst, void 
         return NULL;
     }
     if (reason != arAllFramesReady) return NULL;
+    const double tgf = prof_now();
     const VSFrame *src = vs->getFrameFilter(n, d->node, ctx);
     const int np = d->vi->format.numPlanes, bps = d->vi->format.bytesPerSample;
     mvx_degrain_job job;
@@ -1409,6 +1480,7 @@ static const VSFrame *VS_CC degrainGetFrame(int n, int reason, void *inst, void 
         vs->setFilterError(msg, ctx);
         return NULL;
     }
+    prof_add(PF_GF_DEGRAIN, tgf);
     return dst;
 }
 
