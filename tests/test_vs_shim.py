@@ -402,7 +402,7 @@ def test_concurrent_requests_are_batched_and_bit_identical(tmp_path, bits, pipel
 @pytest.mark.parametrize("bits,pipeline,extra,threads", [(16, "degrain3", ("a.blksize=16", "a.overlap=8"), 32), (8, "degrain1", ("a.blksize=8", "a.overlap=4"), 1),
                                                           (8, "analyse", ("a.blksize=8", "a.overlap=4", "a.delta=2"), 8)])
 def test_lookahead_serves_windows_and_is_bit_identical(tmp_path, bits, pipeline, extra, threads):
-    """mv.Analyse on this plugin's own mv.Super node computes its vector clip a window of 64 frames at a time (one search launch per
+    """mv.Analyse on this plugin's own mv.Super node computes its vector clip a window of 128 frames at a time (one search launch per
     window, super frames built on the device from the SOURCE frames; the request protocol stays MVAnalyse.c:84-113's arInitial /
     arAllFramesReady).  The clip must be the one the per-frame path gives (MVX_VS_LOOKAHEAD=0, which the other tests tie to the oracle),
     with at least ten times fewer launches than frames."""
@@ -419,4 +419,4 @@ def test_lookahead_serves_windows_and_is_bit_identical(tmp_path, bits, pipeline,
     stats = [l for l in r1.stderr.splitlines() if l.startswith("mvtools_vs: Analyse")]
     assert len(stats) == 1, r1.stderr
     kv = {k: int(v) for k, v in (t.split("=") for t in stats[0].split()[2:])}
-    assert kv["jobs"] == n * kv["instances"] and kv["launches"] * 10 <= kv["jobs"] and kv["largest_batch"] == 64, stats[0]
+    assert kv["jobs"] == n * kv["instances"] and kv["launches"] * 10 <= kv["jobs"] and kv["largest_batch"] == 128, stats[0]

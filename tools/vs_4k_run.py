@@ -32,7 +32,7 @@ if verify or not (os.path.exists(src) and os.path.getsize(src) == per_frame * N)
 host, plugin = os.path.join(ROOT, "vapoursynth-mvtools_amd", "mvx_vs_host"), os.path.join(ROOT, "vapoursynth-mvtools_amd", "libmvtools_vs.so")
 env = dict(os.environ, MVX_VS_STATS="1", MVX_HOST_TIMES="1")
 t0 = time.time()
-r = subprocess.run([host, plugin, "run", "degrain3", src, str(w), str(h), str(bits), str(N), out, "a.blksize=16", "a.overlap=8", "x.threads=%d" % T] + (["x.order=frame"] if os.environ.get("VS_ORDER", "frame") == "frame" else []),
+r = subprocess.run([host, plugin, "run", "degrain3", src, str(w), str(h), str(bits), str(N), out, "a.blksize=16", "a.overlap=8", "x.threads=%d" % T] + (["x.order=frame"] if os.environ.get("VS_ORDER", "frame") == "frame" else []) + (["x.cache=%s" % os.environ["VS_CACHE"]] if os.environ.get("VS_CACHE") else []),
                    capture_output=True, text=True, env=env)
 dt = time.time() - t0
 print(r.stdout.strip()[-200:], r.stderr.strip()[-700:], flush=True)
@@ -42,6 +42,10 @@ import re  # noqa: E402
 m = re.search(r"output clip \(frame order\) ([0-9.]+) s", r.stderr)
 if m:
     print("steady state: %d frames requested in frame order in %s s = %.1f fps (graph construction, which runs the first windows, and the result file excluded)" % (N, m.group(1), N / float(m.group(1))), flush=True)
+marks = [(int(a), float(b)) for a, b in re.findall(r"minihost: (\d+) requests done at ([0-9.]+) s", r.stderr)]
+if len(marks) >= 4:  # the second half of the run: device arenas and host buffers are being recycled by then
+    (n0, t0_), (n1, t1_) = marks[len(marks) // 2 - 1], marks[-1]
+    print("second half of the run: frames %d .. %d in %.2f s = %.1f fps" % (n0, n1, t1_ - t0_, (n1 - n0) / (t1_ - t0_)), flush=True)
 if not verify:
     sys.exit(0)
 

@@ -144,7 +144,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_copy_to_host(void *dst
 #include <cstring>
 namespace {
 struct Stage { void *p = nullptr; size_t cap = 0; bool busy = false; };
-constexpr int kStages = 16;
+constexpr int kStages = 64; // (a frame server runs tens of request threads plus the window builders: with fewer buffers than threads they queue here)
 Stage g_stage[kStages];
 std::mutex g_stage_mu;
 std::condition_variable g_stage_cv;

@@ -112,8 +112,23 @@ static int plane_h(const VSFrame *f, int p) { return p ? f->h >> f->fmt.subSampl
 
 /* large planes on huge pages where the kernel offers them: a 131 MB super frame is 32 000 page faults otherwise, and the faults of
  * 64 worker threads serialise on the process's memory map (VapourSynth recycles frame buffers instead) */
+/* freed plane buffers are kept for reuse, like the frame memory pool of a real core: a recycled buffer costs no page faults */
+#define POOL_MAX 4096
+static struct { void *p; size_t size; } g_pool[POOL_MAX];
+static int g_pool_n;
+static pthread_mutex_t g_pool_mu = PTHREAD_MUTEX_INITIALIZER;
+static void plane_free(void *p, size_t size) {
+    pthread_mutex_lock(&g_pool_mu);
+    if (g_pool_n < POOL_MAX) { g_pool[g_pool_n].p = p; g_pool[g_pool_n].size = size; g_pool_n++; p = NULL; }
+    pthread_mutex_unlock(&g_pool_mu);
+    free(p);
+}
 static uint8_t *plane_alloc(size_t size) {
     void *p = NULL;
+    pthread_mutex_lock(&g_pool_mu);
+    for (int i = g_pool_n - 1; i >= 0; i--) if (g_pool[i].size == size) { p = g_pool[i].p; g_pool[i] = g_pool[--g_pool_n]; break; }
+    pthread_mutex_unlock(&g_pool_mu);
+    if (p) return (uint8_t *)p;
     const size_t big = (size_t)2 << 20;
     if (size >= 2 * big) {
         if (posix_memalign(&p, big, (size + big - 1) / big * big)) abort();
@@ -128,7 +143,9 @@ static VSFrame *VS_CC newVideoFrame(const VSVideoFormat *fmt, int w, int h, cons
     for (int p = 0; p < fmt->numPlanes; p++) {
         f->stride[p] = ((ptrdiff_t)plane_w(f, p) * fmt->bytesPerSample + 63) / 64 * 64;
         f->data[p] = plane_alloc((size_t)f->stride[p] * plane_h(f, p));
-        memset(f->data[p], 0xCD, (size_t)f->stride[p] * plane_h(f, p)); /* new frames are uninitialised in VapourSynth */
+        /* new frames are uninitialised in VapourSynth: poison them so that a filter that forgets to write shows up (small frames always; big
+         * ones only with MVX_HOST_POISON=1 -- a pass over a 131 MB super frame per frame is what a throughput run should not measure) */
+        if ((size_t)f->stride[p] * plane_h(f, p) < ((size_t)8 << 20) || getenv("MVX_HOST_POISON")) memset(f->data[p], 0xCD, (size_t)f->stride[p] * plane_h(f, p));
         f->planeRefs[p] = (int *)malloc(sizeof(int)); *f->planeRefs[p] = 1;
     }
     if (propSrc) copy_map(f->props, propSrc->props);
@@ -143,7 +160,7 @@ static void VS_CC freeFrame(const VSFrame *cf) {
     if (!left) for (int p = 0; p < 3; p++) if (f->planeRefs[p] && --*f->planeRefs[p] == 0) drop[p] = 1;
     pthread_mutex_unlock(&g_host_mu);
     if (left) return;
-    for (int p = 0; p < 3; p++) if (drop[p]) { free(f->data[p]); free(f->planeRefs[p]); }
+    for (int p = 0; p < 3; p++) if (drop[p]) { plane_free(f->data[p], (size_t)f->stride[p] * plane_h(f, p)); free(f->planeRefs[p]); }
     freeMap(f->props); free(f);
 }
 static const VSFrame *frame_addref(const VSFrame *f) { pthread_mutex_lock(&g_host_mu); ((VSFrame *)f)->refs++; pthread_mutex_unlock(&g_host_mu); return f; }
@@ -184,7 +201,8 @@ static int VS_CC getFrameHeight(const VSFrame *f, int p) { return plane_h(f, p);
 
 /* ---------------------------------------------------------------------------------------------------- nodes */
 
-struct VSNode { int refs; VSVideoInfo vi; VSFilterGetFrame getFrame; VSFilterFree freeFn; void *inst; const VSFrame **cache; unsigned char *busy; char name[32]; };
+struct VSNode { int refs; VSVideoInfo vi; VSFilterGetFrame getFrame; VSFilterFree freeFn; void *inst; const VSFrame **cache; unsigned char *busy; char name[32]; int ncached, lowest; };
+static int g_cache_limit; /* x.cache=N: a node keeps at most N frames (the lowest-numbered ones go first), 0 = all, like the bounded caches of a real core */
 struct VSFrameContext { int n; struct { int n; VSNode *node; const VSFrame *f; } req[1024]; int nreq; char error[1024]; };
 
 static VSAPI g_api;
@@ -231,11 +249,20 @@ static const VSFrame *eval_frame(int n, VSNode *node, char *err, int errsz) {
         if (!ctx.error[0]) out = node->getFrame(n, arAllFramesReady, node->inst, &fd, &ctx, NULL, &g_api);
     }
     for (int i = 0; i < ctx.nreq; i++) if (ctx.req[i].f) freeFrame(ctx.req[i].f);
+    const VSFrame *evict[8];
+    int nev = 0;
     pthread_mutex_lock(&g_host_mu);
-    if (out) { node->cache[n] = out; ((VSFrame *)out)->refs++; }
+    if (out && !node->cache[n]) { node->cache[n] = out; ((VSFrame *)out)->refs++; node->ncached++; if (n < node->lowest) node->lowest = n; }
     if (node->busy) node->busy[n] = 0;
+    while (g_cache_limit > 0 && node->ncached > g_cache_limit && nev < 8) { /* drop the oldest frames (this one excepted) */
+        int i = node->lowest;
+        while (i < node->vi.numFrames && (!node->cache[i] || i == n)) i++;
+        if (i >= node->vi.numFrames) break;
+        evict[nev++] = node->cache[i]; node->cache[i] = NULL; node->ncached--; node->lowest = i + 1;
+    }
     pthread_cond_broadcast(&g_host_cv);
     pthread_mutex_unlock(&g_host_mu);
+    for (int i = 0; i < nev; i++) freeFrame(evict[i]);
     if (!out) { snprintf(err, (size_t)errsz, "%s", ctx.error[0] ? ctx.error : "filter returned no frame"); return NULL; }
     return out;
 }
@@ -411,7 +438,8 @@ static void dump_frame(FILE *fp, const VSFrame *f) {
 static void die(const char *what, const char *err) { printf("ERROR %s: %s\n", what, err); exit(1); }
 
 /* x.threads=N: request frames 0..count-1 of up to four nodes from N threads at once (results stay in the nodes' frame tables) */
-typedef struct Work { VSNode *nodes[4]; int nnodes, count, next; char err[2048]; } Work;
+typedef struct Work { VSNode *nodes[4]; int nnodes, count, next, done; char err[2048]; } Work;
+static double g_phase_t0;
 static void *worker(void *arg) {
     Work *w = (Work *)arg;
     for (;;) {
@@ -423,6 +451,12 @@ static void *worker(void *arg) {
         /* node-major order: every thread first asks the first node, so that one filter instance sees all requests at once */
         const VSFrame *f = eval_frame(i % w->count, w->nodes[i / w->count], err, sizeof(err));
         if (f) freeFrame(f);
+        if (getenv("MVX_HOST_TIMES")) { /* progress: when every 64th request completed (the rate of the later part of a run = the steady state) */
+            pthread_mutex_lock(&g_host_mu);
+            const int done = ++w->done;
+            pthread_mutex_unlock(&g_host_mu);
+            if (done % 64 == 0) fprintf(stderr, "minihost: %d requests done at %.2f s\n", done, mono_s() - g_phase_t0);
+        }
         else { pthread_mutex_lock(&g_host_mu); if (!w->err[0]) snprintf(w->err, sizeof(w->err), "%s", err); pthread_mutex_unlock(&g_host_mu); }
     }
 }
@@ -433,6 +467,7 @@ static void prefetch_parallel(int threads, int count, VSNode **nodes, int nnodes
     for (int i = 0; i < nnodes; i++) w.nodes[i] = nodes[i];
     w.nnodes = nnodes; w.count = count;
     pthread_t *t = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    g_phase_t0 = mono_s();
     for (int i = 0; i < threads; i++) pthread_create(&t[i], NULL, worker, &w);
     for (int i = 0; i < threads; i++) pthread_join(t[i], NULL);
     free(t);
@@ -502,6 +537,7 @@ int main(int argc, char **argv) {
     int threads = 1;
     for (int i = 0; i < nextra; i++) if (!strncmp(extra[i], "x.fieldorder=", 13)) g_field_order = atoi(extra[i] + 13);
     for (int i = 0; i < nextra; i++) if (!strncmp(extra[i], "x.threads=", 10)) threads = atoi(extra[i] + 10);
+    for (int i = 0; i < nextra; i++) if (!strncmp(extra[i], "x.cache=", 8)) g_cache_limit = atoi(extra[i] + 8);
     VSNode *clip = source_clip(inPath, w, hh, bits, nframes);
     FILE *fo = fopen(outPath, "wb");
     if (!fo) { fprintf(stderr, "cannot write %s\n", outPath); return 2; }

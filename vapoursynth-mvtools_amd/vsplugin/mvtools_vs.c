@@ -55,7 +55,7 @@ static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 static void *g_frame_stream;
 static int g_frame_stream_tried;
 /* MVX_VS_STATS=1: thread-seconds by category, printed with the launch statistics when the plugin is unloaded */
-enum { PF_STREAM, PF_UPLOAD, PF_DOWNLOAD, PF_SUPER, PF_SEARCH_WAIT, PF_DEGRAIN, PF_ALLOC, PF_LA_BLOCKED, PF_BUILD_LOCK, PF_GF_SUPER, PF_GF_ANALYSE, PF_GF_DEGRAIN, PF_N };
+enum { PF_STREAM, PF_UPLOAD, PF_DOWNLOAD, PF_SUPER, PF_SEARCH_WAIT, PF_DEGRAIN, PF_ALLOC, PF_LA_BLOCKED, PF_BUILD_LOCK, PF_GF_SUPER, PF_GF_ANALYSE, PF_GF_DEGRAIN, PF_LA_BUILD, PF_LA_ARENA, PF_LA_LAUNCH, PF_LA_SRCUP, PF_N };
 static double g_prof[PF_N];
 static long g_prof_n[PF_N];
 static int g_prof_on = -1;
@@ -484,6 +484,7 @@ static SuperData *super_lookup(VSNode *out) {
  * time: six vector clips ask for the same frames.  Returns 0 or an MVX_E_* code (entries pinned so far are released on failure). */
 static pthread_mutex_t g_build_mu = PTHREAD_MUTEX_INITIALIZER;
 #define BUILD_THREADS 8
+static long env_long_early(const char *name, long def) { const char *e = getenv(name); return e ? atol(e) : def; }
 typedef struct BuildJob { SuperData *sd; const VSAPI *vs; const int *miss; int nmiss; const VSFrame *const *srcs; void **srcArena, **arena; const void **sp; void **dp; int next, rc; pthread_mutex_t mu; } BuildJob;
 static void *build_worker(void *arg) { /* uploads source frames and prepares their (zero-filled) super arenas, one frame at a time */
     BuildJob *j = (BuildJob *)arg;
@@ -496,9 +497,13 @@ static void *build_worker(void *arg) { /* uploads source frames and prepares the
         if (k < 0) return NULL;
         const int i = j->miss[k];
         void *d3[3];
+        double tq = prof_now();
         int rc = upload_plane_set(d3, &j->srcArena[k], j->srcs[i], j->sd->srcPitch, g->si.num_planes, g->bps, j->vs);
+        prof_add(PF_LA_SRCUP, tq);
         for (int p = 0; p < 3; p++) j->sp[k * 3 + p] = d3[p];
+        tq = prof_now();
         if (!rc && !(j->arena[k] = shell_alloc(g->bytes))) rc = MVX_E_NOMEM;
+        prof_add(PF_LA_ARENA, tq);
         if (!rc) rc = mvx_dev_memset(j->arena[k], 0, g->bytes, st);
         for (int p = 0; p < g->si.num_planes && !rc; p++) j->dp[k * 3 + p] = (char *)j->arena[k] + g->off[p];
         if (rc) { pthread_mutex_lock(&j->mu); if (!j->rc) j->rc = rc; pthread_mutex_unlock(&j->mu); }
@@ -526,7 +531,11 @@ static int super_build_device(SuperData *sd, int n, const int *nums, const VSFra
                          * frames is 1.6 GB, which one thread moves in ~0.4 s -- as long as it takes to consume the window */
         BuildJob job = { sd, vs, miss, nmiss, srcs, srcArena, arena, sp, dp, 0, 0, PTHREAD_MUTEX_INITIALIZER };
         pthread_t th[BUILD_THREADS];
-        int nth = nmiss >= 2 * BUILD_THREADS ? BUILD_THREADS : (nmiss > 1 ? 2 : 1), started = 0;
+        int want = (int)env_long_early("MVX_VS_BUILD_THREADS", 4);
+        if (want < 1) want = 1;
+        if (want > BUILD_THREADS) want = BUILD_THREADS;
+        int nth = nmiss >= 2 * want ? want : (nmiss > 1 ? 2 : 1), started = 0;
+        if (nth > want) nth = want;
         for (int t = 1; t < nth; t++) if (pthread_create(&th[started], NULL, build_worker, &job) == 0) started++;
         build_worker(&job);
         for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
@@ -757,7 +766,7 @@ __attribute__((destructor)) static void print_stats(void) {
     {
         fprintf(stderr, "mvtools_vs: Analyse instances=%ld launches=%ld jobs=%ld largest_batch=%ld\n", g_stat_instances, g_stat_launches, g_stat_jobs, g_stat_largest);
         static const char *nm[PF_N] = { "stream_create", "upload", "download", "super_kernels", "search_wait", "degrain", "dev_alloc", "lookahead_blocked", "build_lock",
-                                        "getframe_super", "getframe_analyse", "getframe_degrain" };
+                                        "getframe_super", "getframe_analyse", "getframe_degrain", "window_build", "window_arena_alloc", "window_launch_call", "window_source_upload" };
         fprintf(stderr, "mvtools_vs: thread-seconds");
         for (int k = 0; k < PF_N; k++) fprintf(stderr, " %s=%.2f/%ld", nm[k], g_prof[k], g_prof_n[k]);
         fprintf(stderr, "\n");
@@ -898,7 +907,7 @@ static int la_launch(AnalyseData *d, LaWindow *s, int v, VSFrameContext *ctx, co
         top[i] = frame_top_field(&d->fo, srcs[i], nums[i], &missing, vs); /* mv.Super copies the props of its source frame (MVSuper.c:104) */
     }
     if (!rc && missing && d->fo.fields) rc = -1000; /* reported by the caller with the reference's message */
-    if (!rc) rc = super_build_device(d->la.sd, nn, nums, srcs, pins, vs);
+    { const double tq = prof_now(); if (!rc) rc = super_build_device(d->la.sd, nn, nums, srcs, pins, vs); prof_add(PF_LA_BUILD, tq); }
     for (int i = 0; i < nn; i++) if (srcs && srcs[i]) vs->freeFrame(srcs[i]);
     const size_t stride = ((size_t)d->blobSize + 255) / 256 * 256;
     void *dblobs = rc ? NULL : shell_alloc(stride * (size_t)count);
@@ -924,7 +933,9 @@ static int la_launch(AnalyseData *d, LaWindow *s, int v, VSFrameContext *ctx, co
             jobs[i].field_shift = (haveRef && d->fo.fields && d->ad.nPel > 1 && (d->ad.nDeltaFrame % 2)) ? field_shift_of(top[is], top[ir], d->ad.nPel) : 0;
         }
         s->stream = d->cb.stream[v & 3];
+        const double tq = prof_now();
         rc = mvx_analyse_frames(d->an, count, jobs, s->stream);
+        prof_add(PF_LA_LAUNCH, tq);
         if (!rc) rc = mvx_copy_to_host(blobs, d->blobSize, dblobs, (ptrdiff_t)stride, (size_t)d->blobSize, (size_t)count, s->stream);
         pthread_mutex_lock(&g_lock);
         g_stat_launches++; g_stat_jobs += count; if (count > g_stat_largest) g_stat_largest = count;
@@ -1157,9 +1168,9 @@ static void VS_CC analyseCreate(const VSMap *in, VSMap *out, void *user, VSCore 
     d->cb.lastUs = (long)((double)d->ad.nBlkX * d->ad.nBlkY * 4.0 / 3.0 * 2.5);
     VSFilterDependency deps[2] = { { node, rpGeneral }, { NULL, rpGeneral } };
     int ndeps = 1;
-    { /* look-ahead when `super` is this plugin's own mv.Super node (MVX_VS_LOOKAHEAD = window length in frames, 0 = off; default 64) */
+    { /* look-ahead when `super` is this plugin's own mv.Super node (MVX_VS_LOOKAHEAD = window length in frames, 0 = off; default 128) */
         SuperData *sd = super_lookup(node);
-        const long B = env_long("MVX_VS_LOOKAHEAD", 64);
+        const long B = env_long("MVX_VS_LOOKAHEAD", 128);
         if (sd && !sd->pelMode && B > 0 && vi->numFrames > 1) {
             d->la.on = 1; d->la.B = (int)(B > 512 ? 512 : B); d->la.sd = sd;
             /* windows started ahead of the one being consumed.  Two: gathering a window's source frames and building its super frames
