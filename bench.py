@@ -119,13 +119,13 @@ class Pipeline:
         self.out = mv.arena_frames(batch, [tuple(p.shape) for p in self.src[0]], device, zero=False)
         self.ev = []  # (start, end) events around the search launches
 
-    def step(self, time_search=False):
+    def step(self, time_search=False, src=None):
         with self.torch.cuda.stream(self.stream):
-            self._step(time_search)
+            self._step(time_search, self.src if src is None else src)
 
-    def _step(self, time_search):
+    def _step(self, time_search, src):
         torch, tr, B = self.torch, self.tr, self.B
-        self.sup.build(self.src, out=self.supers)
+        self.sup.build(src, out=self.supers)
         # all 2*tr vector clips share one parameter block (delta / isb only pick the reference frame), so every chain
         # of the step goes into ONE launch: 2*tr*B chains resident at once
         jobs, blobs = [], []
@@ -141,7 +141,7 @@ class Pipeline:
             self.ev.append((e0, e1))
         djobs = []
         for n, refs, i in self.plan.degrains():
-            djobs.append((self.src[n], [self.supers[r] if r is not None else None for r in refs], [self.blobs[key][i] for key in self.plan.clips]))
+            djobs.append((src[n], [self.supers[r] if r is not None else None for r in refs], [self.blobs[key][i] for key in self.plan.clips]))
         self.dg.run(djobs, out=self.out)
 
     def level_grids(self):
@@ -365,6 +365,51 @@ def measure_traffic(args, B):
     return 2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each, in this run; 2 * FETCH_SIZE KB + WRITE_SIZE KB (gfx950 correction)"
 
 
+def ingest_run(torch, pipe, steps, warmup):
+    """Secondary, ingest-inclusive measurement (--ingest; DegrainN configurations): every step first receives its source frames from
+    PINNED host memory and its output frames go back to pinned host memory, on a copy stream, overlapped with the compute of the
+    neighbouring steps (the source clip is double-buffered on the device; the output download of step i runs under Super + search of
+    step i + 1 and is waited for before step i + 1's Degrain writes).  Returns seconds per step."""
+    dev_a = pipe.src[0][0]._base                              # the clip's arena (mv.arena_frames: one allocation)
+    dev_b = torch.empty_like(dev_a)
+    off = [[p.storage_offset() for p in f] for f in pipe.src]
+    src_b = [[dev_b[o:o + p.numel()].view(p.shape) for p, o in zip(f, of)] for f, of in zip(pipe.src, off)]
+    bufs, srcs = [dev_a, dev_b], [pipe.src, src_b]
+    out_dev = pipe.out[0][0]._base
+    host_src = torch.empty(dev_a.numel(), dtype=torch.uint8).pin_memory()
+    host_src.copy_(dev_a)
+    host_out = torch.empty(out_dev.numel(), dtype=torch.uint8).pin_memory()
+    cs = torch.cuda.Stream(device=dev_a.device)
+    torch.cuda.synchronize()
+    up_ev, done_ev, dl_ev = {}, None, None
+
+    def upload(i):
+        with torch.cuda.stream(cs):
+            bufs[i % 2].copy_(host_src, non_blocking=True)
+            up_ev[i] = cs.record_event()
+    t0 = None
+    upload(0)
+    for i in range(warmup + steps):
+        if i == warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        if i + 1 < warmup + steps:
+            if done_ev is not None:
+                cs.wait_event(done_ev)                        # (the buffer being refilled was read by step i - 1)
+            upload(i + 1)
+        pipe.stream.wait_event(up_ev[i])
+        if dl_ev is not None:
+            pipe.stream.wait_event(dl_ev)                     # (conservative: the whole step waits for the previous download, not only its Degrain)
+        pipe.step(src=srcs[i % 2])
+        done_ev = pipe.stream.record_event()
+        with torch.cuda.stream(cs):
+            cs.wait_event(done_ev)
+            host_out.copy_(out_dev, non_blocking=True)
+            dl_ev = cs.record_event()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps, dev_a.numel(), out_dev.numel()
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU) through torch.distributed.run, the
     same way the driver does, and hand back its exit status.  Fails loudly when the node has fewer than N GPUs."""
@@ -405,6 +450,8 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="with --no-cpu: skip the oracle comparison of the timed step too")
     ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure the search launch's HBM traffic")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--ingest", action="store_true", help="also measure the step with its source frames arriving from / its output frames leaving to pinned host memory "
+                    "(secondary metric `ingest_inclusive` of the JSON line; `value` stays the resident-input number)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -481,6 +528,10 @@ def main():
                          # the search is a serial chain per (frame, direction) -- its own yardstick is block steps per second
                          "blocks_per_chain": nblk, "chain_steps_per_s": chains * nblk / (avg_launch_ms * 1e-3)},
         }
+        if args.ingest and world == 1 and not fpsconv:
+            sps, up_b, down_b = ingest_run(torch, pipe, max(2, min(args.steps, 4)), 1)
+            out["ingest_inclusive"] = {"value": units / sps, "unit": "fps", "ms_per_step": sps * 1e3, "h2d_bytes_per_step": up_b, "d2h_bytes_per_step": down_b,
+                                       "how": "source frames from pinned host memory (double-buffered on the device), output frames to pinned host memory, one copy stream, overlapped with compute"}
         if world == 1 and not (args.no_cpu and args.no_parity):
             # the CPU leg doubles as the parity check of the timed step: the oracle runs on frames of the SAME clip
             th = args.cpu_threads or min(os.cpu_count() or 1, 64)   # min(host cores, 64)

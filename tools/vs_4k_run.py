@@ -43,6 +43,8 @@ m = re.search(r"output clip \(frame order\) ([0-9.]+) s", r.stderr)
 if m:
     print("steady state: %d frames requested in frame order in %s s = %.1f fps (graph construction, which runs the first windows, and the result file excluded)" % (N, m.group(1), N / float(m.group(1))), flush=True)
 marks = [(int(a), float(b)) for a, b in re.findall(r"minihost: (\d+) requests done at ([0-9.]+) s", r.stderr)]
+if os.environ.get("VS_MARKS"):
+    print("progress (requests done, seconds): " + " ".join("%d:%.2f" % m for m in marks), flush=True)
 if len(marks) >= 4:  # the second half of the run: device arenas and host buffers are being recycled by then
     (n0, t0_), (n1, t1_) = marks[len(marks) // 2 - 1], marks[-1]
     print("second half of the run: frames %d .. %d in %.2f s = %.1f fps" % (n0, n1, t1_ - t0_, (n1 - n0) / (t1_ - t0_)), flush=True)

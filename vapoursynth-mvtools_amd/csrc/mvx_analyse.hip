@@ -29,6 +29,7 @@ struct MvxDebug {
     int cpw1 = 0;      // one chain per workgroup (general kernels)
     int no_wpe2 = 0, no_wpe3 = 0, wpe3_u16 = 0;
     int fast_cpw = 0;  // lean kernel: chains per workgroup (<= 4 * chains per SIMD)
+    int fast_lds_min = 0; // lean kernel: LDS floor per workgroup in bytes (fewer workgroups per CU: a host that runs other kernels beside long search launches keeps registers free for them)
     int fast_k = 0;    // lean kernel: build for exactly that many chains per SIMD whatever the launch carries (several launches sharing the GPU)
     int fast_flags = -1; // lean kernel: MVX_FAST_* bits, -1 = default
     int pad_runs = -1;   // lean kernel: 1 = pad the job table so that the chains of one reference frame never straddle two workgroups
@@ -42,7 +43,7 @@ struct MvxDebug {
 };
 static MvxDebug g_dbg;
 extern "C" __attribute__((visibility("default"))) int mvx_debug_option(const char *name, int value) {
-    struct { const char *n; int *p; } tab[] = { { "general", &g_dbg.general }, { "fast_wpe", &g_dbg.fast_wpe }, { "cpw1", &g_dbg.cpw1 }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "fast_cpw", &g_dbg.fast_cpw }, { "fast_k", &g_dbg.fast_k }, { "fast_flags", &g_dbg.fast_flags }, { "pad_runs", &g_dbg.pad_runs }, { "shadow_planes", &g_dbg.shadow_planes }, { "degrain_xcd", &g_dbg.degrain_xcd }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min }, { "super_rows_off", &g_dbg.super_rows_off }, { "win", &g_dbg.win },
+    struct { const char *n; int *p; } tab[] = { { "general", &g_dbg.general }, { "fast_wpe", &g_dbg.fast_wpe }, { "cpw1", &g_dbg.cpw1 }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "fast_cpw", &g_dbg.fast_cpw }, { "fast_k", &g_dbg.fast_k }, { "fast_lds_min", &g_dbg.fast_lds_min }, { "fast_flags", &g_dbg.fast_flags }, { "pad_runs", &g_dbg.pad_runs }, { "shadow_planes", &g_dbg.shadow_planes }, { "degrain_xcd", &g_dbg.degrain_xcd }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min }, { "super_rows_off", &g_dbg.super_rows_off }, { "win", &g_dbg.win },
 #ifdef MVX_LAB
         { "ablate", &g_dbg.ablate },
 #endif
@@ -393,6 +394,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
             // XCD-contiguous workgroup order: neighbours in the (reference-sorted) job table share an L2 (+0.5 %, 4K16)
             const int flags = (g_dbg.fast_flags >= 0 ? g_dbg.fast_flags : MVX_FAST_XCD_REMAP) | ((P.shadow[1] != 0 && P.chroma) ? MVX_FAST_UV : 0);
             ALaunch L = { ntab, fNeed, fRow, fRow, fBins, fNeed, simds, cpw, k, syncEvery, k, flags, st, a->dP, S.d };
+            L.ldsBytes = g_dbg.fast_lds_min; // (floor of the workgroup's LDS request, 0 = none)
             int rc = useWin ? mvx_analyse_launch_win(P, L) : P.bps == 1 ? mvx_analyse_launch_fast_u8(P, L) : mvx_analyse_launch_fast_u16(P, L);
             if (rc == MVX_OK) {
                 g_lastLaunch[0] = k; g_lastLaunch[1] = cpw; g_lastLaunch[2] = syncEvery; g_lastLaunch[3] = ntab; g_lastLaunch[4] = useWin;

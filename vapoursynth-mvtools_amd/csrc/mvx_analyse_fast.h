@@ -844,7 +844,8 @@ __global__ __launch_bounds__(64 * MAXCPW, WPE) void analyse_fast_kernel(const AP
 template <int BPS, int BW, int WPE, int MAXCPW, bool UV> static int launch_analyse_fast_uv(const ALaunch &L) {
     const int perChain = (L.ldsNeed + 255) & ~255;
     const int cpw = L.cpw < MAXCPW ? L.cpw : MAXCPW;
-    const int lds = perChain * cpw;
+    int lds = perChain * cpw;
+    if (L.ldsBytes > lds && L.ldsBytes <= 160 * 1024) lds = L.ldsBytes; // developer / host option: fewer workgroups per CU
     if (lds > 64 * 1024)
         HIP_CHECK(hipFuncSetAttribute((const void *)analyse_fast_kernel<BPS, BW, WPE, MAXCPW, UV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL((analyse_fast_kernel<BPS, BW, WPE, MAXCPW, UV>), dim3((L.njobs + cpw - 1) / cpw), dim3(64 * cpw), lds, L.st, L.dP, L.dJobs,

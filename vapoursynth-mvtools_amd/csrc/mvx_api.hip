@@ -138,59 +138,73 @@ extern "C" __attribute__((visibility("default"))) int mvx_copy_to_host(void *dst
 }
 // ---- synchronous 2-D transfers between PAGEABLE host memory (a frame server owns its frames) and the device, through pinned staging
 // buffers: hipMemcpy2D on pageable memory moves a 131 MB super frame at a few GB/s, a linear copy into pinned memory runs at PCIe
-// speed and the row-by-row repacking is an ordinary memcpy that the caller's threads do in parallel.  A fixed number of staging
-// buffers (they grow to the largest request) bounds the pinned memory; callers wait for a free one.
+// speed and the row-by-row repacking is an ordinary memcpy that the caller's threads do in parallel.  r3: the staging buffers have ONE
+// fixed size (16 MiB) and a transfer goes through two of them in turn, chunk by chunk -- the DMA of one chunk runs under the memcpy of the
+// next.  (Buffers that grew to the largest request were re-allocated until all 64 of them held 88 MB: 5 s of hipHostMalloc / hipHostFree
+// once per process, during which every other HIP call of the frame server stalled.)  The pool is bounded; callers wait for a free buffer.
 #include <condition_variable>
 #include <cstring>
 namespace {
-struct Stage { void *p = nullptr; size_t cap = 0; bool busy = false; };
-constexpr int kStages = 64; // (a frame server runs tens of request threads plus the window builders: with fewer buffers than threads they queue here)
+constexpr size_t kStageBytes = (size_t)16 << 20;
+struct Stage { void *p = nullptr; bool busy = false; };
+constexpr int kStages = 96; // two per transfer in flight: a frame server runs tens of request threads plus the window builders
 Stage g_stage[kStages];
 std::mutex g_stage_mu;
 std::condition_variable g_stage_cv;
-Stage *stage_acquire(size_t bytes) {
+Stage *stage_acquire() {
     std::unique_lock<std::mutex> lk(g_stage_mu);
     Stage *s = nullptr;
     g_stage_cv.wait(lk, [&] {
-        Stage *fit = nullptr, *any = nullptr;
-        for (auto &t : g_stage) if (!t.busy) { if (t.cap >= bytes && (!fit || t.cap < fit->cap)) fit = &t; if (!any || t.cap < any->cap) any = &t; }
-        s = fit ? fit : any;
+        Stage *fresh = nullptr;
+        for (auto &t : g_stage) if (!t.busy) { if (t.p) { s = &t; return true; } if (!fresh) fresh = &t; } // (an allocated one first)
+        s = fresh;
         return s != nullptr;
     });
     s->busy = true;
     lk.unlock();
-    if (s->cap < bytes) {
-        if (s->p) (void)hipHostFree(s->p);
-        s->p = nullptr; s->cap = 0;
-        if (hipHostMalloc(&s->p, bytes, hipHostMallocDefault) != hipSuccess) {
-            mvx_set_error("hipHostMalloc(%zu) failed", bytes);
-            { std::lock_guard<std::mutex> g(g_stage_mu); s->busy = false; }
-            g_stage_cv.notify_one();
-            return nullptr;
-        }
-        s->cap = bytes;
+    if (!s->p && hipHostMalloc(&s->p, kStageBytes, hipHostMallocDefault) != hipSuccess) {
+        s->p = nullptr;
+        mvx_set_error("hipHostMalloc(%zu) failed", kStageBytes);
+        { std::lock_guard<std::mutex> g(g_stage_mu); s->busy = false; }
+        g_stage_cv.notify_one();
+        return nullptr;
     }
     return s;
 }
 void stage_release(Stage *s) {
+    if (!s) return;
     { std::lock_guard<std::mutex> g(g_stage_mu); s->busy = false; }
     g_stage_cv.notify_one();
 }
+// rows of a transfer that fit one staging buffer (device pitch dp; the last row of a chunk needs row_bytes only)
+size_t chunk_rows(ptrdiff_t dp, size_t row_bytes) { const size_t n = (kStageBytes - row_bytes) / (size_t)dp + 1; return n ? n : 1; }
 }
 extern "C" __attribute__((visibility("default"))) int mvx_upload_2d(void *dev, ptrdiff_t dp, const void *host, ptrdiff_t hp, size_t row_bytes, size_t rows, void *stream) {
     if (!rows || !row_bytes) return MVX_OK;
     if (dp < (ptrdiff_t)row_bytes) { mvx_set_error("mvx_upload_2d: device pitch smaller than a row"); return MVX_E_ARG; }
-    const size_t bytes = (rows - 1) * (size_t)dp + row_bytes;
-    Stage *s = stage_acquire(bytes);
-    if (!s) return MVX_E_DEVICE;
-    for (size_t r = 0; r < rows; r++) {
-        memcpy((char *)s->p + r * (size_t)dp, (const char *)host + (ptrdiff_t)r * hp, row_bytes);
-        // the pitch padding travels with the linear copy: zero it (a staging buffer holds whatever an earlier transfer left)
-        if (r + 1 < rows && (size_t)dp > row_bytes) memset((char *)s->p + r * (size_t)dp + row_bytes, 0, (size_t)dp - row_bytes);
+    if (row_bytes > kStageBytes) { mvx_set_error("mvx_upload_2d: row longer than a staging buffer"); return MVX_E_ARG; }
+    const size_t per = chunk_rows(dp, row_bytes);
+    Stage *st[2] = { stage_acquire(), rows > per ? stage_acquire() : nullptr };
+    if (!st[0] || (rows > per && !st[1])) { stage_release(st[0]); stage_release(st[1]); return MVX_E_DEVICE; }
+    auto fill = [&](Stage *s, size_t r0, size_t n) {
+        for (size_t r = 0; r < n; r++) {
+            memcpy((char *)s->p + r * (size_t)dp, (const char *)host + (ptrdiff_t)(r0 + r) * hp, row_bytes);
+            // the pitch padding travels with the linear copy: zero it (a staging buffer holds whatever an earlier transfer left)
+            if (r + 1 < n && (size_t)dp > row_bytes) memset((char *)s->p + r * (size_t)dp + row_bytes, 0, (size_t)dp - row_bytes);
+        }
+    };
+    hipError_t e = hipSuccess;
+    int cur = 0;
+    size_t r0 = 0, n = rows < per ? rows : per;
+    fill(st[0], 0, n);
+    while (e == hipSuccess && r0 < rows) {
+        e = hipMemcpyAsync((char *)dev + r0 * (size_t)dp, st[cur]->p, (n - 1) * (size_t)dp + row_bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+        const size_t r1 = r0 + n, n1 = r1 < rows ? (rows - r1 < per ? rows - r1 : per) : 0;
+        if (n1) fill(st[cur ^ 1], r1, n1); // (under the DMA of the chunk just queued)
+        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+        r0 = r1; n = n1; cur ^= 1;
     }
-    hipError_t e = hipMemcpyAsync(dev, s->p, bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
-    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
-    stage_release(s);
+    stage_release(st[0]); stage_release(st[1]);
     if (e != hipSuccess) { mvx_set_error("mvx_upload_2d: %s", hipGetErrorString(e)); return MVX_E_DEVICE; }
     return MVX_OK;
 }
@@ -198,14 +212,24 @@ extern "C" __attribute__((visibility("default"))) int mvx_upload_2d(void *dev, p
 extern "C" __attribute__((visibility("default"))) int mvx_download_2d(void *host, ptrdiff_t hp, const void *dev, ptrdiff_t dp, size_t row_bytes, size_t rows, void *stream) {
     if (!rows || !row_bytes) return MVX_OK;
     if (dp < (ptrdiff_t)row_bytes) { mvx_set_error("mvx_download_2d: device pitch smaller than a row"); return MVX_E_ARG; }
-    const size_t bytes = (rows - 1) * (size_t)dp + row_bytes;
-    Stage *s = stage_acquire(bytes);
-    if (!s) return MVX_E_DEVICE;
-    hipError_t e = hipMemcpyAsync(s->p, dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream);
-    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
-    if (e == hipSuccess)
-        for (size_t r = 0; r < rows; r++) memcpy((char *)host + (ptrdiff_t)r * hp, (const char *)s->p + r * (size_t)dp, row_bytes);
-    stage_release(s);
+    if (row_bytes > kStageBytes) { mvx_set_error("mvx_download_2d: row longer than a staging buffer"); return MVX_E_ARG; }
+    const size_t per = chunk_rows(dp, row_bytes);
+    Stage *st[2] = { stage_acquire(), rows > per ? stage_acquire() : nullptr };
+    if (!st[0] || (rows > per && !st[1])) { stage_release(st[0]); stage_release(st[1]); return MVX_E_DEVICE; }
+    auto bytes_of = [&](size_t n) { return (n - 1) * (size_t)dp + row_bytes; };
+    hipError_t e = hipSuccess;
+    int cur = 0;
+    size_t r0 = 0, n = rows < per ? rows : per;
+    e = hipMemcpyAsync(st[0]->p, dev, bytes_of(n), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    while (e == hipSuccess && r0 < rows) {
+        e = hipStreamSynchronize((hipStream_t)stream);
+        if (e != hipSuccess) break;
+        const size_t r1 = r0 + n, n1 = r1 < rows ? (rows - r1 < per ? rows - r1 : per) : 0;
+        if (n1) e = hipMemcpyAsync(st[cur ^ 1]->p, (const char *)dev + r1 * (size_t)dp, bytes_of(n1), hipMemcpyDeviceToHost, (hipStream_t)stream);
+        for (size_t r = 0; r < n; r++) memcpy((char *)host + (ptrdiff_t)(r0 + r) * hp, (const char *)st[cur]->p + r * (size_t)dp, row_bytes); // (under the DMA of the next chunk)
+        r0 = r1; n = n1; cur ^= 1;
+    }
+    stage_release(st[0]); stage_release(st[1]);
     if (e != hipSuccess) { mvx_set_error("mvx_download_2d: %s", hipGetErrorString(e)); return MVX_E_DEVICE; }
     return MVX_OK;
 }

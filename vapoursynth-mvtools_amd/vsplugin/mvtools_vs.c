@@ -130,6 +130,10 @@ static size_t cache_budget(void) { /* g_lock held */
         size_t fr = 0, tot = 0;
         if (!b && mvx_dev_mem_info(&fr, &tot) == 0) budget = 0.4 * (double)fr;
         g_cache_budget = budget < 1.0 ? 1 : (size_t)budget;
+        /* evicted arenas must be REUSED, not freed: hipFree synchronises the whole device, i.e. waits for the search launches in flight (0.5 s
+         * each) -- a window of 128 new 4K16 super frames evicts 34 GB, more than the pool's default 24 GiB holds, and the frees that followed
+         * stalled every request thread for seconds.  The free list may therefore hold a quarter of the device memory. */
+        if (tot || mvx_dev_mem_info(&fr, &tot) == 0) mvx_dev_pool_limit(tot / 4);
     }
     return g_cache_budget;
 }
@@ -750,7 +754,7 @@ typedef struct Combiner {
  * for at arInitial and fetched at arAllFramesReady); the extra requests go to the source clip, declared as a second dependency. */
 #define LA_SLOTS 6
 enum { LW_EMPTY, LW_BUILDING, LW_LAUNCHED, LW_SYNCING, LW_READY, LW_FAILED };
-typedef struct LaWindow { int w, state, first, count, users, rc; char *blobs; size_t blobsCap; void *dblobs; size_t dstride; DevFrame **pins; int npins; void *stream; } LaWindow; /* blobs: pinned host memory, kept with the slot */
+typedef struct LaWindow { int w, state, first, count, users, rc; void *dblobs; size_t dstride; DevFrame **pins; int npins; void *stream; } LaWindow; /* dblobs: the window's vectors, on the device until the slot is recycled */
 typedef struct LookAhead { int on, B, depth; VSNode *srcNode; SuperData *sd; pthread_mutex_t mu; pthread_cond_t cv; LaWindow win[LA_SLOTS]; } LookAhead;
 #define LA_DEPTH_MAX 3
 typedef struct LaReq { int legacy, w, hold[1 + LA_DEPTH_MAX], want[1 + LA_DEPTH_MAX]; } LaReq;
@@ -776,7 +780,8 @@ __attribute__((destructor)) static void print_stats(void) {
 static void combiner_init(Combiner *c) {
     memset(c, 0, sizeof(*c));
     pthread_mutex_init(&c->mu, NULL); pthread_cond_init(&c->done, NULL); pthread_cond_init(&c->more, NULL);
-    for (int i = 0; i < 4; i++) c->stream[i] = mvx_stream_create_priority(-1); /* NULL (the default stream) still works, it only serialises the launches */
+    /* priority of the search streams: MVX_VS_SEARCH_PRIO (-1 lowest = default, 0, 1); NULL (the default stream) still works, it only serialises the launches */
+    for (int i = 0; i < 4; i++) c->stream[i] = mvx_stream_create_priority((int)env_long("MVX_VS_SEARCH_PRIO", -1));
     pthread_mutex_lock(&g_lock); g_stat_instances++; pthread_mutex_unlock(&g_lock);
     c->maxBatch = (int)env_long("MVX_VS_BATCH_MAX", 1024);
     c->waitUs = env_long("MVX_VS_BATCH_WAIT_US", 2000);
@@ -861,7 +866,7 @@ static void la_window_release(LaWindow *s) { /* frees what a finished / failed w
     for (int i = 0; i < s->npins; i++) cache_unpin(s->pins[i]);
     free(s->pins); s->pins = NULL; s->npins = 0;
     if (s->dblobs) { mvx_dev_free(s->dblobs); s->dblobs = NULL; }
-    s->state = LW_EMPTY; s->count = 0; s->rc = 0; /* (the pinned host array stays with the slot for its next window) */
+    s->state = LW_EMPTY; s->count = 0; s->rc = 0;
 }
 /* the slot of window w, recycled from an older finished window if nobody uses it; NULL if it is taken.  mu held. */
 static LaWindow *la_slot(AnalyseData *d, int w) {
@@ -911,18 +916,11 @@ static int la_launch(AnalyseData *d, LaWindow *s, int v, VSFrameContext *ctx, co
     for (int i = 0; i < nn; i++) if (srcs && srcs[i]) vs->freeFrame(srcs[i]);
     const size_t stride = ((size_t)d->blobSize + 255) / 256 * 256;
     void *dblobs = rc ? NULL : shell_alloc(stride * (size_t)count);
-    /* the vectors come back by an asynchronous copy queued behind the search on the window's stream, into page-locked memory that
-     * belongs to the slot: whoever needs the window first only waits for the stream (a synchronous 175 MB download at that point
-     * stalled every request thread of the window, six vector clips in turn) */
-    const size_t hostBytes = (size_t)d->blobSize * (size_t)count;
-    if (!rc && s->blobsCap < hostBytes) {
-        mvx_host_free_pinned(s->blobs);
-        s->blobsCap = (size_t)d->blobSize * (size_t)d->la.B;
-        s->blobs = (char *)mvx_host_alloc_pinned(s->blobsCap);
-        if (!s->blobs) s->blobsCap = 0;
-    }
-    char *blobs = s->blobs;
-    if (!rc && (!dblobs || !blobs)) rc = MVX_E_NOMEM;
+    /* the window's vectors stay on the device; every request downloads its own 2.7 MB when it is served.  (Bringing a whole window to the
+     * host at once was tried both ways: a synchronous 350 MB download by the first waiter stalled all request threads six times per window,
+     * and page-locked per-slot arrays for an asynchronous copy cost 0.4 s of hipHostMalloc each, during which every HIP call of the process
+     * waits.) */
+    if (!rc && !dblobs) rc = MVX_E_NOMEM;
     if (!rc) {
         for (int i = 0; i < count; i++) {
             const int k = first + i, nref = analyse_nref(d, k);
@@ -936,7 +934,6 @@ static int la_launch(AnalyseData *d, LaWindow *s, int v, VSFrameContext *ctx, co
         const double tq = prof_now();
         rc = mvx_analyse_frames(d->an, count, jobs, s->stream);
         prof_add(PF_LA_LAUNCH, tq);
-        if (!rc) rc = mvx_copy_to_host(blobs, d->blobSize, dblobs, (ptrdiff_t)stride, (size_t)d->blobSize, (size_t)count, s->stream);
         pthread_mutex_lock(&g_lock);
         g_stat_launches++; g_stat_jobs += count; if (count > g_stat_largest) g_stat_largest = count;
         pthread_mutex_unlock(&g_lock);
@@ -949,7 +946,7 @@ static int la_launch(AnalyseData *d, LaWindow *s, int v, VSFrameContext *ctx, co
     free(nums); free(top); free(srcs); free(jobs);
     return rc;
 }
-/* waits until window s is READY (or FAILED): the first waiter synchronises the window's stream and brings its blobs to the host */
+/* waits until window s is READY (or FAILED): the first waiter synchronises the window's stream */
 static int la_wait(AnalyseData *d, LaWindow *s) {
     pthread_mutex_lock(&d->la.mu);
     for (;;) {
@@ -958,12 +955,11 @@ static int la_wait(AnalyseData *d, LaWindow *s) {
             s->state = LW_SYNCING;
             pthread_mutex_unlock(&d->la.mu);
             const double t0 = prof_now();
-            const int rc = mvx_stream_sync(s->stream); /* the search and the copy of its vectors into s->blobs */
+            const int rc = mvx_stream_sync(s->stream);
             prof_add(PF_SEARCH_WAIT, t0);
             pthread_mutex_lock(&d->la.mu);
             for (int i = 0; i < s->npins; i++) cache_unpin(s->pins[i]);
             free(s->pins); s->pins = NULL; s->npins = 0;
-            mvx_dev_free(s->dblobs); s->dblobs = NULL;
             s->rc = rc; s->state = rc ? LW_FAILED : LW_READY;
             pthread_cond_broadcast(&d->la.cv);
             continue;
@@ -1040,14 +1036,18 @@ static const VSFrame *VS_CC analyseGetFrame(int n, int reason, void *inst, void 
             if (!rc) rc = la_wait(d, s);
             const VSFrame *src = vs->getFrameFilter(n, d->node, ctx);
             VSFrame *dst = NULL;
+            char *blob = rc ? NULL : (char *)malloc((size_t)d->blobSize);
+            if (!rc && !blob) rc = MVX_E_NOMEM;
+            if (!rc) rc = timed_download(blob, d->blobSize, (const char *)s->dblobs + s->dstride * (size_t)(n - s->first), d->blobSize, (size_t)d->blobSize, 1);
             if (!rc && src) { /* src/MVAnalyse.c:224-239 */
                 dst = vs->copyFrame(src, core);
                 VSMap *props = vs->getFramePropertiesRW(dst);
                 vs->mapSetData(props, PROP_ADATA, (const char *)&d->ad, sizeof(d->ad), dtBinary, maReplace);
-                vs->mapSetData(props, PROP_VECTORS, s->blobs + (size_t)(n - s->first) * (size_t)d->blobSize, d->blobSize, dtBinary, maReplace);
+                vs->mapSetData(props, PROP_VECTORS, blob, d->blobSize, dtBinary, maReplace);
             } else
                 vs->setFilterError(rc == -1000 ? "Analyse: _Field property not found in input frame. Therefore, you must pass tff argument." :
                                    rc == MVX_E_NOMEM ? "Analyse: out of memory." : mvx_last_error(), ctx);
+            free(blob);
             if (src) vs->freeFrame(src);
             la_release_req(d, r);
             prof_add(PF_GF_ANALYSE, tgf);
@@ -1120,7 +1120,6 @@ static void VS_CC analyseFree(void *inst, VSCore *core, const VSAPI *vs) {
             LaWindow *s = &d->la.win[i];
             if (s->state == LW_LAUNCHED) (void)mvx_stream_sync(s->stream); /* nobody came for it */
             la_window_release(s);
-            mvx_host_free_pinned(s->blobs); s->blobs = NULL; s->blobsCap = 0;
         }
         vs->freeNode(d->la.srcNode);
         pthread_mutex_destroy(&d->la.mu); pthread_cond_destroy(&d->la.cv);
@@ -1164,6 +1163,11 @@ static void VS_CC analyseCreate(const VSMap *in, VSMap *out, void *user, VSCore 
     d->blobSize = mvx_analyse_blob_size(d->an);
     if (d->geo.copies > 1) mvx_analyse_set_ref_shadow(d->an, d->geo.shadowStride); /* every device super frame of this shell carries its copies */
     combiner_init(&d->cb);
+    { /* MVX_VS_SEARCH_LDS=<bytes>: LDS floor of a search workgroup (four chains): 54000 caps a CU at eight chains = two per SIMD, so that the
+       * per-frame kernels of the other request threads (Super, Degrain) find registers beside the long-running low-priority search waves */
+        const long f = env_long("MVX_VS_SEARCH_LDS", 0);
+        if (f > 0) mvx_debug_option("fast_lds_min", (int)f);
+    }
     /* before the first launch has been timed: a chain walks every block of every level, a few microseconds each */
     d->cb.lastUs = (long)((double)d->ad.nBlkX * d->ad.nBlkY * 4.0 / 3.0 * 2.5);
     VSFilterDependency deps[2] = { { node, rpGeneral }, { NULL, rpGeneral } };
