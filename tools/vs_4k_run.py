@@ -35,6 +35,10 @@ t0 = time.time()
 r = subprocess.run([host, plugin, "run", "degrain3", src, str(w), str(h), str(bits), str(N), out, "a.blksize=16", "a.overlap=8", "x.threads=%d" % T] + (["x.order=frame"] if os.environ.get("VS_ORDER", "frame") == "frame" else []) + (["x.cache=%s" % os.environ["VS_CACHE"]] if os.environ.get("VS_CACHE") else []),
                    capture_output=True, text=True, env=env)
 dt = time.time() - t0
+if os.environ.get("MVX_VS_TRACE"):  # the window events of the look-ahead (one line each), kept whole
+    trace_lines = [ln for ln in r.stderr.splitlines() if "trace" in ln]
+    open(os.path.join(ROOT, "gpurun_out", "vs_trace_events.txt"), "w").write("\n".join(trace_lines) + "\n")
+    r.stderr = "\n".join(ln for ln in r.stderr.splitlines() if "trace" not in ln)
 print(r.stdout.strip()[-200:], r.stderr.strip()[-700:], flush=True)
 assert r.returncode == 0 and "DONE" in r.stdout
 print("shell: %d output frames, %d request threads: %.1f s wall = %.2f fps (reads the clip file, uploads, PCIe both ways, writes the result file)" % (N, T, dt, N / dt), flush=True)

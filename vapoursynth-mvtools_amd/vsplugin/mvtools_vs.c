@@ -66,6 +66,13 @@ static void prof_add(int k, double t0) {
     const double dt = prof_now() - t0;
     pthread_mutex_lock(&g_lock); g_prof[k] += dt; g_prof_n[k]++; pthread_mutex_unlock(&g_lock);
 }
+/* MVX_VS_TRACE=1: one line on stderr per look-ahead window event (seconds since the first event) */
+static int g_trace_on = -1;
+static double g_trace_t0;
+static void la_trace(const void *inst, int w, const char *what, double dur) {
+    if (g_trace_on < 0) { g_trace_on = getenv("MVX_VS_TRACE") != NULL; g_trace_t0 = prof_now(); }
+    if (g_trace_on) fprintf(stderr, "mvtools_vs trace %8.3f  analyse %p window %d %s (%.3f s)\n", prof_now() - g_trace_t0, inst, w, what, dur);
+}
 static void prof_add_locked_ok(int k, double t0) { prof_add(k, t0); } /* (g_lock is a different mutex than the callers hold) */
 static void *thread_stream(void) {
     if (!__atomic_load_n(&g_frame_stream_tried, __ATOMIC_ACQUIRE)) {
@@ -739,7 +746,7 @@ typedef struct AnReq { mvx_analyse_job job; int rc, done; struct AnReq *next; } 
 typedef struct Combiner {
     pthread_mutex_t mu; pthread_cond_t done, more;
     AnReq *head, *tail; int n, leader;
-    void *stream[4]; unsigned nextStream; int maxBatch; long waitUs, quietMaxUs; /* a few streams: the next batch may start while the previous one runs */
+    int maxBatch; long waitUs, quietMaxUs; /* a few streams: the next batch may start while the previous one runs */
     long lastUs; /* duration of the previous launch: a search of few chains takes as long as one of hundreds, so waiting a fraction of it for more requests is cheap */
     long batches, jobs, largest; /* statistics (MVX_VS_STATS=1 prints them when the filter is freed) */
 } Combiner;
@@ -777,11 +784,30 @@ __attribute__((destructor)) static void print_stats(void) {
     }
 }
 
+/* Streams of the search launches, shared by every mv.Analyse instance and handed out round robin.  The runtime maps streams onto a few
+ * hardware queues per priority level, in creation order, and launches that share a queue run one after the other: with four streams per
+ * instance the six instances of a Degrain3 graph put the six searches of a window on the SAME queue (traced: 128-chain launches enqueued
+ * together finished 0.6 s apart, two at a time).  One pool makes consecutive launches land on different queues; plugin init raises the
+ * number of queues (GPU_MAX_HW_QUEUES, unless the user set it) to SEARCH_STREAMS.  Priority: MVX_VS_SEARCH_PRIO (-1 lowest = default, 0, 1);
+ * a NULL entry (the default stream) still works, it only serialises. */
+#define SEARCH_STREAMS 12
+static void *g_search_stream[SEARCH_STREAMS];
+static unsigned g_search_next;
+static int g_search_made;
+static void *search_stream_next(void) {
+    pthread_mutex_lock(&g_lock);
+    if (!g_search_made) {
+        g_search_made = 1;
+        for (int i = 0; i < SEARCH_STREAMS; i++) g_search_stream[i] = mvx_stream_create_priority((int)env_long("MVX_VS_SEARCH_PRIO", -1));
+    }
+    void *st = g_search_stream[g_search_next++ % SEARCH_STREAMS];
+    pthread_mutex_unlock(&g_lock);
+    return st;
+}
 static void combiner_init(Combiner *c) {
     memset(c, 0, sizeof(*c));
     pthread_mutex_init(&c->mu, NULL); pthread_cond_init(&c->done, NULL); pthread_cond_init(&c->more, NULL);
     /* priority of the search streams: MVX_VS_SEARCH_PRIO (-1 lowest = default, 0, 1); NULL (the default stream) still works, it only serialises the launches */
-    for (int i = 0; i < 4; i++) c->stream[i] = mvx_stream_create_priority((int)env_long("MVX_VS_SEARCH_PRIO", -1));
     pthread_mutex_lock(&g_lock); g_stat_instances++; pthread_mutex_unlock(&g_lock);
     c->maxBatch = (int)env_long("MVX_VS_BATCH_MAX", 1024);
     c->waitUs = env_long("MVX_VS_BATCH_WAIT_US", 2000);
@@ -790,7 +816,6 @@ static void combiner_init(Combiner *c) {
 }
 static void combiner_free(Combiner *c, const char *what) {
     (void)what;
-    for (int i = 0; i < 4; i++) mvx_stream_destroy(c->stream[i]);
     pthread_mutex_destroy(&c->mu); pthread_cond_destroy(&c->done); pthread_cond_destroy(&c->more);
 }
 /* blocks until the request's blob is computed; returns its MVX_* code */
@@ -827,7 +852,7 @@ static int combiner_submit(Combiner *c, mvx_analyse *an, AnReq *r) {
     AnReq *list = c->head;
     const int n = c->n;
     c->head = c->tail = NULL; c->n = 0; c->leader = 0; /* the next arrival leads the next batch while this one runs */
-    void *stream = c->stream[c->nextStream++ % 4];
+    void *stream = search_stream_next();
     c->batches++; c->jobs += n; if (n > c->largest) c->largest = n;
     pthread_mutex_unlock(&c->mu);
     pthread_mutex_lock(&g_lock);
@@ -897,6 +922,7 @@ static int analyse_nref(const AnalyseData *d, int n);
 static int la_launch(AnalyseData *d, LaWindow *s, int v, VSFrameContext *ctx, const VSAPI *vs) {
     int lo, hi, fixed;
     la_inputs(d, v, &lo, &hi, &fixed);
+    const double tl0 = prof_now();
     const int first = v * d->la.B, count = (first + d->la.B < d->vi->numFrames ? first + d->la.B : d->vi->numFrames) - first;
     const int extra = fixed >= 0 && (fixed < lo || fixed > hi);
     const int nn = hi - lo + 1 + extra;
@@ -912,7 +938,8 @@ static int la_launch(AnalyseData *d, LaWindow *s, int v, VSFrameContext *ctx, co
         top[i] = frame_top_field(&d->fo, srcs[i], nums[i], &missing, vs); /* mv.Super copies the props of its source frame (MVSuper.c:104) */
     }
     if (!rc && missing && d->fo.fields) rc = -1000; /* reported by the caller with the reference's message */
-    { const double tq = prof_now(); if (!rc) rc = super_build_device(d->la.sd, nn, nums, srcs, pins, vs); prof_add(PF_LA_BUILD, tq); }
+    la_trace(d, v, "source frames fetched", prof_now() - tl0);
+    { const double tq = prof_now(); if (!rc) rc = super_build_device(d->la.sd, nn, nums, srcs, pins, vs); prof_add(PF_LA_BUILD, tq); la_trace(d, v, "super frames on the device", prof_now() - tq); }
     for (int i = 0; i < nn; i++) if (srcs && srcs[i]) vs->freeFrame(srcs[i]);
     const size_t stride = ((size_t)d->blobSize + 255) / 256 * 256;
     void *dblobs = rc ? NULL : shell_alloc(stride * (size_t)count);
@@ -930,10 +957,11 @@ static int la_launch(AnalyseData *d, LaWindow *s, int v, VSFrameContext *ctx, co
             jobs[i].blob = (char *)dblobs + stride * (size_t)i;
             jobs[i].field_shift = (haveRef && d->fo.fields && d->ad.nPel > 1 && (d->ad.nDeltaFrame % 2)) ? field_shift_of(top[is], top[ir], d->ad.nPel) : 0;
         }
-        s->stream = d->cb.stream[v & 3];
+        s->stream = search_stream_next();
         const double tq = prof_now();
         rc = mvx_analyse_frames(d->an, count, jobs, s->stream);
         prof_add(PF_LA_LAUNCH, tq);
+        la_trace(d, v, "search enqueued", prof_now() - tl0);
         pthread_mutex_lock(&g_lock);
         g_stat_launches++; g_stat_jobs += count; if (count > g_stat_largest) g_stat_largest = count;
         pthread_mutex_unlock(&g_lock);
@@ -957,6 +985,7 @@ static int la_wait(AnalyseData *d, LaWindow *s) {
             const double t0 = prof_now();
             const int rc = mvx_stream_sync(s->stream);
             prof_add(PF_SEARCH_WAIT, t0);
+            la_trace(d, s->w, "first waiter saw the search finish", prof_now() - t0);
             pthread_mutex_lock(&d->la.mu);
             for (int i = 0; i < s->npins; i++) cache_unpin(s->pins[i]);
             free(s->pins); s->pins = NULL; s->npins = 0;
@@ -1006,7 +1035,7 @@ static const VSFrame *VS_CC analyseGetFrame(int n, int reason, void *inst, void 
                     /* one source frame of the window that will be started next: by the time some request sees that window empty and asks
                      * for all of its frames, the requests of this window have had the host produce them, in parallel */
                     { const int ahead = n + (d->la.depth + 1) * d->la.B; if (ahead < d->vi->numFrames) vs->requestFrameFilter(ahead, d->la.srcNode, ctx); }
-                    for (int i = 0; i <= LA_DEPTH_MAX; i++) if (r->want[i]) la_request_inputs(d, r->w + i, ctx, vs);
+                    for (int i = 0; i <= LA_DEPTH_MAX; i++) if (r->want[i]) { la_trace(d, r->w + i, "source frames requested", 0.0); la_request_inputs(d, r->w + i, ctx, vs); }
                     return NULL;
                 }
             }
@@ -1496,6 +1525,7 @@ static const VSFrame *VS_CC degrainGetFrame(int n, int reason, void *inst, void 
         return NULL;
     }
     prof_add(PF_GF_DEGRAIN, tgf);
+    if ((n & 31) == 0) la_trace(d, n, "(Degrain output frame of this number done)", prof_now() - tgf);
     return dst;
 }
 
@@ -1889,6 +1919,9 @@ static void VS_CC fpsCreate(const VSMap *in, VSMap *out, void *user, VSCore *cor
 
 /* replaces src/EntryPoint.c:28-52 for the filters of the hot path */
 VS_EXTERNAL_API(void) VapourSynthPluginInit2(VSPlugin *plugin, const VSPLUGINAPI *vspapi) {
+    /* hardware queues for the search streams (see search_stream_next); read by the HIP runtime when it initialises, i.e. at this plugin's
+     * first device call -- no effect, and no harm, if the process has used the runtime before or the user has set the variable */
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     vspapi->configPlugin("com.nodame.mvtools", "mv", "MVTools v24", VS_MAKE_VERSION(24, 0), VS_MAKE_VERSION(VAPOURSYNTH_API_MAJOR, VAPOURSYNTH_API_MINOR), 0, plugin);
     vspapi->registerFunction("Super",
                              "clip:vnode;hpad:int:opt;vpad:int:opt;pel:int:opt;levels:int:opt;chroma:int:opt;sharp:int:opt;rfilter:int:opt;pelclip:vnode:opt;opt:int:opt;",
