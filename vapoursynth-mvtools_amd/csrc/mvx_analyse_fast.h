@@ -23,7 +23,47 @@
 #ifndef MVX_ROLL_LOADS
 #define MVX_ROLL_LOADS 1 // rolling load windows in the candidate evaluation (0: batches of four, the first form)
 #endif
+#ifndef MVX_GSUM2
+#define MVX_GSUM2 1 // group sums of the luma and chroma SADs as two interleaved v_add_u32_dpp chains (0: v_mov_dpp + v_add per step, the first form)
+#endif
+#ifndef MVX_SRC_AHEAD
+#define MVX_SRC_AHEAD 2 // the candidate evaluation reads the source block's LDS pieces this many pieces ahead of their use (0: each read right before its use)
+#endif
+#ifndef MVX_INFLIGHT
+#define MVX_INFLIGHT 12 // reference loads a lane keeps in flight while it evaluates a candidate (the pieces beyond that are requested as registers free up)
+#endif
+#ifndef MVX_PRED_LANES
+#define MVX_PRED_LANES 1 // the predictor pass picks its candidates with v_writelane + two DPP moves (0: a chain of compares and selects)
+#endif
 #include "mvx_analyse_kernel.h"
+
+// sums of a and b over aligned groups of 1 << LOGG lanes (1 <= LOGG <= 3), every lane ends up with its group's totals.  v_add_u32_dpp
+// reads the register it wrote one step earlier, which needs two wait states: the other chain's step and one s_nop provide them, so a
+// step costs 1.5 instructions per value instead of the 4 (v_mov, s_nop, v_mov_dpp, v_add) the update_dpp builtin compiles to.
+template <int LOGG> __device__ __forceinline__ void group_sum2(unsigned &a, unsigned &b) {
+#if MVX_GSUM2
+    static_assert(LOGG >= 1 && LOGG <= 3, "group_sum2: groups of 2, 4 or 8 lanes");
+    asm volatile("s_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_u32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+                 : "+v"(a), "+v"(b));
+    if (LOGG >= 2)
+        asm volatile("s_nop 0\n\t"
+                     "v_add_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_add_u32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                     : "+v"(a), "+v"(b));
+    if (LOGG >= 3)
+        asm volatile("s_nop 0\n\t"
+                     "v_add_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                     "v_add_u32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf"
+                     : "+v"(a), "+v"(b));
+    // (the sums are consumed by plain VALU instructions; the compiler's hazard recogniser treats an asm statement's outputs as just
+    // written and adds what a DPP or lane read of them would need)
+#else
+    a = group_sum_c<LOGG>(a);
+    b = group_sum_c<LOGG>(b);
+#endif
+}
 
 template <int BPS, int BW> struct FGeo {
     static constexpr int BH = BW;
@@ -135,17 +175,21 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
         else if (CB == 4) return v4u{*(GL_AS const uv1 *)q, 0, 0, 0};
         else return v4u{*(GL_AS const uh1 *)q, 0, 0, 0};
     }
-    template <int CB> __device__ __forceinline__ static unsigned sad_piece(const lds_u8 *l, const v4u &r, unsigned acc) {
-        if (CB == 16) {
-            const v4u a = *(const LDS_AS v4u *)l;
-            acc = sad32<BPS>(a[0], r[0], acc); acc = sad32<BPS>(a[1], r[1], acc);
-            acc = sad32<BPS>(a[2], r[2], acc); acc = sad32<BPS>(a[3], r[3], acc);
-        } else if (CB == 8) {
-            const v2u a = *(const LDS_AS v2u *)l;
-            acc = sad32<BPS>(a[0], r[0], acc); acc = sad32<BPS>(a[1], r[1], acc);
-        } else if (CB == 4) acc = sad32<BPS>(*(const LDS_AS unsigned *)l, r[0], acc);
-        else acc = sad32<BPS>(*(const LDS_AS unsigned short *)l, r[0], acc);
+    // one CB-byte piece of the source block from LDS / its SAD against the reference piece r
+    template <int CB> __device__ __forceinline__ static v4u lds_piece(const lds_u8 *l) {
+        if (CB == 16) return *(const LDS_AS v4u *)l;
+        else if (CB == 8) { const v2u a = *(const LDS_AS v2u *)l; return v4u{a[0], a[1], 0, 0}; }
+        else if (CB == 4) return v4u{*(const LDS_AS unsigned *)l, 0, 0, 0};
+        else return v4u{*(const LDS_AS unsigned short *)l, 0, 0, 0};
+    }
+    template <int CB> __device__ __forceinline__ static unsigned sad_regs(const v4u &a, const v4u &r, unsigned acc) {
+        acc = sad32<BPS>(a[0], r[0], acc);
+        if (CB >= 8) acc = sad32<BPS>(a[1], r[1], acc);
+        if (CB == 16) { acc = sad32<BPS>(a[2], r[2], acc); acc = sad32<BPS>(a[3], r[3], acc); }
         return acc;
+    }
+    template <int CB> __device__ __forceinline__ static unsigned sad_piece(const lds_u8 *l, const v4u &r, unsigned acc) {
+        return sad_regs<CB>(lds_piece<CB>(l), r, acc);
     }
     template <int LOGG, int T, int LOGC, int CB, int ROWB>
     __device__ __forceinline__ unsigned region(int s, const lds_u8 *src, gl_u8 *base, unsigned off, unsigned refPitch, unsigned acc) const {
@@ -172,6 +216,20 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
                 auto issue = [&]() { const v4u v = ld_ref<CB>(base + po); po += step; asm("" : "+v"(po)); return v; };
 #pragma unroll
                 for (int k = 0; k < NB; k++) r[k] = issue();
+                constexpr int D = MVX_SRC_AHEAD < N ? MVX_SRC_AHEAD : N;
+                if (D > 0) { // the LDS reads run D pieces ahead: a read issued right before its use costs the wave a full LDS round trip per piece
+                    v4u a[D > 0 ? D : 1];
+#pragma unroll
+                    for (int k = 0; k < D; k++) a[k] = lds_piece<CB>(sp + k * lstep);
+#pragma unroll
+                    for (int k = 0; k < N; k++) {
+                        const v4u cur = a[k % D];
+                        if (k + D < N) a[k % D] = lds_piece<CB>(sp + (k + D) * lstep);
+                        acc = sad_regs<CB>(cur, r[k % NB], acc);
+                        if (k + NB < N) r[k % NB] = issue();
+                    }
+                    return acc;
+                }
 #pragma unroll
                 for (int k = 0; k < N; k++) {
                     acc = sad_piece<CB>(sp + k * lstep, r[k % NB], acc);
@@ -215,7 +273,7 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
     __device__ __forceinline__ void region2(int s, const lds_u8 *srcA, gl_u8 *baseA, unsigned offA, unsigned pitchA, unsigned &accA,
                                             const lds_u8 *srcB, gl_u8 *baseB, unsigned offB, unsigned pitchB, unsigned &accB) const {
         constexpr int GG = 1 << LOGG, CA = 1 << LOGCA, CB_ = 1 << LOGCB;
-        constexpr int NA = TA / GG, NBB = TB / GG, NT = NA + NBB, W = NT < 6 ? NT : 6;
+        constexpr int NA = TA / GG, NBB = TB / GG, NT = NA + NBB, W = NT < MVX_INFLIGHT ? NT : MVX_INFLIGHT;
         const int rowA = s >> LOGCA, xbA = (s & (CA - 1)) * CBA, rowB = s >> LOGCB, xbB = (s & (CB_ - 1)) * CBB;
         unsigned poA = offA + (unsigned)rowA * pitchA + (unsigned)xbA, poB = offB + (unsigned)rowB * pitchB + (unsigned)xbB;
         const lds_u8 *spA = srcA + rowA * ROWBA + xbA, *spB = srcB + rowB * ROWBB + xbB;
@@ -228,6 +286,22 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
         auto issueB = [&]() { const v4u v = ld_ref<CBB>(baseB + poB); poB += stepB; asm volatile("" : "+v"(poB) : : "memory"); return v; };
 #pragma unroll
         for (int k = 0; k < W; k++) r[k] = k < NA ? issueA() : issueB();
+        constexpr int D = MVX_SRC_AHEAD < NT ? MVX_SRC_AHEAD : NT;
+        if (D > 0) { // source pieces D ahead of their use (see region); the compiler barrier inside issueA / issueB keeps the distance
+            auto src_piece = [&](int k) { return k < NA ? lds_piece<CBA>(spA + k * lstepA) : lds_piece<CBB>(spB + (k - NA) * lstepB); };
+            v4u a[D > 0 ? D : 1];
+#pragma unroll
+            for (int k = 0; k < D; k++) a[k] = src_piece(k);
+#pragma unroll
+            for (int k = 0; k < NT; k++) {
+                const v4u cur = a[k % D];
+                if (k + D < NT) a[k % D] = src_piece(k + D);
+                if (k < NA) accA = sad_regs<CBA>(cur, r[k % W], accA);
+                else accB = sad_regs<CBB>(cur, r[k % W], accB);
+                if (k + W < NT) r[k % W] = (k + W) < NA ? issueA() : issueB();
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < NT; k++) {
             if (k < NA) accA = sad_piece<CBA>(spA + k * lstepA, r[k % W], accA);
@@ -266,8 +340,10 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
         if (LOGG <= 2) asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v));
         asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
                      "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-                     "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-                     "s_nop 1"
+                     "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+#if !MVX_GSUM2
+                     "\n\ts_nop 1" // (redundant: the compiler puts the wait state a v_readlane of an asm output needs in front of it)
+#endif
                      : "+v"(v));
         return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
     }
@@ -314,8 +390,7 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
         const bool ok = g < TOTAL && vector_ok(vx, vy);
         unsigned aL = 0, aC = 0;
         if (ok) eval<LOGG>(s, vx, vy, vy, aL, aC);
-        aL = group_sum_c<LOGG>(aL);
-        aC = group_sum_c<LOGG>(aC);
+        group_sum2<LOGG>(aL, aC);
         const int tot = (int)aL + (chroma ? (int)aC : 0);
         const int cc = cost_new(vx, vy, aL, aC);
         const bool first = KIND != K_HEXSQ || g < 6;
@@ -340,6 +415,23 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
             int g = lane >> 3;
             const int s = lane & 7;
             asm("" : "+v"(g)); // keeps the (g == k) masks out of scalar registers across the block loop
+#if MVX_PRED_LANES
+            // the seven vectors, packed (|x|, |y| < 30000: mvx_fast_eligible), go to the first lane of their groups; two DPP moves spread
+            // them over the eight lanes (quad broadcast, then lanes 4..7 of every group copy lanes 0..3: row_shr:4 into banks 1 and 3)
+            auto pk = [](int x, int y) { return (int)(((unsigned)x & 0xffffu) | ((unsigned)y << 16)); };
+            int c = pk(0, fieldShift);
+            asm("" : "+v"(c));
+            auto wl = [&c](int v, int lane_) { asm("v_writelane_b32 %0, %1, %2" : "+v"(c) : "s"(uni(v)), "n"(lane_)); };
+            wl(pk(gmvx, gmvy), 8);
+            wl(pk(predX, predY), 16);
+            wl(pk(pX[0], pY[0]), 24);
+            wl(pk(pX[1], pY[1]), 32);
+            wl(pk(pX[2], pY[2]), 40);
+            wl(pk(pX[3], pY[3]), 48);
+            c = __builtin_amdgcn_update_dpp(c, c, 0x00, 0xf, 0xf, false);  // quad_perm:[0,0,0,0]
+            c = __builtin_amdgcn_update_dpp(c, c, 0x114, 0xf, 0xa, false); // row_shr:4, banks 1 and 3
+            int vx = (int)(short)(c & 0xffff), vy = c >> 16;
+#else
             int vx = 0, vy = fieldShift;
             vx = g == 1 ? gmvx : vx; vy = g == 1 ? gmvy : vy;
             vx = g == 2 ? predX : vx; vy = g == 2 ? predY : vy;
@@ -347,12 +439,12 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
             vx = g == 4 ? pX[1] : vx; vy = g == 4 ? pY[1] : vy;
             vx = g == 5 ? pX[2] : vx; vy = g == 5 ? pY[2] : vy;
             vx = g == 6 ? pX[3] : vx; vy = g == 6 ? pY[3] : vy;
+#endif
             const int vyc = g == 0 ? 0 : vy; // the zero candidate's chroma ignores fieldShift (:836-839)
             const bool ok = g < 7;            // (all of them are clipped vectors)
             unsigned aL = 0, aC = 0;
             if (ok) eval<3>(s, vx, vy, vyc, aL, aC);
-            aL = group_sum_c<3>(aL);
-            aC = group_sum_c<3>(aC);
+            group_sum2<3>(aL, aC);
             const int tot = (int)aL + (chroma ? (int)aC : 0);
             const int pen = g == 0 ? penaltyZero : (g == 1 ? pglobal : 0);                 // :846, :870, :894
             int cc = tot + (int)(((long long)pen * tot) >> 8);
@@ -418,8 +510,7 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
             const bool ok = i < total && vector_ok(vx, vy);
             unsigned aL = 0, aC = 0;
             if (ok) eval<3>(s, vx, vy, vy, aL, aC);
-            aL = group_sum_c<3>(aL);
-            aC = group_sum_c<3>(aC);
+            group_sum2<3>(aL, aC);
             const int tot = (int)aL + (chroma ? (int)aC : 0);
             const int cc = cost_new(vx, vy, aL, aC);
             const int w = accept<3>((ok && cc < nMinCost) ? cc : 0x7fffffff, tot);
