@@ -32,6 +32,12 @@
 #ifndef MVX_INFLIGHT
 #define MVX_INFLIGHT 12 // reference loads a lane keeps in flight while it evaluates a candidate (the pieces beyond that are requested as registers free up)
 #endif
+#ifndef MVX_PRED_DEDUP
+#define MVX_PRED_DEDUP 1 // predictor pass: a candidate whose vector an earlier candidate of the pass already has takes that one's SADs instead of loading its block again (needs MVX_PRED_LANES)
+#endif
+#ifndef MVX_HEX_SPEC
+#define MVX_HEX_SPEC 1 // 1: the hexagon pass also evaluates, speculatively, the square around the same centre (one pass less when no hexagon point wins, eight more candidates when one does)
+#endif
 #ifndef MVX_PRED_LANES
 #define MVX_PRED_LANES 1 // the predictor pass picks its candidates with v_writelane + two DPP moves (0: a chain of compares and selects)
 #endif
@@ -364,14 +370,14 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
         return sat_add(motion_distortion(vx, vy), cc);
     }
 
-    enum { K_SQUARE, K_HEXSQ, K_EXH2 };
+    enum { K_SQUARE, K_HEXSQ, K_EXH2, K_HEX6 };
     // one pass of the default refinement around (cx, cy).  K_SQUARE: the 8 points of pobExpandingSearch(1, 1) (:636-658).
     // K_HEXSQ: the hexagon (:682-687) and, speculatively, the square around the SAME centre; the square's results are used
     // only when no hexagon point improved the cost (then the reference runs exactly that square against the unchanged
     // nMinCost).  K_EXH2: rings 1 and 2 (:786-791).  Returns the index of the winning candidate, -1 if none.
     template <int KIND> __device__ __forceinline__ int refine_pass(int cx, int cy) {
         constexpr int LOGG = KIND == K_EXH2 ? 1 : KIND == K_HEXSQ ? 2 : 3;
-        constexpr int TOTAL = KIND == K_SQUARE ? 8 : KIND == K_HEXSQ ? 14 : 24;
+        constexpr int TOTAL = KIND == K_SQUARE ? 8 : KIND == K_HEXSQ ? 14 : KIND == K_HEX6 ? 6 : 24;
         const int lane = lane_id();
         const int g = lane >> LOGG, s = lane & ((1 << LOGG) - 1);
         int dx, dy;
@@ -380,6 +386,7 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
             dx = g < 6 ? tab8(HEX2X >> 8, g & 7) : tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), k);
             dy = g < 6 ? tab8(HEX2Y >> 8, g & 7) : tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), k);
         } else if (KIND == K_SQUARE) { dx = tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), g & 7); dy = tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), g & 7); }
+        else if (KIND == K_HEX6) { dx = tab8(HEX2X >> 8, g & 7); dy = tab8(HEX2Y >> 8, g & 7); } // the hexagon alone (:682-687), eight lanes per point
         else {
             const int k = g < 8 ? g : g - 8;
             if (g < 8) { dx = tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), k); dy = tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), k); }
@@ -396,7 +403,7 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
         const bool first = KIND != K_HEXSQ || g < 6;
         int w = accept<LOGG>((ok && first && cc < nMinCost) ? cc : 0x7fffffff, tot);
         if (w >= 0) {
-            if (KIND != K_HEXSQ) { bestX = bcast_i(vx, w); bestY = bcast_i(vy, w); } // (the hexagon is pobCheckMVdir: bestMV.x/y untouched)
+            if (KIND != K_HEXSQ && KIND != K_HEX6) { bestX = bcast_i(vx, w); bestY = bcast_i(vy, w); } // (the hexagon is pobCheckMVdir: bestMV.x/y untouched)
             return w >> LOGG;
         }
         if (KIND == K_HEXSQ) {
@@ -419,15 +426,11 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
             // the seven vectors, packed (|x|, |y| < 30000: mvx_fast_eligible), go to the first lane of their groups; two DPP moves spread
             // them over the eight lanes (quad broadcast, then lanes 4..7 of every group copy lanes 0..3: row_shr:4 into banks 1 and 3)
             auto pk = [](int x, int y) { return (int)(((unsigned)x & 0xffffu) | ((unsigned)y << 16)); };
-            int c = pk(0, fieldShift);
+            const int pc[7] = {pk(0, fieldShift), uni(pk(gmvx, gmvy)), uni(pk(predX, predY)), uni(pk(pX[0], pY[0])), uni(pk(pX[1], pY[1])), uni(pk(pX[2], pY[2])), uni(pk(pX[3], pY[3]))};
+            int c = pc[0];
             asm("" : "+v"(c));
-            auto wl = [&c](int v, int lane_) { asm("v_writelane_b32 %0, %1, %2" : "+v"(c) : "s"(uni(v)), "n"(lane_)); };
-            wl(pk(gmvx, gmvy), 8);
-            wl(pk(predX, predY), 16);
-            wl(pk(pX[0], pY[0]), 24);
-            wl(pk(pX[1], pY[1]), 32);
-            wl(pk(pX[2], pY[2]), 40);
-            wl(pk(pX[3], pY[3]), 48);
+#pragma unroll
+            for (int k = 1; k < 7; k++) asm("v_writelane_b32 %0, %1, %2" : "+v"(c) : "s"(pc[k]), "n"(8 * k));
             c = __builtin_amdgcn_update_dpp(c, c, 0x00, 0xf, 0xf, false);  // quad_perm:[0,0,0,0]
             c = __builtin_amdgcn_update_dpp(c, c, 0x114, 0xf, 0xa, false); // row_shr:4, banks 1 and 3
             int vx = (int)(short)(c & 0xffff), vy = c >> 16;
@@ -443,8 +446,27 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
             const int vyc = g == 0 ? 0 : vy; // the zero candidate's chroma ignores fieldShift (:836-839)
             const bool ok = g < 7;            // (all of them are clipped vectors)
             unsigned aL = 0, aC = 0;
+#if MVX_PRED_LANES && MVX_PRED_DEDUP
+            // Predictors repeat (a still or evenly moving area: most of the seven are one vector).  The SADs depend on the vector alone, so
+            // a group whose vector an EARLIER group has does not load its block: it takes that group's sums (the costs are still computed
+            // per group, with the group's own penalty; where two costs tie the earlier group wins anyway, as in the reference's sequential
+            // strict `<`).  The zero candidate is a source only without a field shift (its chroma ignores the shift).
+            int srcg = g;
+            {
+#pragma unroll
+                for (int k = 5; k >= 0; k--) { // (min: a group at or before k keeps itself)
+                    const bool same = c == pc[k] && (k > 0 || fieldShift == 0);
+                    srcg = same ? min(srcg, k) : srcg;
+                }
+            }
+            if (ok && srcg == g) eval<3>(s, vx, vy, vyc, aL, aC);
+            group_sum2<3>(aL, aC);
+            aL = (unsigned)__builtin_amdgcn_ds_bpermute(srcg << 5, (int)aL); // lane 8 * srcg: every lane of a group holds the group's sums
+            aC = (unsigned)__builtin_amdgcn_ds_bpermute(srcg << 5, (int)aC);
+#else
             if (ok) eval<3>(s, vx, vy, vyc, aL, aC);
             group_sum2<3>(aL, aC);
+#endif
             const int tot = (int)aL + (chroma ? (int)aC : 0);
             const int pen = g == 0 ? penaltyZero : (g == 1 ? pglobal : 0);                 // :846, :870, :894
             int cc = tot + (int)(((long long)pen * tot) >> 8);
@@ -457,12 +479,19 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
         if (searchType == SearchHex2) { // pobHex2Search :667-724 with i_me_range <= 3: no half-hexagon iterations
             if (nSearchParam > 1) {
                 const int bmx = bestX, bmy = bestY;
+#if MVX_HEX_SPEC
                 const int dir = refine_pass<K_HEXSQ>(bmx, bmy); // >= 0: a hexagon point won; < 0: the square around (bmx, bmy) is done too
                 if (dir >= 0) {
                     const int nx = bmx + tab8(HEX2X, dir + 1), ny = bmy + tab8(HEX2Y, dir + 1);
                     bestX = nx; bestY = ny;
                     refine_pass<K_SQUARE>(nx, ny);
                 }
+#else
+                const int dir = refine_pass<K_HEX6>(bmx, bmy);
+                int nx = bmx, ny = bmy;
+                if (dir >= 0) { nx += tab8(HEX2X, dir + 1); ny += tab8(HEX2Y, dir + 1); bestX = nx; bestY = ny; }
+                refine_pass<K_SQUARE>(nx, ny); // :714-723
+#endif
             } else
                 refine_pass<K_SQUARE>(bestX, bestY);
         } else
