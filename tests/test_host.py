@@ -143,3 +143,25 @@ def test_public_header_is_plain_c(tmp_path):
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         assert subprocess.run([str(exe)]).returncode == 0
+
+
+def test_shadow_layout_is_checked_before_the_device_is_touched(mv):
+    """with shadow planes Super writes, and Analyse reads, more than height x pitch bytes behind a plane pointer; a frame
+    that was not allocated with that room is refused on the host (no GPU needed: the check precedes every device call)."""
+    import torch
+    sup = mv.Super(64, 48, 16)
+    assert sup.shadow and max(sup.slots) > 1
+    H, W = sup.info.plane_height, sup.pitch  # (alloc() itself refuses to run without a device: the layout it makes, by hand)
+    good = [torch.zeros(sup.shadow_stride[p] * sup.slots[p], dtype=torch.uint8)[:H[p] * W[p]].view(H[p], W[p]) for p in range(sup.nplanes)]
+    sup.check_room([good])
+    plain = [torch.zeros(sup.info.plane_height[p], sup.pitch[p], dtype=torch.uint8) for p in range(sup.nplanes)]
+    with pytest.raises(ValueError, match="Super.alloc"):
+        sup.check_room([plain])
+    with pytest.raises(ValueError, match="Super.alloc"):
+        sup._shadows([plain])
+    an = mv.Analyse(sup, num_frames=4, blksize=16)
+    with pytest.raises(ValueError, match="Analyse input"):
+        an.run([(good, plain)], blobs=[torch.zeros(an.blob_size, dtype=torch.uint8)])
+    sup8 = mv.Super(64, 48, 8, subsampling=(0, 0))  # 4:4:4 8-bit: no shadow data at all, any tensor of the right pitch will do
+    if not sup8.shadow:
+        sup8.check_room([[torch.zeros(sup8.info.plane_height[p], sup8.pitch[p], dtype=torch.uint8) for p in range(sup8.nplanes)]])

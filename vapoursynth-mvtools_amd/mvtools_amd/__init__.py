@@ -312,10 +312,30 @@ class Super:
         self._shadows([fr])
         return fr
 
+    def check_room(self, frames, what="super frame"):
+        """With shadow planes the kernels write (Super) and read (Analyse) shadow_stride[p] * slots[p] bytes from every plane pointer:
+        frames must come from alloc() / build() / from_host() of a Super with this layout.  A plain (height, pitch) tensor is refused
+        here instead of being over-run on the device."""
+        if not self.shadow:
+            return
+        seen = set()
+        for fr in frames:
+            if fr is None or id(fr) in seen:  # (a launch names every frame many times)
+                continue
+            seen.add(id(fr))
+            for p in range(self.nplanes):
+                t = fr[p]
+                have = t.untyped_storage().nbytes() - t.storage_offset() * t.element_size()
+                need = self.shadow_stride[p] * self.slots[p]
+                if t.stride(0) != self.pitch[p] or have < need:
+                    raise ValueError("%s plane %d: pitch %d with %d bytes behind its first sample, this Super's layout needs pitch %d and %d bytes "
+                                     "(the plane and its shadow planes): allocate it with Super.alloc()" % (what, p, t.stride(0), have, self.pitch[p], need))
+
     def _shadows(self, out):
         """fills the shifted copies behind the planes of freshly built super frames"""
         if not self.shadow:
             return
+        self.check_room(out, "output super frame")
         n = len(out)
         pl = (C.c_void_p * (3 * n))()
         for f in range(n):
@@ -381,6 +401,7 @@ class Super:
                 dst[f * 3 + p] = out[f][p].data_ptr()
                 assert frames[f][p].stride(0) == frames[0][p].stride(0) and out[f][p].stride(0) == out[0][p].stride(0)
         if self.shadow:  # one call: the level-0 kernels write the shadow data of level 0 themselves
+            self.check_room(out, "output super frame")
             pad = lambda l: (C.c_ssize_t * 3)(*(list(l) + [0] * (3 - len(l))))
             _check(lib().mvx_super_frames_shadow(self.h, n, src, _pitches(frames[0]), dst, _pitches(out[0]), pad(self.shadow_stride), _stream()))
         else:
@@ -429,6 +450,7 @@ class Analyse:
         if blobs is None:
             blobs = self.alloc_blobs(n, device=jobs[0][0][0].device)
         arr = (AnalyseJob * n)()
+        self.sup.check_room([f for job in jobs for f in job], "Analyse input")  # (the search reads the shadow planes behind every plane)
         for i, (s, r) in enumerate(jobs):
             for p in range(self.sup.nplanes):
                 assert s[p].stride(0) == self.sup.pitch[p]
