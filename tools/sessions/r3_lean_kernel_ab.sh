@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a finished series: the -D switches these variant builds used were removed from mvx_analyse_fast.h once the winners were in; results in profiles/r3_lean_kernel_*_ab.txt)
 # lean search kernel, round-3 instruction / latency trims: parity of the default build, then the same bench with each variant library
 # (tools/build_variant.py: MVX_GSUM2 / MVX_PRED_LANES / MVX_SRC_AHEAD), then the default bench line with its checks
 cd "$(dirname "$0")/../.."

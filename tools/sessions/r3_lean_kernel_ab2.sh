@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a finished series: the -D switches these variant builds used were removed from mvx_analyse_fast.h once the winners were in; results in profiles/r3_lean_kernel_*_ab.txt)
 # lean search kernel: predictor de-duplication and the hexagon pass without the speculative square (less L1 traffic, one pass more)
 cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp

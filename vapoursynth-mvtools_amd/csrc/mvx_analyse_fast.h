@@ -20,34 +20,18 @@
 //     32-bit (block SADs are < 2^27, the motion term saturates);
 //   * the rescue is a loop over passes of eight candidates (eight lanes each) around one evaluation site.
 #pragma once
-#ifndef MVX_ROLL_LOADS
-#define MVX_ROLL_LOADS 1 // rolling load windows in the candidate evaluation (0: batches of four, the first form)
-#endif
-#ifndef MVX_GSUM2
-#define MVX_GSUM2 1 // group sums of the luma and chroma SADs as two interleaved v_add_u32_dpp chains (0: v_mov_dpp + v_add per step, the first form)
-#endif
-#ifndef MVX_SRC_AHEAD
-#define MVX_SRC_AHEAD 2 // the candidate evaluation reads the source block's LDS pieces this many pieces ahead of their use (0: each read right before its use)
-#endif
-#ifndef MVX_INFLIGHT
-#define MVX_INFLIGHT 12 // reference loads a lane keeps in flight while it evaluates a candidate (the pieces beyond that are requested as registers free up)
-#endif
-#ifndef MVX_PRED_DEDUP
-#define MVX_PRED_DEDUP 1 // predictor pass: a candidate whose vector an earlier candidate of the pass already has takes that one's SADs instead of loading its block again (needs MVX_PRED_LANES)
-#endif
-#ifndef MVX_HEX_SPEC
-#define MVX_HEX_SPEC 1 // 1: the hexagon pass also evaluates, speculatively, the square around the same centre (one pass less when no hexagon point wins, eight more candidates when one does)
-#endif
-#ifndef MVX_PRED_LANES
-#define MVX_PRED_LANES 1 // the predictor pass picks its candidates with v_writelane + two DPP moves (0: a chain of compares and selects)
-#endif
+// Tuning constants of the candidate evaluation.  Their alternatives (and the forms this file had before: group sums through the
+// update_dpp builtin, LDS reads right before use, six loads in flight, a compare / select chain for the predictor candidates, no
+// de-duplication, the hexagon pass without its speculative square) were measured one switch at a time: DESIGN.md 4.2.3,
+// profiles/r3_lean_kernel_trims_ab.txt, r3_lean_kernel_dedup_nospec_ab.txt.
+#define MVX_SRC_AHEAD 2 // the source block's LDS pieces are read this many pieces ahead of their use (a read right before its use costs the wave an LDS round trip per piece)
+#define MVX_INFLIGHT 12 // reference loads a lane keeps in flight while it evaluates a candidate: all twelve of a hexagon-pass candidate
 #include "mvx_analyse_kernel.h"
 
 // sums of a and b over aligned groups of 1 << LOGG lanes (1 <= LOGG <= 3), every lane ends up with its group's totals.  v_add_u32_dpp
 // reads the register it wrote one step earlier, which needs two wait states: the other chain's step and one s_nop provide them, so a
 // step costs 1.5 instructions per value instead of the 4 (v_mov, s_nop, v_mov_dpp, v_add) the update_dpp builtin compiles to.
 template <int LOGG> __device__ __forceinline__ void group_sum2(unsigned &a, unsigned &b) {
-#if MVX_GSUM2
     static_assert(LOGG >= 1 && LOGG <= 3, "group_sum2: groups of 2, 4 or 8 lanes");
     asm volatile("s_nop 1\n\t"
                  "v_add_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
@@ -65,10 +49,6 @@ template <int LOGG> __device__ __forceinline__ void group_sum2(unsigned &a, unsi
                      : "+v"(a), "+v"(b));
     // (the sums are consumed by plain VALU instructions; the compiler's hazard recogniser treats an asm statement's outputs as just
     // written and adds what a DPP or lane read of them would need)
-#else
-    a = group_sum_c<LOGG>(a);
-    b = group_sum_c<LOGG>(b);
-#endif
 }
 
 template <int BPS, int BW> struct FGeo {
@@ -216,29 +196,21 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
             constexpr int lstep = (GG >> LOGC) * ROWB;
             // rolling window: NB loads in flight, the register of a consumed piece is reloaded at once (issuing NB, consuming NB,
             // issuing the next NB costs one memory round trip per batch)
-            constexpr bool ROLL = MVX_ROLL_LOADS && N > NB && N <= 8;
+            constexpr bool ROLL = N > NB && N <= 8;
             if (ROLL) {
                 v4u r[NB];
                 auto issue = [&]() { const v4u v = ld_ref<CB>(base + po); po += step; asm("" : "+v"(po)); return v; };
 #pragma unroll
                 for (int k = 0; k < NB; k++) r[k] = issue();
-                constexpr int D = MVX_SRC_AHEAD < N ? MVX_SRC_AHEAD : N;
-                if (D > 0) { // the LDS reads run D pieces ahead: a read issued right before its use costs the wave a full LDS round trip per piece
-                    v4u a[D > 0 ? D : 1];
+                constexpr int D = MVX_SRC_AHEAD < N ? MVX_SRC_AHEAD : N; // the LDS reads run D pieces ahead
+                v4u a[D];
 #pragma unroll
-                    for (int k = 0; k < D; k++) a[k] = lds_piece<CB>(sp + k * lstep);
-#pragma unroll
-                    for (int k = 0; k < N; k++) {
-                        const v4u cur = a[k % D];
-                        if (k + D < N) a[k % D] = lds_piece<CB>(sp + (k + D) * lstep);
-                        acc = sad_regs<CB>(cur, r[k % NB], acc);
-                        if (k + NB < N) r[k % NB] = issue();
-                    }
-                    return acc;
-                }
+                for (int k = 0; k < D; k++) a[k] = lds_piece<CB>(sp + k * lstep);
 #pragma unroll
                 for (int k = 0; k < N; k++) {
-                    acc = sad_piece<CB>(sp + k * lstep, r[k % NB], acc);
+                    const v4u cur = a[k % D];
+                    if (k + D < N) a[k % D] = lds_piece<CB>(sp + (k + D) * lstep);
+                    acc = sad_regs<CB>(cur, r[k % NB], acc);
                     if (k + NB < N) r[k % NB] = issue();
                 }
                 return acc;
@@ -292,33 +264,25 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
         auto issueB = [&]() { const v4u v = ld_ref<CBB>(baseB + poB); poB += stepB; asm volatile("" : "+v"(poB) : : "memory"); return v; };
 #pragma unroll
         for (int k = 0; k < W; k++) r[k] = k < NA ? issueA() : issueB();
+        // source pieces D ahead of their use (see region); the compiler barrier inside issueA / issueB keeps the distance
         constexpr int D = MVX_SRC_AHEAD < NT ? MVX_SRC_AHEAD : NT;
-        if (D > 0) { // source pieces D ahead of their use (see region); the compiler barrier inside issueA / issueB keeps the distance
-            auto src_piece = [&](int k) { return k < NA ? lds_piece<CBA>(spA + k * lstepA) : lds_piece<CBB>(spB + (k - NA) * lstepB); };
-            v4u a[D > 0 ? D : 1];
+        auto src_piece = [&](int k) { return k < NA ? lds_piece<CBA>(spA + k * lstepA) : lds_piece<CBB>(spB + (k - NA) * lstepB); };
+        v4u a[D];
 #pragma unroll
-            for (int k = 0; k < D; k++) a[k] = src_piece(k);
-#pragma unroll
-            for (int k = 0; k < NT; k++) {
-                const v4u cur = a[k % D];
-                if (k + D < NT) a[k % D] = src_piece(k + D);
-                if (k < NA) accA = sad_regs<CBA>(cur, r[k % W], accA);
-                else accB = sad_regs<CBB>(cur, r[k % W], accB);
-                if (k + W < NT) r[k % W] = (k + W) < NA ? issueA() : issueB();
-            }
-            return;
-        }
+        for (int k = 0; k < D; k++) a[k] = src_piece(k);
 #pragma unroll
         for (int k = 0; k < NT; k++) {
-            if (k < NA) accA = sad_piece<CBA>(spA + k * lstepA, r[k % W], accA);
-            else accB = sad_piece<CBB>(spB + (k - NA) * lstepB, r[k % W], accB);
+            const v4u cur = a[k % D];
+            if (k + D < NT) a[k % D] = src_piece(k + D);
+            if (k < NA) accA = sad_regs<CBA>(cur, r[k % W], accA);
+            else accB = sad_regs<CBB>(cur, r[k % W], accB);
             if (k + W < NT) r[k % W] = (k + W) < NA ? issueA() : issueB();
         }
     }
     // partial SADs (this lane's share) of candidate (vx, vy); vyc = the vertical component the chroma planes use (:836-839)
     template <int LOGG> __device__ __forceinline__ void eval(int s, int vx, int vy, int vyc, unsigned &aL, unsigned &aC) const {
         constexpr int GG = 1 << LOGG;
-        constexpr bool STREAM = MVX_ROLL_LOADS && UV && G::LT >= GG && G::UVT >= GG && GG >= (1 << G::LLOGC) && GG >= (1 << G::UVLOGC) && (G::LT + G::UVT) / GG >= 2 && (G::LT + G::UVT) / GG <= 12;
+        constexpr bool STREAM = UV && G::LT >= GG && G::UVT >= GG && GG >= (1 << G::LLOGC) && GG >= (1 << G::UVLOGC) && (G::LT + G::UVT) / GG >= 2 && (G::LT + G::UVT) / GG <= 12;
         if (STREAM && chroma) {
             const unsigned co = ref_chroma_off(vx, vyc);
             region2<LOGG, G::LT, G::LLOGC, G::LCB, G::LROWB, G::UVT, G::UVLOGC, G::UVCB, G::UVROWB>(s, lds, refY, ref_luma_off(vx, vy), pitchY, aL, lds + G::UOFF, refUV, 2 * co, 2 * pitchC, aC);
@@ -347,10 +311,7 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
         asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
                      "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
                      "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
-#if !MVX_GSUM2
-                     "\n\ts_nop 1" // (redundant: the compiler puts the wait state a v_readlane of an asm output needs in front of it)
-#endif
-                     : "+v"(v));
+                     : "+v"(v)); // (the compiler puts the wait state a v_readlane of an asm output needs in front of it)
         return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
     }
     template <int LOGG> __device__ __forceinline__ int accept(int cost, int tot) {
@@ -370,14 +331,14 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
         return sat_add(motion_distortion(vx, vy), cc);
     }
 
-    enum { K_SQUARE, K_HEXSQ, K_EXH2, K_HEX6 };
+    enum { K_SQUARE, K_HEXSQ, K_EXH2 };
     // one pass of the default refinement around (cx, cy).  K_SQUARE: the 8 points of pobExpandingSearch(1, 1) (:636-658).
     // K_HEXSQ: the hexagon (:682-687) and, speculatively, the square around the SAME centre; the square's results are used
     // only when no hexagon point improved the cost (then the reference runs exactly that square against the unchanged
     // nMinCost).  K_EXH2: rings 1 and 2 (:786-791).  Returns the index of the winning candidate, -1 if none.
     template <int KIND> __device__ __forceinline__ int refine_pass(int cx, int cy) {
         constexpr int LOGG = KIND == K_EXH2 ? 1 : KIND == K_HEXSQ ? 2 : 3;
-        constexpr int TOTAL = KIND == K_SQUARE ? 8 : KIND == K_HEXSQ ? 14 : KIND == K_HEX6 ? 6 : 24;
+        constexpr int TOTAL = KIND == K_SQUARE ? 8 : KIND == K_HEXSQ ? 14 : 24;
         const int lane = lane_id();
         const int g = lane >> LOGG, s = lane & ((1 << LOGG) - 1);
         int dx, dy;
@@ -386,7 +347,6 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
             dx = g < 6 ? tab8(HEX2X >> 8, g & 7) : tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), k);
             dy = g < 6 ? tab8(HEX2Y >> 8, g & 7) : tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), k);
         } else if (KIND == K_SQUARE) { dx = tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), g & 7); dy = tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), g & 7); }
-        else if (KIND == K_HEX6) { dx = tab8(HEX2X >> 8, g & 7); dy = tab8(HEX2Y >> 8, g & 7); } // the hexagon alone (:682-687), eight lanes per point
         else {
             const int k = g < 8 ? g : g - 8;
             if (g < 8) { dx = tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), k); dy = tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), k); }
@@ -403,7 +363,7 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
         const bool first = KIND != K_HEXSQ || g < 6;
         int w = accept<LOGG>((ok && first && cc < nMinCost) ? cc : 0x7fffffff, tot);
         if (w >= 0) {
-            if (KIND != K_HEXSQ && KIND != K_HEX6) { bestX = bcast_i(vx, w); bestY = bcast_i(vy, w); } // (the hexagon is pobCheckMVdir: bestMV.x/y untouched)
+            if (KIND != K_HEXSQ) { bestX = bcast_i(vx, w); bestY = bcast_i(vy, w); } // (the hexagon is pobCheckMVdir: bestMV.x/y untouched)
             return w >> LOGG;
         }
         if (KIND == K_HEXSQ) {
@@ -422,7 +382,6 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
             int g = lane >> 3;
             const int s = lane & 7;
             asm("" : "+v"(g)); // keeps the (g == k) masks out of scalar registers across the block loop
-#if MVX_PRED_LANES
             // the seven vectors, packed (|x|, |y| < 30000: mvx_fast_eligible), go to the first lane of their groups; two DPP moves spread
             // them over the eight lanes (quad broadcast, then lanes 4..7 of every group copy lanes 0..3: row_shr:4 into banks 1 and 3)
             auto pk = [](int x, int y) { return (int)(((unsigned)x & 0xffffu) | ((unsigned)y << 16)); };
@@ -434,19 +393,9 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
             c = __builtin_amdgcn_update_dpp(c, c, 0x00, 0xf, 0xf, false);  // quad_perm:[0,0,0,0]
             c = __builtin_amdgcn_update_dpp(c, c, 0x114, 0xf, 0xa, false); // row_shr:4, banks 1 and 3
             int vx = (int)(short)(c & 0xffff), vy = c >> 16;
-#else
-            int vx = 0, vy = fieldShift;
-            vx = g == 1 ? gmvx : vx; vy = g == 1 ? gmvy : vy;
-            vx = g == 2 ? predX : vx; vy = g == 2 ? predY : vy;
-            vx = g == 3 ? pX[0] : vx; vy = g == 3 ? pY[0] : vy;
-            vx = g == 4 ? pX[1] : vx; vy = g == 4 ? pY[1] : vy;
-            vx = g == 5 ? pX[2] : vx; vy = g == 5 ? pY[2] : vy;
-            vx = g == 6 ? pX[3] : vx; vy = g == 6 ? pY[3] : vy;
-#endif
             const int vyc = g == 0 ? 0 : vy; // the zero candidate's chroma ignores fieldShift (:836-839)
             const bool ok = g < 7;            // (all of them are clipped vectors)
             unsigned aL = 0, aC = 0;
-#if MVX_PRED_LANES && MVX_PRED_DEDUP
             // Predictors repeat (a still or evenly moving area: most of the seven are one vector).  The SADs depend on the vector alone, so
             // a group whose vector an EARLIER group has does not load its block: it takes that group's sums (the costs are still computed
             // per group, with the group's own penalty; where two costs tie the earlier group wins anyway, as in the reference's sequential
@@ -463,10 +412,6 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
             group_sum2<3>(aL, aC);
             aL = (unsigned)__builtin_amdgcn_ds_bpermute(srcg << 5, (int)aL); // lane 8 * srcg: every lane of a group holds the group's sums
             aC = (unsigned)__builtin_amdgcn_ds_bpermute(srcg << 5, (int)aC);
-#else
-            if (ok) eval<3>(s, vx, vy, vyc, aL, aC);
-            group_sum2<3>(aL, aC);
-#endif
             const int tot = (int)aL + (chroma ? (int)aC : 0);
             const int pen = g == 0 ? penaltyZero : (g == 1 ? pglobal : 0);                 // :846, :870, :894
             int cc = tot + (int)(((long long)pen * tot) >> 8);
@@ -479,19 +424,14 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
         if (searchType == SearchHex2) { // pobHex2Search :667-724 with i_me_range <= 3: no half-hexagon iterations
             if (nSearchParam > 1) {
                 const int bmx = bestX, bmy = bestY;
-#if MVX_HEX_SPEC
+                // (without the speculative square -- 8 fewer candidate blocks whenever a hexagon point wins, one more pass whenever none
+                // does -- the launch takes 8 % longer: DESIGN.md 4.2.3)
                 const int dir = refine_pass<K_HEXSQ>(bmx, bmy); // >= 0: a hexagon point won; < 0: the square around (bmx, bmy) is done too
                 if (dir >= 0) {
                     const int nx = bmx + tab8(HEX2X, dir + 1), ny = bmy + tab8(HEX2Y, dir + 1);
                     bestX = nx; bestY = ny;
                     refine_pass<K_SQUARE>(nx, ny);
                 }
-#else
-                const int dir = refine_pass<K_HEX6>(bmx, bmy);
-                int nx = bmx, ny = bmy;
-                if (dir >= 0) { nx += tab8(HEX2X, dir + 1); ny += tab8(HEX2Y, dir + 1); bestX = nx; bestY = ny; }
-                refine_pass<K_SQUARE>(nx, ny); // :714-723
-#endif
             } else
                 refine_pass<K_SQUARE>(bestX, bestY);
         } else
