@@ -21,6 +21,20 @@ enum { SearchOnetime, SearchNstep, SearchLogarithmic, SearchExhaustive, SearchHe
 
 static const mvo_vector zeroMV = { 0, 0, -1 }; /* MVAnalysisData.h:79 */
 
+/* -DMVO_STATS (tools/search_stats.py builds its own copy of the library with it; the test library has none of this): how the default
+ * search behaves on a clip -- which predictor a block's predictor phase ends on, how many different vectors the seven predictors are,
+ * how often a hexagon point wins -- the numbers a kernel design wants to know before it speculates.  Counted per level. */
+#ifdef MVO_STATS
+enum { ST_BLOCKS, ST_WIN0, ST_WIN6 = ST_WIN0 + 6, ST_BEST_IS_PRED, ST_BEST_IS_MEDIAN, ST_BEST_IS_LEFT, ST_DISTINCT1, ST_DISTINCT7 = ST_DISTINCT1 + 6, ST_HEX_WON, ST_HEX_TRIED, ST_RESCUE, ST_N };
+static long long g_stat[16][ST_N];
+void mvo_stats_get(long long *out, int levels) { memcpy(out, g_stat, sizeof(long long) * ST_N * (size_t)(levels < 16 ? levels : 16)); }
+void mvo_stats_reset(void) { memset(g_stat, 0, sizeof(g_stat)); }
+int mvo_stats_fields(void) { return ST_N; }
+#define STAT(lvl, k, n) (g_stat[(lvl) & 15][k] += (n))
+#else
+#define STAT(lvl, k, n) ((void)0)
+#endif
+
 /* ------------------------------------------------------------------ SAD / SATD / luma */
 
 #define DEFINE_SAD(T, SFX)                                                                                   \
@@ -340,6 +354,7 @@ static void Hex2Search(pob *p, int i_me_range) { /* :667-724 */
     if (i_me_range > 1) {
         CheckMVdir(p, bmx - 2, bmy, &dir, 0); CheckMVdir(p, bmx - 1, bmy + 2, &dir, 1); CheckMVdir(p, bmx + 1, bmy + 2, &dir, 2);
         CheckMVdir(p, bmx + 2, bmy, &dir, 3); CheckMVdir(p, bmx + 1, bmy - 2, &dir, 4); CheckMVdir(p, bmx - 1, bmy - 2, &dir, 5);
+        STAT(p->nLogScale, ST_HEX_TRIED, 1); STAT(p->nLogScale, ST_HEX_WON, dir != -2);
         if (dir != -2) {
             bmx += hex2[dir + 1][0]; bmy += hex2[dir + 1][1];
             for (int i = 1; i < i_me_range / 2 && vector_ok(p, bmx, bmy); i++) {
@@ -437,11 +452,26 @@ static void PseudoEPZSearch(pob *p) {
         p->nMinCost = p->verybigSAD + 1;
         for (int i = 0; i < npred + 3; i++)
             if (nMinCostMany[i] < p->nMinCost) { p->bestMV = bestMVMany[i]; p->nMinCost = nMinCostMany[i]; }
-    } else
+    } else {
+#ifdef MVO_STATS
+        {
+            const int lv = p->nLogScale;
+            mvo_vector c[7] = { p->zeroMVfieldShifted, p->globalMVPredictor, p->predictor, p->predictors[0], p->predictors[1], p->predictors[2], p->predictors[3] };
+            int win = 0, distinct = 0;
+            for (int i = 6; i >= 0; i--) if (c[i].x == p->bestMV.x && c[i].y == p->bestMV.y) win = i; /* the first candidate with the winning vector */
+            for (int i = 0; i < 7; i++) { int dup = 0; for (int j = 0; j < i; j++) dup |= c[j].x == c[i].x && c[j].y == c[i].y; distinct += !dup; }
+            STAT(lv, ST_BLOCKS, 1); STAT(lv, ST_WIN0 + win, 1); STAT(lv, ST_DISTINCT1 + distinct - 1, 1);
+            STAT(lv, ST_BEST_IS_PRED, p->bestMV.x == p->predictor.x && p->bestMV.y == p->predictor.y);
+            STAT(lv, ST_BEST_IS_MEDIAN, p->bestMV.x == p->predictors[0].x && p->bestMV.y == p->predictors[0].y);
+            STAT(lv, ST_BEST_IS_LEFT, p->bestMV.x == p->predictors[1].x && p->bestMV.y == p->predictors[1].y);
+        }
+#endif
         Refine(p);
+    }
 
     int64_t foundSAD = p->bestMV.sad;
     if (p->blkIdx > 1 && foundSAD > (p->badSAD + p->badSAD * p->badcount / 16)) { /* :942 */
+        STAT(p->nLogScale, ST_RESCUE, 1);
         p->badcount++;
         if (p->badrange > 0)
             UMHSearch(p, p->badrange * (1 << p->nLogPel), 0, 0);
