@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record: the MVX_SPEC_HEX code this probe ran lives in commit afd59f1 only -- it measured slower and was removed)
 # the fused predictor + hexagon pass (MVX_SPEC_HEX=1, tools/variants/spec_hex.so), as far as the last 48 seconds of the round's GPU time go:
 # the default bench with it, then the search parity cases (every Analyse configuration + the full-size 4K16 byte parity)
 cd "$(dirname "$0")/../.."

@@ -26,17 +26,6 @@
 // profiles/r3_lean_kernel_trims_ab.txt, r3_lean_kernel_dedup_nospec_ab.txt.
 #define MVX_SRC_AHEAD 2 // the source block's LDS pieces are read this many pieces ahead of their use (a read right before its use costs the wave an LDS round trip per piece)
 #define MVX_INFLIGHT 12 // reference loads a lane keeps in flight while it evaluates a candidate: all twelve of a hexagon-pass candidate
-#ifndef MVX_SPEC_HEX
-// 1: the hexagon pass is evaluated TOGETHER with the predictor pass, around a guessed centre (the median predictor, which is the left
-// neighbour's result most of the time), as one stream of loads; when the predictor pass ends on exactly that vector -- tools/search_stats.py:
-// 99 % of the finest-level blocks of the bench clip -- the block saves the hexagon pass's memory round trip, otherwise the guess is dropped
-// and the hexagon pass runs as before.  Same results by construction (same sums, same acceptance code).  WRITTEN AT THE END OF ROUND 3
-// WITHOUT GPU TIME LEFT TO RUN IT: off, not part of the default build; first item of the next round.
-#define MVX_SPEC_HEX 0
-#endif
-#ifndef MVX_SPEC_INFLIGHT
-#define MVX_SPEC_INFLIGHT 18 // loads in flight in the fused pass: all of them (6 + 12 for 16 x 16 blocks) -- anything less and the second set's tail is requested one round trip late
-#endif
 #include "mvx_analyse_kernel.h"
 
 // sums of a and b over aligned groups of 1 << LOGG lanes (1 <= LOGG <= 3), every lane ends up with its group's totals.  v_add_u32_dpp
@@ -310,74 +299,6 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
         }
     }
 
-#if MVX_SPEC_HEX
-    // can two candidate sets (groups of 1 << LOGG1 and of 1 << LOGG2 lanes) run as one load stream?  (the geometry test of eval's STREAM, for both)
-    template <int LOGG> static constexpr bool streamable() {
-        constexpr int GG = 1 << LOGG;
-        return UV && G::LT >= GG && G::UVT >= GG && GG >= (1 << G::LLOGC) && GG >= (1 << G::UVLOGC) && (G::LT + G::UVT) / GG >= 2 && (G::LT + G::UVT) / GG <= 12;
-    }
-    // Two candidates per lane -- (vx1, vy1) shared by a group of 1 << LOGG1 lanes (this lane is its lane s1), (vx2, vy2) by a group of
-    // 1 << LOGG2 lanes (lane s2) -- as ONE stream of reference loads: luma 1, UV 1, luma 2, UV 2, MVX_INFLIGHT in flight, each set under
-    // its own predicate: a lane whose predicate is off still loads (its vectors must be valid ones) and gets 0 for its sums.  (chroma on, UV plane: streamable<>)
-    template <int LOGG1, int LOGG2>
-    __device__ __forceinline__ void eval_two(bool ok1, int s1, int vx1, int vy1, int vyc1, unsigned &aL1, unsigned &aC1,
-                                             bool ok2, int s2, int vx2, int vy2, unsigned &aL2, unsigned &aC2) const {
-        constexpr int G1 = 1 << LOGG1, G2 = 1 << LOGG2, LC = 1 << G::LLOGC, UC = 1 << G::UVLOGC;
-        constexpr int N0 = G::LT / G1, N1 = G::UVT / G1, N2 = G::LT / G2, N3 = G::UVT / G2, NT = N0 + N1 + N2 + N3;
-        // region r of the stream: 0 / 1 = luma / UV of set 1, 2 / 3 = of set 2
-        auto reg = [](int k) { return k < N0 ? 0 : k < N0 + N1 ? 1 : k < N0 + N1 + N2 ? 2 : 3; };
-        auto idx = [](int k) { return k < N0 ? k : k < N0 + N1 ? k - N0 : k < N0 + N1 + N2 ? k - N0 - N1 : k - N0 - N1 - N2; };
-        const int rL1 = s1 >> G::LLOGC, xL1 = (s1 & (LC - 1)) * G::LCB, rC1 = s1 >> G::UVLOGC, xC1 = (s1 & (UC - 1)) * G::UVCB;
-        const int rL2 = s2 >> G::LLOGC, xL2 = (s2 & (LC - 1)) * G::LCB, rC2 = s2 >> G::UVLOGC, xC2 = (s2 & (UC - 1)) * G::UVCB;
-        const unsigned pitchUV = 2 * pitchC;
-        unsigned po0 = ref_luma_off(vx1, vy1) + (unsigned)rL1 * pitchY + (unsigned)xL1;
-        unsigned po1 = 2 * ref_chroma_off(vx1, vyc1) + (unsigned)rC1 * pitchUV + (unsigned)xC1;
-        unsigned po2 = ref_luma_off(vx2, vy2) + (unsigned)rL2 * pitchY + (unsigned)xL2;
-        unsigned po3 = 2 * ref_chroma_off(vx2, vy2) + (unsigned)rC2 * pitchUV + (unsigned)xC2;
-        const unsigned st0 = (unsigned)(G1 >> G::LLOGC) * pitchY, st1 = (unsigned)(G1 >> G::UVLOGC) * pitchUV;
-        const unsigned st2 = (unsigned)(G2 >> G::LLOGC) * pitchY, st3 = (unsigned)(G2 >> G::UVLOGC) * pitchUV;
-        const lds_u8 *sp0 = lds + rL1 * G::LROWB + xL1, *sp1 = lds + G::UOFF + rC1 * G::UVROWB + xC1;
-        const lds_u8 *sp2 = lds + rL2 * G::LROWB + xL2, *sp3 = lds + G::UOFF + rC2 * G::UVROWB + xC2;
-        constexpr int ls0 = (G1 >> G::LLOGC) * G::LROWB, ls1 = (G1 >> G::UVLOGC) * G::UVROWB, ls2 = (G2 >> G::LLOGC) * G::LROWB, ls3 = (G2 >> G::UVLOGC) * G::UVROWB;
-        // (the memory clobber keeps the loads in program order, as in region2)
-        // Every load of both sets is requested before the first is consumed (NT registers: anything less and the tail of set 2 would be
-        // requested a round trip late, which is the round trip this pass exists to save).  The loads are NOT predicated: putting them
-        // under `if (ok)` splits the pass into basic blocks and the register allocator then wants 236 registers (276 bytes of scratch at
-        // the 168 of three waves); every lane therefore loads, from a valid address the caller supplies, and a lane whose predicate is off
-        // throws its sums away.  (the memory clobber keeps the loads in program order, as in region2)
-        static_assert(NT <= MVX_SPEC_INFLIGHT, "eval_two: every load in flight at once");
-        v4u r[NT];
-#pragma unroll
-        for (int k = 0; k < N0; k++) { r[k] = ld_ref<G::LCB>(refY + po0); po0 += st0; asm volatile("" : "+v"(po0) : : "memory"); }
-#pragma unroll
-        for (int k = 0; k < N1; k++) { r[N0 + k] = ld_ref<G::UVCB>(refUV + po1); po1 += st1; asm volatile("" : "+v"(po1) : : "memory"); }
-#pragma unroll
-        for (int k = 0; k < N2; k++) { r[N0 + N1 + k] = ld_ref<G::LCB>(refY + po2); po2 += st2; asm volatile("" : "+v"(po2) : : "memory"); }
-#pragma unroll
-        for (int k = 0; k < N3; k++) { r[N0 + N1 + N2 + k] = ld_ref<G::UVCB>(refUV + po3); po3 += st3; asm volatile("" : "+v"(po3) : : "memory"); }
-        auto src_piece = [&](int k) {
-            const int rg = reg(k), i = idx(k);
-            return rg == 0 ? lds_piece<G::LCB>(sp0 + i * ls0) : rg == 1 ? lds_piece<G::UVCB>(sp1 + i * ls1) : rg == 2 ? lds_piece<G::LCB>(sp2 + i * ls2) : lds_piece<G::UVCB>(sp3 + i * ls3);
-        };
-        constexpr int D = MVX_SRC_AHEAD < NT ? MVX_SRC_AHEAD : NT;
-        v4u a[D];
-#pragma unroll
-        for (int k = 0; k < D; k++) a[k] = src_piece(k);
-        unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-#pragma unroll
-        for (int k = 0; k < NT; k++) {
-            const v4u cur = a[k % D];
-            if (k + D < NT) a[k % D] = src_piece(k + D);
-            const int rg = reg(k);
-            if (rg == 0) c0 = sad_regs<G::LCB>(cur, r[k], c0);
-            else if (rg == 1) c1 = sad_regs<G::UVCB>(cur, r[k], c1);
-            else if (rg == 2) c2 = sad_regs<G::LCB>(cur, r[k], c2);
-            else c3 = sad_regs<G::UVCB>(cur, r[k], c3);
-        }
-        aL1 = ok1 ? c0 : 0u; aC1 = ok1 ? c1 : 0u; aL2 = ok2 ? c2 : 0u; aC2 = ok2 ? c3 : 0u; // (lanes that loaded nothing summed stale registers)
-    }
-#endif
-
     // Acceptance of a pass: every lane of a candidate's group holds the candidate's cost (0x7fffffff = not a candidate / not
     // better); groups are ordered by lane, so the lowest lane with the minimum is the FIRST minimal candidate -- the one the
     // reference's sequential strict `<` update ends on (PlaneOfBlocks.cpp:229,239,248).  Returns the winning lane or -1.
@@ -415,57 +336,6 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
     // K_HEXSQ: the hexagon (:682-687) and, speculatively, the square around the SAME centre; the square's results are used
     // only when no hexagon point improved the cost (then the reference runs exactly that square against the unchanged
     // nMinCost).  K_EXH2: rings 1 and 2 (:786-791).  Returns the index of the winning candidate, -1 if none.
-#if MVX_SPEC_HEX // (the same pass in two halves, so that the speculative set can enter at the second)
-    // candidate of lane `lane` in a pass of kind KIND around (cx, cy): its group g, its lane s inside the group, the vector, whether it is evaluated
-    template <int KIND> __device__ __forceinline__ void pass_candidate(int cx, int cy, int &g, int &s, int &vx, int &vy, bool &ok) const {
-        constexpr int LOGG = KIND == K_EXH2 ? 1 : KIND == K_HEXSQ ? 2 : 3;
-        constexpr int TOTAL = KIND == K_SQUARE ? 8 : KIND == K_HEXSQ ? 14 : 24;
-        const int lane = lane_id();
-        g = lane >> LOGG; s = lane & ((1 << LOGG) - 1);
-        int dx, dy;
-        if (KIND == K_HEXSQ) {
-            const int k = (g + 2) & 7; // square index of groups 6..13
-            dx = g < 6 ? tab8(HEX2X >> 8, g & 7) : tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), k);
-            dy = g < 6 ? tab8(HEX2Y >> 8, g & 7) : tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), k);
-        } else if (KIND == K_SQUARE) { dx = tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), g & 7); dy = tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), g & 7); }
-        else {
-            const int k = g < 8 ? g : g - 8;
-            if (g < 8) { dx = tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), k); dy = tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), k); }
-            else if (k < 8) { dx = tab8(PACK8(-1, -1, 0, 0, 1, 1, -2, 2), k); dy = tab8(PACK8(-2, 2, -2, 2, -2, 2, -1, -1), k); }
-            else { dx = tab8(PACK8(-2, 2, -2, 2, -2, -2, 2, 2), k - 8); dy = tab8(PACK8(0, 0, 1, 1, -2, 2, -2, 2), k - 8); }
-        }
-        vx = cx + dx; vy = cy + dy;
-        ok = g < TOTAL && vector_ok(vx, vy);
-    }
-    // the rest of a pass once every lane holds its share (aL, aC) of its candidate's SADs: sums, costs, acceptance in the reference's order
-    template <int KIND> __device__ __forceinline__ int pass_finish(int g, int vx, int vy, bool ok, unsigned aL, unsigned aC) {
-        constexpr int LOGG = KIND == K_EXH2 ? 1 : KIND == K_HEXSQ ? 2 : 3;
-        group_sum2<LOGG>(aL, aC);
-        const int tot = (int)aL + (chroma ? (int)aC : 0);
-        const int cc = cost_new(vx, vy, aL, aC);
-        const bool first = KIND != K_HEXSQ || g < 6;
-        int w = accept<LOGG>((ok && first && cc < nMinCost) ? cc : 0x7fffffff, tot);
-        if (w >= 0) {
-            if (KIND != K_HEXSQ) { bestX = bcast_i(vx, w); bestY = bcast_i(vy, w); } // (the hexagon is pobCheckMVdir: bestMV.x/y untouched)
-            return w >> LOGG;
-        }
-        if (KIND == K_HEXSQ) {
-            w = accept<LOGG>((ok && !first && cc < nMinCost) ? cc : 0x7fffffff, tot);
-            if (w >= 0) { bestX = bcast_i(vx, w); bestY = bcast_i(vy, w); }
-        }
-        return -1;
-    }
-    template <int KIND> __device__ __forceinline__ int refine_pass(int cx, int cy) {
-        constexpr int LOGG = KIND == K_EXH2 ? 1 : KIND == K_HEXSQ ? 2 : 3;
-        int g, s, vx, vy;
-        bool ok;
-        pass_candidate<KIND>(cx, cy, g, s, vx, vy, ok);
-        unsigned aL = 0, aC = 0;
-        if (ok) eval<LOGG>(s, vx, vy, vy, aL, aC);
-        return pass_finish<KIND>(g, vx, vy, ok, aL, aC);
-    }
-
-#else
     template <int KIND> __device__ __forceinline__ int refine_pass(int cx, int cy) {
         constexpr int LOGG = KIND == K_EXH2 ? 1 : KIND == K_HEXSQ ? 2 : 3;
         constexpr int TOTAL = KIND == K_SQUARE ? 8 : KIND == K_HEXSQ ? 14 : 24;
@@ -503,16 +373,10 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
         return -1;
     }
 
-#endif
     // pobPseudoEPZSearch (:819-968) for the default parameters
     __device__ __forceinline__ void search_block() {
         // ---- the predictor set (:832-915): zero, global, hierarchical predictor, median, left, up, ahead; eight lanes each
         gmvx = clipx(gmvx); gmvy = clipy(gmvy); // cumulative clip (:859)
-#if MVX_SPEC_HEX
-        bool spec = false, specOk = false;
-        int specX = 0, specY = 0, specG = 0, specVx = 0, specVy = 0;
-        unsigned specL = 0, specC = 0;
-#endif
         {
             const int lane = lane_id();
             int g = lane >> 3;
@@ -544,20 +408,6 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
                     srcg = same ? min(srcg, k) : srcg;
                 }
             }
-#if MVX_SPEC_HEX
-            // the hexagon pass around the guessed centre rides along (see MVX_SPEC_HEX)
-            constexpr bool SPEC_GEO = streamable<3>() && streamable<2>();
-            spec = SPEC_GEO && chroma && searchType == SearchHex2 && nSearchParam > 1;
-            specX = pX[0]; specY = pY[0];
-            if (spec) {
-                if constexpr (SPEC_GEO) {
-                    int s2;
-                    pass_candidate<K_HEXSQ>(specX, specY, specG, s2, specVx, specVy, specOk);
-                    // (lanes without a candidate of their own load the centre's block: a vector that is certainly inside the frame)
-                    eval_two<3, 2>(ok && srcg == g, s, vx, vy, vyc, aL, aC, specOk, s2, specOk ? specVx : specX, specOk ? specVy : specY, specL, specC);
-                }
-            } else
-#endif
             if (ok && srcg == g) eval<3>(s, vx, vy, vyc, aL, aC);
             group_sum2<3>(aL, aC);
             aL = (unsigned)__builtin_amdgcn_ds_bpermute(srcg << 5, (int)aL); // lane 8 * srcg: every lane of a group holds the group's sums
@@ -576,12 +426,7 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
                 const int bmx = bestX, bmy = bestY;
                 // (without the speculative square -- 8 fewer candidate blocks whenever a hexagon point wins, one more pass whenever none
                 // does -- the launch takes 8 % longer: DESIGN.md 4.2.3)
-#if MVX_SPEC_HEX
-                const int dir = (spec && bmx == specX && bmy == specY) ? pass_finish<K_HEXSQ>(specG, specVx, specVy, specOk, specL, specC) // the guess was right: the sums are here
-                                                                       : refine_pass<K_HEXSQ>(bmx, bmy);
-#else
                 const int dir = refine_pass<K_HEXSQ>(bmx, bmy); // >= 0: a hexagon point won; < 0: the square around (bmx, bmy) is done too
-#endif
                 if (dir >= 0) {
                     const int nx = bmx + tab8(HEX2X, dir + 1), ny = bmy + tab8(HEX2Y, dir + 1);
                     bestX = nx; bestY = ny;
