@@ -28,6 +28,17 @@
 #define MVX_INFLIGHT 12 // reference loads a lane keeps in flight while it evaluates a candidate: all twelve of a hexagon-pass candidate
 #include "mvx_analyse_kernel.h"
 
+// -DMVX_FAST_PROF (tools/build_variant.py; read back by tools/fastprof.py): cycles of ONE chain per phase of the block loop, stamped with
+// s_memtime.  A stamp waits for the scalar counter only, not for the vector loads in flight, so the phases overlap as they do in the
+// normal build; what a phase shows is where the wave's time goes, including time it waits while the SIMD's other waves issue.
+#ifdef MVX_FAST_PROF
+#define FPROF_N 12
+static __device__ unsigned long long g_fastprof[FPROF_N];
+#define FPROF(i, t0) do { const long long t1_ = (long long)__builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" : : "s"(t1_) : "memory"); prof[i] += t1_ - (t0); (t0) = t1_; } while (0)
+#else
+#define FPROF(i, t0) ((void)0)
+#endif
+
 // sums of a and b over aligned groups of 1 << LOGG lanes (1 <= LOGG <= 3), every lane ends up with its group's totals.  v_add_u32_dpp
 // reads the register it wrote one step earlier, which needs two wait states: the other chain's step and one s_nop provide them, so a
 // step costs 1.5 instructions per value instead of the 4 (v_mov, s_nop, v_mov_dpp, v_add) the update_dpp builtin compiles to.
@@ -116,6 +127,10 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
     int nLambda;               // (0 <= nLambda <= the level's lambda < 2^31: mvx_fast_eligible)
     int bestX, bestY, bestSad; // bestMV
     int nMinCost;              // 0x7fffffff = nothing accepted yet (every real cost is smaller: see cost32)
+#ifdef MVX_FAST_PROF
+    long long prof[FPROF_N], tp; // 0 loop top + barrier, 1 group fetch + source block, 2 limits / predictors / lambda, 3 predictor pass: loads + SADs, 4 its sums + acceptance,
+                                 // 5 hexagon pass: loads + SADs, 6 its sums + acceptance, 7 square pass, 8 other refinement, 9 rescue, 10 result, 11 blocks counted
+#endif
 
     __device__ FastSearcher(const AParams &p, const AJob &j) : P(p), J(j) {}
 
@@ -357,6 +372,7 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
         const bool ok = g < TOTAL && vector_ok(vx, vy);
         unsigned aL = 0, aC = 0;
         if (ok) eval<LOGG>(s, vx, vy, vy, aL, aC);
+        if (KIND == K_HEXSQ) FPROF(5, tp);
         group_sum2<LOGG>(aL, aC);
         const int tot = (int)aL + (chroma ? (int)aC : 0);
         const int cc = cost_new(vx, vy, aL, aC);
@@ -364,11 +380,13 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
         int w = accept<LOGG>((ok && first && cc < nMinCost) ? cc : 0x7fffffff, tot);
         if (w >= 0) {
             if (KIND != K_HEXSQ) { bestX = bcast_i(vx, w); bestY = bcast_i(vy, w); } // (the hexagon is pobCheckMVdir: bestMV.x/y untouched)
+            if (KIND == K_HEXSQ) FPROF(6, tp);
             return w >> LOGG;
         }
         if (KIND == K_HEXSQ) {
             w = accept<LOGG>((ok && !first && cc < nMinCost) ? cc : 0x7fffffff, tot);
             if (w >= 0) { bestX = bcast_i(vx, w); bestY = bcast_i(vy, w); }
+            FPROF(6, tp);
         }
         return -1;
     }
@@ -408,7 +426,9 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
                     srcg = same ? min(srcg, k) : srcg;
                 }
             }
+            FPROF(2, tp);
             if (ok && srcg == g) eval<3>(s, vx, vy, vyc, aL, aC);
+            FPROF(3, tp);
             group_sum2<3>(aL, aC);
             aL = (unsigned)__builtin_amdgcn_ds_bpermute(srcg << 5, (int)aL); // lane 8 * srcg: every lane of a group holds the group's sums
             aC = (unsigned)__builtin_amdgcn_ds_bpermute(srcg << 5, (int)aC);
@@ -419,6 +439,7 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
             nMinCost = 0x7fffffff;
             const int w = accept<3>(ok ? cc : 0x7fffffff, tot); // (group 0 always has a finite cost)
             bestX = bcast_i(vx, w); bestY = bcast_i(vy, w);
+            FPROF(4, tp);
         }
         // ---- pobRefine (:773-816)
         if (searchType == SearchHex2) { // pobHex2Search :667-724 with i_me_range <= 3: no half-hexagon iterations
@@ -431,13 +452,18 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
                     const int nx = bmx + tab8(HEX2X, dir + 1), ny = bmy + tab8(HEX2Y, dir + 1);
                     bestX = nx; bestY = ny;
                     refine_pass<K_SQUARE>(nx, ny);
+                    FPROF(7, tp);
                 }
-            } else
+            } else {
                 refine_pass<K_SQUARE>(bestX, bestY);
-        } else
+                FPROF(7, tp);
+            }
+        } else {
             refine_pass<K_EXH2>(bestX, bestY);
+            FPROF(8, tp);
+        }
         // ---- bad vector: wide search (:938-963)
-        if (__builtin_expect(blkIdx > 1 && (long long)bestSad > badSAD + badSAD * badcount / 16, 0)) rescue();
+        if (__builtin_expect(blkIdx > 1 && (long long)bestSad > badSAD + badSAD * badcount / 16, 0)) { rescue(); FPROF(9, tp); }
     }
 
     // candidate i of the rescue patterns, in the reference's order
@@ -760,8 +786,12 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
         A4x32 pf[G::NPF];
         pf_issue(hpad, vpad, pf); // block (0, 0)
         int curIb = 0, curBy = 0;
+#ifdef MVX_FAST_PROF
+        tp = (long long)__builtin_amdgcn_s_memtime();
+#endif
         for (int n = 0; n < nBlk; n++) {
             if (syncEvery && (curIb & (syncEvery - 1)) == 0) __builtin_amdgcn_s_barrier(); // keeps the chains of a workgroup on neighbouring blocks (shared reference lines)
+            FPROF(0, tp);
             const int blky = curBy;
             const bool fwd = (blky & 1) == 0 || !meander;
             const int blkx = fwd ? curIb : nBlkX - 1 - curIb;
@@ -794,6 +824,7 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
                 const int nbx = nf ? curIb : nBlkX - 1 - curIb;
                 pf_issue(hpad + stepX * nbx, vpad + stepY * nby, pf);
             }
+            FPROF(1, tp);
             // ---- motion-vector limits (:1094-1097)
             nDxMax = (pw - x0 - BW - hpad + hps) << logPel;
             nDyMax = (ph - y0 - BW - vpad + vps) << logPel;
@@ -832,6 +863,9 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
             __builtin_amdgcn_wave_barrier(); // single wave: DS ops are in order; keeps the compiler from moving LDS reads above the staging writes
             search_block();
             __builtin_amdgcn_wave_barrier();
+#ifdef MVX_FAST_PROF
+            prof[11] += 1;
+#endif
             // ---- result (:967, :1106): collected per group, stored when the group (or the row) ends
             { const bool mine = l == col; bOut[0] = mine ? (unsigned)bestX : bOut[0]; bOut[1] = mine ? (unsigned)bestY : bOut[1]; bOut[2] = mine ? (unsigned)bestSad : bOut[2]; }
             prevX = bestX; prevY = bestY; prevSad = bestSad;
@@ -845,6 +879,7 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
                     rowbuf[c] = bOut;
                 }
             }
+            FPROF(10, tp);
         }
         // vectors[] of this level feed the next level's interpolation / global-MV estimate (other lanes read them)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -891,6 +926,9 @@ __global__ __launch_bounds__(64 * MAXCPW, WPE) void analyse_fast_kernel(const AP
     FastSearcher<BPS, BW, UV> S(P, J);
     S.lds = (lds_u8 *)smem + uni((int)(threadIdx.x >> 6)) * ldsChain;
     S.ldsRow = ldsRow; S.ldsHist = ldsHist; S.histBins = histBins;
+#ifdef MVX_FAST_PROF
+    for (int i = 0; i < FPROF_N; i++) S.prof[i] = 0;
+#endif
     int gx = 0, gy = 0; // zeroMV, MVAnalysisData.h:79
     GL_AS const GVec *coarse = nullptr;
     int cbx = 0, cby = 0, clp = 0;
@@ -899,7 +937,15 @@ __global__ __launch_bounds__(64 * MAXCPW, WPE) void analyse_fast_kernel(const AP
         S.search_level(lvl, gx, gy, coarse, cbx, cby, clp, cpw > 1 ? syncEvery : 0);
         coarse = S.vectors; cbx = P.lv[lvl].nBlkX; cby = P.lv[lvl].nBlkY; clp = P.lv[lvl].logPel;
     }
+#ifdef MVX_FAST_PROF
+    if (l == 0 && chain == 5) for (int i = 0; i < FPROF_N; i++) g_fastprof[i] = (unsigned long long)S.prof[i];
+#endif
 }
+#if defined(MVX_FAST_PROF) && defined(MVX_PROF_EXPORT)
+extern "C" __attribute__((visibility("default"))) int mvx_debug_fastprof(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fastprof), sizeof(unsigned long long) * FPROF_N) == hipSuccess ? 0 : -1;
+}
+#endif
 
 template <int BPS, int BW, int WPE, int MAXCPW, bool UV> static int launch_analyse_fast_uv(const ALaunch &L) {
     const int perChain = (L.ldsNeed + 255) & ~255;
