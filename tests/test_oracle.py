@@ -189,3 +189,17 @@ def test_mask_upsizer_against_reference_object(oracle):
         hw[:dw] = (hw[:dw] << 16) | (16384 - hw[:dw])  # the AVX2 kernel's packed form of the weights (simpleInit, SimpleResize.cpp:152-155)
         r.ref_simple_resize_u8_avx2(want.ctypes.data, want.shape[1], src.ctypes.data, src.shape[1], dw, dh, sw, sh, vo.ctypes.data, vw.ctypes.data, ho.ctypes.data, hw.ctypes.data)
         assert np.array_equal(got[:, :dw], want[:, :dw]), (sw, sh, dw, dh)
+
+
+def test_search_statistics_tool_runs():
+    """tools/search_stats.py (the oracle built with -DMVO_STATS, counters only): runs on a small clip and its percentages are sane."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "search_stats.py"), "256", "144", "8", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-500:]
+    m = re.search(r"level 0: (\d+) blocks", r.stdout)
+    assert m and int(m.group(1)) == 2 * 31 * 17  # two searches, (256 / 8 - 1) x (144 / 8 - 1) blocks of 16 with overlap 8
+    ends = re.search(r"predictor phase ends on[^:]*: (.*)", r.stdout).group(1)
+    assert abs(sum(float(v) for v in re.findall(r"([0-9.]+) %", ends)) - 100.0) < 0.5
