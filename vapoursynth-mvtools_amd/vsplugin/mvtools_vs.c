@@ -95,6 +95,14 @@ static void *download_stream(void) {
     }
     return g_dl_stream ? g_dl_stream : thread_stream();
 }
+/* Error paths: a getFrame that failed after it enqueued work skipped its stream waits, and mvx_dev_free hands a buffer straight to the next
+ * caller (no stream ordering in the pool: ADVICE r2) -- so before such a path frees device memory it waits for whatever is still queued on the
+ * streams it used.  A no-op when rc == 0. */
+static void shell_quiesce(int rc) {
+    if (!rc) return;
+    (void)mvx_stream_sync(thread_stream());
+    if (g_dl_stream) (void)mvx_stream_sync(g_dl_stream);
+}
 static int timed_download_on(void *stream, void *dst, ptrdiff_t dp, const void *src, ptrdiff_t sp, size_t rb, size_t rows) {
     const double t0 = prof_now();
     const int rc = mvx_download_2d(dst, dp, src, sp, rb, rows, stream);
@@ -297,7 +305,7 @@ static int super_to_device(DevRef *r, const VSFrame *f, const SuperGeo *g, const
     }
     if (!rc) rc = super_shadows(g, r->plane, st);
     if (!rc) rc = mvx_stream_sync(st); /* consumers launch on their own streams */
-    if (rc) { mvx_dev_free(arena); memset(r, 0, sizeof(*r)); return rc; }
+    if (rc) { shell_quiesce(rc); mvx_dev_free(arena); memset(r, 0, sizeof(*r)); return rc; }
     if (!err && (r->cached = cache_insert(id, print, arena, g)) != NULL) return 0; /* keep it for the next consumer */
     r->temp = arena;
     return 0;
@@ -642,6 +650,7 @@ static const VSFrame *VS_CC superGetFrame(int n, int reason, void *inst, void **
             rc = timed_download(vs->getWritePtr(dst, p), vs->getStride(dst, p), ddst[p], g->pitch[p], (size_t)g->si.plane_width[p] * g->bps, (size_t)g->si.plane_height[p]);
         if (!rc) rc = mvx_stream_sync(st);
     }
+    shell_quiesce(rc);
     if (srcArena) mvx_dev_free(srcArena);
     if (pelArena) mvx_dev_free(pelArena);
     if (pf) vs->freeFrame(pf);
@@ -967,6 +976,8 @@ static int la_launch(AnalyseData *d, LaWindow *s, int v, VSFrameContext *ctx, co
         pthread_mutex_unlock(&g_lock);
     }
     if (rc) {
+        shell_quiesce(rc);
+        if (s->stream) (void)mvx_stream_sync(s->stream);
         for (int i = 0; i < nn; i++) if (pins && pins[i]) cache_unpin(pins[i]);
         free(pins);
         if (dblobs) mvx_dev_free(dblobs);
@@ -1124,6 +1135,7 @@ static const VSFrame *VS_CC analyseGetFrame(int n, int reason, void *inst, void 
         if (!rc) rc = timed_download(blob, d->blobSize, dblob, d->blobSize, (size_t)d->blobSize, 1);
         if (!rc) rc = mvx_stream_sync(thread_stream());
     }
+    shell_quiesce(rc);
     dev_release(&ds); dev_release(&dr);
     if (dblob) mvx_dev_free(dblob);
     if (ref) vs->freeFrame(ref);
@@ -1247,6 +1259,7 @@ static const VSFrame *VS_CC finestGetFrame(int n, int reason, void *inst, void *
         if (!rc) rc = mvx_stream_sync(thread_stream());
     }
     dev_release(&ds);
+    shell_quiesce(rc);
     if (arena) mvx_dev_free(arena);
     vs->freeFrame(ref);
     if (rc) { vs->freeFrame(dst); vs->setFilterError(rc == MVX_E_NOMEM ? "Finest: out of memory." : mvx_last_error(), ctx); return NULL; }
@@ -1303,6 +1316,7 @@ static const VSFrame *VS_CC scdGetFrame(int n, int reason, void *inst, void **fd
     int32_t sc = 0;
     char lerr[MVX_ERRLEN];
     if (!rc) { const void *b1[1] = { dblob }; rc = mvx_scdetect(&d->ad, d->thscd1, d->thscd2, 1, b1, &sc, thread_stream(), lerr); }
+    shell_quiesce(rc);
     if (dblob) mvx_dev_free(dblob);
     if (rc) { vs->freeFrame(dst); vs->setFilterError(rc == MVX_E_ARG ? "SCDetection: vector clip frame without a valid MVTools_vectors property." : mvx_last_error(), ctx); return NULL; }
     vs->mapSetInt(vs->getFramePropertiesRW(dst), d->ad.isBackward ? "_SceneChangeNext" : "_SceneChangePrev", sc, maReplace); /* :62-64 */
@@ -1384,6 +1398,7 @@ static const VSFrame *VS_CC recalcGetFrame(int n, int reason, void *inst, void *
         if (!rc) rc = timed_download(blob, d->blobSize, dblob, d->blobSize, (size_t)d->blobSize, 1);
         if (!rc) rc = mvx_stream_sync(thread_stream());
     }
+    shell_quiesce(rc);
     dev_release(&ds); dev_release(&dr);
     if (dblob) mvx_dev_free(dblob);
     if (oldBlob) mvx_dev_free(oldBlob);
@@ -1513,6 +1528,7 @@ static const VSFrame *VS_CC degrainGetFrame(int n, int reason, void *inst, void 
             rc = timed_download(vs->getWritePtr(dst, p), vs->getStride(dst, p), job.dst[p], d->pitch[p], (size_t)vs->getFrameWidth(dst, p) * bps, (size_t)vs->getFrameHeight(dst, p));
         if (!rc) rc = mvx_stream_sync(thread_stream());
     }
+    shell_quiesce(rc);
     for (int r = 0; r < nr; r++) { dev_release(&refs[r]); if (blobArena[r]) mvx_dev_free(blobArena[r]); }
     if (srcArena) mvx_dev_free(srcArena);
     if (dstArena) mvx_dev_free(dstArena);
@@ -1680,6 +1696,7 @@ static const VSFrame *VS_CC compGetFrame(int n, int reason, void *inst, void **f
             rc = timed_download(vs->getWritePtr(dst, p), vs->getStride(dst, p), job.dst[p], d->pitch[p], (size_t)vs->getFrameWidth(dst, p) * bps, (size_t)vs->getFrameHeight(dst, p));
         if (!rc) rc = mvx_stream_sync(thread_stream());
     }
+    shell_quiesce(rc);
     dev_release(&ds); dev_release(&dr);
     if (dblob) mvx_dev_free(dblob);
     if (dstArena) mvx_dev_free(dstArena);
@@ -1819,6 +1836,7 @@ static const VSFrame *VS_CC fpsGetFrame(int n, int reason, void *inst, void **fd
         if (!rc) rc = mvx_stream_sync(thread_stream());
     }
     dev_release(&ds); dev_release(&dr2);
+    shell_quiesce(rc);
     if (blobF) mvx_dev_free(blobF);
     if (blobB) mvx_dev_free(blobB);
     if (arenaL) mvx_dev_free(arenaL);
