@@ -26,3 +26,18 @@ def mv():
     import mvtools_amd
     mvtools_amd.lib()
     return mvtools_amd
+
+
+@pytest.fixture(scope="session")
+def fakedev(tmp_path_factory, oracle):
+    """path of the TEST DOUBLE of the device layer (tests/fakedev/mvx_fakedev.c), built into a temporary directory: LD_PRELOADed in front of
+    libmvtools_amd.so it lets the real VapourSynth plugin run in the real mini host on a CPU-only machine (the oracle computes).  Test
+    infrastructure; the product never loads it."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path_factory.mktemp("fakedev") / "libmvx_fakedev.so")
+    odir = os.path.join(root, "oracle")
+    subprocess.check_call(["gcc", "-std=gnu11", "-O1", "-Wall", "-Wextra", "-shared", "-fPIC", "-I" + os.path.join(root, "include"), "-I" + odir,
+                           os.path.join(root, "tests", "fakedev", "mvx_fakedev.c"), "-o", so, "-L" + odir, "-lmvoracle", "-Wl,-rpath," + odir, "-ldl", "-lpthread"])
+    return so

@@ -6,7 +6,7 @@
  * Why it exists: the VapourSynth filter shell (vsplugin/mvtools_vs.c) is host logic -- request protocol, look-ahead windows, the cache of
  * device frames, pinning, eviction, thread synchronisation -- and the only way to run it used to be a GPU.  With this file in front of the
  * library the shell's calls that would touch the device land in host memory ("device" buffers are malloc'ed, copies are memcpy, streams
- * are tokens) and the three kernels of the Super -> Analyse -> Degrain path are the ORACLE's functions (oracle/mvoracle.h), so a graph
+ * are tokens) and the kernel calls (Super incl. pelclip, Finest, Analyse, Recalculate, Degrain, Compensate, BlockFPS, SCDetection) are the ORACLE's functions (oracle/mvoracle.h), so a graph
  * evaluated through the real plugin and the real mini host on a CPU-only machine must reproduce the oracle bit for bit, whatever the
  * thread count and the look-ahead configuration.  What it tests is the shell; it says nothing about the HIP kernels (the -m gpu suite does).
  *
@@ -29,10 +29,13 @@
 /* ---- what the oracle needs to know about the handles the real library made */
 typedef struct Rec {
     const void *handle;
-    int kind; /* 1 super, 2 analyse, 3 degrain */
-    mvo_super s;
+    int kind; /* 1 super, 2 analyse, 3 degrain, 4 compensate, 5 recalculate, 6 blockfps */
+    mvo_super s; /* (kinds > 1: a copy of the super clip's geometry) */
     mvo_analyse an;
     mvo_degrain dg;
+    mvo_compensate cp;
+    mvo_recalculate rc;
+    mvo_blockfps bf;
     int superPitch[3], srcPitch[3], dstPitch[3];
     struct Rec *next;
 } Rec;
@@ -226,5 +229,166 @@ API int mvx_degrain_frames(mvx_degrain *d, int nframes, const mvx_degrain_job *j
         }
         mvo_degrain_frame(&r->dg, src, r->srcPitch, (const uint8_t *const (*)[3])refs, (const int (*)[3])pitches, blobs, dst, r->dstPitch);
     }
+    return MVX_OK;
+}
+
+/* ---- mv.Super(pelclip=...), mv.Finest */
+API int mvx_super_frames_pelclip(mvx_super *s, int n, const void *const *src, const ptrdiff_t sp[3], const void *const *pel, const ptrdiff_t pp[3], int mode,
+                                 void *const *dst, const ptrdiff_t dp[3], void *st) {
+    (void)st;
+    const Rec *r = rec_find(s, 1);
+    const int spi[3] = { (int)sp[0], (int)sp[1], (int)sp[2] }, ppi[3] = { (int)pp[0], (int)pp[1], (int)pp[2] }, dpi[3] = { (int)dp[0], (int)dp[1], (int)dp[2] };
+    for (int f = 0; f < n; f++) {
+        const uint8_t *sv[3] = { (const uint8_t *)src[f * 3], (const uint8_t *)src[f * 3 + 1], (const uint8_t *)src[f * 3 + 2] };
+        const uint8_t *pv[3] = { (const uint8_t *)pel[f * 3], (const uint8_t *)pel[f * 3 + 1], (const uint8_t *)pel[f * 3 + 2] };
+        uint8_t *dv[3] = { (uint8_t *)dst[f * 3], (uint8_t *)dst[f * 3 + 1], (uint8_t *)dst[f * 3 + 2] };
+        mvo_super_frame_pelclip(&r->s, sv, spi, pv, ppi, mode, dv, dpi);
+    }
+    return MVX_OK;
+}
+API int mvx_finest_frames(const mvx_super *s, int n, const void *const *sup, const ptrdiff_t sp[3], void *const *dst, const ptrdiff_t dp[3], void *st) {
+    (void)st;
+    const Rec *r = rec_find(s, 1);
+    const int spi[3] = { (int)sp[0], (int)sp[1], (int)sp[2] }, dpi[3] = { (int)dp[0], (int)dp[1], (int)dp[2] };
+    for (int f = 0; f < n; f++) {
+        const uint8_t *sv[3] = { (const uint8_t *)sup[f * 3], (const uint8_t *)sup[f * 3 + 1], (const uint8_t *)sup[f * 3 + 2] };
+        uint8_t *dv[3] = { (uint8_t *)dst[f * 3], (uint8_t *)dst[f * 3 + 1], (uint8_t *)dst[f * 3 + 2] };
+        mvo_finest_frame(&r->s, sv, spi, dv, dpi);
+    }
+    return MVX_OK;
+}
+
+/* ---- mv.Compensate */
+API int mvx_compensate_create(const mvx_compensate_args *a, const mvx_analysis_data *vd, const mvx_super *sup, const ptrdiff_t super_pitch[3],
+                              const ptrdiff_t dst_pitch[3], mvx_compensate **out, char *err) {
+    int (*f)(const mvx_compensate_args *, const mvx_analysis_data *, const mvx_super *, const ptrdiff_t *, const ptrdiff_t *, mvx_compensate **, char *) =
+        (int (*)(const mvx_compensate_args *, const mvx_analysis_data *, const mvx_super *, const ptrdiff_t *, const ptrdiff_t *, mvx_compensate **, char *))real("mvx_compensate_create");
+    const int rc = f(a, vd, sup, super_pitch, dst_pitch, out, err);
+    if (rc == MVX_OK) {
+        const Rec *rs = rec_find(sup, 1);
+        Rec *r = rec_new(*out, 4);
+        mvo_analysis_data ad;
+        memcpy(&ad, vd, sizeof(ad));
+        char e2[MVO_ERR];
+        if (mvo_compensate_init(&r->cp, &ad, &rs->s, a->scbehavior, a->thsad, a->time, a->thscd1, a->thscd2, e2)) {
+            fprintf(stderr, "mvx_fakedev: the oracle refuses what the library accepted: %s\n", e2); abort();
+        }
+        for (int p = 0; p < 3; p++) { r->superPitch[p] = (int)super_pitch[p]; r->dstPitch[p] = (int)dst_pitch[p]; }
+    }
+    return rc;
+}
+API void mvx_compensate_destroy(mvx_compensate *c) {
+    void (*f)(mvx_compensate *) = (void (*)(mvx_compensate *))real("mvx_compensate_destroy");
+    if (c) rec_drop(c, 4);
+    f(c);
+}
+API int mvx_compensate_frames(mvx_compensate *c, int n, const mvx_compensate_job *jobs, void *st) {
+    (void)st;
+    const Rec *r = rec_find(c, 4);
+    for (int i = 0; i < n; i++) {
+        const uint8_t *src[3] = { (const uint8_t *)jobs[i].src_super[0], (const uint8_t *)jobs[i].src_super[1], (const uint8_t *)jobs[i].src_super[2] };
+        const uint8_t *ref[3] = { (const uint8_t *)jobs[i].ref_super[0], (const uint8_t *)jobs[i].ref_super[1], (const uint8_t *)jobs[i].ref_super[2] };
+        uint8_t *dst[3] = { (uint8_t *)jobs[i].dst[0], (uint8_t *)jobs[i].dst[1], (uint8_t *)jobs[i].dst[2] };
+        mvo_compensate_frame(&r->cp, src, r->superPitch, jobs[i].ref_super[0] ? ref : NULL, r->superPitch, (const uint8_t *)jobs[i].blob, dst, r->dstPitch, jobs[i].field_shift);
+    }
+    return MVX_OK;
+}
+
+/* ---- mv.Recalculate */
+API int mvx_recalculate_create(const mvx_recalculate_args *a, const mvx_super *sup, const mvx_analysis_data *vd, const ptrdiff_t super_pitch[3], mvx_recalculate **out, char *err) {
+    int (*f)(const mvx_recalculate_args *, const mvx_super *, const mvx_analysis_data *, const ptrdiff_t *, mvx_recalculate **, char *) =
+        (int (*)(const mvx_recalculate_args *, const mvx_super *, const mvx_analysis_data *, const ptrdiff_t *, mvx_recalculate **, char *))real("mvx_recalculate_create");
+    const int rc = f(a, sup, vd, super_pitch, out, err);
+    if (rc == MVX_OK) {
+        const Rec *rs = rec_find(sup, 1);
+        Rec *r = rec_new(*out, 5);
+        mvo_recalculate_args oa = { a->thsad, a->smooth, a->blksize, a->blksizev, a->search, a->searchparam, a->lambda, a->chroma, a->truemotion, a->pnew, a->overlap,
+                                    a->overlapv, a->divide, a->meander, a->dct }; /* (`fields` only shifts the job's reference rows; the shell computes that) */
+        mvo_analysis_data ad;
+        memcpy(&ad, vd, sizeof(ad));
+        char e2[MVO_ERR];
+        if (mvo_recalculate_init(&r->rc, &oa, &rs->s, &ad, e2)) { fprintf(stderr, "mvx_fakedev: the oracle refuses what the library accepted: %s\n", e2); abort(); }
+        for (int p = 0; p < 3; p++) r->superPitch[p] = (int)super_pitch[p];
+    }
+    return rc;
+}
+API void mvx_recalculate_destroy(mvx_recalculate *x) {
+    void (*f)(mvx_recalculate *) = (void (*)(mvx_recalculate *))real("mvx_recalculate_destroy");
+    if (x) rec_drop(x, 5);
+    f(x);
+}
+API int mvx_recalculate_frames(mvx_recalculate *x, int n, const mvx_recalculate_job *jobs, void *st) {
+    (void)st;
+    const Rec *r = rec_find(x, 5);
+    for (int i = 0; i < n; i++) {
+        const uint8_t *src[3] = { (const uint8_t *)jobs[i].src[0], (const uint8_t *)jobs[i].src[1], (const uint8_t *)jobs[i].src[2] };
+        const uint8_t *ref[3] = { (const uint8_t *)jobs[i].ref[0], (const uint8_t *)jobs[i].ref[1], (const uint8_t *)jobs[i].ref[2] };
+        mvo_recalculate_frame(&r->rc, src, r->superPitch, jobs[i].ref[0] ? ref : NULL, r->superPitch, (const uint8_t *)jobs[i].old_blob, (uint8_t *)jobs[i].blob);
+    }
+    return MVX_OK;
+}
+
+/* ---- mv.BlockFPS */
+API int mvx_blockfps_create(const mvx_blockfps_args *a, const mvx_analysis_data *bw, const mvx_analysis_data *fw, const mvx_super *sup, int num_frames, int64_t fps_num,
+                            int64_t fps_den, const ptrdiff_t super_pitch[3], const ptrdiff_t clip_pitch[3], const ptrdiff_t dst_pitch[3], mvx_blockfps **out, char *err) {
+    int (*f)(const mvx_blockfps_args *, const mvx_analysis_data *, const mvx_analysis_data *, const mvx_super *, int, int64_t, int64_t, const ptrdiff_t *, const ptrdiff_t *,
+             const ptrdiff_t *, mvx_blockfps **, char *) =
+        (int (*)(const mvx_blockfps_args *, const mvx_analysis_data *, const mvx_analysis_data *, const mvx_super *, int, int64_t, int64_t, const ptrdiff_t *, const ptrdiff_t *,
+                 const ptrdiff_t *, mvx_blockfps **, char *))real("mvx_blockfps_create");
+    const int rc = f(a, bw, fw, sup, num_frames, fps_num, fps_den, super_pitch, clip_pitch, dst_pitch, out, err);
+    if (rc == MVX_OK) {
+        const Rec *rs = rec_find(sup, 1);
+        Rec *r = rec_new(*out, 6);
+        r->s = rs->s;
+        mvo_analysis_data b, w;
+        memcpy(&b, bw, sizeof(b)); memcpy(&w, fw, sizeof(w));
+        char e2[MVO_ERR];
+        if (mvo_blockfps_init(&r->bf, &b, &w, &rs->s, num_frames, fps_num, fps_den, a->num, a->den, a->mode, a->ml, a->blend, a->thscd1, a->thscd2, e2)) {
+            fprintf(stderr, "mvx_fakedev: the oracle refuses what the library accepted: %s\n", e2); abort();
+        }
+        for (int p = 0; p < 3; p++) { r->superPitch[p] = (int)super_pitch[p]; r->srcPitch[p] = (int)clip_pitch[p]; r->dstPitch[p] = (int)dst_pitch[p]; }
+    }
+    return rc;
+}
+API void mvx_blockfps_destroy(mvx_blockfps *b) {
+    void (*f)(mvx_blockfps *) = (void (*)(mvx_blockfps *))real("mvx_blockfps_destroy");
+    if (b) rec_drop(b, 6);
+    f(b);
+}
+API int mvx_blockfps_frames(mvx_blockfps *b, int n, const mvx_blockfps_job *jobs, void *st) {
+    (void)st;
+    const Rec *r = rec_find(b, 6);
+    const int bps = (r->s.bits + 7) / 8, planes = (r->s.modeYUV & 6) ? 3 : 1;
+    for (int i = 0; i < n; i++) {
+        const mvx_blockfps_job *j = &jobs[i];
+        const uint8_t *src[3] = { (const uint8_t *)j->src_super[0], (const uint8_t *)j->src_super[1], (const uint8_t *)j->src_super[2] };
+        const uint8_t *ref[3] = { (const uint8_t *)j->ref_super[0], (const uint8_t *)j->ref_super[1], (const uint8_t *)j->ref_super[2] };
+        const uint8_t *cl[3] = { (const uint8_t *)j->clip_left[0], (const uint8_t *)j->clip_left[1], (const uint8_t *)j->clip_left[2] };
+        const uint8_t *cr[3] = { (const uint8_t *)j->clip_right[0], (const uint8_t *)j->clip_right[1], (const uint8_t *)j->clip_right[2] };
+        uint8_t *dst[3] = { (uint8_t *)j->dst[0], (uint8_t *)j->dst[1], (uint8_t *)j->dst[2] };
+        int copy = j->time256 == 0 ? 1 : j->time256 == 256 ? 2 : 0; /* MVBlockFPS.c:245-254 */
+        if (!copy) {
+            const int good = j->src_super[0] && j->ref_super[0] && j->blob_fw && j->blob_bw;
+            if (mvo_blockfps_frame(&r->bf, j->time256, good ? src : NULL, r->superPitch, good ? ref : NULL, r->superPitch, good ? (const uint8_t *)j->blob_fw : NULL,
+                                   good ? (const uint8_t *)j->blob_bw : NULL, cl, r->srcPitch, cr, r->srcPitch, dst, r->dstPitch) == 1) copy = 1;
+        }
+        if (copy)
+            for (int p = 0; p < planes; p++) {
+                const int wdt = p ? r->s.width / r->s.xRatioUV : r->s.width, hgt = p ? r->s.height / r->s.yRatioUV : r->s.height;
+                copy2d(dst[p], r->dstPitch[p], copy == 1 ? cl[p] : cr[p], r->srcPitch[p], (size_t)wdt * bps, (size_t)hgt);
+            }
+    }
+    return MVX_OK;
+}
+
+/* ---- mv.SCDetection: scene_change[i] = the i-th blob is not usable (MVSCDetection.c:43-73) */
+API int mvx_scdetect(const mvx_analysis_data *vd, int64_t thscd1, int32_t thscd2, int n, const void *const *blobs, int32_t *scene_change, void *st, char *err) {
+    (void)st; (void)err;
+    mvo_analysis_data ad;
+    memcpy(&ad, vd, sizeof(ad));
+    int64_t t1 = thscd1 == MVX_UNSET ? 400 : thscd1; /* MVSCDetection.c:125-130 */
+    int t2 = thscd2 == MVX_UNSET ? 130 : thscd2;
+    mvo_scale_thscd(&t1, &t2, &ad);
+    for (int i = 0; i < n; i++) scene_change[i] = !mvo_blob_is_usable(&ad, (const uint8_t *)blobs[i], t1, t2);
     return MVX_OK;
 }

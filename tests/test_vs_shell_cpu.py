@@ -15,16 +15,6 @@ import pipeline as pl
 from test_vs_shim import HOST, PLUGIN, ROOT, _read_frames, _write_clip, host
 
 
-@pytest.fixture(scope="module")
-def fakedev(tmp_path_factory, oracle):
-    host("list")  # (builds the plugin and the mini host if they are missing)
-    so = str(tmp_path_factory.mktemp("fakedev") / "libmvx_fakedev.so")
-    odir = os.path.join(ROOT, "oracle")
-    subprocess.check_call(["gcc", "-std=gnu11", "-O1", "-Wall", "-Wextra", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + odir,
-                           os.path.join(ROOT, "tests", "fakedev", "mvx_fakedev.c"), "-o", so, "-L" + odir, "-lmvoracle", "-Wl,-rpath," + odir, "-ldl", "-lpthread"])
-    return so
-
-
 def _run(fakedev, args, out, extra, env):
     e = dict(os.environ, LD_PRELOAD=fakedev, MVX_FAKEDEV_STATS="1", MVX_VS_STATS="1")
     e.update(env)

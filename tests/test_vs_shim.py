@@ -19,16 +19,38 @@ HOST = os.path.join(PKG, "mvx_vs_host")
 PLUGIN = os.path.join(PKG, "libmvtools_vs.so")
 
 
+_PRELOAD = None  # the `shell` fixture's "double" mode: path of the test double of the device layer (tests/fakedev), else None
+
+
+def proc_env(**extra):
+    """environment of a mini-host process in the current mode"""
+    e = dict(os.environ)
+    if _PRELOAD:
+        e["LD_PRELOAD"] = _PRELOAD
+    e.update(extra)
+    return e
+
+
 def host(*args, check=True):
     if not (os.path.exists(HOST) and os.path.exists(PLUGIN)):
         import sys
         sys.path.insert(0, PKG)
         import build
         build.build()
-    r = subprocess.run([HOST, PLUGIN] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([HOST, PLUGIN] + [str(a) for a in args], capture_output=True, text=True, timeout=600, env=proc_env())
     if check:
         assert r.returncode == 0, r.stdout + r.stderr
     return r.stdout
+
+
+@pytest.fixture(params=[pytest.param("device", marks=pytest.mark.gpu), "double"])
+def shell(request):
+    """Every graph test of the shell runs twice: on the GPU (`device`, -m gpu), and on a CPU-only machine over the test double of the
+    device layer (`double`: tests/fakedev/mvx_fakedev.c in front of the library, oracle kernels) -- there it tests the shell's own logic."""
+    global _PRELOAD
+    _PRELOAD = request.getfixturevalue("fakedev") if request.param == "double" else None  # (built only when a CPU twin runs)
+    yield request.param
+    _PRELOAD = None
 
 
 DEGRAIN_TAIL = "thsad:int:opt;thsadc:int:opt;plane:int:opt;limit:int:opt;limitc:int:opt;thscd1:int:opt;thscd2:int:opt;opt:int:opt;"
@@ -105,9 +127,8 @@ def _read_frames(path, w, h, bits, n):
     return out
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("bits", [8, 16])
-def test_creation_errors_with_real_frames(bits):
+def test_creation_errors_with_real_frames(shell, bits):
     # these need frame 0 of the super / vector clips, i.e. a GPU
     assert host("error", "Analyse", 128, 96, bits, "f.blksize=7").strip().startswith("ERROR Analyse: the block size must be")
     assert host("error", "Analyse", 128, 96, bits, "s.levels=1", "f.levels=3").strip() == "ERROR Analyse: super clip has 1 levels. Analyse needs 3 levels."
@@ -117,9 +138,8 @@ def test_creation_errors_with_real_frames(bits):
     assert host("error", "Degrain1", 128, 96, bits).strip().startswith("OK 128x96")
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("w,h,bits,nf,sargs,aargs", [(128, 96, 8, 4, {}, dict(blksize=8, overlap=4)), (192, 112, 16, 3, dict(pel=1), dict(blksize=16, overlap=8))])
-def test_shell_super_and_analyse_match_oracle(oracle, tmp_path, w, h, bits, nf, sargs, aargs):
+def test_shell_super_and_analyse_match_oracle(shell, oracle, tmp_path, w, h, bits, nf, sargs, aargs):
     frames = pl.moving_clip(w, h, bits, nf, seed=31, noise=3)
     src = tmp_path / "in.raw"
     _write_clip(src, frames)
@@ -159,9 +179,8 @@ def test_shell_super_and_analyse_match_oracle(oracle, tmp_path, w, h, bits, nf, 
     assert off == blob.size
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("w,h,bits,radius,dargs", [(128, 96, 8, 1, {}), (192, 112, 16, 2, dict(thsad=300, limit=2000)), (128, 96, 8, 3, dict(plane=0))])
-def test_shell_degrain_matches_oracle(oracle, tmp_path, w, h, bits, radius, dargs):
+def test_shell_degrain_matches_oracle(shell, oracle, tmp_path, w, h, bits, radius, dargs):
     nf = 2 * radius + 2
     aargs = dict(blksize=8, overlap=4)
     frames = pl.moving_clip(w, h, bits, nf, seed=33, noise=3)
@@ -187,8 +206,7 @@ def test_shell_degrain_matches_oracle(oracle, tmp_path, w, h, bits, radius, darg
             assert np.array_equal(got[n][p], want[p]), (n, p)
 
 
-@pytest.mark.gpu
-def test_shell_compensate_matches_oracle(oracle, tmp_path):
+def test_shell_compensate_matches_oracle(shell, oracle, tmp_path):
     w, h, bits, nf = 128, 96, 8, 4
     aargs = dict(blksize=8, overlap=4)
     frames = pl.moving_clip(w, h, bits, nf, seed=35, noise=3)
@@ -207,9 +225,8 @@ def test_shell_compensate_matches_oracle(oracle, tmp_path):
             assert np.array_equal(got[n][p], want[p]), (n, p)
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("bits,pel,padded", [(8, 2, False), (16, 4, False), (8, 2, True)])
-def test_shell_super_pelclip_matches_oracle(oracle, tmp_path, bits, pel, padded):
+def test_shell_super_pelclip_matches_oracle(shell, oracle, tmp_path, bits, pel, padded):
     w, h, nf = 128, 96, 2
     frames = pl.moving_clip(w, h, bits, nf, seed=38, noise=3)
     osup = oracle.Super(w, h, bits, pel=pel)
@@ -230,9 +247,8 @@ def test_shell_super_pelclip_matches_oracle(oracle, tmp_path, bits, pel, padded)
         assert not pl.defined_equal(osup, osup.frame_pelclip(frames[n], pelframes[n]), got)
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("how", ["tff1", "tff0", "props1", "props0"])
-def test_shell_fields_match_oracle(oracle, tmp_path, how):
+def test_shell_fields_match_oracle(shell, oracle, tmp_path, how):
     """fields=True through the shell: parity from tff (overrides) or from the frames' _Field props (src/MVAnalyse.c:135-179,
     src/MVCompensate.c:188-225); Analyse and Compensate both apply the +-pel/2 shift"""
     w, h, bits, nf, pel = 128, 96, 8, 4, 2
@@ -275,8 +291,7 @@ def test_shell_fields_match_oracle(oracle, tmp_path, how):
     assert shifts == {1, -1}
 
 
-@pytest.mark.gpu
-def test_shell_fields_need_parity_information():
+def test_shell_fields_need_parity_information(shell):
     # no _Field prop on the frames and no tff: a frame-time error in the reference's words
     msg = "_Field property not found in input frame. Therefore, you must pass tff argument."
     import tempfile
@@ -294,9 +309,8 @@ def test_shell_fields_need_parity_information():
     assert host("error", "Compensate", 128, 96, 8, "s.pel=1", "f.fields=1").strip() == "ERROR Compensate: fields option requires pel > 1."
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("bits,bargs", [(8, dict(num=60, den=1)), (16, dict(num=60, den=1, mode=4, ml="40.0")), (8, dict(num=60, den=1, thscd1=20, thscd2=10))])
-def test_shell_blockfps_matches_oracle(oracle, tmp_path, bits, bargs):
+def test_shell_blockfps_matches_oracle(shell, oracle, tmp_path, bits, bargs):
     w, h, nf = 128, 96, 5
     aargs = dict(blksize=8, overlap=4)
     frames = pl.moving_clip(w, h, bits, nf, seed=37, noise=3)
@@ -321,10 +335,9 @@ def test_shell_blockfps_matches_oracle(oracle, tmp_path, bits, bargs):
             assert np.array_equal(got[n][p], want[p][:, :got[n][p].shape[1]]), (n, p, ob.map(n))
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("bits,aargs,rargs,dargs", [(8, dict(blksize=16, overlap=8), dict(blksize=8, overlap=4, thsad=100), {}),
                                                     (16, dict(blksize=16, overlap=8, divide=2), dict(blksize=8, overlap=4, thsad=60, divide=1), {})])
-def test_shell_recalculate_and_divide_match_oracle(oracle, tmp_path, bits, aargs, rargs, dargs):
+def test_shell_recalculate_and_divide_match_oracle(shell, oracle, tmp_path, bits, aargs, rargs, dargs):
     w, h, nf = 192, 128, 3
     frames = pl.moving_clip(w, h, bits, nf, seed=39, noise=3)
     src = tmp_path / "in.raw"
@@ -350,8 +363,7 @@ def test_shell_recalculate_and_divide_match_oracle(oracle, tmp_path, bits, aargs
     assert off == blob.size
 
 
-@pytest.mark.gpu
-def test_shell_finest_and_scdetection(oracle, tmp_path):
+def test_shell_finest_and_scdetection(shell, oracle, tmp_path):
     w, h, bits, nf = 128, 96, 8, 3
     frames = pl.moving_clip(w, h, bits, nf, seed=43, noise=3)
     src = tmp_path / "in.raw"
@@ -376,9 +388,8 @@ def test_shell_finest_and_scdetection(oracle, tmp_path):
             assert np.array_equal(passthrough[n][p], frames[n][p])
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("bits,pipeline,extra", [(8, "degrain1", ("a.blksize=8", "a.overlap=4")), (16, "degrain3", ("a.blksize=16", "a.overlap=8")), (16, "analyse", ("a.blksize=16", "a.overlap=8"))])
-def test_concurrent_requests_are_batched_and_bit_identical(tmp_path, bits, pipeline, extra):
+def test_concurrent_requests_are_batched_and_bit_identical(shell, tmp_path, bits, pipeline, extra):
     """fmParallel (src/MVAnalyse.c:634): 64 worker threads request frames at once.  The shell's combining queue turns the concurrent
     getFrame calls of one Analyse instance into a single search launch; the clip that comes out must be the one the frame-by-frame
     evaluation gives (which the other tests compare with the oracle)."""
@@ -387,7 +398,7 @@ def test_concurrent_requests_are_batched_and_bit_identical(tmp_path, bits, pipel
     src, seq, par = str(tmp_path / "in.raw"), str(tmp_path / "seq.raw"), str(tmp_path / "par.raw")
     _write_clip(src, frames)
     assert "DONE" in host("run", pipeline, src, w, h, bits, n, seq, *extra)
-    env = dict(os.environ, MVX_VS_STATS="1", MVX_VS_BATCH_WAIT_US="20000")
+    env = proc_env(MVX_VS_STATS="1", MVX_VS_BATCH_WAIT_US="20000")
     r = subprocess.run([HOST, PLUGIN] + [str(a) for a in ("run", pipeline, src, w, h, bits, n, par)] + list(extra) + ["x.threads=64"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "DONE" in r.stdout, r.stdout + r.stderr
     assert open(seq, "rb").read() == open(par, "rb").read()
@@ -398,10 +409,9 @@ def test_concurrent_requests_are_batched_and_bit_identical(tmp_path, bits, pipel
     assert kv["jobs"] == n * kv["instances"] and kv["launches"] <= 8 * kv["instances"] and kv["largest_batch"] >= 32, stats[0]
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("bits,pipeline,extra,threads", [(16, "degrain3", ("a.blksize=16", "a.overlap=8"), 32), (8, "degrain1", ("a.blksize=8", "a.overlap=4"), 1),
                                                           (8, "analyse", ("a.blksize=8", "a.overlap=4", "a.delta=2"), 8)])
-def test_lookahead_serves_windows_and_is_bit_identical(tmp_path, bits, pipeline, extra, threads):
+def test_lookahead_serves_windows_and_is_bit_identical(shell, tmp_path, bits, pipeline, extra, threads):
     """mv.Analyse on this plugin's own mv.Super node computes its vector clip a window of 128 frames at a time (one search launch per
     window, super frames built on the device from the SOURCE frames; the request protocol stays MVAnalyse.c:84-113's arInitial /
     arAllFramesReady).  The clip must be the one the per-frame path gives (MVX_VS_LOOKAHEAD=0, which the other tests tie to the oracle),
@@ -411,9 +421,9 @@ def test_lookahead_serves_windows_and_is_bit_identical(tmp_path, bits, pipeline,
     src, ref, la = str(tmp_path / "in.raw"), str(tmp_path / "ref.raw"), str(tmp_path / "la.raw")
     _write_clip(src, frames)
     args = [str(a) for a in ("run", pipeline, src, w, h, bits, n)]
-    r0 = subprocess.run([HOST, PLUGIN] + args + [ref] + list(extra) + ["x.threads=16"], capture_output=True, text=True, timeout=900, env=dict(os.environ, MVX_VS_LOOKAHEAD="0"))
+    r0 = subprocess.run([HOST, PLUGIN] + args + [ref] + list(extra) + ["x.threads=16"], capture_output=True, text=True, timeout=900, env=proc_env(MVX_VS_LOOKAHEAD="0"))
     assert r0.returncode == 0 and "DONE" in r0.stdout, r0.stdout + r0.stderr
-    r1 = subprocess.run([HOST, PLUGIN] + args + [la] + list(extra) + ["x.threads=%d" % threads], capture_output=True, text=True, timeout=900, env=dict(os.environ, MVX_VS_STATS="1"))
+    r1 = subprocess.run([HOST, PLUGIN] + args + [la] + list(extra) + ["x.threads=%d" % threads], capture_output=True, text=True, timeout=900, env=proc_env(MVX_VS_STATS="1"))
     assert r1.returncode == 0 and "DONE" in r1.stdout, r1.stdout + r1.stderr
     assert open(ref, "rb").read() == open(la, "rb").read()
     stats = [l for l in r1.stderr.splitlines() if l.startswith("mvtools_vs: Analyse")]
