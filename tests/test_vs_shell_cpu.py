@@ -56,7 +56,7 @@ def test_shell_reproduces_the_oracle_without_a_gpu(tmp_path, oracle, fakedev, bi
     frames = pl.moving_clip(w, h, bits, n, seed=5 + radius, noise=3)
     src, out = str(tmp_path / "in.raw"), str(tmp_path / "out.raw")
     _write_clip(src, frames)
-    extra = ["a.blksize=16", "a.overlap=8", "x.threads=%d" % threads] + (["x.order=frame"] if threads > 1 else [])
+    extra = ["a.blksize=16", "a.overlap=8", "x.threads=%d" % threads, "x.free=1"] + (["x.order=frame"] if threads > 1 else [])
     stats = _run(fakedev, ("run", "degrain%d" % radius, src, w, h, bits, n), out, extra, env)
     got = _read_frames(out, w, h, bits, n)
     want = _oracle_degrain(oracle, frames, w, h, bits, radius, 16, 8)
@@ -116,10 +116,10 @@ def test_shell_under_sanitizers(tmp_path, oracle, sanitizer):
     src, out = str(tmp_path / "in.raw"), str(tmp_path / "out.raw")
     _write_clip(src, frames)
     env = dict(os.environ, LD_PRELOAD=rt + " " + fake, MVX_VS_LOOKAHEAD="8", MVX_FAKEDEV_MEM=str(3 << 20), MVX_VS_STATS="1",
-               TSAN_OPTIONS="halt_on_error=0", ASAN_OPTIONS="detect_leaks=0:halt_on_error=1")
-    r = subprocess.run([hst, plug, "run", "degrain3", src, str(w), str(h), str(bits), str(n), out, "a.blksize=16", "a.overlap=8", "x.threads=8", "x.order=frame"],
+               TSAN_OPTIONS="halt_on_error=0", ASAN_OPTIONS="detect_leaks=1:halt_on_error=1")  # (the graph is torn down at the end: what is still allocated then is a leak)
+    r = subprocess.run([hst, plug, "run", "degrain3", src, str(w), str(h), str(bits), str(n), out, "a.blksize=16", "a.overlap=8", "x.threads=8", "x.order=frame", "x.free=1"],
                        capture_output=True, text=True, timeout=900, env=env)
-    assert r.returncode == 0 and "DONE" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    assert r.returncode == 0 and "FREED" in r.stdout and "DONE" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]  # (x.free=1: every filter's free callback ran)
     assert "Sanitizer" not in r.stderr, r.stderr[-4000:]
     got = _read_frames(out, w, h, bits, n)
     want = _oracle_degrain(oracle, frames, w, h, bits, 3, 16, 8)

@@ -566,10 +566,12 @@ int main(int argc, char **argv) {
     int R = 1;
     if (!strncmp(pipeline, "degrain", 7)) R = atoi(pipeline + 7);
     VSNode *vec[12];
+    VSMap *amaps[12] = { NULL };
     for (int r = 0; r < R; r++)
         for (int isb = 1; isb >= 0; isb--) {
             VSMap *am = createMap(); mapSetNode(am, "super", sup, maReplace); add_args(am, 'a', nextra, extra);
             mapSetInt(am, "isb", isb, maReplace); mapSetInt(am, "delta", r + 1, maReplace);
+            amaps[2 * r + (isb ? 0 : 1)] = am;
             vec[2 * r + (isb ? 0 : 1)] = invoke("Analyse", am, err, sizeof(err));
             if (!vec[2 * r + (isb ? 0 : 1)]) die("Analyse", err);
         }
@@ -677,6 +679,17 @@ int main(int argc, char **argv) {
     }
     fclose(fo);
     if (times) fprintf(stderr, "minihost: result file written in %.2f s; threads waited %.2f thread-seconds for frames other threads were producing\n", now_s() - t0, g_wait_s);
+    for (int i = 0; i < nextra; i++)
+        if (!strcmp(extra[i], "x.free=1")) { /* tear the graph down like a core that is being freed: every filter's free callback runs, consumers before producers */
+            freeMap(m); freeMap(sm);
+            for (int r = 0; r < 2 * R; r++) freeMap(amaps[r]);
+            node_free(out);
+            for (int r = 0; r < 2 * R; r++) node_free(vec[r]);
+            node_free(sup);
+            if (pelclip) node_free(pelclip);
+            node_free(clip);
+            printf("FREED\n");
+        }
     printf("DONE\n");
     return 0;
 }
