@@ -4,7 +4,7 @@ register allocation the compiler reports (-Rpass-analysis=kernel-resource-usage)
 assembly (whole kernel and, with --loop, the largest innermost-to-outermost loop body that contains a given label
 pattern).  Developer tool: it is how the round-2 register / instruction diet of the search kernel was driven.
 
-    python tools/isa_report.py vapoursynth-mvtools_amd/csrc/mvx_analyse_u16.hip [-D MVX_X1 ...] [--filter Li16ELi16] [--keep out.s]
+    python tools/isa_report.py vapoursynth-mvtools_amd/csrc/mvx_analyse_u16.hip [-D MVX_FAST_PROF ...] [--filter Li16ELi16] [--keep out.s]
 """
 import collections
 import os
