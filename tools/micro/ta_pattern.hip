@@ -25,6 +25,14 @@ __device__ __forceinline__ long long lane_off(int pat, int l, bool &active) {
     case 8: return (long long)(l >> 3) * PITCH + (l & 7) * 16;                         // 8 rows x 128 B (full lines)
     case 9: { const int c = l >> 3, s = l & 7; return (long long)(s >> 1) * PITCH + (s & 1) * 16 + c * 4; } // 8 candidates on the SAME 4 rows (x offsets 2 px apart)
     case 10: { const int c = l >> 3, s = l & 7; return (long long)((s >> 1) * 8 + c) * PITCH + (s & 1) * 16 + 6; } // 8 candidates x 4 rows, all different rows (same as 2, other order)
+    // r3 (for the next round's layout decision: the lean search kernel runs at 0.77 L1 accesses per cycle and CU, i.e. at the tag rate --
+    // DESIGN.md 4.2.3 -- so what matters is how many accesses one load instruction becomes): the same 32 x 32 B pieces with the rows of a
+    // block packed closer than the plane's pitch, as a strip-wise copy of the reference planes would have them
+    case 11: return (long long)(l >> 1) * 64 + (l & 1) * 16;                           // row pitch 64 B: two rows per 128-byte line, 32 B used of every 64
+    case 12: return (long long)(l >> 1) * 64 + (l & 1) * 16 + 16;                      // same, the block sits at byte 16 of its 64-byte rows
+    case 13: return (long long)(l >> 1) * 128 + (l & 1) * 16;                          // row pitch 128 B: one row per line, neighbouring lines
+    case 14: return (long long)(l >> 2) * PITCH + (l & 3) * 16;                        // 16 rows x 64 B, 16-byte aligned (7 is its 2-byte-aligned form)
+    case 15: return (long long)(l >> 1) * 32 + (l & 1) * 16;                           // row pitch 32 B = pattern 0 written as rows (control)
     default: return 0;
     }
 }
@@ -62,9 +70,10 @@ int main() {
     unsigned long long *d; hipMalloc(&d, 8 * 4 * maxBlocks);
     const int iters = 2000, NIF = 4;
     const char *names[] = {"0 coalesced 64x16B contiguous (8 lines)", "1 32 rows x 32B aligned", "2 32 rows x 32B, 2B-aligned", "3 64 rows x 16B", "4 16 cand x2 rows on 4 rows (non-neighbour merge)",
-                           "5 pattern 2, lanes 32-63 off", "6 pattern 2, alternate lane pairs off", "7 16 rows x 64B", "8 8 rows x 128B (full lines)", "9 8 cand on the same 4 rows", "10 pattern 2 rows, candidate-major order"};
+                           "5 pattern 2, lanes 32-63 off", "6 pattern 2, alternate lane pairs off", "7 16 rows x 64B", "8 8 rows x 128B (full lines)", "9 8 cand on the same 4 rows", "10 pattern 2 rows, candidate-major order",
+                           "11 32 rows x 32B, row pitch 64B (2 rows per line)", "12 same, block at byte 16 of its rows", "13 32 rows x 32B, row pitch 128B", "14 16 rows x 64B aligned", "15 32 rows x 32B, row pitch 32B (= 0)"};
     for (int blocks : {256, 512}) { // one / two workgroups of four waves per CU
-        for (int pat = 0; pat <= 10; pat++) {
+        for (int pat = 0; pat <= 15; pat++) {
             for (int rep = 0; rep < 2; rep++) { hipLaunchKernelGGL(k<NIF>, dim3(blocks), dim3(256), 0, 0, buf, d, pat, iters, waveStride); hipDeviceSynchronize(); }
             std::vector<unsigned long long> h(blocks * 4);
             hipMemcpy(h.data(), d, 8 * blocks * 4, hipMemcpyDeviceToHost);
