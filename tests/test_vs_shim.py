@@ -2,8 +2,11 @@
 
 CPU part: the plugin loads, registers the reference's plugin id / namespace / function names / argument strings
 (src/EntryPoint.c:28-33, src/MVSuper.c:279-291, src/MVAnalyse.c:639-671, src/MVDegrains.cpp:813-932,
-src/MVCompensate.c:579-592) and reports the reference's creation-time errors.  GPU part: whole filter graphs
-(Super -> Analyse x2 -> Degrain / Compensate) evaluated frame by frame through the shell equal the oracle.
+src/MVCompensate.c:579-592) and reports the reference's creation-time errors.  Graph part: whole filter graphs
+(Super -> Analyse x2 -> Degrain / Compensate / BlockFPS / Recalculate / Finest / SCDetection) evaluated frame by frame through the shell
+equal the oracle.  Every graph test takes the `shell` fixture and so runs twice: `[device-...]` on the GPU (-m gpu), `[double-...]` on a
+CPU-only machine with the test double of the device layer in front of the library (tests/fakedev/mvx_fakedev.c) -- the same plugin, the
+same mini host, the oracle's kernels: what that run tests is the shell's own logic.
 """
 import os
 import subprocess
