@@ -25,7 +25,9 @@ static const mvo_vector zeroMV = { 0, 0, -1 }; /* MVAnalysisData.h:79 */
  * search behaves on a clip -- which predictor a block's predictor phase ends on, how many different vectors the seven predictors are,
  * how often a hexagon point wins -- the numbers a kernel design wants to know before it speculates.  Counted per level. */
 #ifdef MVO_STATS
-enum { ST_BLOCKS, ST_WIN0, ST_WIN6 = ST_WIN0 + 6, ST_BEST_IS_PRED, ST_BEST_IS_MEDIAN, ST_BEST_IS_LEFT, ST_DISTINCT1, ST_DISTINCT7 = ST_DISTINCT1 + 6, ST_HEX_WON, ST_HEX_TRIED, ST_RESCUE, ST_N };
+enum { ST_BLOCKS, ST_WIN0, ST_WIN6 = ST_WIN0 + 6, ST_BEST_IS_PRED, ST_BEST_IS_MEDIAN, ST_BEST_IS_LEFT, ST_DISTINCT1, ST_DISTINCT7 = ST_DISTINCT1 + 6, ST_HEX_WON, ST_HEX_TRIED, ST_RESCUE,
+       /* r4: what a kernel that evaluates the candidates that do NOT depend on the left neighbour ahead of the serial walk would find */
+       ST_PRED_HIT, ST_CENTRE_UP, ST_CENTRE_AHEAD, ST_CENTRE_HIER, ST_CENTRE_ANY5, ST_FULL_UP, ST_FULL_ANY5, ST_LEFT_IN, ST_MEDIAN_IN, ST_N };
 static long long g_stat[16][ST_N];
 void mvo_stats_get(long long *out, int levels) { memcpy(out, g_stat, sizeof(long long) * ST_N * (size_t)(levels < 16 ? levels : 16)); }
 void mvo_stats_reset(void) { memset(g_stat, 0, sizeof(g_stat)); }
@@ -464,6 +466,25 @@ static void PseudoEPZSearch(pob *p) {
             STAT(lv, ST_BEST_IS_PRED, p->bestMV.x == p->predictor.x && p->bestMV.y == p->predictor.y);
             STAT(lv, ST_BEST_IS_MEDIAN, p->bestMV.x == p->predictors[0].x && p->bestMV.y == p->predictors[0].y);
             STAT(lv, ST_BEST_IS_LEFT, p->bestMV.x == p->predictors[1].x && p->bestMV.y == p->predictors[1].y);
+            {   /* the left-independent set: zero, global, hierarchical, up, ahead (c[0], c[1], c[2], c[5], c[6]) */
+                static const int ind[5] = { 0, 1, 2, 5, 6 };
+                int leftIn = 0, medIn = 0, bestIn = 0;
+                for (int k = 0; k < 5; k++) {
+                    const mvo_vector *q = &c[ind[k]];
+                    if (k == 0 && p->zeroMVfieldShifted.y != 0) continue; /* (its chroma ignores the shift: not a plain vector) */
+                    leftIn |= q->x == c[4].x && q->y == c[4].y;
+                    medIn |= q->x == c[3].x && q->y == c[3].y;
+                    bestIn |= q->x == p->bestMV.x && q->y == p->bestMV.y;
+                }
+                const int predHit = leftIn && medIn;
+                const int up = p->bestMV.x == c[5].x && p->bestMV.y == c[5].y;
+                STAT(lv, ST_LEFT_IN, leftIn); STAT(lv, ST_MEDIAN_IN, medIn); STAT(lv, ST_PRED_HIT, predHit);
+                STAT(lv, ST_CENTRE_UP, up);
+                STAT(lv, ST_CENTRE_AHEAD, p->bestMV.x == c[6].x && p->bestMV.y == c[6].y);
+                STAT(lv, ST_CENTRE_HIER, p->bestMV.x == c[2].x && p->bestMV.y == c[2].y);
+                STAT(lv, ST_CENTRE_ANY5, bestIn);
+                STAT(lv, ST_FULL_UP, predHit && up); STAT(lv, ST_FULL_ANY5, predHit && bestIn);
+            }
         }
 #endif
         Refine(p);

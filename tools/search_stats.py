@@ -24,14 +24,16 @@ subprocess.check_call(["gcc", "-std=gnu99", "-O2", "-mavx2", "-fPIC", "-ffp-cont
 mo.build = lambda force=False: so  # this process counts
 
 w, h, bits, n = (int(v) for v in (sys.argv[1:5] + ["3840", "2160", "16", "3"][len(sys.argv) - 1:]))
-frames = pl.moving_clip(w, h, bits, n, seed=3, noise=2)
+noise = int(os.environ.get("NOISE", "2"))
+bs = int(os.environ.get("BLK", "16"))
+frames = pl.moving_clip(w, h, bits, n, seed=3, noise=noise)
 sup = mo.Super(w, h, bits)
 sf = [sup.frame(f) for f in frames]
 L = mo.lib()
 L.mvo_stats_reset()
 jobs = 0
 for isb in (1, 0):
-    an = mo.Analyse(sup, isb=isb, delta=1, blksize=16, overlap=8)
+    an = mo.Analyse(sup, isb=isb, delta=1, blksize=bs, overlap=bs // 2)
     for k in range(n):
         r = k + 1 if isb else k - 1
         if 0 <= r < n:
@@ -53,4 +55,6 @@ for lv in range(levels):
     print("   predictor phase ends on (first candidate with the winning vector): " + ", ".join("%s %s" % (names[i], pct(s[1 + i]).strip()) for i in range(7)))
     print("   its vector == hierarchical predictor %s, == median %s, == left neighbour's result %s" % (pct(s[8]), pct(s[9]), pct(s[10])))
     print("   distinct vectors among the seven: " + ", ".join("%d: %s" % (i + 1, pct(s[11 + i]).strip()) for i in range(7)))
+    print("   r4 speculation: left in {zero, global, hier, up, ahead} %s, median in it %s, both %s;  predictor phase ends on up %s, ahead %s, hier %s, any of the five %s" % tuple(pct(s[21 + i]) for i in (7, 8, 0, 1, 2, 3, 4)))
+    print("   r4 speculation: whole predictor phase + refinement centre known before the walk: centre == up %s, centre in the five %s" % (pct(s[26]), pct(s[27])))
     print("   first hexagon: a point wins in %s of %d tries;  rescue of a bad block: %s" % ("%.1f %%" % (100.0 * s[18] / max(1, s[19])), int(s[19]), pct(s[20])))
