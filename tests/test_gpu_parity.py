@@ -184,7 +184,7 @@ def dbg(mv):
         used.append(name)
     yield set_
     for name in used:
-        mv.debug_option(name, -1 if name in ("cpw_sync", "lds_min") else 0)
+        mv.debug_option(name, -1 if name in ("cpw_sync", "lds_min") else 1 if name == "spec" else 0)
 
 
 ANALYSE_CASES = [
@@ -470,15 +470,20 @@ def test_analyse_two_chains_per_simd(oracle, mv, dbg, kernel, bits, akw):
     (256, 144, 8, dict(pel=4), dict(blksize=8, overlap=2)),
     (256, 144, 8, dict(pel=1), dict(blksize=8, chroma=0)),
 ])
-@pytest.mark.parametrize("variant", ["general", "plain-layout"])
+@pytest.mark.parametrize("variant", ["general", "plain-layout", "serial", "spec-off"])
 def test_analyse_default_search_other_kernels(oracle, mv, dbg, variant, w, h, bits, skw, akw):
-    """The default search normally runs in the lean kernel (mvx_analyse_fast.h) on super frames that carry shadow copies.
-    The same cases through the general kernel ("general" = 1) and through the lean kernel on the plain layout (no shadow
-    copies: unaligned loads) must give the same blobs."""
+    """The default search normally runs in the speculative kernel (mvx_analyse_spec.h) on super frames that carry shadow copies.
+    The same cases through the general kernel ("general" = 1), through the speculative kernel on the plain layout (no shadow
+    copies: unaligned loads), through the serial lean kernel (mvx_analyse_fast.h, "spec" = 0) and through the speculative kernel's
+    code with speculation switched off ("spec" = 2: every block searched live) must give the same blobs."""
     akw = dict(akw)
     noise = akw.pop("_noise", 3)
     if variant == "general":
         dbg("general", 1)
+    if variant == "serial":
+        dbg("spec", 0)
+    if variant == "spec-off":
+        dbg("spec", 2)
     frames = pl.moving_clip(w, h, bits, 3, seed=13, noise=noise)
     osup = oracle.Super(w, h, bits, **skw)
     gsup = mv.Super(w, h, bits, shadow=(variant != "plain-layout"), **skw)
@@ -491,7 +496,7 @@ def test_analyse_default_search_other_kernels(oracle, mv, dbg, variant, w, h, bi
         assert np.array_equal(gan.run([(gsf[1], gsf[ref])])[0].cpu().numpy(), oan.frame(osf[1], osf[ref]))
 
 
-@pytest.mark.parametrize("w,h,skw,akw", [
+WINDOW_CASES = [
     (384, 224, {}, dict(blksize=16, overlap=8)),                                  # cfg3 shape
     (320, 192, {}, dict(blksize=16, overlap=8, _noise=14)),                       # many bad blocks: the rescue (global path) between window blocks
     (320, 192, {}, dict(blksize=16, overlap=8, _noise=14, badsad=400, badrange=-3)),
@@ -504,7 +509,42 @@ def test_analyse_default_search_other_kernels(oracle, mv, dbg, variant, w, h, bi
     (256, 144, {}, dict(blksize=16, overlap=8, meander=0, levels=2)),
     (200, 120, dict(hpad=8, vpad=8), dict(blksize=16, overlap=8)),               # small padding: windows clamp at the plane edges
     (1000, 64, {}, dict(blksize=16, overlap=8)),                                  # several 64-block groups per row
+]
+
+
+@pytest.mark.parametrize("w,h,skw,akw", WINDOW_CASES + [
+    (1000, 96, {}, dict(blksize=16, overlap=8, meander=0)),                       # several groups per row, always left to right
+    (640, 360, {}, dict(blksize=16, overlap=8, _noise=0)),                        # a clean clip: long verified runs
+    (320, 192, {}, dict(blksize=16, overlap=8, _noise=14, badsad=400, badrange=6)),  # UMH rescue between verified runs
+    (520, 96, dict(hpad=4, vpad=4), dict(blksize=16, overlap=8, pglobal=20)),     # tiny padding: the global predictor is clipped block by block
 ])
+def test_analyse_speculative_kernel(oracle, mv, w, h, skw, akw):
+    """The speculative kernel of the default search (mvx_analyse_spec.h; the default): groups of 32 blocks evaluated ahead of the serial
+    walk under the hypothesis left == up, verified block by block, everything else searched live.  Same blobs as the oracle -- forward,
+    backward, with a field shift, with a missing reference; noisy clips (most hypotheses fail), rescues, every refinement shape."""
+    akw = dict(akw)
+    noise = akw.pop("_noise", 3)
+    frames = pl.moving_clip(w, h, 16, 3, seed=17, noise=noise, motion=(5, -2))
+    osup = oracle.Super(w, h, 16, **skw)
+    gsup = mv.Super(w, h, 16, **skw)
+    osf = [osup.frame(f) for f in frames]
+    gsf = gsup.build([mv.frame_to_device(f) for f in frames])
+    info = (C.c_int * 5)()
+    for isb in (1, 0):
+        oan = oracle.Analyse(osup, isb=isb, **akw)
+        gan = mv.Analyse(gsup, isb=isb, **akw)
+        ref = 2 if isb else 0
+        got = gan.run([(gsf[1], gsf[ref]), (gsf[1], None)])
+        mv.lib().mvx_debug_last_launch(info)
+        assert info[4] == 2, "the speculative kernel did not run (%s)" % list(info)
+        assert np.array_equal(got[0].cpu().numpy(), oan.frame(osf[1], osf[ref]))
+        assert np.array_equal(got[1].cpu().numpy(), oan.frame(osf[1], None))
+        if skw.get("pel", 2) == 2:
+            for fs in (1, -1):  # fields: the zero candidate's luma is shifted, its chroma is not (PlaneOfBlocks.cpp:836-839)
+                assert np.array_equal(gan.run([(gsf[1], gsf[ref])], field_shift=fs)[0].cpu().numpy(), oan.frame(osf[1], osf[ref], field_shift=fs))
+
+
+@pytest.mark.parametrize("w,h,skw,akw", WINDOW_CASES)
 def test_analyse_window_kernel(oracle, mv, dbg, w, h, skw, akw):
     """The LDS-window kernel of the default search (mvx_analyse_win.h; opt-in, "win" = 1): candidates served from LDS windows that
     LDS-DMA fills once per block.  Same blobs as the oracle -- forward, backward, with a field shift, with a missing reference."""

@@ -7,6 +7,9 @@
 #include "mvx_analyse_kernel.h"
 #include "mvx_analyse_fast.h"
 #include "mvx_analyse_win.h"
+#include "mvx_analyse_spec.h"
+int mvx_analyse_launch_spec_u8(const AParams &P, const ASpecLaunch &S);
+int mvx_analyse_launch_spec_u16(const AParams &P, const ASpecLaunch &S);
 
 // ------------------------------------------------------------------------------------------------ host
 
@@ -37,13 +40,14 @@ struct MvxDebug {
     int degrain_xcd = -1;  // Degrain cell kernels: XCD-contiguous tile order (1 / 0), -1 = default
     int cpw_sync = -1; // barrier interval inside a workgroup (power of two, 0 = none)
     int lds_min = -1;  // LDS floor of the one-chain launches
+    int spec = 1;      // default search: 1 = the speculative kernel (mvx_analyse_spec.h), 0 = the lean serial kernel (mvx_analyse_fast.h), 2 = the speculative kernel's code with speculation off (every block live)
     int win = 0;       // 1: the LDS-window kernel of the default search (mvx_analyse_win.h) where it applies: bit-exact, measured slower
     int super_rows_off = 0; // 1: mv.Super level 0 / first reduction through the LDS-tile / per-sample kernels only
     int ablate = 0;
 };
 static MvxDebug g_dbg;
 extern "C" __attribute__((visibility("default"))) int mvx_debug_option(const char *name, int value) {
-    struct { const char *n; int *p; } tab[] = { { "general", &g_dbg.general }, { "fast_wpe", &g_dbg.fast_wpe }, { "cpw1", &g_dbg.cpw1 }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "fast_cpw", &g_dbg.fast_cpw }, { "fast_k", &g_dbg.fast_k }, { "fast_lds_min", &g_dbg.fast_lds_min }, { "fast_flags", &g_dbg.fast_flags }, { "pad_runs", &g_dbg.pad_runs }, { "shadow_planes", &g_dbg.shadow_planes }, { "degrain_xcd", &g_dbg.degrain_xcd }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min }, { "super_rows_off", &g_dbg.super_rows_off }, { "win", &g_dbg.win },
+    struct { const char *n; int *p; } tab[] = { { "general", &g_dbg.general }, { "fast_wpe", &g_dbg.fast_wpe }, { "cpw1", &g_dbg.cpw1 }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "fast_cpw", &g_dbg.fast_cpw }, { "fast_k", &g_dbg.fast_k }, { "fast_lds_min", &g_dbg.fast_lds_min }, { "fast_flags", &g_dbg.fast_flags }, { "pad_runs", &g_dbg.pad_runs }, { "shadow_planes", &g_dbg.shadow_planes }, { "degrain_xcd", &g_dbg.degrain_xcd }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min }, { "super_rows_off", &g_dbg.super_rows_off }, { "win", &g_dbg.win }, { "spec", &g_dbg.spec },
 #ifdef MVX_LAB
         { "ablate", &g_dbg.ablate },
 #endif
@@ -344,6 +348,16 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         if (fNeed < fRow + fBins * 4) fNeed = fRow + fBins * 4;
         // 16-bit 16x16 blocks: the LDS-window kernel (mvx_analyse_win.h) -- its own LDS layout, builds for one to three chains per SIMD
         const bool useWin = g_dbg.win && mvx_win_eligible(P);
+        // the speculative kernel (mvx_analyse_spec.h): [source block | previous row's results, 8 B per block | SAD table of a 32-block group];
+        // the histogram lies over row buffer and table
+        const bool useSpec = !useWin && g_dbg.spec != 0;
+        int sTab = 0;
+        if (useSpec) {
+            const bool anyExh = P.searchType == SearchExhaustive || (P.nLevels > 1 && P.searchTypeCoarse == SearchExhaustive);
+            sTab = fRow + ((fMaxBlkX * 8 + 15) & ~15);
+            fNeed = sTab + (anyExh ? SPEC_SLOTS_EXH : SPEC_SLOTS_HEX) * SPEC_STRIDE;
+            if (fNeed < fRow + fBins * 4) fNeed = fRow + fBins * 4;
+        }
         const int perChain = useWin ? WG16::TOTAL : (fNeed + 255) & ~255;
         // builds per (sample size, block size): chains per SIMD that exist (mvx_analyse_u8.hip / _u16.hip)
         auto have = [&](int k) {
@@ -392,12 +406,14 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
             int syncEvery = k >= 2 ? (P.bps == 2 ? 32 : 256) : 0;
             if (g_dbg.cpw_sync >= 0 && (g_dbg.cpw_sync & (g_dbg.cpw_sync - 1)) == 0) syncEvery = g_dbg.cpw_sync;
             // XCD-contiguous workgroup order: neighbours in the (reference-sorted) job table share an L2 (+0.5 %, 4K16)
-            const int flags = (g_dbg.fast_flags >= 0 ? g_dbg.fast_flags : MVX_FAST_XCD_REMAP) | ((P.shadow[1] != 0 && P.chroma) ? MVX_FAST_UV : 0);
+            const int flags = (g_dbg.fast_flags >= 0 ? g_dbg.fast_flags : MVX_FAST_XCD_REMAP) | ((P.shadow[1] != 0 && P.chroma) ? MVX_FAST_UV : 0) | (g_dbg.spec == 2 ? MVX_FAST_NOSPEC : 0);
             ALaunch L = { ntab, fNeed, fRow, fRow, fBins, fNeed, simds, cpw, k, syncEvery, k, flags, st, a->dP, S.d };
             L.ldsBytes = g_dbg.fast_lds_min; // (floor of the workgroup's LDS request, 0 = none)
-            int rc = useWin ? mvx_analyse_launch_win(P, L) : P.bps == 1 ? mvx_analyse_launch_fast_u8(P, L) : mvx_analyse_launch_fast_u16(P, L);
+            int rc;
+            if (useSpec) { const ASpecLaunch SL = { L, sTab }; rc = P.bps == 1 ? mvx_analyse_launch_spec_u8(P, SL) : mvx_analyse_launch_spec_u16(P, SL); }
+            else rc = useWin ? mvx_analyse_launch_win(P, L) : P.bps == 1 ? mvx_analyse_launch_fast_u8(P, L) : mvx_analyse_launch_fast_u16(P, L);
             if (rc == MVX_OK) {
-                g_lastLaunch[0] = k; g_lastLaunch[1] = cpw; g_lastLaunch[2] = syncEvery; g_lastLaunch[3] = ntab; g_lastLaunch[4] = useWin;
+                g_lastLaunch[0] = k; g_lastLaunch[1] = cpw; g_lastLaunch[2] = syncEvery; g_lastLaunch[3] = ntab; g_lastLaunch[4] = useWin ? 1 : useSpec ? 2 : 0;
                 if (P.divide) hipLaunchKernelGGL(analyse_divide_kernel, dim3((P.lv[0].nBlkX * P.lv[0].nBlkY + 255) / 256, ntab), dim3(256), 0, st, a->dP, S.d);
                 HIP_CHECK(hipGetLastError());
                 return MVX_OK;

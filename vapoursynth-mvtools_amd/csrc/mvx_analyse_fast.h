@@ -25,6 +25,9 @@
 // de-duplication, the hexagon pass without its speculative square) were measured one switch at a time: DESIGN.md 4.2.3,
 // profiles/r3_lean_kernel_trims_ab.txt, r3_lean_kernel_dedup_nospec_ab.txt.
 #define MVX_SRC_AHEAD 2 // the source block's LDS pieces are read this many pieces ahead of their use (a read right before its use costs the wave an LDS round trip per piece)
+#ifndef MVX_STREAM_MAX
+#define MVX_STREAM_MAX 12 // a candidate's pieces per lane up to which luma + chroma are ONE stream of loads (the serial kernel: longer streams measured slower; the speculative kernel's translation units set 48)
+#endif
 #define MVX_INFLIGHT 12 // reference loads a lane keeps in flight while it evaluates a candidate: all twelve of a hexagon-pass candidate
 #include "mvx_analyse_kernel.h"
 
@@ -39,11 +42,11 @@ static __device__ unsigned long long g_fastprof[FPROF_N];
 #define FPROF(i, t0) ((void)0)
 #endif
 
-// sums of a and b over aligned groups of 1 << LOGG lanes (1 <= LOGG <= 3), every lane ends up with its group's totals.  v_add_u32_dpp
+// sums of a and b over aligned groups of 1 << LOGG lanes (1 <= LOGG <= 4), every lane ends up with its group's totals.  v_add_u32_dpp
 // reads the register it wrote one step earlier, which needs two wait states: the other chain's step and one s_nop provide them, so a
 // step costs 1.5 instructions per value instead of the 4 (v_mov, s_nop, v_mov_dpp, v_add) the update_dpp builtin compiles to.
 template <int LOGG> __device__ __forceinline__ void group_sum2(unsigned &a, unsigned &b) {
-    static_assert(LOGG >= 1 && LOGG <= 3, "group_sum2: groups of 2, 4 or 8 lanes");
+    static_assert(LOGG >= 1 && LOGG <= 4, "group_sum2: groups of 2, 4, 8 or 16 lanes");
     asm volatile("s_nop 1\n\t"
                  "v_add_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                  "v_add_u32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
@@ -57,6 +60,11 @@ template <int LOGG> __device__ __forceinline__ void group_sum2(unsigned &a, unsi
         asm volatile("s_nop 0\n\t"
                      "v_add_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
                      "v_add_u32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf"
+                     : "+v"(a), "+v"(b));
+    if (LOGG >= 4) // (both halves of a row are uniform by now: lane i meets lane 15 - i of the other half)
+        asm volatile("s_nop 0\n\t"
+                     "v_add_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                     "v_add_u32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf"
                      : "+v"(a), "+v"(b));
     // (the sums are consumed by plain VALU instructions; the compiler's hazard recogniser treats an asm statement's outputs as just
     // written and adds what a DPP or lane read of them would need)
@@ -297,11 +305,13 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
     // partial SADs (this lane's share) of candidate (vx, vy); vyc = the vertical component the chroma planes use (:836-839)
     template <int LOGG> __device__ __forceinline__ void eval(int s, int vx, int vy, int vyc, unsigned &aL, unsigned &aC) const {
         constexpr int GG = 1 << LOGG;
-        constexpr bool STREAM = UV && G::LT >= GG && G::UVT >= GG && GG >= (1 << G::LLOGC) && GG >= (1 << G::UVLOGC) && (G::LT + G::UVT) / GG >= 2 && (G::LT + G::UVT) / GG <= 12;
-        if (STREAM && chroma) {
-            const unsigned co = ref_chroma_off(vx, vyc);
-            region2<LOGG, G::LT, G::LLOGC, G::LCB, G::LROWB, G::UVT, G::UVLOGC, G::UVCB, G::UVROWB>(s, lds, refY, ref_luma_off(vx, vy), pitchY, aL, lds + G::UOFF, refUV, 2 * co, 2 * pitchC, aC);
-            return;
+        constexpr bool STREAM = UV && G::LT >= GG && G::UVT >= GG && GG >= (1 << G::LLOGC) && GG >= (1 << G::UVLOGC) && (G::LT + G::UVT) / GG >= 2 && (G::LT + G::UVT) / GG <= MVX_STREAM_MAX;
+        if constexpr (STREAM) { // (region2 does not exist for shapes with fewer pieces than lanes)
+            if (chroma) {
+                const unsigned co = ref_chroma_off(vx, vyc);
+                region2<LOGG, G::LT, G::LLOGC, G::LCB, G::LROWB, G::UVT, G::UVLOGC, G::UVCB, G::UVROWB>(s, lds, refY, ref_luma_off(vx, vy), pitchY, aL, lds + G::UOFF, refUV, 2 * co, 2 * pitchC, aC);
+                return;
+            }
         }
         aL = region<LOGG, G::LT, G::LLOGC, G::LCB, G::LROWB>(s, lds, refY, ref_luma_off(vx, vy), pitchY, aL);
         if (chroma) {

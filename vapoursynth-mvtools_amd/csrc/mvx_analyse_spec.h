@@ -1,0 +1,486 @@
+// mvx_analyse_spec.h -- the default search of mv.Analyse with the SAD work taken OFF the serial chain (round 4).
+//
+// The reference walks the blocks of a plane one after the other: block i takes its left predictor (and through it the median)
+// from block i-1 (PlaneOfBlocks.cpp:421-440), so a chain of blocks is strictly serial, and the lean kernel (mvx_analyse_fast.h)
+// pays two memory round trips plus ~700 dependent instructions per block (profiles/r4_fastprof_phase_cycles.txt: a block costs
+// ~12 000 cycles, half of them in the scalar phases around the two candidate passes).  But almost everything a block evaluates does
+// NOT depend on its left neighbour: the zero, global, hierarchical, up and ahead predictors (:834-915), every cost term (lambda and
+// the cost centre come from the interpolated predictor, :449-462) and -- when the predictor phase ends on the up neighbour's vector,
+// which it does whenever the motion field is locally smooth -- the whole refinement pattern around it (:667-724, :786-791).
+// So a chain is processed in GROUPS of 32 blocks of a row:
+//
+//   A   for every block of the group, with all 64 lanes and nothing to wait for but memory: the SADs of the left-independent
+//       predictors and of the refinement pattern around the block's UP predictor, written to a table in LDS;
+//   A2  one LANE per block: costs, penalties, the predictor phase and the refinement in the reference's order (:219-261, strict <)
+//       UNDER THE HYPOTHESIS "the left neighbour's result, clipped, equals my up predictor" (then left == median == up), giving
+//       a speculative result per block and a flag "complete" (centre was up, no hexagon point won, no bad-block rescue);
+//   B   verification, in walk order: a block whose hypothesis holds (its true left result is known by then) and whose flag is set
+//       takes its speculative result -- whole runs of them at once, from a lane mask; any other block is searched live by
+//       FastSearcher::search_block with its true predictors, exactly as the lean kernel does, and the walk goes on behind it.
+//
+// Results are identical by construction: a verified block evaluated the same candidates with the same costs in the same order as
+// the serial walk; everything else IS the serial walk.  tools/search_stats.py (CPU, oracle counters) gives the share of blocks
+// that verify: 99.3 % of the finest level on the bench clip, 88.9 % on the noisy test clip (profiles/r4_search_stats_*.txt).
+// The first block row of a plane, the first block of every row and the coarsest level (whose cost centre is the median, :858)
+// are always searched live.
+#pragma once
+#include "mvx_analyse_fast.h"
+
+#define SPEC_TB 32                        // blocks per group (one table column per block)
+#define SPEC_STRIDE (SPEC_TB * 8 + 8)     // bytes between the slots of the table: 66 dwords, so that the 16 (32) group leaders of a pass write different banks
+// slots: Hex2 levels: 0-5 hexagon, 6-13 square, 14 up, 15 ahead, 16 zero, 17 global, 18 hierarchical; exhaustive levels: 0-23 rings 1 and 2, 24 up, 25 ahead, 26 zero, 27 global, 28 hierarchical
+#define SPEC_SLOTS_HEX 19
+#define SPEC_SLOTS_EXH 29
+#define MVX_FAST_NOSPEC 4                 // flags: verify nothing, search every block live (developer switch: the same kernel as a plain serial walk)
+
+// -DMVX_SPEC_ABL=n (tools/build_variant.py): timing-only ablations of pass A, results are WRONG -- 1: no zero / global / hierarchical pass on Hex2
+// levels, 2: every group of the pattern pass evaluates the centre (same lines for all lanes), 3: every speculative result is taken (no live blocks)
+#ifndef MVX_SPEC_ABL
+#define MVX_SPEC_ABL 0
+#endif
+#ifdef MVX_SPEC_STATS
+static __device__ unsigned long long g_specstat[MVX_MAX_LEVELS][4]; // per level: blocks in speculated rows, of them searched live, live because the flag was clear, rescues
+#endif
+
+template <int BPS, int BW, bool UV> struct SpecSearcher : FastSearcher<BPS, BW, UV> {
+    typedef FastSearcher<BPS, BW, UV> F;
+    typedef FGeo<BPS, BW> G;
+    using F::P; using F::J; using F::lds; using F::ldsRow; using F::ldsHist; using F::histBins;
+    using F::nBlkX; using F::nBlkY; using F::pel; using F::logPel; using F::pw; using F::ph; using F::hpad; using F::vpad;
+    using F::srcY; using F::srcU; using F::srcV; using F::refY; using F::refU; using F::refV; using F::srcUV; using F::refUV;
+    using F::pitchY; using F::pitchC; using F::pstrideY; using F::pstrideC; using F::shadowY; using F::vectors;
+    using F::chroma; using F::searchType; using F::nSearchParam; using F::penaltyNew; using F::penaltyZero; using F::pglobal; using F::badrange; using F::badcount; using F::fieldShift;
+    using F::badSAD; using F::LSAD; using F::gmvx; using F::gmvy;
+    using F::x0; using F::y0; using F::blkIdx; using F::nDxMin; using F::nDyMin; using F::nDxMax; using F::nDyMax;
+    using F::predX; using F::predY; using F::pX; using F::pY; using F::nLambda; using F::bestX; using F::bestY; using F::bestSad;
+    int ldsTab; // byte offset of the SAD table inside the chain's LDS
+
+    __device__ SpecSearcher(const AParams &p, const AJob &j) : F(p, j) {}
+
+    __device__ __forceinline__ static int pk(int x, int y) { return (int)(((unsigned)x & 0xffffu) | ((unsigned)y << 16)); } // |x|, |y| < 30000: mvx_fast_eligible
+    __device__ __forceinline__ static int upx(int c) { return (int)(short)(c & 0xffff); }
+    __device__ __forceinline__ static int upy(int c) { return c >> 16; }
+
+    // GroupOfPlanes.c:69-125 + PlaneOfBlocks.cpp:971-1131 for one level, in groups of SPEC_TB blocks
+    __device__ __forceinline__ void search_level_spec(int lvl, int globalX, int globalY, GL_AS const GVec *coarse, int coarseBlkX, int coarseBlkY, int coarseLogPel, int syncEvery, bool specEnabled) {
+        const int l = lane_id();
+        const ALevel &L = P.lv[lvl];
+        nBlkX = uni(L.nBlkX); nBlkY = uni(L.nBlkY); pel = uni(L.pel); logPel = uni(L.logPel);
+        chroma = uni(P.chroma);
+        pw = uni(L.pw); ph = uni(L.ph); hpad = uni(L.hpad); vpad = uni(L.vpad);
+        auto uptr = [](const unsigned char *p) { return (gl_u8 *)(unsigned long long)uni((long long)(unsigned long long)p); };
+        srcY = uptr(J.src[0] + L.off[0]); refY = uptr(J.ref[0] + L.off[0]);
+        srcU = uptr(J.src[1] + L.off[1]); refU = uptr(J.ref[1] + L.off[1]);
+        srcV = uptr(J.src[2] + L.off[2]); refV = uptr(J.ref[2] + L.off[2]);
+        pitchY = (unsigned)uni((int)P.pitch[0]); pitchC = (unsigned)uni((int)P.pitch[1]); pstrideY = (unsigned)uni((int)L.pstride[0]); pstrideC = (unsigned)uni((int)L.pstride[1]);
+        shadowY = (unsigned)uni((int)P.shadow[0]);
+        srcUV = uptr(J.src[1] + P.shadow[1] + 2 * L.off[1]); refUV = uptr((J.ref[1] ? J.ref[1] : J.src[1]) + P.shadow[1] + 2 * L.off[1]);
+        unsigned char *rec = (unsigned char *)(unsigned long long)uni((long long)(unsigned long long)(J.blob + L.blobOff));
+        vectors = (GL_AS GVec *)(rec + 4);
+        if (l == 0) *(int *)rec = 4 + nBlkX * nBlkY * 16; // pobWriteHeaderToArray :413-416
+        const bool smallestPlane = lvl == P.nLevels - 1;
+        this->interpolate(coarse, coarseBlkX, coarseBlkY, coarseLogPel);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_s_barrier();
+
+        // ---- plane scan set-up (doPobSearchMVs :979-1034); tryMany is off, the search types were checked by the host
+        if (smallestPlane) { searchType = P.nLevels == 1 ? P.searchType : P.searchTypeCoarse; nSearchParam = P.nLevels == 1 ? P.nPelSearch : P.nSearchParam; }
+        else { searchType = lvl == 0 ? P.searchType : P.searchTypeCoarse; nSearchParam = lvl == 0 ? P.nPelSearch : P.nSearchParam; }
+        searchType = uni(searchType); nSearchParam = uni(nSearchParam);
+        fieldShift = uni(lvl == 0 ? J.fieldShift : 0);
+        badSAD = uni(P.badSAD); badrange = uni(P.badrange); badcount = 0;
+        gmvx = pel * globalX; gmvy = pel * globalY + fieldShift;
+        int nLambdaLevel = P.lambda / (pel * pel);
+        const int nScale = 1 << lvl;
+        if (P.plevel == 1) nLambdaLevel = nLambdaLevel * nScale;
+        else if (P.plevel == 2) nLambdaLevel = nLambdaLevel * nScale * nScale;
+        nLambdaLevel = uni(nLambdaLevel);
+        penaltyZero = uni(P.pzero); pglobal = uni(P.global ? P.pglobal : P.pzero); penaltyNew = uni(P.pnew); LSAD = uni((long long)P.lsad);
+        const int stepX = uni(P.blkX - P.ovX), stepY = uni(P.blkY - P.ovY);
+        const int hps = hpad >> lvl, vps = vpad >> lvl; // :1091-1092
+        const bool meander = uni(P.meander) != 0;
+        LDS_AS v2u *rowbuf = (LDS_AS v2u *)(lds + ldsRow); // the previous block row's results, 8 bytes per block: (x | y << 16, sad)
+        lds_u8 *tab = lds + ldsTab;
+        this->pf_setup();
+        auto lambda_of = [&](int predSad) { // :456-462, fp64 as the reference
+            const double scale = (double)LSAD / (double)(LSAD + (long long)(predSad >> 1));
+            return (int)(long long)((double)(long long)nLambdaLevel * scale * scale);
+        };
+        const bool hexLevel = searchType == SearchHex2;
+        const bool specLevel = specEnabled && !smallestPlane;
+        // refinement offsets of this lane's candidate group in pass A (4 lanes per candidate on Hex2 levels, 2 on exhaustive ones)
+        int rdx = 0, rdy = 0;
+        if (hexLevel) {
+            const int g = l >> 2;
+            if (g < 6) { rdx = tab8(HEX2X >> 8, g & 7); rdy = tab8(HEX2Y >> 8, g & 7); }
+            else if (g < 14) { rdx = tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), g - 6); rdy = tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), g - 6); }
+        } else {
+            const int g = l >> 1, k = g < 8 ? g : g - 8;
+            if (g < 8) { rdx = tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), k); rdy = tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), k); }
+            else if (g < 16) { rdx = tab8(PACK8(-1, -1, 0, 0, 1, 1, -2, 2), k); rdy = tab8(PACK8(-2, 2, -2, 2, -2, 2, -1, -1), k); }
+            else if (g < 24) { rdx = tab8(PACK8(-2, 2, -2, 2, -2, -2, 2, 2), k - 8); rdy = tab8(PACK8(0, 0, 1, 1, -2, 2, -2, 2), k - 8); }
+        }
+#ifdef MVX_SPEC_STATS
+        unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
+#endif
+
+        int prevX = 0, prevY = 0, prevSad = 0;
+        for (int blky = 0; blky < nBlkY; blky++) {
+            const bool fwd = (blky & 1) == 0 || !meander;
+            const int dir = fwd ? 1 : -1;
+            y0 = vpad + stepY * blky;
+            nDyMax = (ph - y0 - BW - vpad + vps) << logPel; // :1094-1097 (the vertical limits are the row's)
+            nDyMin = -((y0 - vpad + vps) << logPel);
+            const bool specRow = specLevel && blky > 0;
+            const int ngrp = (nBlkX + 63) >> 6;
+            for (int gi = 0; gi < ngrp; gi++) {
+                const int grp = fwd ? gi : ngrp - 1 - gi;
+                const int c0 = grp << 6, c = c0 + l;
+                const bool in = c < nBlkX;
+                const int ncol = min(64, nBlkX - c0);
+                // ---- 64 columns at a time (lane i <-> column c0 + i): the interpolated predictors of this row and of the blocks "below-ahead",
+                // the previous row's results; lambda lane-parallel (:456-462)
+                v4u bSelf = {0, 0, 0, 0}, bBelow = {0, 0, 0, 0}, bOut = {0, 0, 0, 0};
+                unsigned upPk = 0, upSad = 0;
+                if (in) {
+                    bSelf = this->ld_batch(&vectors[blky * nBlkX + c]);
+                    if (!smallestPlane) bSelf[3] = (unsigned)lambda_of((int)bSelf[2]);
+                    const int cb = c + dir;
+                    if (blky < nBlkY - 1 && cb >= 0 && cb < nBlkX) bBelow = this->ld_batch(&vectors[(blky + 1) * nBlkX + cb]);
+                    if (blky > 0) { const v2u t = rowbuf[c]; upPk = t[0]; upSad = t[1]; }
+                }
+                for (int hi = 0; hi < 2; hi++) {
+                    const int h = fwd ? hi : 1 - hi;
+                    const int lo = h * SPEC_TB, hiE = min(lo + SPEC_TB, ncol);
+                    if (lo >= ncol) continue;
+                    if (syncEvery) __builtin_amdgcn_s_barrier(); // keeps the chains of a workgroup on neighbouring blocks (shared reference lines)
+                    const bool act = l >= lo && l < hiE;
+                    unsigned long long okmask = 0, flagmask = 0;
+                    int rX = 0, rY = 0, rSad = 0;          // this lane's block: speculative result
+                    int pkU = 0, pkAh = 0, pkH = 0, pkG = 0; // this lane's block: clipped up / ahead / hierarchical / global predictors
+                    int gEndX = gmvx;
+                    if (specRow) {
+                        // ======== A1: one lane per block -- limits (:1094-1097) and the predictors that do not depend on the left neighbour (:427-449)
+                        const int xs = stepX * c;
+                        const int dxMin = -((xs + hps) << logPel), dxMax1 = ((pw - xs - hpad - BW - hpad + hps) << logPel) - 1;
+                        auto cx = [&](int v) { return min(max(v, dxMin), dxMax1); };
+                        auto cy = [&](int v) { return min(max(v, nDyMin), nDyMax - 1); };
+                        const int ux = cx(upx((int)upPk)), uy = cy(upy((int)upPk));
+                        pkU = pk(ux, uy);
+                        const bool aheadCol = fwd ? c < nBlkX - 1 : c > 0;
+                        const bool useBelow = blky < nBlkY - 1 && aheadCol;
+                        int ahx = 0, ahy = fieldShift;
+                        if (useBelow) { ahx = (int)bBelow[0]; ahy = (int)bBelow[1]; }
+                        else if (aheadCol && in) { const v2u t = rowbuf[c + dir]; ahx = upx((int)t[0]); ahy = upy((int)t[0]); } // last block row only (:441-447)
+                        const int ax = cx(ahx), ay = cy(ahy);
+                        pkAh = pk(ax, ay);
+                        const int hx = cx((int)bSelf[0]), hy = cy((int)bSelf[1]);
+                        pkH = pk(hx, hy);
+                        // the global predictor is clipped cumulatively (:859): every block clips the running value with its own limits
+                        gmvy = this->clipy(gmvy);
+                        if (__ballot(act && cx(gmvx) != gmvx) == 0) pkG = pk(gmvx, gmvy);
+                        else {
+                            for (int i = 0; i < hiE - lo; i++) {
+                                const int li = fwd ? lo + i : hiE - 1 - i;
+                                const int xb = stepX * (c0 + li);
+                                gmvx = min(max(gmvx, -((xb + hps) << logPel)), ((pw - xb - hpad - BW - hpad + hps) << logPel) - 1);
+                                pkG = l == li ? pk(gmvx, gmvy) : pkG;
+                            }
+                        }
+                        gEndX = gmvx;
+
+                        // ======== A: the SADs of every block of the group, nothing serial in between
+                        A4x32 pf[G::NPF];
+                        this->pf_issue(hpad + stepX * (c0 + (fwd ? lo : hiE - 1)), y0, pf);
+                        for (int i = 0; i < hiE - lo; i++) {
+                            const int li = fwd ? lo + i : hiE - 1 - i;
+                            const int blkx = c0 + li;
+                            __builtin_amdgcn_wave_barrier();
+                            this->pf_store(pf); // (PlaneOfBlocks.cpp:1058-1079)
+                            if (i + 1 < hiE - lo) this->pf_issue(hpad + stepX * (blkx + dir), y0, pf);
+                            x0 = hpad + stepX * blkx;
+                            nDxMax = (pw - x0 - BW - hpad + hps) << logPel;
+                            nDxMin = -((x0 - hpad + hps) << logPel);
+                            const int sU = __builtin_amdgcn_readlane(pkU, li), sAh = __builtin_amdgcn_readlane(pkAh, li);
+                            const int sH = __builtin_amdgcn_readlane(pkH, li), sG = __builtin_amdgcn_readlane(pkG, li);
+                            const int ti8 = (li & (SPEC_TB - 1)) * 8;
+                            __builtin_amdgcn_wave_barrier();
+                            // (every predicate below is bitwise: no branches inside a pass; up / ahead / global / hierarchical are clipped vectors)
+                            auto vok = [&](int vx, int vy) { return (vx >= nDxMin) & (vy >= nDyMin) & (vx < nDxMax) & (vy < nDyMax); };
+                            const int pkZ = pk(0, fieldShift);
+                            if (hexLevel) {
+                                { // hexagon + square around up, up itself, ahead: 16 candidates, 4 lanes each
+                                    const int g = l >> 2, s = l & 3;
+                                    const int base = g == 15 ? sAh : sU;
+                                    const int vx = upx(base) + (MVX_SPEC_ABL == 2 ? 0 : rdx), vy = upy(base) + (MVX_SPEC_ABL == 2 ? 0 : rdy);
+                                    const bool ok = vok(vx, vy) & ((g >= 6) | (nSearchParam > 1));
+                                    unsigned aL = 0, aC = 0;
+                                    if (ok) this->template eval<2>(s, vx, vy, vy, aL, aC);
+                                    group_sum2<2>(aL, aC);
+                                    if (s == 0) *(LDS_AS v2u *)(tab + g * SPEC_STRIDE + ti8) = v2u{aL, aC};
+                                }
+                                { // zero, global, hierarchical: 16 lanes each
+                                    const int g = l >> 4, s = l & 15;
+                                    const int base = g == 1 ? sG : g == 2 ? sH : pkZ;
+                                    const int vx = upx(base), vy = upy(base);
+                                    const int vyc = g == 0 ? 0 : vy; // the zero candidate's chroma ignores fieldShift (:836-839)
+                                    unsigned aL = 0, aC = 0;
+                                    if (g < (MVX_SPEC_ABL == 1 ? 0 : 3)) this->template eval<4>(s, vx, vy, vyc, aL, aC);
+                                    group_sum2<4>(aL, aC);
+                                    if ((s == 0) & (g < 3)) *(LDS_AS v2u *)(tab + (16 + g) * SPEC_STRIDE + ti8) = v2u{aL, aC};
+                                }
+                            } else { // rings 1 and 2 around up, up, ahead, zero, global, hierarchical: 29 candidates, 2 lanes each
+                                const int g = l >> 1, s = l & 1;
+                                const int base = g == 25 ? sAh : g == 26 ? pkZ : g == 27 ? sG : g == 28 ? sH : sU;
+                                const int vx = upx(base) + rdx, vy = upy(base) + rdy;
+                                const int vyc = g == 26 ? 0 : vy;
+                                const bool ok = (vok(vx, vy) | (g == 26)) & (g < SPEC_SLOTS_EXH);
+                                unsigned aL = 0, aC = 0;
+                                if (ok) this->template eval<1>(s, vx, vy, vyc, aL, aC);
+                                group_sum2<1>(aL, aC);
+                                if ((s == 0) & (g < SPEC_SLOTS_EXH)) *(LDS_AS v2u *)(tab + g * SPEC_STRIDE + ti8) = v2u{aL, aC};
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+
+                        // ======== A2: one lane per block -- the predictor phase (:832-915) and the refinement (:773-816) under the hypothesis
+                        // left == median == up, costs as pobCheckMV0 / pobCheckMV (:219-261), strict < in the reference's order
+                        {
+                            const int ti8 = (l & (SPEC_TB - 1)) * 8;
+                            auto rd = [&](int slot) { return *(const LDS_AS v2u *)(tab + slot * SPEC_STRIDE + ti8); };
+                            auto tot = [&](const v2u &t) { return (int)t[0] + (chroma ? (int)t[1] : 0); };
+                            const int lam = (int)bSelf[3]; // (blky > 0, not the coarsest level)
+                            auto md = [&](int vx, int vy) { // motion_distortion (:105-114) around the hierarchical predictor
+                                const unsigned dx = (unsigned)(hx - vx), dy = (unsigned)(hy - vy);
+                                const int dist = (int)(dx * dx + dy * dy);
+                                return (int)(((long long)lam * dist) >> 8);
+                            };
+                            const int sUp = hexLevel ? 14 : 24, sZ = hexLevel ? 16 : 26;
+                            const v2u tU = rd(sUp), tA = rd(sUp + 1), tZ = rd(sZ), tG = rd(sZ + 1), tH = rd(sZ + 2);
+                            int best, bx = 0, by = fieldShift, bs;
+                            { const int t = tot(tZ); int cc = t + (int)(((long long)penaltyZero * t) >> 8); cc = F::sat_add(0, cc); best = cc; bs = t; }
+                            { const int t = tot(tG); int cc = t + (int)(((long long)pglobal * t) >> 8); cc = F::sat_add(0, cc); if (cc < best) { best = cc; bx = upx(pkG); by = upy(pkG); bs = t; } }
+                            { const int t = tot(tH); const int cc = F::sat_add(0, t); if (cc < best) { best = cc; bx = hx; by = hy; bs = t; } }
+                            { const int t = tot(tU); const int cc = F::sat_add(md(ux, uy), t); if (cc < best) { best = cc; bx = ux; by = uy; bs = t; } } // median = left = up
+                            { const int t = tot(tA); const int cc = F::sat_add(md(ax, ay), t); if (cc < best) { best = cc; bx = ax; by = ay; bs = t; } }
+                            bool live = !(bx == ux && by == uy); // the pattern was evaluated around up
+                            auto vok = [&](int vx, int vy) { return vx >= dxMin && vy >= nDyMin && vx <= dxMax1 && vy < nDyMax; };
+                            auto cnew = [&](int vx, int vy, const v2u &t) { // pobCheckMV: penalty for new vectors, saturating
+                                int cc = (int)t[0] + ((penaltyNew * (int)t[0]) >> 8);
+                                if (chroma) cc += (int)t[1] + ((penaltyNew * (int)t[1]) >> 8);
+                                return F::sat_add(md(vx, vy), cc);
+                            };
+                            if (hexLevel) {
+                                if (nSearchParam > 1) { // a hexagon point that beats the predictor phase moves the centre (:682-724): left to the live search
+                                    bool won = false;
+#pragma unroll 1
+                                    for (int k = 0; k < 6; k++) {
+                                        const int vx = ux + tab8(HEX2X >> 8, k), vy = uy + tab8(HEX2Y >> 8, k);
+                                        won = won || (vok(vx, vy) && cnew(vx, vy, rd(k)) < best);
+                                    }
+                                    live = live || won;
+                                }
+#pragma unroll 1
+                                for (int k = 0; k < 8; k++) { // pobExpandingSearch(1, 1) around up (:636-658)
+                                    const int vx = ux + tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), k), vy = uy + tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), k);
+                                    const v2u t = rd(6 + k);
+                                    const int cc = cnew(vx, vy, t);
+                                    if (vok(vx, vy) && cc < best) { best = cc; bx = vx; by = vy; bs = tot(t); }
+                                }
+                            } else {
+#pragma unroll 1
+                                for (int k = 0; k < 24; k++) { // rings 1 and 2 (:786-791)
+                                    int dx, dy;
+                                    if (k < 8) { dx = tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), k); dy = tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), k); }
+                                    else if (k < 16) { dx = tab8(PACK8(-1, -1, 0, 0, 1, 1, -2, 2), k - 8); dy = tab8(PACK8(-2, 2, -2, 2, -2, 2, -1, -1), k - 8); }
+                                    else { dx = tab8(PACK8(-2, 2, -2, 2, -2, -2, 2, 2), k - 16); dy = tab8(PACK8(0, 0, 1, 1, -2, 2, -2, 2), k - 16); }
+                                    const int vx = ux + dx, vy = uy + dy;
+                                    const v2u t = rd(k);
+                                    const int cc = cnew(vx, vy, t);
+                                    if (vok(vx, vy) && cc < best) { best = cc; bx = vx; by = vy; bs = tot(t); }
+                                }
+                            }
+                            // the bad-block rescue (:938-963) is the live search's; a higher badcount later only raises the threshold
+                            live = live || (blky * nBlkX + c > 1 && (long long)bs > badSAD + badSAD * badcount / 16);
+                            rX = bx; rY = by; rSad = bs;
+                            // the hypothesis: my left neighbour's (speculative) result, clipped to MY limits, is my up predictor
+                            int nb = __builtin_amdgcn_ds_bpermute((l - dir) << 2, pk(bx, by));
+                            if (l == (fwd ? lo : hiE - 1)) nb = pk(prevX, prevY);
+                            const bool hyp = cx(upx(nb)) == ux && cy(upy(nb)) == uy;
+                            const bool rowStart = c == (fwd ? 0 : nBlkX - 1); // (no left neighbour: predictors[1] is the zero vector, :421-426)
+                            flagmask = __ballot(act && !live && !rowStart);
+                            okmask = flagmask & __ballot(hyp);
+                            if (MVX_SPEC_ABL == 3) okmask = flagmask = __ballot(act);
+                        }
+                    }
+
+                    // ======== B: verification in walk order; whatever does not verify is searched live with its true predictors
+                    int pos = fwd ? lo : hiE - 1;
+                    const int end = fwd ? hiE : lo - 1;
+                    while (pos != end) {
+                        int run;
+                        if (fwd) { const unsigned long long m = ~(okmask >> pos); run = min(m ? (int)__builtin_ctzll(m) : 64, hiE - pos); }
+                        else { const unsigned long long m = ~(okmask << (63 - pos)); run = min(m ? (int)__builtin_clzll(m) : 64, pos - lo + 1); }
+                        if (run > 0) { // lanes pos, pos + dir, ... take their speculative results
+                            const int a = fwd ? pos : pos - run + 1;
+                            const bool mine = l >= a && l < a + run;
+                            bOut[0] = mine ? (unsigned)rX : bOut[0]; bOut[1] = mine ? (unsigned)rY : bOut[1]; bOut[2] = mine ? (unsigned)rSad : bOut[2];
+                            const int last = fwd ? a + run - 1 : a;
+                            prevX = __builtin_amdgcn_readlane(rX, last); prevY = __builtin_amdgcn_readlane(rY, last); prevSad = __builtin_amdgcn_readlane(rSad, last);
+                            pos += dir * run;
+#ifdef MVX_SPEC_STATS
+                            st0 += run;
+#endif
+                            if (pos == end) break;
+                        }
+                        { // ---- block `pos` live (the lean kernel's block: predictors :419-463, pobPseudoEPZSearch :819-968)
+                            const int li = pos, blkx = c0 + li;
+                            A4x32 sb[G::NPF];
+                            this->pf_issue(hpad + stepX * blkx, y0, sb); // its source block; the scalar set-up below runs under the loads
+                            blkIdx = blky * nBlkX + blkx;
+                            x0 = hpad + stepX * blkx;
+                            nDxMax = (pw - x0 - BW - hpad + hps) << logPel;
+                            nDxMin = -((x0 - hpad + hps) << logPel);
+                            int sfx, sfy, sfs, blx, bly, bls;
+                            this->batch_get(bSelf, li, sfx, sfy, sfs);
+                            this->batch_get(bBelow, li, blx, bly, bls);
+                            const int upk = __builtin_amdgcn_readlane((int)upPk, li), ups = __builtin_amdgcn_readlane((int)upSad, li);
+                            const bool aheadCol = fwd ? blkx < nBlkX - 1 : blkx > 0;
+                            const bool useBelow = blky < nBlkY - 1 && aheadCol;
+                            const bool useUpAhead = !useBelow && blky > 0 && aheadCol; // last block row only (:441-447)
+                            int ahx = blx, ahy = bly, ahs = bls;
+                            if (useUpAhead) {
+                                const v2u t = rowbuf[blkx + dir];
+                                ahx = uni(upx((int)t[0])); ahy = uni(upy((int)t[0])); ahs = uni((int)t[1]);
+                            }
+                            const bool haveAhead = useBelow || useUpAhead;
+                            const bool havePrev = fwd ? blkx > 0 : blkx < nBlkX - 1;
+                            pX[1] = this->clipx(havePrev ? prevX : 0); pY[1] = this->clipy(havePrev ? prevY : fieldShift); const int s1 = havePrev ? prevSad : 0;
+                            pX[2] = this->clipx(blky > 0 ? upx(upk) : 0); pY[2] = this->clipy(blky > 0 ? upy(upk) : fieldShift); const int s2 = blky > 0 ? ups : 0;
+                            pX[3] = this->clipx(haveAhead ? ahx : 0); pY[3] = this->clipy(haveAhead ? ahy : fieldShift); const int s3 = haveAhead ? ahs : 0;
+                            int s0;
+                            if (blky > 0) {
+                                auto med = [](int a, int b, int c2) { return max(min(a, b), min(max(a, b), c2)); };
+                                pX[0] = med(pX[1], pX[2], pX[3]); pY[0] = med(pY[1], pY[2], pY[3]);
+                                s0 = max(s1, max(s2, s3));
+                            } else { pX[0] = pX[1]; pY[0] = pY[1]; s0 = s1; }
+                            int predSad;
+                            if (smallestPlane) { predX = pX[0]; predY = pY[0]; predSad = s0; }
+                            else { predX = this->clipx(sfx); predY = this->clipy(sfy); predSad = sfs; }
+                            nLambda = 0; // row 0 searches without the motion term (:1081-1084)
+                            if (blky > 0) nLambda = smallestPlane ? uni(lambda_of(predSad)) : __builtin_amdgcn_readlane((int)bSelf[3], li);
+                            if (specRow) { const int g = __builtin_amdgcn_readlane(pkG, li); gmvx = upx(g); gmvy = upy(g); } // the running global predictor at this block
+                            __builtin_amdgcn_wave_barrier();
+                            this->pf_store(sb);
+                            __builtin_amdgcn_wave_barrier();
+                            this->search_block();
+                            __builtin_amdgcn_wave_barrier();
+                            { const bool mine = l == li; bOut[0] = mine ? (unsigned)bestX : bOut[0]; bOut[1] = mine ? (unsigned)bestY : bOut[1]; bOut[2] = mine ? (unsigned)bestSad : bOut[2]; }
+                            prevX = bestX; prevY = bestY; prevSad = bestSad;
+#ifdef MVX_SPEC_STATS
+                            if (specRow) { st0 += 1; st1 += 1; st2 += !((flagmask >> li) & 1); }
+#endif
+                            // the next block's hypothesis was checked against this block's SPECULATIVE result: check it against the real one
+                            const int nx = pos + dir;
+                            if (specRow && nx != end) {
+                                const int xb = stepX * (c0 + nx);
+                                const int u = __builtin_amdgcn_readlane(pkU, nx);
+                                const int lx = min(max(bestX, -((xb + hps) << logPel)), ((pw - xb - hpad - BW - hpad + hps) << logPel) - 1);
+                                const bool hyp = lx == upx(u) && this->clipy(bestY) == upy(u);
+                                const unsigned long long bit = 1ull << nx;
+                                okmask = (hyp && (flagmask & bit)) ? (okmask | bit) : (okmask & ~bit);
+                            }
+                            pos += dir;
+                        }
+                    }
+                    if (specRow) gmvx = gEndX;
+                }
+                // ---- results of the 64 columns (:967, :1106)
+                if (in) {
+                    typedef unsigned a4v __attribute__((ext_vector_type(4), aligned(4)));
+                    const a4v t = {bOut[0], bOut[1], bOut[2], 0u}; // (block SADs are non-negative and < 2^31)
+                    *(GL_AS a4v *)&vectors[blky * nBlkX + c] = t;
+                    rowbuf[c] = v2u{(unsigned)pk((int)bOut[0], (int)bOut[1]), bOut[2]};
+                }
+            }
+        }
+#ifdef MVX_SPEC_STATS
+        if (l == 0) { atomicAdd(&g_specstat[lvl][0], st0); atomicAdd(&g_specstat[lvl][1], st1); atomicAdd(&g_specstat[lvl][2], st2); atomicAdd(&g_specstat[lvl][3], (unsigned long long)badcount); }
+#endif
+        // vectors[] of this level feed the next level's interpolation / global-MV estimate (other lanes read them)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_s_barrier();
+    }
+};
+
+// The launch shape is analyse_fast_kernel's: workgroups of 4 * WPE chains that are consecutive entries of the (reference-sorted) job table.
+template <int BPS, int BW, int WPE, int MAXCPW, bool UV>
+__global__ __launch_bounds__(64 * MAXCPW, WPE) void analyse_spec_kernel(const AParams *Pp, const AJob *jobs, int njobs, int ldsChain, int syncEvery, int ldsRow, int ldsHist, int histBins, int ldsTab, int flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const AParams &P = *Pp;
+    const int cpw = (int)(blockDim.x >> 6);
+    int wg = (int)blockIdx.x;
+    if (flags & MVX_FAST_XCD_REMAP) { // workgroup b runs on XCD b % 8 (round-robin dispatch): give every XCD a contiguous range of the table
+        const int n = (int)gridDim.x, x = wg & 7, slot = wg >> 3;
+        wg = x * (n >> 3) + min(x, n & 7) + slot;
+    }
+    const int chain = uni(wg * cpw + (int)(threadIdx.x >> 6));
+    if (chain >= njobs) return; // (a finished wave no longer counts for the workgroup's barriers)
+    const AJob &J = jobs[chain];
+    if (!J.blob) return;        // padding entry of the job table
+    const int l = lane_id();
+    int *hdr = (int *)J.blob;
+    if (!J.valid) { // gopWriteDefaultToArray GroupOfPlanes.c:150-164, pobWriteDefaultToArray PlaneOfBlocks.cpp:1529-1556
+        if (l == 0) { hdr[0] = P.blobSize; hdr[1] = 0; }
+        for (int lvl = P.nLevels - 1; lvl >= 0; lvl--) {
+            const ALevel &L = P.lv[lvl];
+            unsigned char *rec = J.blob + L.blobOff;
+            const int nBlk = L.nBlkX * L.nBlkY;
+            if (l == 0) *(int *)rec = 4 + nBlk * 16;
+            GVec *v = (GVec *)(rec + 4);
+            for (int i = l; i < nBlk; i += WAVE) { GVec d; d.x = 0; d.y = 0; d.sad = P.verybigSAD; v[i] = d; }
+        }
+        return;
+    }
+    if (l == 0) { hdr[0] = P.blobSize; hdr[1] = 1; } // GroupOfPlanes.c:77-85
+    SpecSearcher<BPS, BW, UV> S(P, J);
+    S.lds = (lds_u8 *)smem + uni((int)(threadIdx.x >> 6)) * ldsChain;
+    S.ldsRow = ldsRow; S.ldsHist = ldsHist; S.histBins = histBins; S.ldsTab = ldsTab;
+    int gx = 0, gy = 0; // zeroMV, MVAnalysisData.h:79
+    GL_AS const GVec *coarse = nullptr;
+    int cbx = 0, cby = 0, clp = 0;
+    for (int lvl = P.nLevels - 1; lvl >= 0; lvl--) {
+        if (coarse && P.global) S.estimate_global(coarse, cbx * cby, 8192 * P.lv[lvl + 1].pel, &gx, &gy);
+        S.search_level_spec(lvl, gx, gy, coarse, cbx, cby, clp, cpw > 1 ? syncEvery : 0, !(flags & MVX_FAST_NOSPEC));
+        coarse = S.vectors; cbx = P.lv[lvl].nBlkX; cby = P.lv[lvl].nBlkY; clp = P.lv[lvl].logPel;
+    }
+}
+#if defined(MVX_SPEC_STATS) && defined(MVX_PROF_EXPORT)
+extern "C" __attribute__((visibility("default"))) int mvx_debug_specstats(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_specstat), sizeof(unsigned long long) * MVX_MAX_LEVELS * 4) != hipSuccess) return -1;
+    if (reset) { static unsigned long long z[MVX_MAX_LEVELS * 4]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_specstat), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
+
+// L.ldsRow = offset of the row buffer (8 bytes per block), L.ldsHist = offset of the histogram (lies over row buffer and table: it is
+// only used between levels), L.ldsBytes = offset of the table when L.ldsNeed carries the chain's total
+struct ASpecLaunch { ALaunch L; int ldsTab; };
+template <int BPS, int BW, int WPE, int MAXCPW, bool UV> static int launch_analyse_spec_uv(const ASpecLaunch &S) {
+    const ALaunch &L = S.L;
+    const int perChain = (L.ldsNeed + 255) & ~255;
+    const int cpw = L.cpw < MAXCPW ? L.cpw : MAXCPW;
+    int lds = perChain * cpw;
+    if (L.ldsBytes > lds && L.ldsBytes <= 160 * 1024) lds = L.ldsBytes; // developer / host option: fewer workgroups per CU
+    if (lds > 64 * 1024)
+        HIP_CHECK(hipFuncSetAttribute((const void *)analyse_spec_kernel<BPS, BW, WPE, MAXCPW, UV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((analyse_spec_kernel<BPS, BW, WPE, MAXCPW, UV>), dim3((L.njobs + cpw - 1) / cpw), dim3(64 * cpw), lds, L.st, L.dP, L.dJobs,
+                       L.njobs, perChain, L.syncEvery, L.ldsRow, L.ldsHist, L.histBins, S.ldsTab, L.flags);
+    return MVX_OK;
+}
+template <int BPS, int BW, int WPE, int MAXCPW> static int launch_analyse_spec(const ASpecLaunch &S) {
+    if (S.L.flags & MVX_FAST_UV) return launch_analyse_spec_uv<BPS, BW, WPE, MAXCPW, true>(S);
+    return launch_analyse_spec_uv<BPS, BW, WPE, MAXCPW, false>(S);
+}

@@ -1,0 +1,25 @@
+// 16-bit builds of the speculative default search (mvx_analyse_spec.h): S.L.fast = chains per SIMD it is launched at
+#define MVX_PROF_EXPORT 1
+#define MVX_STREAM_MAX 48 // pass A has nothing else to wait for: whole candidates as one stream of loads, twelve in flight
+#include "mvx_analyse_kernel.h"
+#include "mvx_analyse_spec.h"
+int mvx_analyse_launch_spec_u16(const AParams &P, const ASpecLaunch &S) {
+    const int k = S.L.fast;
+    if (P.blkX == 16) {
+        if (k == 4) return launch_analyse_spec<2, 16, 4, 16>(S);
+        if (k == 3) return launch_analyse_spec<2, 16, 3, 12>(S);
+        if (k == 2) return launch_analyse_spec<2, 16, 2, 8>(S);
+        if (k == 1) return launch_analyse_spec<2, 16, 1, 4>(S);
+    }
+    if (P.blkX == 8) {
+        if (k == 4) return launch_analyse_spec<2, 8, 4, 16>(S);
+        if (k == 2) return launch_analyse_spec<2, 8, 2, 8>(S);
+        if (k == 1) return launch_analyse_spec<2, 8, 1, 4>(S);
+    }
+    if (P.blkX == 32) {
+        if (k == 3) return launch_analyse_spec<2, 32, 3, 12>(S);
+        if (k == 2) return launch_analyse_spec<2, 32, 2, 8>(S);
+        if (k == 1) return launch_analyse_spec<2, 32, 1, 4>(S);
+    }
+    return 1;
+}
