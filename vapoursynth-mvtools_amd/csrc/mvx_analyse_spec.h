@@ -61,6 +61,86 @@ template <int BPS, int BW, bool UV> struct SpecSearcher : FastSearcher<BPS, BW, 
     __device__ __forceinline__ static int upx(int c) { return (int)(short)(c & 0xffff); }
     __device__ __forceinline__ static int upy(int c) { return c >> 16; }
 
+    // ---- pass A as STREAMS of loads (r4, second form).  One candidate = NA luma pieces + NB pieces of the UV plane per lane of its group
+    // (1 << LOGG lanes).  A stream keeps a window of W loads in flight ACROSS blocks: when piece k of block b has been consumed its
+    // register is refilled with piece k + W -- of block b while it has that many, of block b + 1 after that.  A wave therefore never
+    // drains its loads between passes or blocks (pass A, first form: three exposed round trips per block, 895 ms per launch,
+    // profiles/r4_spec_v1_*.txt).
+    template <int LOGG, int WMAX> struct PG {
+        static constexpr int GG = 1 << LOGG, CA = 1 << G::LLOGC, CB = 1 << G::UVLOGC;
+        static constexpr bool OK = UV && G::LT % GG == 0 && G::UVT % GG == 0 && G::LT >= GG && G::UVT >= GG && GG >= CA && GG >= CB;
+        static constexpr int NA = OK ? G::LT / GG : 1, NB = OK ? G::UVT / GG : 1, NT = NA + NB;
+        static constexpr int pickW(int w) { return w <= 1 ? 1 : (NT % w == 0 ? w : pickW(w - 1)); }
+        static constexpr int W = pickW(NT < WMAX ? NT : WMAX); // the largest divisor of NT that fits the budget
+    };
+    template <int LOGG, int WMAX> struct Pass {
+        typedef PG<LOGG, WMAX> Q;
+        v4u r[Q::W];
+        unsigned curA, curB; // byte offsets (luma plane set / UV plane set) of the next piece to request
+        unsigned aL, aC;
+    };
+    static constexpr int LOGGP = PG<4, 4>::OK ? 4 : PG<3, 4>::OK ? 3 : PG<2, 4>::OK ? 2 : 1; // lanes per candidate of the zero / global / hierarchical pass
+    static constexpr bool STREAM_HEX = PG<2, 12>::OK && PG<LOGGP, 4>::OK, STREAM_EXH = PG<1, 12>::OK;
+
+    __device__ __forceinline__ unsigned luma_off_at(int bx0, int vx, int vy) const { // ref_luma_off for a block at bx0 of this row
+        const int ax = (bx0 << logPel) + vx, ay = (y0 << logPel) + vy, m = pel - 1;
+        const unsigned idx = (unsigned)((ax & m) | ((ay & m) << logPel));
+        return F::shadow_off(idx * pstrideY + (unsigned)(ay >> logPel) * pitchY + (unsigned)(ax >> logPel) * BPS, shadowY);
+    }
+    __device__ __forceinline__ unsigned chroma_off_at(int bx0, int vx, int vy) const {
+        const int xb = vx < 0 ? 1 : 0, yb = vy < 0 ? 1 : 0;
+        const int ax = ((bx0 >> 1) << logPel) + ((vx + xb) >> 1), ay = ((y0 >> 1) << logPel) + ((vy + yb) >> 1), m = pel - 1;
+        const unsigned idx = (unsigned)((ax & m) | ((ay & m) << logPel));
+        return idx * pstrideC + (unsigned)(ay >> logPel) * pitchC + (unsigned)(ax >> logPel) * BPS;
+    }
+    // this lane's first luma / UV piece of candidate (vx, vy; chroma rows from vyc) of the block at bx0
+    template <int LOGG, int WMAX> __device__ __forceinline__ void pass_start(int s, int bx0, int vx, int vy, int vyc, unsigned &oA, unsigned &oB) const {
+        typedef PG<LOGG, WMAX> Q;
+        const int rowA = s >> G::LLOGC, xbA = (s & (Q::CA - 1)) * G::LCB, rowB = s >> G::UVLOGC, xbB = (s & (Q::CB - 1)) * G::UVCB;
+        oA = luma_off_at(bx0, vx, vy) + (unsigned)rowA * pitchY + (unsigned)xbA;
+        oB = 2 * chroma_off_at(bx0, vx, vyc) + (unsigned)rowB * 2 * pitchC + (unsigned)xbB;
+    }
+    template <int LOGG, int WMAX> __device__ __forceinline__ v4u pass_issue(Pass<LOGG, WMAX> &T, int piece) const {
+        typedef PG<LOGG, WMAX> Q;
+        v4u v;
+        if (piece < Q::NA) { v = F::template ld_ref<G::LCB>(refY + T.curA); T.curA += (unsigned)(Q::GG >> G::LLOGC) * pitchY; asm volatile("" : "+v"(T.curA) : : "memory"); }
+        else { v = F::template ld_ref<G::UVCB>(refUV + T.curB); T.curB += (unsigned)(Q::GG >> G::UVLOGC) * 2 * pitchC; asm volatile("" : "+v"(T.curB) : : "memory"); }
+        return v;
+    }
+    template <int LOGG, int WMAX> __device__ __forceinline__ void pass_prime(Pass<LOGG, WMAX> &T, unsigned oA, unsigned oB) const {
+        typedef PG<LOGG, WMAX> Q;
+        T.curA = oA; T.curB = oB;
+#pragma unroll
+        for (int k = 0; k < Q::W; k++) T.r[k] = pass_issue(T, k);
+    }
+    // consume the block whose first W pieces are in flight (SADs into T.aL / T.aC), refilling the window; (nA, nB) = start of the NEXT block's candidate
+    template <int LOGG, int WMAX> __device__ __forceinline__ void pass_run(Pass<LOGG, WMAX> &T, int s, unsigned nA, unsigned nB) const {
+        typedef PG<LOGG, WMAX> Q;
+        const int rowA = s >> G::LLOGC, xbA = (s & (Q::CA - 1)) * G::LCB, rowB = s >> G::UVLOGC, xbB = (s & (Q::CB - 1)) * G::UVCB;
+        const lds_u8 *spA = lds + rowA * G::LROWB + xbA, *spB = lds + G::UOFF + rowB * G::UVROWB + xbB;
+        constexpr int lstepA = (Q::GG >> G::LLOGC) * G::LROWB, lstepB = (Q::GG >> G::UVLOGC) * G::UVROWB;
+        auto src_piece = [&](int k) { return k < Q::NA ? F::template lds_piece<G::LCB>(spA + k * lstepA) : F::template lds_piece<G::UVCB>(spB + (k - Q::NA) * lstepB); };
+        constexpr int D = MVX_SRC_AHEAD < Q::NT ? MVX_SRC_AHEAD : Q::NT;
+        v4u a[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) a[k] = src_piece(k);
+        unsigned aL = 0, aC = 0;
+#pragma unroll
+        for (int k = 0; k < Q::NT; k++) {
+            const v4u cur = a[k % D];
+            if (k + D < Q::NT) a[k % D] = src_piece(k + D);
+            if (k < Q::NA) aL = F::template sad_regs<G::LCB>(cur, T.r[k % Q::W], aL);
+            else aC = F::template sad_regs<G::UVCB>(cur, T.r[k % Q::W], aC);
+            // (the refill must FOLLOW the SADs of the register it overwrites: left alone the scheduler renames the register, requests the whole next
+            // window and reads every source piece first -- 150 live registers -- instead of one load per consumed piece)
+            asm volatile("" : "+v"(aL), "+v"(aC) : : "memory");
+            const int kk = k + Q::W;
+            if (kk == Q::NT) { T.curA = nA; T.curB = nB; } // the window moves on to the next block
+            T.r[k % Q::W] = pass_issue(T, kk % Q::NT);
+        }
+        T.aL = aL; T.aC = aC;
+    }
+
     // GroupOfPlanes.c:69-125 + PlaneOfBlocks.cpp:971-1131 for one level, in groups of SPEC_TB blocks
     __device__ __forceinline__ void search_level_spec(int lvl, int globalX, int globalY, GL_AS const GVec *coarse, int coarseBlkX, int coarseBlkY, int coarseLogPel, int syncEvery, bool specEnabled) {
         const int l = lane_id();
@@ -191,55 +271,144 @@ template <int BPS, int BW, bool UV> struct SpecSearcher : FastSearcher<BPS, BW, 
                         gEndX = gmvx;
 
                         // ======== A: the SADs of every block of the group, nothing serial in between
-                        A4x32 pf[G::NPF];
-                        this->pf_issue(hpad + stepX * (c0 + (fwd ? lo : hiE - 1)), y0, pf);
-                        for (int i = 0; i < hiE - lo; i++) {
-                            const int li = fwd ? lo + i : hiE - 1 - i;
-                            const int blkx = c0 + li;
-                            __builtin_amdgcn_wave_barrier();
-                            this->pf_store(pf); // (PlaneOfBlocks.cpp:1058-1079)
-                            if (i + 1 < hiE - lo) this->pf_issue(hpad + stepX * (blkx + dir), y0, pf);
-                            x0 = hpad + stepX * blkx;
-                            nDxMax = (pw - x0 - BW - hpad + hps) << logPel;
-                            nDxMin = -((x0 - hpad + hps) << logPel);
-                            const int sU = __builtin_amdgcn_readlane(pkU, li), sAh = __builtin_amdgcn_readlane(pkAh, li);
-                            const int sH = __builtin_amdgcn_readlane(pkH, li), sG = __builtin_amdgcn_readlane(pkG, li);
-                            const int ti8 = (li & (SPEC_TB - 1)) * 8;
-                            __builtin_amdgcn_wave_barrier();
-                            // (every predicate below is bitwise: no branches inside a pass; up / ahead / global / hierarchical are clipped vectors)
-                            auto vok = [&](int vx, int vy) { return (vx >= nDxMin) & (vy >= nDyMin) & (vx < nDxMax) & (vy < nDyMax); };
+                        const int nb = hiE - lo;
+                        const bool streamed = chroma && (hexLevel ? STREAM_HEX : STREAM_EXH);
+                        if (streamed) {
                             const int pkZ = pk(0, fieldShift);
+                            A4x32 pf[G::NPF];
+                            this->pf_issue(hpad + stepX * (c0 + (fwd ? lo : hiE - 1)), y0, pf);
+                            // the candidates of block li (lane roles as in the table's slots), clipped to what may be loaded: a candidate outside the
+                            // block's limits is replaced by the centre (its table entry is never read: A2 checks the limits itself)
+                            auto r_cand = [&](int li, int &bx0, int &vx, int &vy, int &vyc) { // pattern pass (Hex2 levels) / the only pass (exhaustive levels)
+                                bx0 = hpad + stepX * (c0 + li);
+                                const int xMax = (pw - bx0 - BW - hpad + hps) << logPel, xMin = -((bx0 - hpad + hps) << logPel);
+                                const int sU = __builtin_amdgcn_readlane(pkU, li), sAh = __builtin_amdgcn_readlane(pkAh, li);
+                                int base;
+                                if (hexLevel) base = (l >> 2) == 15 ? sAh : sU;
+                                else {
+                                    const int g = l >> 1;
+                                    const int sH = __builtin_amdgcn_readlane(pkH, li), sG = __builtin_amdgcn_readlane(pkG, li);
+                                    base = g == 25 ? sAh : g == 26 ? pkZ : g == 27 ? sG : g == 28 ? sH : sU;
+                                }
+                                const int cxv = upx(base), cyv = upy(base);
+                                const int tx = cxv + rdx, ty = cyv + rdy;
+                                const bool ok = (tx >= xMin) & (ty >= nDyMin) & (tx < xMax) & (ty < nDyMax);
+                                vx = ok ? tx : cxv; vy = ok ? ty : cyv;
+                                vyc = (!hexLevel && (l >> 1) == 26) ? 0 : vy; // the zero candidate's chroma ignores fieldShift (:836-839)
+                            };
+                            auto p_cand = [&](int li, int &bx0, int &vx, int &vy, int &vyc) { // zero, global, hierarchical (Hex2 levels)
+                                bx0 = hpad + stepX * (c0 + li);
+                                const int g = l >> LOGGP;
+                                const int sH = __builtin_amdgcn_readlane(pkH, li), sG = __builtin_amdgcn_readlane(pkG, li);
+                                const int base = g == 1 ? sG : g == 2 ? sH : pkZ;
+                                vx = upx(base); vy = upy(base); vyc = g == 1 || g == 2 ? vy : 0;
+                            };
                             if (hexLevel) {
-                                { // hexagon + square around up, up itself, ahead: 16 candidates, 4 lanes each
-                                    const int g = l >> 2, s = l & 3;
-                                    const int base = g == 15 ? sAh : sU;
-                                    const int vx = upx(base) + (MVX_SPEC_ABL == 2 ? 0 : rdx), vy = upy(base) + (MVX_SPEC_ABL == 2 ? 0 : rdy);
-                                    const bool ok = vok(vx, vy) & ((g >= 6) | (nSearchParam > 1));
-                                    unsigned aL = 0, aC = 0;
-                                    if (ok) this->template eval<2>(s, vx, vy, vy, aL, aC);
-                                    group_sum2<2>(aL, aC);
-                                    if (s == 0) *(LDS_AS v2u *)(tab + g * SPEC_STRIDE + ti8) = v2u{aL, aC};
+                                if constexpr (STREAM_HEX) {
+                                    Pass<2, 12> R; Pass<LOGGP, 4> Z;
+                                    const int sR = l & 3, sZ = l & ((1 << LOGGP) - 1);
+                                    {
+                                        const int li = fwd ? lo : hiE - 1;
+                                        int bx0, vx, vy, vyc; unsigned oA, oB;
+                                        r_cand(li, bx0, vx, vy, vyc); this->template pass_start<2, 12>(sR, bx0, vx, vy, vyc, oA, oB); this->template pass_prime<2, 12>(R, oA, oB);
+                                        p_cand(li, bx0, vx, vy, vyc); this->template pass_start<LOGGP, 4>(sZ, bx0, vx, vy, vyc, oA, oB); this->template pass_prime<LOGGP, 4>(Z, oA, oB);
+                                    }
+                                    for (int i = 0; i < nb; i++) {
+                                        const int li = fwd ? lo + i : hiE - 1 - i;
+                                        const int lin = i + 1 < nb ? li + dir : li; // (the last block of a group refills its window with its own pieces: dropped)
+                                        __builtin_amdgcn_wave_barrier();
+                                        this->pf_store(pf); // (PlaneOfBlocks.cpp:1058-1079)
+                                        if (i + 1 < nb) this->pf_issue(hpad + stepX * (c0 + lin), y0, pf);
+                                        int bx0, vx, vy, vyc; unsigned nA, nB, mA, mB;
+                                        r_cand(lin, bx0, vx, vy, vyc); this->template pass_start<2, 12>(sR, bx0, vx, vy, vyc, nA, nB);
+                                        p_cand(lin, bx0, vx, vy, vyc); this->template pass_start<LOGGP, 4>(sZ, bx0, vx, vy, vyc, mA, mB);
+                                        __builtin_amdgcn_wave_barrier();
+                                        this->template pass_run<2, 12>(R, sR, nA, nB);
+                                        this->template pass_run<LOGGP, 4>(Z, sZ, mA, mB);
+                                        const int ti8 = (li & (SPEC_TB - 1)) * 8;
+                                        group_sum2<2>(R.aL, R.aC);
+                                        if (sR == 0) *(LDS_AS v2u *)(tab + (l >> 2) * SPEC_STRIDE + ti8) = v2u{R.aL, R.aC};
+                                        group_sum2<LOGGP>(Z.aL, Z.aC);
+                                        if ((sZ == 0) & ((l >> LOGGP) < 3)) *(LDS_AS v2u *)(tab + (16 + (l >> LOGGP)) * SPEC_STRIDE + ti8) = v2u{Z.aL, Z.aC};
+                                    }
                                 }
-                                { // zero, global, hierarchical: 16 lanes each
-                                    const int g = l >> 4, s = l & 15;
-                                    const int base = g == 1 ? sG : g == 2 ? sH : pkZ;
-                                    const int vx = upx(base), vy = upy(base);
-                                    const int vyc = g == 0 ? 0 : vy; // the zero candidate's chroma ignores fieldShift (:836-839)
-                                    unsigned aL = 0, aC = 0;
-                                    if (g < (MVX_SPEC_ABL == 1 ? 0 : 3)) this->template eval<4>(s, vx, vy, vyc, aL, aC);
-                                    group_sum2<4>(aL, aC);
-                                    if ((s == 0) & (g < 3)) *(LDS_AS v2u *)(tab + (16 + g) * SPEC_STRIDE + ti8) = v2u{aL, aC};
+                            } else {
+                                if constexpr (STREAM_EXH) {
+                                    Pass<1, 12> R;
+                                    const int sR = l & 1;
+                                    {
+                                        const int li = fwd ? lo : hiE - 1;
+                                        int bx0, vx, vy, vyc; unsigned oA, oB;
+                                        r_cand(li, bx0, vx, vy, vyc); this->template pass_start<1, 12>(sR, bx0, vx, vy, vyc, oA, oB); this->template pass_prime<1, 12>(R, oA, oB);
+                                    }
+                                    for (int i = 0; i < nb; i++) {
+                                        const int li = fwd ? lo + i : hiE - 1 - i;
+                                        const int lin = i + 1 < nb ? li + dir : li;
+                                        __builtin_amdgcn_wave_barrier();
+                                        this->pf_store(pf);
+                                        if (i + 1 < nb) this->pf_issue(hpad + stepX * (c0 + lin), y0, pf);
+                                        int bx0, vx, vy, vyc; unsigned nA, nB;
+                                        r_cand(lin, bx0, vx, vy, vyc); this->template pass_start<1, 12>(sR, bx0, vx, vy, vyc, nA, nB);
+                                        __builtin_amdgcn_wave_barrier();
+                                        this->template pass_run<1, 12>(R, sR, nA, nB);
+                                        const int ti8 = (li & (SPEC_TB - 1)) * 8;
+                                        group_sum2<1>(R.aL, R.aC);
+                                        if ((sR == 0) & ((l >> 1) < SPEC_SLOTS_EXH)) *(LDS_AS v2u *)(tab + (l >> 1) * SPEC_STRIDE + ti8) = v2u{R.aL, R.aC};
+                                    }
                                 }
-                            } else { // rings 1 and 2 around up, up, ahead, zero, global, hierarchical: 29 candidates, 2 lanes each
-                                const int g = l >> 1, s = l & 1;
-                                const int base = g == 25 ? sAh : g == 26 ? pkZ : g == 27 ? sG : g == 28 ? sH : sU;
-                                const int vx = upx(base) + rdx, vy = upy(base) + rdy;
-                                const int vyc = g == 26 ? 0 : vy;
-                                const bool ok = (vok(vx, vy) | (g == 26)) & (g < SPEC_SLOTS_EXH);
-                                unsigned aL = 0, aC = 0;
-                                if (ok) this->template eval<1>(s, vx, vy, vyc, aL, aC);
-                                group_sum2<1>(aL, aC);
-                                if ((s == 0) & (g < SPEC_SLOTS_EXH)) *(LDS_AS v2u *)(tab + g * SPEC_STRIDE + ti8) = v2u{aL, aC};
+                            }
+                        } else {
+                            // (luma-only searches and block shapes whose pieces do not divide among the lanes: one block at a time, pass by pass)
+                            A4x32 pf[G::NPF];
+                            this->pf_issue(hpad + stepX * (c0 + (fwd ? lo : hiE - 1)), y0, pf);
+                            for (int i = 0; i < hiE - lo; i++) {
+                                const int li = fwd ? lo + i : hiE - 1 - i;
+                                const int blkx = c0 + li;
+                                __builtin_amdgcn_wave_barrier();
+                                this->pf_store(pf); // (PlaneOfBlocks.cpp:1058-1079)
+                                if (i + 1 < hiE - lo) this->pf_issue(hpad + stepX * (blkx + dir), y0, pf);
+                                x0 = hpad + stepX * blkx;
+                                nDxMax = (pw - x0 - BW - hpad + hps) << logPel;
+                                nDxMin = -((x0 - hpad + hps) << logPel);
+                                const int sU = __builtin_amdgcn_readlane(pkU, li), sAh = __builtin_amdgcn_readlane(pkAh, li);
+                                const int sH = __builtin_amdgcn_readlane(pkH, li), sG = __builtin_amdgcn_readlane(pkG, li);
+                                const int ti8 = (li & (SPEC_TB - 1)) * 8;
+                                __builtin_amdgcn_wave_barrier();
+                                // (every predicate below is bitwise: no branches inside a pass; up / ahead / global / hierarchical are clipped vectors)
+                                auto vok = [&](int vx, int vy) { return (vx >= nDxMin) & (vy >= nDyMin) & (vx < nDxMax) & (vy < nDyMax); };
+                                const int pkZ = pk(0, fieldShift);
+                                if (hexLevel) {
+                                    { // hexagon + square around up, up itself, ahead: 16 candidates, 4 lanes each
+                                        const int g = l >> 2, s = l & 3;
+                                        const int base = g == 15 ? sAh : sU;
+                                        const int vx = upx(base) + (MVX_SPEC_ABL == 2 ? 0 : rdx), vy = upy(base) + (MVX_SPEC_ABL == 2 ? 0 : rdy);
+                                        const bool ok = vok(vx, vy) & ((g >= 6) | (nSearchParam > 1));
+                                        unsigned aL = 0, aC = 0;
+                                        if (ok) this->template eval<2>(s, vx, vy, vy, aL, aC);
+                                        group_sum2<2>(aL, aC);
+                                        if (s == 0) *(LDS_AS v2u *)(tab + g * SPEC_STRIDE + ti8) = v2u{aL, aC};
+                                    }
+                                    { // zero, global, hierarchical: 16 lanes each
+                                        const int g = l >> 4, s = l & 15;
+                                        const int base = g == 1 ? sG : g == 2 ? sH : pkZ;
+                                        const int vx = upx(base), vy = upy(base);
+                                        const int vyc = g == 0 ? 0 : vy; // the zero candidate's chroma ignores fieldShift (:836-839)
+                                        unsigned aL = 0, aC = 0;
+                                        if (g < (MVX_SPEC_ABL == 1 ? 0 : 3)) this->template eval<4>(s, vx, vy, vyc, aL, aC);
+                                        group_sum2<4>(aL, aC);
+                                        if ((s == 0) & (g < 3)) *(LDS_AS v2u *)(tab + (16 + g) * SPEC_STRIDE + ti8) = v2u{aL, aC};
+                                    }
+                                } else { // rings 1 and 2 around up, up, ahead, zero, global, hierarchical: 29 candidates, 2 lanes each
+                                    const int g = l >> 1, s = l & 1;
+                                    const int base = g == 25 ? sAh : g == 26 ? pkZ : g == 27 ? sG : g == 28 ? sH : sU;
+                                    const int vx = upx(base) + rdx, vy = upy(base) + rdy;
+                                    const int vyc = g == 26 ? 0 : vy;
+                                    const bool ok = (vok(vx, vy) | (g == 26)) & (g < SPEC_SLOTS_EXH);
+                                    unsigned aL = 0, aC = 0;
+                                    if (ok) this->template eval<1>(s, vx, vy, vyc, aL, aC);
+                                    group_sum2<1>(aL, aC);
+                                    if ((s == 0) & (g < SPEC_SLOTS_EXH)) *(LDS_AS v2u *)(tab + g * SPEC_STRIDE + ti8) = v2u{aL, aC};
+                                }
                             }
                         }
                         __builtin_amdgcn_wave_barrier();

@@ -170,7 +170,7 @@ def lib():
         # developer / test switches: the library itself never reads the environment (mvx_debug_option is its one hook);
         # this TEST binding forwards the MVX_* variables the tools/ scripts use
         for env, opt in (("MVX_GENERAL", "general"), ("MVX_FAST_WPE", "fast_wpe"), ("MVX_NO_WPE2", "no_wpe2"),
-                         ("MVX_NO_WPE3", "no_wpe3"), ("MVX_WPE3", "wpe3_u16"), ("MVX_FAST_CPW", "fast_cpw"), ("MVX_FAST_FLAGS", "fast_flags"), ("MVX_PAD_RUNS", "pad_runs"), ("MVX_SHADOW_PLANES", "shadow_planes"), ("MVX_DEGRAIN_XCD", "degrain_xcd"), ("MVX_CPW_SYNC", "cpw_sync"), ("MVX_LDS_MIN", "lds_min"), ("MVX_SUPER_ROWS_OFF", "super_rows_off"), ("MVX_ABLATE", "ablate"), ("MVX_WIN", "win"), ("MVX_FAST_K", "fast_k"), ("MVX_SPEC", "spec")):
+                         ("MVX_NO_WPE3", "no_wpe3"), ("MVX_WPE3", "wpe3_u16"), ("MVX_FAST_CPW", "fast_cpw"), ("MVX_FAST_FLAGS", "fast_flags"), ("MVX_PAD_RUNS", "pad_runs"), ("MVX_SHADOW_PLANES", "shadow_planes"), ("MVX_DEGRAIN_XCD", "degrain_xcd"), ("MVX_CPW_SYNC", "cpw_sync"), ("MVX_LDS_MIN", "lds_min"), ("MVX_SUPER_ROWS_OFF", "super_rows_off"), ("MVX_ABLATE", "ablate"), ("MVX_WIN", "win"), ("MVX_FAST_K", "fast_k"), ("MVX_SPEC", "spec"), ("MVX_FAST_LDS_MIN", "fast_lds_min")):
             if os.environ.get(env) is not None:
                 L.mvx_debug_option(opt.encode(), int(os.environ[env]))
         if os.environ.get("MVX_CPW") == "1":
@@ -270,6 +270,18 @@ class Super:
         self.bps = 1 if bits <= 8 else 2
         self.nplanes = self.info.num_planes
         self.pitch = [((self.info.plane_width[p] * self.bps + 255) // 256) * 256 for p in range(self.nplanes)]
+        # developer experiment (r4): row pitch as a number of 128-byte lines that is odd / a given residue -- how the rows of a block and the
+        # sub-pel planes spread over the sets of the CU's L1.  MVX_PITCH_LINES="odd" | "<k>" (pitch = smallest number of lines >= the row that is == k mod 64)
+        _pl = os.environ.get("MVX_PITCH_LINES")
+        if _pl:
+            for p in range(self.nplanes):
+                n = (self.info.plane_width[p] * self.bps + 127) // 128
+                if _pl == "odd":
+                    n += 1 - (n & 1)
+                else:
+                    while n % 64 != int(_pl) % 64:
+                        n += 1
+                self.pitch[p] = n * 128
         # shadow planes (mvx_super_shadow_frames; clips of more than 8 bits): the luma plane is followed by its copy shifted by one
         # sample, the U plane by the UV-interleaved plane, so that the search only issues dword-aligned loads.  On by default
         # (MVX_SHADOW=0 / shadow=False: the plain layout).
