@@ -28,10 +28,11 @@ for _p in (os.path.join(ROOT, "vapoursynth-mvtools_amd"), os.path.join(ROOT, "te
 CONFIGS = {
     # name: (width, height, bits, radius, analyse kwargs, super kwargs, default batch, BASELINE.json config string)
     "cfg1": (640, 360, 8, 1, dict(blksize=8), dict(pel=1), 1536, "640x360 YUV420P8 Degrain1 blksize=8 pel=1"),
-    # (default batches: the number of chains = 2 * radius * batch decides how many chains share a SIMD -- cfg3: 3072 chains = three per
-    # SIMD, cfg2: 4096 = four per SIMD, cfg5: 2016 = two per SIMD, all its 1 GB super frames leave room for)
+    # (default batches: the number of chains = 2 * radius * batch decides how many chains share a SIMD -- cfg3: 2046 chains = two per
+    # SIMD in one round (the speculative kernel's 256-register build: r4), cfg2: 4096 = four per SIMD, cfg5: 2016 = two per SIMD, all its
+    # 1 GB super frames leave room for)
     "cfg2": (1920, 1080, 8, 1, dict(blksize=8, overlap=4, search=4), dict(pel=2), 2048, "1080p YUV420P8 Degrain1 blksize=8 overlap=4 pel=2 search=4"),
-    "cfg3": (3840, 2160, 16, 3, dict(blksize=16, overlap=8), dict(pel=2), 512, "4K YUV420P16 Degrain3 blksize=16 overlap=8 pel=2"),
+    "cfg3": (3840, 2160, 16, 3, dict(blksize=16, overlap=8), dict(pel=2), 341, "4K YUV420P16 Degrain3 blksize=16 overlap=8 pel=2"),
     "cfg5": (7680, 4320, 16, 6, dict(blksize=32, overlap=16), dict(pel=2), 168, "8K YUV420P16 Degrain6 blksize=32 overlap=16 pel=2"),
     # BASELINE config 4: frame-rate conversion instead of denoising (radius field = 0 selects PipelineFPS)
     "cfg4": (1920, 1080, 8, 0, dict(blksize=8), dict(pel=2), 2047, "1080p YUV420P8 Compensate + BlockFPS 24->60 blksize=8 pel=2"),
@@ -328,6 +329,14 @@ def oracle_leg_fps(mv, torch, cfg, pipe, threads, F):
     return {"value": fps.num_frames / dt, "unit": "fps", "cores": threads, "kind": "port", "sample": sample}, parity
 
 
+def search_kernel_name(mv):
+    """which kernel the last search launch of this process ran (mvx_debug_last_launch)"""
+    import ctypes as C
+    info = (C.c_int * 5)()
+    mv.lib().mvx_debug_last_launch(info)
+    return "analyse_spec_kernel, %d chains per SIMD" % info[0] if info[4] == 2 else "analyse_win_kernel" if info[4] == 1 else "analyse_fast_kernel, %d chains per SIMD" % info[0] if info[0] else "analyse_kernel"
+
+
 def measure_traffic(args, B):
     """HBM bytes of ONE launch of the search kernel, measured now: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; kernel-trace
     only, one counter per pass) over `bench.py --steps 1 --warmup 0` of the same configuration, corrected as MI355X_MICROARCH.md
@@ -520,7 +529,7 @@ def main():
             "config": {"workload": cfg[7], "frames_per_step_per_gpu": units, "input_frames_per_step_per_gpu": B + 1 if fpsconv else B, "chains_per_step_per_gpu": chains,
                        "sharding": "frame ranges, no collective", "batches_in_flight": len(pipes),
                        "rank0_output_frames": list(plan.out), "rank0_held_frames": list(plan.held)},
-            "roofline": {"bound": "hbm", "kernel": "analyse_fast_kernel (the motion search; one launch = %d chains)" % chains, "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "%s (the motion search; one launch = %d chains)" % (search_kernel_name(mv), chains), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                          "peak_measured": HBM_MEASURED_GBS, "frac_of_measured_peak": achieved / HBM_MEASURED_GBS,
                          "algorithmic_bytes_per_launch": bytes_chain * chains, "avg_launch_ms": avg_launch_ms,

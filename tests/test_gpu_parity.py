@@ -470,12 +470,13 @@ def test_analyse_two_chains_per_simd(oracle, mv, dbg, kernel, bits, akw):
     (256, 144, 8, dict(pel=4), dict(blksize=8, overlap=2)),
     (256, 144, 8, dict(pel=1), dict(blksize=8, chroma=0)),
 ])
-@pytest.mark.parametrize("variant", ["general", "plain-layout", "serial", "spec-off"])
+@pytest.mark.parametrize("variant", ["general", "plain-layout", "serial", "spec-off", "spec-everywhere"])
 def test_analyse_default_search_other_kernels(oracle, mv, dbg, variant, w, h, bits, skw, akw):
     """The default search normally runs in the speculative kernel (mvx_analyse_spec.h) on super frames that carry shadow copies.
     The same cases through the general kernel ("general" = 1), through the speculative kernel on the plain layout (no shadow
     copies: unaligned loads), through the serial lean kernel (mvx_analyse_fast.h, "spec" = 0) and through the speculative kernel's
-    code with speculation switched off ("spec" = 2: every block searched live) must give the same blobs."""
+    code with speculation switched off ("spec" = 2: every block searched live) or forced for shapes it is not the default for ("spec" = 5)
+    must give the same blobs."""
     akw = dict(akw)
     noise = akw.pop("_noise", 3)
     if variant == "general":
@@ -484,6 +485,8 @@ def test_analyse_default_search_other_kernels(oracle, mv, dbg, variant, w, h, bi
         dbg("spec", 0)
     if variant == "spec-off":
         dbg("spec", 2)
+    if variant == "spec-everywhere":
+        dbg("spec", 5)
     frames = pl.moving_clip(w, h, bits, 3, seed=13, noise=noise)
     osup = oracle.Super(w, h, bits, **skw)
     gsup = mv.Super(w, h, bits, shadow=(variant != "plain-layout"), **skw)
@@ -518,12 +521,21 @@ WINDOW_CASES = [
     (320, 192, {}, dict(blksize=16, overlap=8, _noise=14, badsad=400, badrange=6)),  # UMH rescue between verified runs
     (520, 96, dict(hpad=4, vpad=4), dict(blksize=16, overlap=8, pglobal=20)),     # tiny padding: the global predictor is clipped block by block
 ])
-def test_analyse_speculative_kernel(oracle, mv, w, h, skw, akw):
-    """The speculative kernel of the default search (mvx_analyse_spec.h; the default): groups of 32 blocks evaluated ahead of the serial
-    walk under the hypothesis left == up, verified block by block, everything else searched live.  Same blobs as the oracle -- forward,
-    backward, with a field shift, with a missing reference; noisy clips (most hypotheses fail), rescues, every refinement shape."""
+@pytest.mark.parametrize("mode", ["default", "everywhere", "no-runs"])
+def test_analyse_speculative_kernel(oracle, mv, dbg, mode, w, h, skw, akw):
+    """The speculative kernel of the default search (mvx_analyse_spec.h): groups of 32 blocks evaluated ahead of the serial walk under
+    the hypothesis left == up (row passes over windows of seven blocks, strip or block form), verified block by block, everything else
+    searched live.  Same blobs as the oracle -- forward, backward, with a field shift, with a missing reference; noisy clips (most
+    hypotheses fail), rescues, every refinement shape.  "default": the library's own choice (the speculative kernel where its row passes
+    apply, the serial lean kernel elsewhere); "everywhere": forced for every shape it can run ("spec" = 5: the one-block-at-a-time
+    passes); "no-runs": forced, without row passes ("spec" = 3)."""
     akw = dict(akw)
     noise = akw.pop("_noise", 3)
+    if mode == "everywhere":
+        dbg("spec", 5)
+    if mode == "no-runs":
+        dbg("spec", 3)
+    rows_apply = akw.get("blksize", 8) == 16 and akw.get("overlap", 0) == 8 and akw.get("chroma", 1) != 0
     frames = pl.moving_clip(w, h, 16, 3, seed=17, noise=noise, motion=(5, -2))
     osup = oracle.Super(w, h, 16, **skw)
     gsup = mv.Super(w, h, 16, **skw)
@@ -536,7 +548,7 @@ def test_analyse_speculative_kernel(oracle, mv, w, h, skw, akw):
         ref = 2 if isb else 0
         got = gan.run([(gsf[1], gsf[ref]), (gsf[1], None)])
         mv.lib().mvx_debug_last_launch(info)
-        assert info[4] == 2, "the speculative kernel did not run (%s)" % list(info)
+        assert info[4] == (2 if (mode != "default" or rows_apply) else 0), "not the kernel this case is meant to cover (%s)" % list(info)
         assert np.array_equal(got[0].cpu().numpy(), oan.frame(osf[1], osf[ref]))
         assert np.array_equal(got[1].cpu().numpy(), oan.frame(osf[1], None))
         if skw.get("pel", 2) == 2:
@@ -800,9 +812,9 @@ def _fullsize_parity(mv, oracle, w, h, bits, tr, akw, nout, replicas, want_k, la
 
 
 def test_full_size_parity_cfg3(mv, oracle):
-    """BASELINE cfg3 (4K YUV420P16 Degrain3 blk 16 ov 8 pel 2), full size, byte for byte, inside a 2 052-chain launch = the three
-    chains per SIMD build bench.py times"""
-    _fullsize_parity(mv, oracle, 3840, 2160, 16, 3, dict(blksize=16, overlap=8), nout=2, replicas=171, want_k=3, label="cfg3")
+    """BASELINE cfg3 (4K YUV420P16 Degrain3 blk 16 ov 8 pel 2), full size, byte for byte, inside a 2 040-chain launch = the two
+    chains per SIMD build of the speculative kernel that bench.py times (r4)"""
+    _fullsize_parity(mv, oracle, 3840, 2160, 16, 3, dict(blksize=16, overlap=8), nout=2, replicas=170, want_k=2, label="cfg3")
 
 
 def test_full_size_parity_cfg2(mv, oracle):

@@ -40,7 +40,7 @@ struct MvxDebug {
     int degrain_xcd = -1;  // Degrain cell kernels: XCD-contiguous tile order (1 / 0), -1 = default
     int cpw_sync = -1; // barrier interval inside a workgroup (power of two, 0 = none)
     int lds_min = -1;  // LDS floor of the one-chain launches
-    int spec = 1;      // default search: 1 = the speculative kernel (mvx_analyse_spec.h), 0 = the lean serial kernel (mvx_analyse_fast.h), 2 = the speculative kernel's code with speculation off (every block live)
+    int spec = 1;      // default search: 1 = the speculative kernel (mvx_analyse_spec.h), 0 = the lean serial kernel (mvx_analyse_fast.h), 2 = the speculative kernel's code with speculation off (every block live), 3 = speculative without runs (every block's candidates loaded on their own), 5 = speculative for every shape it can run (by default only where its row passes apply)
     int win = 0;       // 1: the LDS-window kernel of the default search (mvx_analyse_win.h) where it applies: bit-exact, measured slower
     int super_rows_off = 0; // 1: mv.Super level 0 / first reduction through the LDS-tile / per-sample kernels only
     int ablate = 0;
@@ -350,13 +350,26 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         const bool useWin = g_dbg.win && mvx_win_eligible(P);
         // the speculative kernel (mvx_analyse_spec.h): [source block | previous row's results, 8 B per block | SAD table of a 32-block group];
         // the histogram lies over row buffer and table
-        const bool useSpec = !useWin && g_dbg.spec != 0;
-        int sTab = 0;
+        // The speculative kernel runs where its row passes apply (16-bit 16x16 blocks overlapping by half, with chroma: cfg3 612 against 555 fps);
+        // one block at a time it loses to the serial lean kernel (cfg2 2 557 / 2 894, cfg4 17 180 / 18 764, cfg5 76 / 92 fps:
+        // profiles/r4_configs_spec_vs_serial.txt), so everything else stays there unless "spec" asks for it (5: wherever it can run).
+        const bool stripShape = P.bps == 2 && P.blkX == 16 && P.chroma && P.ovX == P.blkX / 2;
+        const bool useSpec = !useWin && g_dbg.spec != 0 && (stripShape || g_dbg.spec >= 2);
+        const bool useSpecStrips = useSpec && g_dbg.spec != 3 && stripShape;
+        int sTab = 0, sRow = fRow;
         if (useSpec) {
             const bool anyExh = P.searchType == SearchExhaustive || (P.nLevels > 1 && P.searchTypeCoarse == SearchExhaustive);
-            sTab = fRow + ((fMaxBlkX * 8 + 15) & ~15);
-            fNeed = sTab + (anyExh ? SPEC_SLOTS_EXH : SPEC_SLOTS_HEX) * SPEC_STRIDE;
-            if (fNeed < fRow + fBins * 4) fNeed = fRow + fBins * 4;
+            const int sSrc = (P.bps == 2 && P.blkX == 16 && fRow < 3072) ? 3072 : fRow; // the source strip of a run of seven blocks (mvx_analyse_spec.h: STRIP_OK)
+            sRow = sSrc;
+            sTab = sSrc + ((fMaxBlkX * 8 + 15) & ~15);
+            fNeed = 0; // per level: row buffer (8 B per block of THAT level) + the table of its search type
+            for (int i = 0; i < P.nLevels; i++) {
+                const bool smallest = i == P.nLevels - 1;
+                const int st = smallest ? (P.nLevels == 1 ? P.searchType : P.searchTypeCoarse) : (i == 0 ? P.searchType : P.searchTypeCoarse);
+                const int need = sSrc + ((P.lv[i].nBlkX * 8 + 15) & ~15) + (st == SearchHex2 ? SPEC_SLOTS_HEX : SPEC_SLOTS_EXH) * SPEC_STRIDE;
+                if (need > fNeed) fNeed = need;
+            }
+            if (fNeed < sRow + fBins * 4) fNeed = sRow + fBins * 4;
         }
         const int perChain = useWin ? WG16::TOTAL : (fNeed + 255) & ~255;
         // builds per (sample size, block size): chains per SIMD that exist (mvx_analyse_u8.hip / _u16.hip)
@@ -367,6 +380,9 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
             return k >= 1 && k <= 4;
         };
         int k = njobs > 3 * simds ? 4 : njobs > 2 * simds ? 3 : njobs > simds ? 2 : 1;
+        // the row passes of the speculative kernel (16-bit 16x16) want the 256-register builds: 3072 chains take 878 ms at two per SIMD (in
+        // two rounds) against 919 at three (profiles/r4_spec_loads_in_flight_and_batch.txt)
+        if (useSpecStrips && k > 2) k = 2;
         if (g_dbg.fast_wpe > 0 && g_dbg.fast_wpe < k) k = g_dbg.fast_wpe;
         if (g_dbg.fast_k > 0) k = g_dbg.fast_k;
         while (k > 1 && (!have(k) || (long long)perChain * 4 * k > 160 * 1024)) k--;
@@ -406,8 +422,8 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
             int syncEvery = k >= 2 ? (P.bps == 2 ? 32 : 256) : 0;
             if (g_dbg.cpw_sync >= 0 && (g_dbg.cpw_sync & (g_dbg.cpw_sync - 1)) == 0) syncEvery = g_dbg.cpw_sync;
             // XCD-contiguous workgroup order: neighbours in the (reference-sorted) job table share an L2 (+0.5 %, 4K16)
-            const int flags = (g_dbg.fast_flags >= 0 ? g_dbg.fast_flags : MVX_FAST_XCD_REMAP) | ((P.shadow[1] != 0 && P.chroma) ? MVX_FAST_UV : 0) | (g_dbg.spec == 2 ? MVX_FAST_NOSPEC : 0);
-            ALaunch L = { ntab, fNeed, fRow, fRow, fBins, fNeed, simds, cpw, k, syncEvery, k, flags, st, a->dP, S.d };
+            const int flags = (g_dbg.fast_flags >= 0 ? g_dbg.fast_flags : MVX_FAST_XCD_REMAP) | ((P.shadow[1] != 0 && P.chroma) ? MVX_FAST_UV : 0) | (g_dbg.spec == 2 ? MVX_FAST_NOSPEC : 0) | (g_dbg.spec == 3 ? MVX_FAST_NOSTRIP : 0);
+            ALaunch L = { ntab, fNeed, useSpec ? sRow : fRow, useSpec ? sRow : fRow, fBins, fNeed, simds, cpw, k, syncEvery, k, flags, st, a->dP, S.d };
             L.ldsBytes = g_dbg.fast_lds_min; // (floor of the workgroup's LDS request, 0 = none)
             int rc;
             if (useSpec) { const ASpecLaunch SL = { L, sTab }; rc = P.bps == 1 ? mvx_analyse_launch_spec_u8(P, SL) : mvx_analyse_launch_spec_u16(P, SL); }

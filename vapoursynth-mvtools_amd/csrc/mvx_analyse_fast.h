@@ -28,7 +28,9 @@
 #ifndef MVX_STREAM_MAX
 #define MVX_STREAM_MAX 12 // a candidate's pieces per lane up to which luma + chroma are ONE stream of loads (the serial kernel: longer streams measured slower; the speculative kernel's translation units set 48)
 #endif
+#ifndef MVX_INFLIGHT
 #define MVX_INFLIGHT 12 // reference loads a lane keeps in flight while it evaluates a candidate: all twelve of a hexagon-pass candidate
+#endif
 #include "mvx_analyse_kernel.h"
 
 // -DMVX_FAST_PROF (tools/build_variant.py; read back by tools/fastprof.py): cycles of ONE chain per phase of the block loop, stamped with

@@ -31,6 +31,7 @@
 // slots: Hex2 levels: 0-5 hexagon, 6-13 square, 14 up, 15 ahead, 16 zero, 17 global, 18 hierarchical; exhaustive levels: 0-23 rings 1 and 2, 24 up, 25 ahead, 26 zero, 27 global, 28 hierarchical
 #define SPEC_SLOTS_HEX 19
 #define SPEC_SLOTS_EXH 29
+#define MVX_FAST_NOSTRIP 8                // flags: no runs in pass A (every block's candidates loaded on their own)
 #define MVX_FAST_NOSPEC 4                 // flags: verify nothing, search every block live (developer switch: the same kernel as a plain serial walk)
 
 // -DMVX_SPEC_ABL=n (tools/build_variant.py): timing-only ablations of pass A, results are WRONG -- 1: no zero / global / hierarchical pass on Hex2
@@ -38,11 +39,25 @@
 #ifndef MVX_SPEC_ABL
 #define MVX_SPEC_ABL 0
 #endif
+// -DMVX_SPEC_PROF (tools/specprof.py): cycles of ONE chain per phase of the group loop (s_memtime; a stamp waits for the scalar counter only)
+#ifdef MVX_SPEC_PROF
+#define SPROF_N 16
+static __device__ unsigned long long g_specprof[SPROF_N];
+#define SPROF(i) do { const long long t1_ = (long long)__builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" : : "s"(t1_) : "memory"); sprof[i] += t1_ - sprofT; sprofT = t1_; } while (0)
+#else
+#define SPROF(i) ((void)0)
+#endif
+#ifdef MVX_SPEC_PROF
+#define SPEC_PROF_DUMP_() do { if (l == 0 && chain == 5) for (int i = 0; i < SPROF_N; i++) g_specprof[i] = (unsigned long long)S.sprof[i]; } while (0)
+#else
+#define SPEC_PROF_DUMP_() ((void)0)
+#endif
 #ifdef MVX_SPEC_STATS
 static __device__ unsigned long long g_specstat[MVX_MAX_LEVELS][4]; // per level: blocks in speculated rows, of them searched live, live because the flag was clear, rescues
 #endif
 
-template <int BPS, int BW, bool UV> struct SpecSearcher : FastSearcher<BPS, BW, UV> {
+// SWIN: row loads a lane keeps in flight in the row passes (12 = half a pass; 24 = a whole pass: the builds with 256 registers)
+template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSearcher<BPS, BW, UV> {
     typedef FastSearcher<BPS, BW, UV> F;
     typedef FGeo<BPS, BW> G;
     using F::P; using F::J; using F::lds; using F::ldsRow; using F::ldsHist; using F::histBins;
@@ -54,6 +69,9 @@ template <int BPS, int BW, bool UV> struct SpecSearcher : FastSearcher<BPS, BW, 
     using F::x0; using F::y0; using F::blkIdx; using F::nDxMin; using F::nDyMin; using F::nDxMax; using F::nDyMax;
     using F::predX; using F::predY; using F::pX; using F::pY; using F::nLambda; using F::bestX; using F::bestY; using F::bestSad;
     int ldsTab; // byte offset of the SAD table inside the chain's LDS
+#ifdef MVX_SPEC_PROF
+    long long sprof[SPROF_N], sprofT; // 0 barrier, 1 fetch + A1, 2 row passes, 3 one-block passes, 4 A2, 5 verification, 6 live blocks, 7 results, 8 level prologue, 9 groups, 10 live blocks counted
+#endif
 
     __device__ SpecSearcher(const AParams &p, const AJob &j) : F(p, j) {}
 
@@ -114,7 +132,7 @@ template <int BPS, int BW, bool UV> struct SpecSearcher : FastSearcher<BPS, BW, 
         for (int k = 0; k < Q::W; k++) T.r[k] = pass_issue(T, k);
     }
     // consume the block whose first W pieces are in flight (SADs into T.aL / T.aC), refilling the window; (nA, nB) = start of the NEXT block's candidate
-    template <int LOGG, int WMAX> __device__ __forceinline__ void pass_run(Pass<LOGG, WMAX> &T, int s, unsigned nA, unsigned nB) const {
+    template <int LOGG, int WMAX, bool REFILL = true> __device__ __forceinline__ void pass_run(Pass<LOGG, WMAX> &T, int s, unsigned nA, unsigned nB) const {
         typedef PG<LOGG, WMAX> Q;
         const int rowA = s >> G::LLOGC, xbA = (s & (Q::CA - 1)) * G::LCB, rowB = s >> G::UVLOGC, xbB = (s & (Q::CB - 1)) * G::UVCB;
         const lds_u8 *spA = lds + rowA * G::LROWB + xbA, *spB = lds + G::UOFF + rowB * G::UVROWB + xbB;
@@ -136,13 +154,67 @@ template <int BPS, int BW, bool UV> struct SpecSearcher : FastSearcher<BPS, BW, 
             asm volatile("" : "+v"(aL), "+v"(aC) : : "memory");
             const int kk = k + Q::W;
             if (kk == Q::NT) { T.curA = nA; T.curB = nB; } // the window moves on to the next block
-            T.r[k % Q::W] = pass_issue(T, kk % Q::NT);
+            if (REFILL || kk < Q::NT) T.r[k % Q::W] = pass_issue(T, kk % Q::NT); // (REFILL = false: the last block of a list)
         }
         T.aL = aL; T.aC = aC;
     }
 
+    // ---- pass A for RUNS of blocks with one displacement (r4, third form).  Blocks overlap by half, so a run of L blocks with the same
+    // candidate vector reads ONE contiguous strip of L + 1 sixteen-byte columns per reference row, and the SAD of block m is the sum of the
+    // column sums m and m + 1 -- every column sum is shared by the two blocks that cover it.  Eight lanes per candidate (lane p = column p,
+    // up to seven blocks), eight candidates per pass, 24 rows (16 luma + 8 of the UV plane) per lane and pass.  Against one block at a time:
+    // 128 contiguous bytes per candidate row instead of 7 x 32 scattered ones (~2.3x fewer L1 misses, 3.5x fewer look-ups), half the SADs.
+    // The source blocks of the run are one strip in LDS (3 KB: 24 rows x 8 columns).
+    static constexpr bool STRIP_OK = UV && BPS == 2 && BW == 16;
+    static constexpr int SW_BLOCKS = 7, SNA = 16, SNB = 8, SNT = SNA + SNB, SW = SWIN, S_UV = SNA * 128; // window of blocks, rows, loads in flight, LDS offset of the UV rows
+    struct StripPass { v4u r[SW]; unsigned curA, curB, aL, aC; };
+    __device__ __forceinline__ v4u strip_issue(StripPass &T, int piece) const {
+        v4u v;
+        if (piece < SNA) { v = F::template ld_ref<16>(refY + T.curA); T.curA += pitchY; asm volatile("" : "+v"(T.curA) : : "memory"); }
+        else { v = F::template ld_ref<16>(refUV + T.curB); T.curB += 2 * pitchC; asm volatile("" : "+v"(T.curB) : : "memory"); }
+        return v;
+    }
+    __device__ __forceinline__ void strip_prime(StripPass &T, unsigned oA, unsigned oB) const {
+        T.curA = oA; T.curB = oB;
+#pragma unroll
+        for (int k = 0; k < SW; k++) T.r[k] = strip_issue(T, k);
+    }
+    template <bool REFILL> __device__ __forceinline__ void strip_run(StripPass &T, int p, unsigned nA, unsigned nB) const {
+        const lds_u8 *sp = lds + p * 16;
+        auto src_piece = [&](int k) { return F::template lds_piece<16>(sp + (k < SNA ? k * 128 : S_UV + (k - SNA) * 128)); };
+        constexpr int D = MVX_SRC_AHEAD;
+        v4u a[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) a[k] = src_piece(k);
+        unsigned aL = 0, aC = 0;
+#pragma unroll
+        for (int k = 0; k < SNT; k++) {
+            const v4u cur = a[k % D];
+            if (k + D < SNT) a[k % D] = src_piece(k + D);
+            if (k < SNA) aL = F::template sad_regs<16>(cur, T.r[k % SW], aL);
+            else aC = F::template sad_regs<16>(cur, T.r[k % SW], aC);
+            asm volatile("" : "+v"(aL), "+v"(aC) : : "memory");
+            const int kk = k + SW;
+            if (kk == SNT) { T.curA = nA; T.curB = nB; }
+            if (REFILL || kk < SNT) T.r[k % SW] = strip_issue(T, kk % SNT);
+        }
+        T.aL = aL; T.aC = aC;
+    }
+    // offsets (dx, dy) of pattern point idx in the reference's order: Hex2 levels 0-5 hexagon (:682-687), 6-13 square (:636-658); exhaustive levels rings 1 and 2 (:786-791)
+    __device__ __forceinline__ static void pat_delta(bool hex, int idx, int &dx, int &dy) {
+        dx = 0; dy = 0;
+        if (hex) {
+            if (idx < 6) { dx = tab8(HEX2X >> 8, idx & 7); dy = tab8(HEX2Y >> 8, idx & 7); }
+            else if (idx < 14) { dx = tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), idx - 6); dy = tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), idx - 6); }
+        } else {
+            if (idx < 8) { dx = tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), idx); dy = tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), idx); }
+            else if (idx < 16) { dx = tab8(PACK8(-1, -1, 0, 0, 1, 1, -2, 2), idx - 8); dy = tab8(PACK8(-2, 2, -2, 2, -2, 2, -1, -1), idx - 8); }
+            else if (idx < 24) { dx = tab8(PACK8(-2, 2, -2, 2, -2, -2, 2, 2), idx - 16); dy = tab8(PACK8(0, 0, 1, 1, -2, 2, -2, 2), idx - 16); }
+        }
+    }
+
     // GroupOfPlanes.c:69-125 + PlaneOfBlocks.cpp:971-1131 for one level, in groups of SPEC_TB blocks
-    __device__ __forceinline__ void search_level_spec(int lvl, int globalX, int globalY, GL_AS const GVec *coarse, int coarseBlkX, int coarseBlkY, int coarseLogPel, int syncEvery, bool specEnabled) {
+    __device__ __forceinline__ void search_level_spec(int lvl, int globalX, int globalY, GL_AS const GVec *coarse, int coarseBlkX, int coarseBlkY, int coarseLogPel, int syncEvery, bool specEnabled, bool stripEnabled) {
         const int l = lane_id();
         const ALevel &L = P.lv[lvl];
         nBlkX = uni(L.nBlkX); nBlkY = uni(L.nBlkY); pel = uni(L.pel); logPel = uni(L.logPel);
@@ -181,8 +253,9 @@ template <int BPS, int BW, bool UV> struct SpecSearcher : FastSearcher<BPS, BW, 
         const int hps = hpad >> lvl, vps = vpad >> lvl; // :1091-1092
         const bool meander = uni(P.meander) != 0;
         LDS_AS v2u *rowbuf = (LDS_AS v2u *)(lds + ldsRow); // the previous block row's results, 8 bytes per block: (x | y << 16, sad)
-        lds_u8 *tab = lds + ldsTab;
+        lds_u8 *tab = lds + ldsRow + ((nBlkX * 8 + 15) & ~15); // the group's SAD table follows the row buffer of THIS level (the host sizes the chain's LDS for the worst level)
         this->pf_setup();
+        SPROF(8);
         auto lambda_of = [&](int predSad) { // :456-462, fp64 as the reference
             const double scale = (double)LSAD / (double)(LSAD + (long long)(predSad >> 1));
             return (int)(long long)((double)(long long)nLambdaLevel * scale * scale);
@@ -201,11 +274,26 @@ template <int BPS, int BW, bool UV> struct SpecSearcher : FastSearcher<BPS, BW, 
             else if (g < 16) { rdx = tab8(PACK8(-1, -1, 0, 0, 1, 1, -2, 2), k); rdy = tab8(PACK8(-2, 2, -2, 2, -2, 2, -1, -1), k); }
             else if (g < 24) { rdx = tab8(PACK8(-2, 2, -2, 2, -2, -2, 2, 2), k - 8); rdy = tab8(PACK8(0, 0, 1, 1, -2, 2, -2, 2), k - 8); }
         }
+        // the pattern offsets of this lane's candidates in the row passes, one byte per pass (dx in the low, dy in the high nibble): a table
+        // look-up by lane inside the pass loop would keep a dozen 64-bit table constants in vector registers across the whole level
+        unsigned sPat = 0, bPat0 = 0, bPat1 = 0;
+        {
+            const int gb = l >= 42 ? 3 : l >= 28 ? 2 : l >= 14 ? 1 : 0;
+            for (int q = 0; q < 8; q++) {
+                int dx, dy;
+                if (q < 4) { pat_delta(hexLevel, q * 8 + (l >> 3), dx, dy); sPat |= (unsigned)((dx & 15) | ((dy & 15) << 4)) << (8 * q); }
+                pat_delta(hexLevel, q * 4 + gb, dx, dy);
+                const unsigned b = (unsigned)((dx & 15) | ((dy & 15) << 4)) << (8 * (q & 3));
+                if (q < 4) bPat0 |= b; else bPat1 |= b;
+            }
+        }
 #ifdef MVX_SPEC_STATS
         unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
 #endif
 
         int prevX = 0, prevY = 0, prevSad = 0;
+        int syncCount = 0;
+        if (syncEvery > 0 && syncEvery < 32) syncEvery = 32; // (a group is the unit)
         for (int blky = 0; blky < nBlkY; blky++) {
             const bool fwd = (blky & 1) == 0 || !meander;
             const int dir = fwd ? 1 : -1;
@@ -221,24 +309,21 @@ template <int BPS, int BW, bool UV> struct SpecSearcher : FastSearcher<BPS, BW, 
                 const int ncol = min(64, nBlkX - c0);
                 // ---- 64 columns at a time (lane i <-> column c0 + i): the interpolated predictors of this row and of the blocks "below-ahead",
                 // the previous row's results; lambda lane-parallel (:456-462)
-                v4u bSelf = {0, 0, 0, 0}, bBelow = {0, 0, 0, 0}, bOut = {0, 0, 0, 0};
-                unsigned upPk = 0, upSad = 0;
-                if (in) {
-                    bSelf = this->ld_batch(&vectors[blky * nBlkX + c]);
-                    if (!smallestPlane) bSelf[3] = (unsigned)lambda_of((int)bSelf[2]);
-                    const int cb = c + dir;
-                    if (blky < nBlkY - 1 && cb >= 0 && cb < nBlkX) bBelow = this->ld_batch(&vectors[(blky + 1) * nBlkX + cb]);
-                    if (blky > 0) { const v2u t = rowbuf[c]; upPk = t[0]; upSad = t[1]; }
-                }
+                // ---- 64 columns at a time (lane i <-> column c0 + i).  What a group keeps in registers across its passes is little: the results and,
+                // in speculated rows, four packed predictors and lambda per block; the live search of a single block reads its predictors itself.
+                v4u bOut = {0, 0, 0, 0};
                 for (int hi = 0; hi < 2; hi++) {
                     const int h = fwd ? hi : 1 - hi;
                     const int lo = h * SPEC_TB, hiE = min(lo + SPEC_TB, ncol);
                     if (lo >= ncol) continue;
-                    if (syncEvery) __builtin_amdgcn_s_barrier(); // keeps the chains of a workgroup on neighbouring blocks (shared reference lines)
+                    SPROF(7);
+                    if (syncEvery && (syncCount++ & ((syncEvery >> 5) - 1)) == 0) __builtin_amdgcn_s_barrier(); // keeps the chains of a workgroup on neighbouring blocks (shared reference lines): every syncEvery / 32 groups
+                    SPROF(0);
                     const bool act = l >= lo && l < hiE;
                     unsigned long long okmask = 0, flagmask = 0;
                     int rX = 0, rY = 0, rSad = 0;          // this lane's block: speculative result
                     int pkU = 0, pkAh = 0, pkH = 0, pkG = 0; // this lane's block: clipped up / ahead / hierarchical / global predictors
+                    int lam = 0;                             // this lane's block: lambda
                     int gEndX = gmvx;
                     if (specRow) {
                         // ======== A1: one lane per block -- limits (:1094-1097) and the predictors that do not depend on the left neighbour (:427-449)
@@ -246,6 +331,16 @@ template <int BPS, int BW, bool UV> struct SpecSearcher : FastSearcher<BPS, BW, 
                         const int dxMin = -((xs + hps) << logPel), dxMax1 = ((pw - xs - hpad - BW - hpad + hps) << logPel) - 1;
                         auto cx = [&](int v) { return min(max(v, dxMin), dxMax1); };
                         auto cy = [&](int v) { return min(max(v, nDyMin), nDyMax - 1); };
+                        // the interpolated predictors of this row and of the blocks "below-ahead", the previous row's results (one load each per 64 columns)
+                        v4u bSelf = {0, 0, 0, 0}, bBelow = {0, 0, 0, 0};
+                        unsigned upPk = 0;
+                        if (in) {
+                            bSelf = this->ld_batch(&vectors[blky * nBlkX + c]);
+                            const int cb = c + dir;
+                            if (blky < nBlkY - 1 && cb >= 0 && cb < nBlkX) bBelow = this->ld_batch(&vectors[(blky + 1) * nBlkX + cb]);
+                            upPk = rowbuf[c][0];
+                        }
+                        lam = in ? lambda_of((int)bSelf[2]) : 0; // :456-462 lane-parallel (fp64): every level but the coarsest scales lambda by the block's OWN interpolated SAD
                         const int ux = cx(upx((int)upPk)), uy = cy(upy((int)upPk));
                         pkU = pk(ux, uy);
                         const bool aheadCol = fwd ? c < nBlkX - 1 : c > 0;
@@ -275,8 +370,154 @@ template <int BPS, int BW, bool UV> struct SpecSearcher : FastSearcher<BPS, BW, 
                         const bool streamed = chroma && (hexLevel ? STREAM_HEX : STREAM_EXH);
                         if (streamed) {
                             const int pkZ = pk(0, fieldShift);
-                            A4x32 pf[G::NPF];
-                            this->pf_issue(hpad + stepX * (c0 + (fwd ? lo : hiE - 1)), y0, pf);
+                            const int slotUp = hexLevel ? 14 : 24, slotZ = hexLevel ? 16 : 26; // (ahead = slotUp + 1, global / hierarchical = slotZ + 1 / + 2)
+                            unsigned long long pbMask = __ballot(act), p3Mask = 0; // blocks evaluated one at a time: every candidate / only ahead, global, hierarchical
+
+                            SPROF(1);
+                            // ======== A, row passes: windows of seven columns.  Every pass loads ONE row per lane and load instruction (24 rows: 16 luma,
+                            // 8 of the UV plane), against the window's source strip in LDS.  Strip form (the window's blocks share the up predictor and keep
+                            // the whole pattern inside their limits): lane = (candidate, 16-byte column), eight candidates per pass.  Block form (any
+                            // vectors): lane = (candidate, block, half), four candidates per pass -- neighbouring blocks with similar vectors still read
+                            // neighbouring bytes of the same lines in the same instruction.
+                            if constexpr (STRIP_OK) {
+                                if (stripEnabled && stepX == BW / 2) {
+                                    const int nw = (nb + SW_BLOCKS - 1) / SW_BLOCKS;
+                                    const bool ok2 = (ux - 2 >= dxMin) & (ux + 2 <= dxMax1) & (uy - 2 >= nDyMin) & (uy + 2 < nDyMax);
+                                    unsigned stripW = 0; // windows in strip form
+                                    for (int w = 0; w < nw; w++) {
+                                        const int f = lo + SW_BLOCKS * w, e = min(f + SW_BLOCKS, hiE);
+                                        const bool inw = (l >= f) & (l < e);
+                                        const int u0 = __builtin_amdgcn_readlane(pkU, f);
+                                        if (e - f >= 2 && __ballot(inw & ((pkU != u0) | !ok2)) == 0) stripW |= 1u << w;
+                                    }
+                                    pbMask = 0;
+                                    const int npat = hexLevel ? 14 : 24;
+                                    const int NQS = hexLevel ? 3 : 5;  // strip form: pattern + up + zero in passes of eight, then one block-form pass for ahead / global / hierarchical
+                                    const int NQB = hexLevel ? 5 : 8;  // block form: pattern, up, ahead, zero, global, hierarchical in passes of four
+                                    // lane roles: strip form (candidate l >> 3, column l & 7); block form (candidate l / 14, block (l % 14) >> 1, half l & 1)
+                                    // (the roles are recomputed from an opaque lane number in every pass: values derived from the lane number are loop
+                                    // invariants, the compiler hoists all of them to the top of the level and then has to spill them -- 177 spilled registers)
+                                    int lq = l;
+                                    asm volatile("" : "+v"(lq));
+                                    int gS = lq >> 3, pS = lq & 7;
+                                    int gB = lq >= 42 ? 3 : lq >= 28 ? 2 : lq >= 14 ? 1 : 0;
+                                    int rB = lq >= 56 ? lq - 56 : lq - 14 * gB, mB = rB >> 1, hB = rB & 1; // (lanes 56-63 repeat candidate 3 of block 0..3 and write nothing)
+                                    bool idleB = lq >= 56;
+                                    auto roles = [&]() {
+                                        lq = l;
+                                        asm volatile("" : "+v"(lq));
+                                        gS = lq >> 3; pS = lq & 7;
+                                        gB = lq >= 42 ? 3 : lq >= 28 ? 2 : lq >= 14 ? 1 : 0;
+                                        rB = lq >= 56 ? lq - 56 : lq - 14 * gB; mB = rB >> 1; hB = rB & 1;
+                                        idleB = lq >= 56;
+                                    };
+                                    // this lane's share of pass q of window w: table slot (-1: nothing to write), source column, first reference piece
+                                    auto w_cand = [&](int w, int q, int &slot, int &L, int &srcCol, unsigned &oA, unsigned &oB) {
+                                        const int f = lo + SW_BLOCKS * w;
+                                        L = min(SW_BLOCKS, hiE - f);
+                                        const bool strip = (stripW >> w) & 1;
+                                        const int bxf = hpad + stepX * (c0 + f);
+                                        if (strip && q < NQS - 1) {
+                                            const int sU = __builtin_amdgcn_readlane(pkU, f);
+                                            const int idx = q * 8 + gS;
+                                            const int dd = (int)(sPat >> (8 * q)), dx = (dd << 28) >> 28, dy = (dd << 24) >> 28;
+                                            slot = idx < npat ? idx : idx == npat ? slotUp : idx == npat + 1 ? slotZ : -1;
+                                            const bool isZ = idx == npat + 1;
+                                            const int base = isZ ? pkZ : sU;
+                                            const int vx = upx(base) + dx, vy = upy(base) + dy, vyc = isZ ? 0 : vy;
+                                            const int pe = min(pS, L) * 16; // (columns beyond the run re-read its last one)
+                                            if (pS >= L) slot = -1;
+                                            srcCol = pS;
+                                            oA = luma_off_at(bxf, vx, vy) + (unsigned)pe;
+                                            oB = 2 * chroma_off_at(bxf, vx, vyc) + (unsigned)pe;
+                                        } else {
+                                            // block form: candidate list of the window: strip windows: ahead, global, hierarchical; others: pattern 0.., up, ahead, zero, global, hierarchical
+                                            const int ci = strip ? gB : q * 4 + gB;
+                                            const int me = min(mB, L - 1), col = f + me; // (lanes beyond the window repeat its last block)
+                                            const int bU = __builtin_amdgcn_ds_bpermute(col << 2, pkU), bAh = __builtin_amdgcn_ds_bpermute(col << 2, pkAh);
+                                            const int bG = __builtin_amdgcn_ds_bpermute(col << 2, pkG), bH = __builtin_amdgcn_ds_bpermute(col << 2, pkH);
+                                            int base, dx = 0, dy = 0;
+                                            bool isZ = false;
+                                            if (strip) { base = ci == 0 ? bAh : ci == 1 ? bG : bH; slot = ci == 0 ? slotUp + 1 : ci == 1 ? slotZ + 1 : ci == 2 ? slotZ + 2 : -1; }
+                                            else {
+                                                const int dd = (int)((q < 4 ? bPat0 : bPat1) >> (8 * (q & 3)));
+                                                dx = (dd << 28) >> 28; dy = (dd << 24) >> 28;
+                                                const int k = ci - npat; // 0 up, 1 ahead, 2 zero, 3 global, 4 hierarchical
+                                                base = k == 1 ? bAh : k == 2 ? pkZ : k == 3 ? bG : k == 4 ? bH : bU;
+                                                isZ = k == 2;
+                                                slot = ci < npat ? ci : k == 0 ? slotUp : k == 1 ? slotUp + 1 : k <= 4 ? slotZ + k - 2 : -1;
+                                            }
+                                            const int bx0 = hpad + stepX * (c0 + col);
+                                            const int xMax = (pw - bx0 - BW - hpad + hps) << logPel, xMin = -((bx0 - hpad + hps) << logPel);
+                                            const int cxv = upx(base), cyv = upy(base), tx = cxv + dx, ty = cyv + dy;
+                                            const bool ok = (tx >= xMin) & (ty >= nDyMin) & (tx < xMax) & (ty < nDyMax); // (outside the block's limits: the centre instead; A2 never reads the entry)
+                                            const int vx = ok ? tx : cxv, vy = ok ? ty : cyv, vyc = isZ ? 0 : vy;
+                                            if (idleB | (hB != 0) | (mB >= L)) slot = -1;
+                                            srcCol = me + hB;
+                                            oA = luma_off_at(bx0, vx, vy) + (unsigned)(hB * 16);
+                                            oB = 2 * chroma_off_at(bx0, vx, vyc) + (unsigned)(hB * 16);
+                                        }
+                                    };
+                                    // the source strip of window w: lane = (row l >> 3 of 8, column l & 7); luma rows r and r + 8, UV row r
+                                    A4x32 sa0, sa1, sb;
+                                    auto stage_issue = [&](int w) {
+                                        const int f = lo + SW_BLOCKS * w, L = min(SW_BLOCKS, hiE - f), bx0 = hpad + stepX * (c0 + f), pe = min(pS, L) * 16;
+                                        const unsigned oy = (unsigned)(y0 + gS) * pitchY + (unsigned)bx0 * BPS + (unsigned)pe;
+                                        sa0 = ld_chunk_g(srcY + oy, 16); sa1 = ld_chunk_g(srcY + oy + 8 * pitchY, 16);
+                                        sb = ld_chunk_g(srcUV + (unsigned)((y0 >> 1) + gS) * 2 * pitchC + (unsigned)(bx0 >> 1) * 2 * BPS + (unsigned)pe, 16);
+                                    };
+                                    auto stage_store = [&]() {
+                                        st_chunk_l(lds + gS * 128 + pS * 16, sa0, 16); st_chunk_l(lds + (gS + 8) * 128 + pS * 16, sa1, 16);
+                                        st_chunk_l(lds + S_UV + gS * 128 + pS * 16, sb, 16);
+                                    };
+                                    // (a leading-edge prefetch -- one dword of every line a window two ahead will need, four scattered loads per window --
+                                    // was measured and removed: 493 -> 544 ms per 2046-chain launch, profiles/r4_spec_prefetch.txt)
+                                    auto widx = [&](int i) { return fwd ? i : nw - 1 - i; }; // windows in walk order
+                                    int wi = 0, w = widx(0), q = 0;
+                                    StripPass T;
+                                    int slot, L, srcCol; unsigned oA, oB;
+                                    w_cand(w, q, slot, L, srcCol, oA, oB);
+                                    strip_prime(T, oA, oB);
+                                    stage_issue(w);
+                                    for (;;) {
+                                        // the pass after this one (its loads refill the window of loads while this one is consumed)
+                                        roles();
+                                        const bool stripNow = (stripW >> w) & 1;
+                                        int wn = w, qn = q + 1, win = wi;
+                                        if (qn >= (stripNow ? NQS : NQB)) { qn = 0; win = wi + 1; wn = widx(win); }
+                                        const bool more = win < nw;
+                                        int slotN = -1, LN = 0, srcN = 0; unsigned nA = 0, nB = 0;
+                                        SPROF(2);
+                                        if (more) w_cand(wn, qn, slotN, LN, srcN, nA, nB);
+                                        SPROF(11);
+                                        if (q == 0) { // a new window: its source strip (requested one window ahead)
+                                            __builtin_amdgcn_wave_barrier();
+                                            stage_store();
+                                            if (wi + 1 < nw) stage_issue(widx(wi + 1));
+                                            __builtin_amdgcn_wave_barrier();
+                                        }
+                                        SPROF(12);
+                                        if (more) strip_run<true>(T, srcCol, nA, nB); else strip_run<false>(T, srcCol, 0, 0);
+                                        SPROF(13);
+                                        // strip form: block m = columns m and m + 1; block form: the two halves of a block sit in neighbouring lanes
+                                        const bool stripPass = stripNow && q < NQS - 1;
+                                        const unsigned nL = stripPass ? (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aL, 0x101, 0xf, 0xf, true) : (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aL, 0xB1, 0xf, 0xf, true);
+                                        const unsigned nC = stripPass ? (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aC, 0x101, 0xf, 0xf, true) : (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aC, 0xB1, 0xf, 0xf, true);
+                                        const int colW = lo + SW_BLOCKS * w + (stripPass ? pS : mB);
+                                        if (slot >= 0) *(LDS_AS v2u *)(tab + slot * SPEC_STRIDE + (colW & (SPEC_TB - 1)) * 8) = v2u{T.aL + nL, T.aC + nC};
+                                        SPROF(14);
+#ifdef MVX_SPEC_PROF
+                                        sprof[15] += 1;
+#endif
+                                        if (!more) break;
+                                        w = wn; wi = win; q = qn; slot = slotN; L = LN; srcCol = srcN;
+                                    }
+                                    __builtin_amdgcn_wave_barrier();
+                                }
+                            }
+
+                            SPROF(2);
+                            // ======== A, one block at a time: what no run covers
                             // the candidates of block li (lane roles as in the table's slots), clipped to what may be loaded: a candidate outside the
                             // block's limits is replaced by the centre (its table entry is never read: A2 checks the limits itself)
                             auto r_cand = [&](int li, int &bx0, int &vx, int &vy, int &vyc) { // pattern pass (Hex2 levels) / the only pass (exhaustive levels)
@@ -296,64 +537,111 @@ template <int BPS, int BW, bool UV> struct SpecSearcher : FastSearcher<BPS, BW, 
                                 vx = ok ? tx : cxv; vy = ok ? ty : cyv;
                                 vyc = (!hexLevel && (l >> 1) == 26) ? 0 : vy; // the zero candidate's chroma ignores fieldShift (:836-839)
                             };
-                            auto p_cand = [&](int li, int &bx0, int &vx, int &vy, int &vyc) { // zero, global, hierarchical (Hex2 levels)
+                            // three candidates, 1 << LOGGP lanes each: zero (ahFirst: ahead), global, hierarchical
+                            auto p_cand = [&](int li, bool ahFirst, int &bx0, int &vx, int &vy, int &vyc) {
                                 bx0 = hpad + stepX * (c0 + li);
                                 const int g = l >> LOGGP;
-                                const int sH = __builtin_amdgcn_readlane(pkH, li), sG = __builtin_amdgcn_readlane(pkG, li);
-                                const int base = g == 1 ? sG : g == 2 ? sH : pkZ;
-                                vx = upx(base); vy = upy(base); vyc = g == 1 || g == 2 ? vy : 0;
+                                const int sH = __builtin_amdgcn_readlane(pkH, li), sG = __builtin_amdgcn_readlane(pkG, li), sAh = __builtin_amdgcn_readlane(pkAh, li);
+                                const int base = g == 1 ? sG : g == 2 ? sH : ahFirst ? sAh : pkZ;
+                                vx = upx(base); vy = upy(base); vyc = ((g == 1) | (g == 2) | ahFirst) ? vy : 0;
                             };
-                            if (hexLevel) {
-                                if constexpr (STREAM_HEX) {
-                                    Pass<2, 12> R; Pass<LOGGP, 4> Z;
-                                    const int sR = l & 3, sZ = l & ((1 << LOGGP) - 1);
-                                    {
-                                        const int li = fwd ? lo : hiE - 1;
-                                        int bx0, vx, vy, vyc; unsigned oA, oB;
-                                        r_cand(li, bx0, vx, vy, vyc); this->template pass_start<2, 12>(sR, bx0, vx, vy, vyc, oA, oB); this->template pass_prime<2, 12>(R, oA, oB);
-                                        p_cand(li, bx0, vx, vy, vyc); this->template pass_start<LOGGP, 4>(sZ, bx0, vx, vy, vyc, oA, oB); this->template pass_prime<LOGGP, 4>(Z, oA, oB);
+                            auto first_of = [](unsigned long long m) { return (int)__builtin_ctzll(m); };
+                            if (pbMask) {
+                                A4x32 pf[G::NPF];
+                                unsigned long long m = pbMask;
+                                int li = first_of(m);
+                                m &= m - 1;
+                                this->pf_issue(hpad + stepX * (c0 + li), y0, pf);
+                                if (hexLevel) {
+                                    if constexpr (STREAM_HEX) {
+                                        Pass<2, 12> R; Pass<LOGGP, 4> Z;
+                                        const int sR = l & 3, sZ = l & ((1 << LOGGP) - 1);
+                                        {
+                                            int bx0, vx, vy, vyc; unsigned oA, oB;
+                                            r_cand(li, bx0, vx, vy, vyc); this->template pass_start<2, 12>(sR, bx0, vx, vy, vyc, oA, oB); this->template pass_prime<2, 12>(R, oA, oB);
+                                            p_cand(li, false, bx0, vx, vy, vyc); this->template pass_start<LOGGP, 4>(sZ, bx0, vx, vy, vyc, oA, oB); this->template pass_prime<LOGGP, 4>(Z, oA, oB);
+                                        }
+                                        for (;;) {
+                                            const bool more = m != 0;
+                                            const int lin = more ? first_of(m) : li;
+                                            m &= m - 1;
+                                            __builtin_amdgcn_wave_barrier();
+                                            this->pf_store(pf); // (PlaneOfBlocks.cpp:1058-1079)
+                                            if (more) this->pf_issue(hpad + stepX * (c0 + lin), y0, pf);
+                                            int bx0, vx, vy, vyc; unsigned nA = 0, nB = 0, mA = 0, mB = 0;
+                                            if (more) {
+                                                r_cand(lin, bx0, vx, vy, vyc); this->template pass_start<2, 12>(sR, bx0, vx, vy, vyc, nA, nB);
+                                                p_cand(lin, false, bx0, vx, vy, vyc); this->template pass_start<LOGGP, 4>(sZ, bx0, vx, vy, vyc, mA, mB);
+                                            }
+                                            __builtin_amdgcn_wave_barrier();
+                                            if (more) { this->template pass_run<2, 12, true>(R, sR, nA, nB); this->template pass_run<LOGGP, 4, true>(Z, sZ, mA, mB); }
+                                            else { this->template pass_run<2, 12, false>(R, sR, 0, 0); this->template pass_run<LOGGP, 4, false>(Z, sZ, 0, 0); }
+                                            const int ti8 = (li & (SPEC_TB - 1)) * 8;
+                                            group_sum2<2>(R.aL, R.aC);
+                                            if (sR == 0) *(LDS_AS v2u *)(tab + (l >> 2) * SPEC_STRIDE + ti8) = v2u{R.aL, R.aC};
+                                            group_sum2<LOGGP>(Z.aL, Z.aC);
+                                            if ((sZ == 0) & ((l >> LOGGP) < 3)) *(LDS_AS v2u *)(tab + (16 + (l >> LOGGP)) * SPEC_STRIDE + ti8) = v2u{Z.aL, Z.aC};
+                                            if (!more) break;
+                                            li = lin;
+                                        }
                                     }
-                                    for (int i = 0; i < nb; i++) {
-                                        const int li = fwd ? lo + i : hiE - 1 - i;
-                                        const int lin = i + 1 < nb ? li + dir : li; // (the last block of a group refills its window with its own pieces: dropped)
-                                        __builtin_amdgcn_wave_barrier();
-                                        this->pf_store(pf); // (PlaneOfBlocks.cpp:1058-1079)
-                                        if (i + 1 < nb) this->pf_issue(hpad + stepX * (c0 + lin), y0, pf);
-                                        int bx0, vx, vy, vyc; unsigned nA, nB, mA, mB;
-                                        r_cand(lin, bx0, vx, vy, vyc); this->template pass_start<2, 12>(sR, bx0, vx, vy, vyc, nA, nB);
-                                        p_cand(lin, bx0, vx, vy, vyc); this->template pass_start<LOGGP, 4>(sZ, bx0, vx, vy, vyc, mA, mB);
-                                        __builtin_amdgcn_wave_barrier();
-                                        this->template pass_run<2, 12>(R, sR, nA, nB);
-                                        this->template pass_run<LOGGP, 4>(Z, sZ, mA, mB);
-                                        const int ti8 = (li & (SPEC_TB - 1)) * 8;
-                                        group_sum2<2>(R.aL, R.aC);
-                                        if (sR == 0) *(LDS_AS v2u *)(tab + (l >> 2) * SPEC_STRIDE + ti8) = v2u{R.aL, R.aC};
-                                        group_sum2<LOGGP>(Z.aL, Z.aC);
-                                        if ((sZ == 0) & ((l >> LOGGP) < 3)) *(LDS_AS v2u *)(tab + (16 + (l >> LOGGP)) * SPEC_STRIDE + ti8) = v2u{Z.aL, Z.aC};
+                                } else {
+                                    if constexpr (STREAM_EXH) {
+                                        Pass<1, 12> R;
+                                        const int sR = l & 1;
+                                        {
+                                            int bx0, vx, vy, vyc; unsigned oA, oB;
+                                            r_cand(li, bx0, vx, vy, vyc); this->template pass_start<1, 12>(sR, bx0, vx, vy, vyc, oA, oB); this->template pass_prime<1, 12>(R, oA, oB);
+                                        }
+                                        for (;;) {
+                                            const bool more = m != 0;
+                                            const int lin = more ? first_of(m) : li;
+                                            m &= m - 1;
+                                            __builtin_amdgcn_wave_barrier();
+                                            this->pf_store(pf);
+                                            if (more) this->pf_issue(hpad + stepX * (c0 + lin), y0, pf);
+                                            int bx0, vx, vy, vyc; unsigned nA = 0, nB = 0;
+                                            if (more) { r_cand(lin, bx0, vx, vy, vyc); this->template pass_start<1, 12>(sR, bx0, vx, vy, vyc, nA, nB); }
+                                            __builtin_amdgcn_wave_barrier();
+                                            if (more) this->template pass_run<1, 12, true>(R, sR, nA, nB); else this->template pass_run<1, 12, false>(R, sR, 0, 0);
+                                            const int ti8 = (li & (SPEC_TB - 1)) * 8;
+                                            group_sum2<1>(R.aL, R.aC);
+                                            if ((sR == 0) & ((l >> 1) < SPEC_SLOTS_EXH)) *(LDS_AS v2u *)(tab + (l >> 1) * SPEC_STRIDE + ti8) = v2u{R.aL, R.aC};
+                                            if (!more) break;
+                                            li = lin;
+                                        }
                                     }
                                 }
-                            } else {
-                                if constexpr (STREAM_EXH) {
-                                    Pass<1, 12> R;
-                                    const int sR = l & 1;
+                            }
+                            // ahead / global / hierarchical of the runs that do not share them
+                            if constexpr (STRIP_OK) {
+                                if (p3Mask) {
+                                    A4x32 pf[G::NPF];
+                                    unsigned long long m = p3Mask;
+                                    int li = first_of(m);
+                                    m &= m - 1;
+                                    this->pf_issue(hpad + stepX * (c0 + li), y0, pf);
+                                    Pass<LOGGP, 4> Z;
+                                    const int sZ = l & ((1 << LOGGP) - 1), g = l >> LOGGP;
                                     {
-                                        const int li = fwd ? lo : hiE - 1;
                                         int bx0, vx, vy, vyc; unsigned oA, oB;
-                                        r_cand(li, bx0, vx, vy, vyc); this->template pass_start<1, 12>(sR, bx0, vx, vy, vyc, oA, oB); this->template pass_prime<1, 12>(R, oA, oB);
+                                        p_cand(li, true, bx0, vx, vy, vyc); this->template pass_start<LOGGP, 4>(sZ, bx0, vx, vy, vyc, oA, oB); this->template pass_prime<LOGGP, 4>(Z, oA, oB);
                                     }
-                                    for (int i = 0; i < nb; i++) {
-                                        const int li = fwd ? lo + i : hiE - 1 - i;
-                                        const int lin = i + 1 < nb ? li + dir : li;
+                                    for (;;) {
+                                        const bool more = m != 0;
+                                        const int lin = more ? first_of(m) : li;
+                                        m &= m - 1;
                                         __builtin_amdgcn_wave_barrier();
                                         this->pf_store(pf);
-                                        if (i + 1 < nb) this->pf_issue(hpad + stepX * (c0 + lin), y0, pf);
-                                        int bx0, vx, vy, vyc; unsigned nA, nB;
-                                        r_cand(lin, bx0, vx, vy, vyc); this->template pass_start<1, 12>(sR, bx0, vx, vy, vyc, nA, nB);
+                                        if (more) this->pf_issue(hpad + stepX * (c0 + lin), y0, pf);
+                                        int bx0, vx, vy, vyc; unsigned mA = 0, mB = 0;
+                                        if (more) { p_cand(lin, true, bx0, vx, vy, vyc); this->template pass_start<LOGGP, 4>(sZ, bx0, vx, vy, vyc, mA, mB); }
                                         __builtin_amdgcn_wave_barrier();
-                                        this->template pass_run<1, 12>(R, sR, nA, nB);
-                                        const int ti8 = (li & (SPEC_TB - 1)) * 8;
-                                        group_sum2<1>(R.aL, R.aC);
-                                        if ((sR == 0) & ((l >> 1) < SPEC_SLOTS_EXH)) *(LDS_AS v2u *)(tab + (l >> 1) * SPEC_STRIDE + ti8) = v2u{R.aL, R.aC};
+                                        if (more) this->template pass_run<LOGGP, 4, true>(Z, sZ, mA, mB); else this->template pass_run<LOGGP, 4, false>(Z, sZ, 0, 0);
+                                        group_sum2<LOGGP>(Z.aL, Z.aC);
+                                        if ((sZ == 0) & (g < 3)) *(LDS_AS v2u *)(tab + (g == 0 ? slotUp + 1 : slotZ + g) * SPEC_STRIDE + (li & (SPEC_TB - 1)) * 8) = v2u{Z.aL, Z.aC};
+                                        if (!more) break;
+                                        li = lin;
                                     }
                                 }
                             }
@@ -413,13 +701,13 @@ template <int BPS, int BW, bool UV> struct SpecSearcher : FastSearcher<BPS, BW, 
                         }
                         __builtin_amdgcn_wave_barrier();
 
+                        SPROF(3);
                         // ======== A2: one lane per block -- the predictor phase (:832-915) and the refinement (:773-816) under the hypothesis
                         // left == median == up, costs as pobCheckMV0 / pobCheckMV (:219-261), strict < in the reference's order
                         {
                             const int ti8 = (l & (SPEC_TB - 1)) * 8;
                             auto rd = [&](int slot) { return *(const LDS_AS v2u *)(tab + slot * SPEC_STRIDE + ti8); };
                             auto tot = [&](const v2u &t) { return (int)t[0] + (chroma ? (int)t[1] : 0); };
-                            const int lam = (int)bSelf[3]; // (blky > 0, not the coarsest level)
                             auto md = [&](int vx, int vy) { // motion_distortion (:105-114) around the hierarchical predictor
                                 const unsigned dx = (unsigned)(hx - vx), dy = (unsigned)(hy - vy);
                                 const int dist = (int)(dx * dx + dy * dy);
@@ -484,6 +772,7 @@ template <int BPS, int BW, bool UV> struct SpecSearcher : FastSearcher<BPS, BW, 
                         }
                     }
 
+                    SPROF(4);
                     // ======== B: verification in walk order; whatever does not verify is searched live with its true predictors
                     int pos = fwd ? lo : hiE - 1;
                     const int end = fwd ? hiE : lo - 1;
@@ -503,6 +792,7 @@ template <int BPS, int BW, bool UV> struct SpecSearcher : FastSearcher<BPS, BW, 
 #endif
                             if (pos == end) break;
                         }
+                        SPROF(5);
                         { // ---- block `pos` live (the lean kernel's block: predictors :419-463, pobPseudoEPZSearch :819-968)
                             const int li = pos, blkx = c0 + li;
                             A4x32 sb[G::NPF];
@@ -511,11 +801,11 @@ template <int BPS, int BW, bool UV> struct SpecSearcher : FastSearcher<BPS, BW, 
                             x0 = hpad + stepX * blkx;
                             nDxMax = (pw - x0 - BW - hpad + hps) << logPel;
                             nDxMin = -((x0 - hpad + hps) << logPel);
-                            int sfx, sfy, sfs, blx, bly, bls;
-                            this->batch_get(bSelf, li, sfx, sfy, sfs);
-                            this->batch_get(bBelow, li, blx, bly, bls);
-                            const int upk = __builtin_amdgcn_readlane((int)upPk, li), ups = __builtin_amdgcn_readlane((int)upSad, li);
                             const bool aheadCol = fwd ? blkx < nBlkX - 1 : blkx > 0;
+                            int sfx, sfy, sfs, blx = 0, bly = 0, bls = 0, upk = 0, ups = 0;
+                            { const v4u t = this->ld_batch(&vectors[blkIdx]); sfx = uni((int)t[0]); sfy = uni((int)t[1]); sfs = uni((int)t[2]); } // (still the interpolated predictor: results are stored when the group ends)
+                            if (blky < nBlkY - 1 && aheadCol) { const v4u t = this->ld_batch(&vectors[(blky + 1) * nBlkX + blkx + dir]); blx = uni((int)t[0]); bly = uni((int)t[1]); bls = uni((int)t[2]); }
+                            if (blky > 0) { const v2u t = rowbuf[blkx]; upk = uni((int)t[0]); ups = uni((int)t[1]); }
                             const bool useBelow = blky < nBlkY - 1 && aheadCol;
                             const bool useUpAhead = !useBelow && blky > 0 && aheadCol; // last block row only (:441-447)
                             int ahx = blx, ahy = bly, ahs = bls;
@@ -538,7 +828,7 @@ template <int BPS, int BW, bool UV> struct SpecSearcher : FastSearcher<BPS, BW, 
                             if (smallestPlane) { predX = pX[0]; predY = pY[0]; predSad = s0; }
                             else { predX = this->clipx(sfx); predY = this->clipy(sfy); predSad = sfs; }
                             nLambda = 0; // row 0 searches without the motion term (:1081-1084)
-                            if (blky > 0) nLambda = smallestPlane ? uni(lambda_of(predSad)) : __builtin_amdgcn_readlane((int)bSelf[3], li);
+                            if (blky > 0) nLambda = uni(lambda_of(predSad)); // :456-462
                             if (specRow) { const int g = __builtin_amdgcn_readlane(pkG, li); gmvx = upx(g); gmvy = upy(g); } // the running global predictor at this block
                             __builtin_amdgcn_wave_barrier();
                             this->pf_store(sb);
@@ -551,6 +841,10 @@ template <int BPS, int BW, bool UV> struct SpecSearcher : FastSearcher<BPS, BW, 
                             if (specRow) { st0 += 1; st1 += 1; st2 += !((flagmask >> li) & 1); }
 #endif
                             // the next block's hypothesis was checked against this block's SPECULATIVE result: check it against the real one
+                            SPROF(6);
+#ifdef MVX_SPEC_PROF
+                            sprof[10] += 1;
+#endif
                             const int nx = pos + dir;
                             if (specRow && nx != end) {
                                 const int xb = stepX * (c0 + nx);
@@ -564,6 +858,10 @@ template <int BPS, int BW, bool UV> struct SpecSearcher : FastSearcher<BPS, BW, 
                         }
                     }
                     if (specRow) gmvx = gEndX;
+                    SPROF(5);
+#ifdef MVX_SPEC_PROF
+                    sprof[9] += 1;
+#endif
                 }
                 // ---- results of the 64 columns (:967, :1106)
                 if (in) {
@@ -577,6 +875,7 @@ template <int BPS, int BW, bool UV> struct SpecSearcher : FastSearcher<BPS, BW, 
 #ifdef MVX_SPEC_STATS
         if (l == 0) { atomicAdd(&g_specstat[lvl][0], st0); atomicAdd(&g_specstat[lvl][1], st1); atomicAdd(&g_specstat[lvl][2], st2); atomicAdd(&g_specstat[lvl][3], (unsigned long long)badcount); }
 #endif
+        SPROF(7);
         // vectors[] of this level feed the next level's interpolation / global-MV estimate (other lanes read them)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -614,18 +913,33 @@ __global__ __launch_bounds__(64 * MAXCPW, WPE) void analyse_spec_kernel(const AP
         return;
     }
     if (l == 0) { hdr[0] = P.blobSize; hdr[1] = 1; } // GroupOfPlanes.c:77-85
-    SpecSearcher<BPS, BW, UV> S(P, J);
+    SpecSearcher<BPS, BW, UV, (WPE <= 2 ? 24 : 12)> S(P, J);
     S.lds = (lds_u8 *)smem + uni((int)(threadIdx.x >> 6)) * ldsChain;
     S.ldsRow = ldsRow; S.ldsHist = ldsHist; S.histBins = histBins; S.ldsTab = ldsTab;
+#ifdef MVX_SPEC_PROF
+    for (int i = 0; i < SPROF_N; i++) S.sprof[i] = 0;
+    S.sprofT = (long long)__builtin_amdgcn_s_memtime();
+#endif
     int gx = 0, gy = 0; // zeroMV, MVAnalysisData.h:79
     GL_AS const GVec *coarse = nullptr;
     int cbx = 0, cby = 0, clp = 0;
     for (int lvl = P.nLevels - 1; lvl >= 0; lvl--) {
         if (coarse && P.global) S.estimate_global(coarse, cbx * cby, 8192 * P.lv[lvl + 1].pel, &gx, &gy);
-        S.search_level_spec(lvl, gx, gy, coarse, cbx, cby, clp, cpw > 1 ? syncEvery : 0, !(flags & MVX_FAST_NOSPEC));
+        S.search_level_spec(lvl, gx, gy, coarse, cbx, cby, clp, cpw > 1 ? syncEvery : 0, !(flags & MVX_FAST_NOSPEC), !(flags & MVX_FAST_NOSTRIP));
         coarse = S.vectors; cbx = P.lv[lvl].nBlkX; cby = P.lv[lvl].nBlkY; clp = P.lv[lvl].logPel;
     }
+    SPEC_PROF_DUMP_();
 }
+#ifdef MVX_SPEC_PROF
+#define SPEC_PROF_DUMP() do { if (l == 0 && chain == 5) for (int i = 0; i < SPROF_N; i++) g_specprof[i] = (unsigned long long)S.sprof[i]; } while (0)
+#else
+#define SPEC_PROF_DUMP() ((void)0)
+#endif
+#if defined(MVX_SPEC_PROF) && defined(MVX_PROF_EXPORT)
+extern "C" __attribute__((visibility("default"))) int mvx_debug_specprof(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_specprof), sizeof(unsigned long long) * SPROF_N) == hipSuccess ? 0 : -1;
+}
+#endif
 #if defined(MVX_SPEC_STATS) && defined(MVX_PROF_EXPORT)
 extern "C" __attribute__((visibility("default"))) int mvx_debug_specstats(unsigned long long *out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_specstat), sizeof(unsigned long long) * MVX_MAX_LEVELS * 4) != hipSuccess) return -1;
