@@ -337,6 +337,26 @@ def search_kernel_name(mv):
     return "analyse_spec_kernel, %d chains per SIMD" % info[0] if info[4] == 2 else "analyse_win_kernel" if info[4] == 1 else "analyse_fast_kernel, %d chains per SIMD" % info[0] if info[0] else "analyse_kernel"
 
 
+def other_configs():
+    """The other BASELINE configurations that run on one GPU, each as a short child run of this script (2 timed steps after 1 warm-up, its
+    own two-frame comparison against the oracle; the parent has released its device memory): {"cfg2": {...}, ...}.  Outside every timed region."""
+    import subprocess
+    res = {}
+    for c in ("cfg2", "cfg4", "cfg5"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", c, "--steps", "2", "--warmup", "1", "--no-cpu", "--no-traffic", "--no-others"]
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=420)
+            line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1]
+            d = json.loads(line)
+            r = d["roofline"]
+            res[c] = {"workload": d["config"]["workload"], "fps": d["value"], "ms_per_step": d["ms_per_step"], "frames_per_step": d["config"].get("frames_per_step_per_gpu"),
+                      "search_kernel": r.get("kernel"), "launch_ms": r.get("avg_launch_ms"), "frac": r.get("frac"),
+                      "parity": bool(d.get("parity_check", {}).get("identical")), "parity_frames": d.get("parity_check", {}).get("frames"), "rc": p.returncode}
+        except Exception as e:  # (a failed side run must not cost the headline line)
+            res[c] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return res
+
+
 def measure_traffic(args, B):
     """HBM bytes of ONE launch of the search kernel, measured now: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; kernel-trace
     only, one counter per pass) over `bench.py --steps 1 --warmup 0` of the same configuration, corrected as MI355X_MICROARCH.md
@@ -458,6 +478,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline (a two-frame parity check of the timed step still runs)")
     ap.add_argument("--no-parity", action="store_true", help="with --no-cpu: skip the oracle comparison of the timed step too")
     ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure the search launch's HBM traffic")
+    ap.add_argument("--no-others", action="store_true", help="default cfg3 run: do not add the short runs of cfg2 / cfg4 / cfg5 (`other_configs` of the JSON line)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--ingest", action="store_true", help="also measure the step with its source frames arriving from / its output frames leaving to pinned host memory "
                     "(secondary metric `ingest_inclusive` of the JSON line; `value` stays the resident-input number)")
@@ -561,6 +582,12 @@ def main():
             torch.cuda.empty_cache()
             traffic, traffic_note = measure_traffic(args, B)
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = traffic, traffic_note
+        if "cpu_baseline" in out:
+            # what the reference's own SIMD build would do with the same cores, relative to this scalar port (an estimate, not a measurement)
+            out["cpu_baseline"]["reference_ratio_estimate"] = ("<= 2x this figure on 16-bit clips (the reference has no AVX2 kernels there: scalar C overlap-add, SSE2 SAD)" if cfg[2] > 8 else
+                                                               "several x this figure on 8-bit clips (reference AVX2 SAD ~16x, overlap-add ~5-6x the scalar port per kernel)")
+        if world == 1 and args.config == "cfg3" and not args.no_others and not args.no_cpu and not args.no_traffic and not args.batch:
+            out["other_configs"] = other_configs()
         print(json.dumps(out))
         if rc:
             sys.stderr.write("bench.py: the timed step's results differ from the oracle: %s\n" % out["parity_check"].get("mismatches"))

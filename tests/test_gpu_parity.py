@@ -1104,3 +1104,32 @@ def test_staged_copies_round_trip(mv):
         t.join()
     L.mvx_stream_destroy(stream)
     assert not errors, errors
+
+
+@pytest.mark.gpu
+def test_staged_copies_row_longer_than_a_staging_buffer(mv):
+    """a single row of more than 16 MiB (the shell moves whole vector blobs as one row: 4K with 8x8 blocks and divide, 8K with 8x8 blocks) goes
+    through the staging buffers segment by segment (such rows were rejected)"""
+    L = mv.lib()
+    L.mvx_upload_2d.argtypes = L.mvx_download_2d.argtypes = [C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_size_t, C.c_size_t, C.c_void_p]
+    L.mvx_dev_alloc_uninit.restype = C.c_void_p
+    L.mvx_dev_alloc_uninit.argtypes = [C.c_size_t]
+    L.mvx_dev_free.argtypes = [C.c_void_p]
+    L.mvx_stream_create_priority.restype = C.c_void_p
+    L.mvx_stream_create_priority.argtypes = [C.c_int]
+    L.mvx_stream_destroy.argtypes = [C.c_void_p]
+    stream = L.mvx_stream_create_priority(1)
+    rb = (44 << 20) + 12345  # 44 MiB and a bit: two full segments and a tail
+    rows = 2
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 256, (rows, rb + 3), dtype=np.uint8)
+    dst = np.zeros((rows, rb + 5), dtype=np.uint8)
+    dp = (rb + 255) // 256 * 256
+    dev = L.mvx_dev_alloc_uninit(rows * dp)
+    try:
+        assert L.mvx_upload_2d(dev, dp, src.ctypes.data, src.strides[0], rb, rows, stream) == 0, mv.last_error() if hasattr(mv, "last_error") else "upload failed"
+        assert L.mvx_download_2d(dst.ctypes.data, dst.strides[0], dev, dp, rb, rows, stream) == 0
+        assert np.array_equal(dst[:, :rb], src[:, :rb]) and not dst[:, rb:].any()
+    finally:
+        L.mvx_dev_free(dev)
+        L.mvx_stream_destroy(stream)

@@ -30,6 +30,9 @@ def proc_env(**extra):
     e = dict(os.environ)
     if _PRELOAD:
         e["LD_PRELOAD"] = _PRELOAD
+        # the test double reports 64 MiB of free device memory so that the frame cache really evicts; the look-ahead windows are sized from
+        # the free memory too (r4) -- the tests that count launches mean the default window length
+        e.setdefault("MVX_VS_LOOKAHEAD_AUTOSIZE", "0")
     e.update(extra)
     return e
 
@@ -410,6 +413,36 @@ def test_concurrent_requests_are_batched_and_bit_identical(shell, tmp_path, bits
     kv = {k: int(v) for k, v in (t.split("=") for t in stats[0].split()[2:])}
     # every Analyse instance served its 70 frames in a handful of launches, the largest with most of the 64 concurrent requests
     assert kv["jobs"] == n * kv["instances"] and kv["launches"] <= 8 * kv["instances"] and kv["largest_batch"] >= 32, stats[0]
+
+
+def test_lookahead_windows_shrink_with_the_device_memory(fakedev, tmp_path):
+    """the look-ahead windows (length, number ahead) are sized from the free device memory; on a device that cannot hold the
+    default three windows of 128 frames the vector clip is still the per-frame path's, served from shorter windows -- or, when not even one
+    small window fits, by the per-frame path itself.  (CPU only: the test double reports the memory MVX_FAKEDEV_MEM names.)"""
+    global _PRELOAD
+    _PRELOAD = fakedev
+    try:
+        w, h, n, bits = 192, 112, 60, 16
+        frames = pl.moving_clip(w, h, bits, n, seed=23, noise=3)
+        src, ref = str(tmp_path / "in.raw"), str(tmp_path / "ref.raw")
+        _write_clip(src, frames)
+        args = [str(a) for a in ("run", "degrain1", src, w, h, bits, n)]
+        extra = ["a.blksize=16", "a.overlap=8", "x.threads=8"]
+        r0 = subprocess.run([HOST, PLUGIN] + args + [ref] + extra, capture_output=True, text=True, timeout=900, env=proc_env(MVX_VS_LOOKAHEAD="0"))
+        assert r0.returncode == 0 and "DONE" in r0.stdout, r0.stdout + r0.stderr
+        for mem, expect in ((str(24 << 20), "short"), (str(1 << 20), "off")):
+            out = str(tmp_path / ("la_%s.raw" % expect))
+            r1 = subprocess.run([HOST, PLUGIN] + args + [out] + extra, capture_output=True, text=True, timeout=900,
+                                env=proc_env(MVX_VS_STATS="1", MVX_VS_LOOKAHEAD_AUTOSIZE="1", MVX_FAKEDEV_MEM=mem))
+            assert r1.returncode == 0 and "DONE" in r1.stdout, r1.stdout + r1.stderr
+            assert open(ref, "rb").read() == open(out, "rb").read(), expect
+            stats = [l for l in r1.stderr.splitlines() if l.startswith("mvtools_vs: Analyse")]
+            kv = {k: int(v) for k, v in (t.split("=") for t in stats[0].split()[2:])}
+            assert kv["jobs"] == n * kv["instances"], stats[0]
+            if expect == "short":
+                assert 1 < kv["largest_batch"] < 128, stats[0]   # windows, but not the default ones
+    finally:
+        _PRELOAD = None
 
 
 @pytest.mark.parametrize("bits,pipeline,extra,threads", [(16, "degrain3", ("a.blksize=16", "a.overlap=8"), 32), (8, "degrain1", ("a.blksize=8", "a.overlap=4"), 1),

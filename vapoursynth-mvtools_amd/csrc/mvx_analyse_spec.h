@@ -35,7 +35,7 @@
 #define MVX_FAST_NOSPEC 4                 // flags: verify nothing, search every block live (developer switch: the same kernel as a plain serial walk)
 
 // -DMVX_SPEC_ABL=n (tools/build_variant.py): timing-only ablations of pass A, results are WRONG -- 1: no zero / global / hierarchical pass on Hex2
-// levels, 2: every group of the pattern pass evaluates the centre (same lines for all lanes), 3: every speculative result is taken (no live blocks)
+// levels, 2: every group of the pattern pass evaluates the centre (same lines for all lanes), 3: every speculative result is taken (no live blocks); row passes: 4: no LDS source reads, 5: no reference loads, 6: no SADs
 #ifndef MVX_SPEC_ABL
 #define MVX_SPEC_ABL 0
 #endif
@@ -190,13 +190,15 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
 #pragma unroll
         for (int k = 0; k < SNT; k++) {
             const v4u cur = a[k % D];
-            if (k + D < SNT) a[k % D] = src_piece(k + D);
-            if (k < SNA) aL = F::template sad_regs<16>(cur, T.r[k % SW], aL);
-            else aC = F::template sad_regs<16>(cur, T.r[k % SW], aC);
+            if (MVX_SPEC_ABL != 4 && k + D < SNT) a[k % D] = src_piece(k + D);
+            if (MVX_SPEC_ABL != 6) {
+                if (k < SNA) aL = F::template sad_regs<16>(cur, T.r[k % SW], aL);
+                else aC = F::template sad_regs<16>(cur, T.r[k % SW], aC);
+            } else { aL += cur[0] + T.r[k % SW][0]; }
             asm volatile("" : "+v"(aL), "+v"(aC) : : "memory");
             const int kk = k + SW;
             if (kk == SNT) { T.curA = nA; T.curB = nB; }
-            if (REFILL || kk < SNT) T.r[k % SW] = strip_issue(T, kk % SNT);
+            if (MVX_SPEC_ABL != 5 && (REFILL || kk < SNT)) T.r[k % SW] = strip_issue(T, kk % SNT);
         }
         T.aL = aL; T.aC = aC;
     }

@@ -151,25 +151,32 @@ constexpr int kStages = 96; // two per transfer in flight: a frame server runs t
 Stage g_stage[kStages];
 std::mutex g_stage_mu;
 std::condition_variable g_stage_cv;
-Stage *stage_acquire() {
-    std::unique_lock<std::mutex> lk(g_stage_mu);
-    Stage *s = nullptr;
-    g_stage_cv.wait(lk, [&] {
-        Stage *fresh = nullptr;
-        for (auto &t : g_stage) if (!t.busy) { if (t.p) { s = &t; return true; } if (!fresh) fresh = &t; } // (an allocated one first)
-        s = fresh;
-        return s != nullptr;
-    });
-    s->busy = true;
-    lk.unlock();
-    if (!s->p && hipHostMalloc(&s->p, kStageBytes, hipHostMallocDefault) != hipSuccess) {
-        s->p = nullptr;
-        mvx_set_error("hipHostMalloc(%zu) failed", kStageBytes);
-        { std::lock_guard<std::mutex> g(g_stage_mu); s->busy = false; }
-        g_stage_cv.notify_one();
-        return nullptr;
+// one or two buffers at once: a transfer that took its first buffer and then waited for the second could wait forever once every buffer
+// of the pool was some transfer's first
+bool stage_acquire_n(Stage **out, int n) {
+    out[0] = out[1] = nullptr;
+    {
+        std::unique_lock<std::mutex> lk(g_stage_mu);
+        g_stage_cv.wait(lk, [&] {
+            int have = 0;
+            Stage *pick[2] = { nullptr, nullptr };
+            for (auto &t : g_stage) if (!t.busy && t.p && have < n) pick[have++] = &t;   // allocated ones first
+            for (auto &t : g_stage) if (!t.busy && !t.p && have < n) pick[have++] = &t;
+            if (have < n) return false;
+            for (int i = 0; i < n; i++) { pick[i]->busy = true; out[i] = pick[i]; }
+            return true;
+        });
     }
-    return s;
+    for (int i = 0; i < n; i++)
+        if (!out[i]->p && hipHostMalloc(&out[i]->p, kStageBytes, hipHostMallocDefault) != hipSuccess) {
+            out[i]->p = nullptr;
+            mvx_set_error("hipHostMalloc(%zu) failed", kStageBytes);
+            { std::lock_guard<std::mutex> g(g_stage_mu); for (int k = 0; k < n; k++) out[k]->busy = false; }
+            g_stage_cv.notify_all();
+            out[0] = out[1] = nullptr;
+            return false;
+        }
+    return true;
 }
 void stage_release(Stage *s) {
     if (!s) return;
@@ -182,10 +189,20 @@ size_t chunk_rows(ptrdiff_t dp, size_t row_bytes) { const size_t n = (kStageByte
 extern "C" __attribute__((visibility("default"))) int mvx_upload_2d(void *dev, ptrdiff_t dp, const void *host, ptrdiff_t hp, size_t row_bytes, size_t rows, void *stream) {
     if (!rows || !row_bytes) return MVX_OK;
     if (dp < (ptrdiff_t)row_bytes) { mvx_set_error("mvx_upload_2d: device pitch smaller than a row"); return MVX_E_ARG; }
-    if (row_bytes > kStageBytes) { mvx_set_error("mvx_upload_2d: row longer than a staging buffer"); return MVX_E_ARG; }
+    if (row_bytes > kStageBytes) { // a row longer than a staging buffer (the shell moves whole vector blobs as one row): segment by segment
+        for (size_t r = 0; r < rows; r++) {
+            char *d = (char *)dev + r * (size_t)dp;
+            const char *h = (const char *)host + (ptrdiff_t)r * hp;
+            const size_t full = row_bytes / kStageBytes, tail = row_bytes % kStageBytes;
+            int rc = mvx_upload_2d(d, (ptrdiff_t)kStageBytes, h, (ptrdiff_t)kStageBytes, kStageBytes, full, stream);
+            if (rc == MVX_OK && tail) rc = mvx_upload_2d(d + full * kStageBytes, (ptrdiff_t)tail, h + full * kStageBytes, (ptrdiff_t)tail, tail, 1, stream);
+            if (rc != MVX_OK) return rc;
+        }
+        return MVX_OK;
+    }
     const size_t per = chunk_rows(dp, row_bytes);
-    Stage *st[2] = { stage_acquire(), rows > per ? stage_acquire() : nullptr };
-    if (!st[0] || (rows > per && !st[1])) { stage_release(st[0]); stage_release(st[1]); return MVX_E_DEVICE; }
+    Stage *st[2];
+    if (!stage_acquire_n(st, rows > per ? 2 : 1)) return MVX_E_DEVICE;
     auto fill = [&](Stage *s, size_t r0, size_t n) {
         for (size_t r = 0; r < n; r++) {
             memcpy((char *)s->p + r * (size_t)dp, (const char *)host + (ptrdiff_t)(r0 + r) * hp, row_bytes);
@@ -204,6 +221,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_upload_2d(void *dev, p
         if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
         r0 = r1; n = n1; cur ^= 1;
     }
+    if (e != hipSuccess) (void)hipStreamSynchronize((hipStream_t)stream); // (a copy queued from a staging buffer must be over before the buffer is handed on)
     stage_release(st[0]); stage_release(st[1]);
     if (e != hipSuccess) { mvx_set_error("mvx_upload_2d: %s", hipGetErrorString(e)); return MVX_E_DEVICE; }
     return MVX_OK;
@@ -212,10 +230,20 @@ extern "C" __attribute__((visibility("default"))) int mvx_upload_2d(void *dev, p
 extern "C" __attribute__((visibility("default"))) int mvx_download_2d(void *host, ptrdiff_t hp, const void *dev, ptrdiff_t dp, size_t row_bytes, size_t rows, void *stream) {
     if (!rows || !row_bytes) return MVX_OK;
     if (dp < (ptrdiff_t)row_bytes) { mvx_set_error("mvx_download_2d: device pitch smaller than a row"); return MVX_E_ARG; }
-    if (row_bytes > kStageBytes) { mvx_set_error("mvx_download_2d: row longer than a staging buffer"); return MVX_E_ARG; }
+    if (row_bytes > kStageBytes) { // (as mvx_upload_2d)
+        for (size_t r = 0; r < rows; r++) {
+            const char *d = (const char *)dev + r * (size_t)dp;
+            char *h = (char *)host + (ptrdiff_t)r * hp;
+            const size_t full = row_bytes / kStageBytes, tail = row_bytes % kStageBytes;
+            int rc = mvx_download_2d(h, (ptrdiff_t)kStageBytes, d, (ptrdiff_t)kStageBytes, kStageBytes, full, stream);
+            if (rc == MVX_OK && tail) rc = mvx_download_2d(h + full * kStageBytes, (ptrdiff_t)tail, d + full * kStageBytes, (ptrdiff_t)tail, tail, 1, stream);
+            if (rc != MVX_OK) return rc;
+        }
+        return MVX_OK;
+    }
     const size_t per = chunk_rows(dp, row_bytes);
-    Stage *st[2] = { stage_acquire(), rows > per ? stage_acquire() : nullptr };
-    if (!st[0] || (rows > per && !st[1])) { stage_release(st[0]); stage_release(st[1]); return MVX_E_DEVICE; }
+    Stage *st[2];
+    if (!stage_acquire_n(st, rows > per ? 2 : 1)) return MVX_E_DEVICE;
     auto bytes_of = [&](size_t n) { return (n - 1) * (size_t)dp + row_bytes; };
     hipError_t e = hipSuccess;
     int cur = 0;
@@ -229,6 +257,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_download_2d(void *host
         for (size_t r = 0; r < n; r++) memcpy((char *)host + (ptrdiff_t)(r0 + r) * hp, (const char *)st[cur]->p + r * (size_t)dp, row_bytes); // (under the DMA of the next chunk)
         r0 = r1; n = n1; cur ^= 1;
     }
+    if (e != hipSuccess) (void)hipStreamSynchronize((hipStream_t)stream);
     stage_release(st[0]); stage_release(st[1]);
     if (e != hipSuccess) { mvx_set_error("mvx_download_2d: %s", hipGetErrorString(e)); return MVX_E_DEVICE; }
     return MVX_OK;

@@ -38,7 +38,8 @@
 
 /* ------------------------------------------------------------------------------------------------ device frame cache */
 
-typedef struct DevFrame { int64_t id; void *arena; void *plane[3]; size_t bytes; int pins; uint64_t stamp; uint64_t print; } DevFrame;
+typedef struct DevFrame { int64_t id; void *arena; void *plane[3]; size_t bytes; int pins; uint64_t stamp; uint64_t print;
+                         int trusted; /* built by this plugin's own mv.Super (superGetFrame / super_build_device), not uploaded from a host frame that merely carries the id */ } DevFrame;
 #define CACHE_MAX 2048
 static DevFrame g_cache[CACHE_MAX];
 static int g_cache_cap = -1;       /* entries (MVX_VS_CACHE_FRAMES), at most CACHE_MAX */
@@ -222,13 +223,16 @@ static uint64_t frame_print(const VSFrame *f, const SuperGeo *g, const VSAPI *vs
     return h;
 }
 
-/* returns a pinned cache entry holding frame `id` with that fingerprint, or NULL.  any_print: entries are trusted by id alone
- * (the caller knows that the frames of this id range come straight from this plugin's mv.Super: look-ahead, superGetFrame) */
-static DevFrame *cache_find_ex(int64_t id, uint64_t print, int any_print) {
+/* returns a pinned cache entry holding frame `id` with that fingerprint, or NULL.  own_bytes != 0: look-up by id alone, for entries this
+ * plugin's own mv.Super built (`trusted`) with exactly that layout size -- a frame uploaded from the host under the same id (a filter
+ * between mv.Super and its consumer may copy the properties and change the pixels) never answers it. */
+static DevFrame *cache_find_ex(int64_t id, uint64_t print, size_t own_bytes) {
     DevFrame *r = NULL;
     pthread_mutex_lock(&g_lock);
-    for (int i = 0; i < cache_cap(); i++)
-        if (g_cache[i].arena && g_cache[i].id == id && (any_print || g_cache[i].print == print)) { r = &g_cache[i]; r->pins++; r->stamp = g_stamp++; break; }
+    for (int i = 0; i < cache_cap(); i++) {
+        DevFrame *e = &g_cache[i];
+        if (e->arena && e->id == id && (own_bytes ? (e->trusted && e->bytes == own_bytes) : e->print == print)) { r = e; r->pins++; r->stamp = g_stamp++; break; }
+    }
     pthread_mutex_unlock(&g_lock);
     return r;
 }
@@ -245,7 +249,7 @@ static void cache_evict_instance(int64_t instance) {
 }
 /* hands a freshly filled arena to the cache (pinned); returns NULL if the cache is full of pinned frames / disabled.  Entries are
  * evicted least recently used first until the new frame fits the byte budget. */
-static DevFrame *cache_insert(int64_t id, uint64_t print, void *arena, const SuperGeo *g) {
+static DevFrame *cache_insert(int64_t id, uint64_t print, void *arena, const SuperGeo *g, int trusted) {
     DevFrame *slot = NULL;
     void *victims[CACHE_MAX];
     int nv = 0;
@@ -253,7 +257,7 @@ static DevFrame *cache_insert(int64_t id, uint64_t print, void *arena, const Sup
     const size_t budget = cache_budget();
     for (int i = 0; i < cache_cap(); i++) { /* a stale unpinned copy of the same frame goes first */
         DevFrame *e = &g_cache[i];
-        if (e->arena && e->id == id && e->pins == 0) { victims[nv++] = e->arena; e->arena = NULL; g_cache_bytes -= e->bytes; e->bytes = 0; }
+        if (e->arena && e->id == id && e->pins == 0 && (trusted || !e->trusted)) { victims[nv++] = e->arena; e->arena = NULL; g_cache_bytes -= e->bytes; e->bytes = 0; } /* (an upload never displaces the genuine copy) */
     }
     while (g_cache_bytes + g->bytes > budget) {
         void *v = cache_evict_lru_locked();
@@ -267,7 +271,7 @@ static DevFrame *cache_insert(int64_t id, uint64_t print, void *arena, const Sup
         if (v) { victims[nv++] = v; for (int i = 0; i < cache_cap(); i++) if (!g_cache[i].arena) { slot = &g_cache[i]; break; } }
     }
     if (slot) {
-        slot->id = id; slot->print = print; slot->arena = arena; slot->bytes = g->bytes; slot->pins = 1; slot->stamp = g_stamp++;
+        slot->id = id; slot->print = print; slot->arena = arena; slot->bytes = g->bytes; slot->pins = 1; slot->stamp = g_stamp++; slot->trusted = trusted;
         g_cache_bytes += g->bytes;
         for (int p = 0; p < 3; p++) slot->plane[p] = p < g->si.num_planes ? (char *)arena + g->off[p] : NULL;
     }
@@ -306,7 +310,7 @@ static int super_to_device(DevRef *r, const VSFrame *f, const SuperGeo *g, const
     if (!rc) rc = super_shadows(g, r->plane, st);
     if (!rc) rc = mvx_stream_sync(st); /* consumers launch on their own streams */
     if (rc) { shell_quiesce(rc); mvx_dev_free(arena); memset(r, 0, sizeof(*r)); return rc; }
-    if (!err && (r->cached = cache_insert(id, print, arena, g)) != NULL) return 0; /* keep it for the next consumer */
+    if (!err && (r->cached = cache_insert(id, print, arena, g, 0)) != NULL) return 0; /* keep it for the next consumer (found again by id AND fingerprint only) */
     r->temp = arena;
     return 0;
 }
@@ -541,7 +545,7 @@ static int super_build_device(SuperData *sd, int n, const int *nums, const VSFra
     if (!miss || !srcArena || !arena || !sp || !dp) rc = MVX_E_NOMEM;
     for (int i = 0; i < n; i++) out[i] = NULL;
     for (int i = 0; i < n && !rc; i++) {
-        out[i] = cache_find_ex((sd->instance << 32) | (uint32_t)nums[i], 0, 1);
+        out[i] = cache_find_ex((sd->instance << 32) | (uint32_t)nums[i], 0, g->bytes);
         if (!out[i]) miss[nmiss++] = i;
     }
     void *st = thread_stream();
@@ -565,12 +569,13 @@ static int super_build_device(SuperData *sd, int n, const int *nums, const VSFra
         else rc = mvx_super_frames(sd->sup, nmiss, sp, sd->srcPitch, dp, g->pitch, st);
     }
     if (!rc && nmiss) rc = mvx_stream_sync(st);
+    else if (rc && nmiss) (void)mvx_stream_sync(st); /* (part of the work may be queued: the arenas below go back to a pool that knows nothing of streams) */
     prof_add(PF_SUPER, tp);
     for (int k = 0; k < nmiss; k++) {
         if (srcArena && srcArena[k]) mvx_dev_free(srcArena[k]);
         if (!rc) {
             const int i = miss[k];
-            out[i] = cache_insert((sd->instance << 32) | (uint32_t)nums[i], 0, arena[k], g); /* (print 0: superGetFrame fills it in when it hands the host frame out) */
+            out[i] = cache_insert((sd->instance << 32) | (uint32_t)nums[i], 0, arena[k], g, 1); /* (print 0: superGetFrame fills it in when it hands the host frame out) */
             if (!out[i]) { rc = MVX_E_NOMEM; mvx_dev_free(arena[k]); }
         } else if (arena && arena[k]) mvx_dev_free(arena[k]);
     }
@@ -606,7 +611,7 @@ static const VSFrame *VS_CC superGetFrame(int n, int reason, void *inst, void **
     const VSFrame *src = vs->getFrameFilter(n, d->node, ctx);
     const SuperGeo *g = &d->geo;
     const int64_t id = (d->instance << 32) | (uint32_t)n;
-    DevFrame *have = d->pelMode ? NULL : cache_find_ex(id, 0, 1); /* built on the device already (a vector clip's look-ahead): only the download is left */
+    DevFrame *have = d->pelMode ? NULL : cache_find_ex(id, 0, g->bytes); /* built on the device already (a vector clip's look-ahead): only the download is left */
     if (have) {
         int rc2 = 0;
         VSFrame *dst2 = vs->newVideoFrame(&d->vi.format, d->vi.width, d->vi.height, src, core);
@@ -663,7 +668,7 @@ static const VSFrame *VS_CC superGetFrame(int n, int reason, void *inst, void **
     }
     super_frame_props(dst, n, id, g, vs);
     /* the device copy stays resident for the consumers */
-    DevFrame *e = cache_insert(id, frame_print(dst, g, vs), arena, g);
+    DevFrame *e = cache_insert(id, frame_print(dst, g, vs), arena, g, 1);
     if (e) cache_unpin(e); else mvx_dev_free(arena);
     prof_add(PF_GF_SUPER, tgf);
     return dst;
@@ -771,7 +776,7 @@ typedef struct Combiner {
 #define LA_SLOTS 6
 enum { LW_EMPTY, LW_BUILDING, LW_LAUNCHED, LW_SYNCING, LW_READY, LW_FAILED };
 typedef struct LaWindow { int w, state, first, count, users, rc; void *dblobs; size_t dstride; DevFrame **pins; int npins; void *stream; } LaWindow; /* dblobs: the window's vectors, on the device until the slot is recycled */
-typedef struct LookAhead { int on, B, depth; VSNode *srcNode; SuperData *sd; pthread_mutex_t mu; pthread_cond_t cv; LaWindow win[LA_SLOTS]; } LookAhead;
+typedef struct LookAhead { int on, B, depth; volatile int degraded; /* a window ran out of device memory: new requests take the per-frame path */ VSNode *srcNode; SuperData *sd; pthread_mutex_t mu; pthread_cond_t cv; LaWindow win[LA_SLOTS]; } LookAhead;
 #define LA_DEPTH_MAX 3
 typedef struct LaReq { int legacy, w, hold[1 + LA_DEPTH_MAX], want[1 + LA_DEPTH_MAX]; } LaReq;
 
@@ -1031,7 +1036,7 @@ static const VSFrame *VS_CC analyseGetFrame(int n, int reason, void *inst, void 
             if (r) {
                 r->w = n / d->la.B;
                 pthread_mutex_lock(&d->la.mu);
-                LaWindow *s0 = la_slot(d, r->w);
+                LaWindow *s0 = d->la.degraded ? NULL : la_slot(d, r->w);
                 if (!s0) r->legacy = 1;
                 else {
                     s0->users++; r->hold[0] = 1; r->want[0] = s0->state == LW_EMPTY;
@@ -1068,6 +1073,7 @@ static const VSFrame *VS_CC analyseGetFrame(int n, int reason, void *inst, void 
                 const int lrc = la_launch(d, s, r->w + i, ctx, vs);
                 pthread_mutex_lock(&d->la.mu);
                 s->rc = lrc; s->state = lrc ? LW_FAILED : LW_LAUNCHED;
+                if (lrc == MVX_E_NOMEM) d->la.degraded = 1; /* (the requests already waiting for this window fail -- their reference frames were never asked for -- but nothing after them does) */
                 pthread_cond_broadcast(&d->la.cv);
                 pthread_mutex_unlock(&d->la.mu);
                 if (lrc && i == 0) rc = lrc;
@@ -1155,13 +1161,15 @@ static const VSFrame *VS_CC analyseGetFrame(int n, int reason, void *inst, void 
 static void VS_CC analyseFree(void *inst, VSCore *core, const VSAPI *vs) {
     (void)core;
     AnalyseData *d = (AnalyseData *)inst;
-    vs->freeNode(d->node);
-    if (d->la.on) {
+    if (d->la.on) { /* the windows' pins go first: freeing the super node may run mv.Super's free callback, which drops its unpinned frames from the cache */
         for (int i = 0; i < LA_SLOTS; i++) {
             LaWindow *s = &d->la.win[i];
             if (s->state == LW_LAUNCHED) (void)mvx_stream_sync(s->stream); /* nobody came for it */
             la_window_release(s);
         }
+    }
+    vs->freeNode(d->node);
+    if (d->la.on) {
         vs->freeNode(d->la.srcNode);
         pthread_mutex_destroy(&d->la.mu); pthread_cond_destroy(&d->la.cv);
     }
@@ -1216,13 +1224,26 @@ static void VS_CC analyseCreate(const VSMap *in, VSMap *out, void *user, VSCore 
     { /* look-ahead when `super` is this plugin's own mv.Super node (MVX_VS_LOOKAHEAD = window length in frames, 0 = off; default 128) */
         SuperData *sd = super_lookup(node);
         const long B = env_long("MVX_VS_LOOKAHEAD", 128);
-        if (sd && !sd->pelMode && B > 0 && vi->numFrames > 1) {
+        if (sd && !sd->pelMode && B > 0 && vi->numFrames > 1 && cache_cap() > 0) { /* (no device cache, no windows: they live in it) */
             d->la.on = 1; d->la.B = (int)(B > 512 ? 512 : B); d->la.sd = sd;
             /* windows started ahead of the one being consumed.  Two: gathering a window's source frames and building its super frames
              * takes a host about as long as consuming a window does, and the search itself another ~0.5 s */
             d->la.depth = (int)env_long("MVX_VS_LOOKAHEAD_DEPTH", 2);
             if (d->la.depth < 0) d->la.depth = 0;
             if (d->la.depth > LA_DEPTH_MAX) d->la.depth = LA_DEPTH_MAX;
+            { /* what the windows in flight pin must fit the device: every window holds B + delta super frames (with their shadow planes)
+               * and B blobs; half of the free memory is left to the other vector clips' share, Degrain's frames and the allocator's pool */
+                size_t fr = 0, tot = 0;
+                if (env_long("MVX_VS_LOOKAHEAD_AUTOSIZE", 1) && mvx_dev_mem_info(&fr, &tot) == 0 && fr) {
+                    const int delta = d->ad.nDeltaFrame > 0 ? d->ad.nDeltaFrame : 1;
+                    const double per = (double)sd->geo.bytes * 1.2 + (double)d->blobSize, avail = 0.5 * (double)fr;
+                    while (d->la.depth > 0 && (double)(d->la.depth + 1) * (d->la.B + delta) * per > avail) d->la.depth--;
+                    while (d->la.B > 8 && (double)(d->la.depth + 1) * (d->la.B + delta) * per > avail) d->la.B /= 2;
+                    if ((double)(d->la.depth + 1) * (d->la.B + delta) * per > avail) d->la.on = 0; /* not even one small window: the per-frame path */
+                }
+            }
+        }
+        if (d->la.on) {
             d->la.srcNode = vs->addNodeRef(sd->node);
             pthread_mutex_init(&d->la.mu, NULL); pthread_cond_init(&d->la.cv, NULL);
             for (int i = 0; i < LA_SLOTS; i++) d->la.win[i].w = -1;
