@@ -382,7 +382,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         int k = njobs > 3 * simds ? 4 : njobs > 2 * simds ? 3 : njobs > simds ? 2 : 1;
         // the row passes of the speculative kernel (16-bit 16x16) want the 256-register builds: 3072 chains take 878 ms at two per SIMD (in
         // two rounds) against 919 at three (profiles/r4_spec_loads_in_flight_and_batch.txt)
-        if (useSpecStrips && k > 2) k = 2;
+        if (useSpecStrips && k > 2 && g_dbg.fast_k != 3) k = 2;
         if (g_dbg.fast_wpe > 0 && g_dbg.fast_wpe < k) k = g_dbg.fast_wpe;
         if (g_dbg.fast_k > 0) k = g_dbg.fast_k;
         while (k > 1 && (!have(k) || (long long)perChain * 4 * k > 160 * 1024)) k--;

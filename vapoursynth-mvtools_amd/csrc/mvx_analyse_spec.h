@@ -39,6 +39,9 @@
 #ifndef MVX_SPEC_ABL
 #define MVX_SPEC_ABL 0
 #endif
+#ifndef MVX_SPEC_SW3
+#define MVX_SPEC_SW3 12 // row loads in flight per lane in the builds for three or more chains per SIMD (168 registers)
+#endif
 // -DMVX_SPEC_PROF (tools/specprof.py): cycles of ONE chain per phase of the group loop (s_memtime; a stamp waits for the scalar counter only)
 #ifdef MVX_SPEC_PROF
 #define SPROF_N 16
@@ -915,7 +918,7 @@ __global__ __launch_bounds__(64 * MAXCPW, WPE) void analyse_spec_kernel(const AP
         return;
     }
     if (l == 0) { hdr[0] = P.blobSize; hdr[1] = 1; } // GroupOfPlanes.c:77-85
-    SpecSearcher<BPS, BW, UV, (WPE <= 2 ? 24 : 12)> S(P, J);
+    SpecSearcher<BPS, BW, UV, (WPE <= 2 ? 24 : MVX_SPEC_SW3)> S(P, J);
     S.lds = (lds_u8 *)smem + uni((int)(threadIdx.x >> 6)) * ldsChain;
     S.ldsRow = ldsRow; S.ldsHist = ldsHist; S.histBins = histBins; S.ldsTab = ldsTab;
 #ifdef MVX_SPEC_PROF
