@@ -55,6 +55,9 @@ static __device__ unsigned long long g_specprof[SPROF_N];
 #else
 #define SPEC_PROF_DUMP_() ((void)0)
 #endif
+#if MVX_SPEC_ABL == 9
+static __device__ int g_specdbg[4 * 64 * 12];
+#endif
 #ifdef MVX_SPEC_STATS
 static __device__ unsigned long long g_specstat[MVX_MAX_LEVELS][4]; // per level: blocks in speculated rows, of them searched live, live because the flag was clear, rescues
 #endif
@@ -370,6 +373,68 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                         }
                         gEndX = gmvx;
 
+                        // ---- A2's pieces (one lane per block; the table is read per lane): the predictor phase (:832-915) under the hypothesis left == median == up,
+                        // and the refinement (:773-816) around a centre, costs as pobCheckMV0 / pobCheckMV (:219-261), strict < in the reference's order
+                        const int ti8L = (l & (SPEC_TB - 1)) * 8;
+                        auto rd = [&](int slot) { return *(const LDS_AS v2u *)(tab + slot * SPEC_STRIDE + ti8L); };
+                        auto tot = [&](const v2u &t) { return (int)t[0] + (chroma ? (int)t[1] : 0); };
+                        auto md = [&](int vx, int vy) { // motion_distortion (:105-114) around the hierarchical predictor
+                            const unsigned dx = (unsigned)(hx - vx), dy = (unsigned)(hy - vy);
+                            const int dist = (int)(dx * dx + dy * dy);
+                            return (int)(((long long)lam * dist) >> 8);
+                        };
+                        auto a2_pred = [&](int &best, int &bx, int &by, int &bs) {
+                            const int sUp = hexLevel ? 14 : 24, sZ = hexLevel ? 16 : 26;
+                            const v2u tU = rd(sUp), tA = rd(sUp + 1), tZ = rd(sZ), tG = rd(sZ + 1), tH = rd(sZ + 2);
+                            bx = 0; by = fieldShift;
+                            { const int t = tot(tZ); int cc = t + (int)(((long long)penaltyZero * t) >> 8); cc = F::sat_add(0, cc); best = cc; bs = t; }
+                            { const int t = tot(tG); int cc = t + (int)(((long long)pglobal * t) >> 8); cc = F::sat_add(0, cc); if (cc < best) { best = cc; bx = upx(pkG); by = upy(pkG); bs = t; } }
+                            { const int t = tot(tH); const int cc = F::sat_add(0, t); if (cc < best) { best = cc; bx = hx; by = hy; bs = t; } }
+                            { const int t = tot(tU); const int cc = F::sat_add(md(ux, uy), t); if (cc < best) { best = cc; bx = ux; by = uy; bs = t; } } // median = left = up
+                            { const int t = tot(tA); const int cc = F::sat_add(md(ax, ay), t); if (cc < best) { best = cc; bx = ax; by = ay; bs = t; } }
+                        };
+                        // refinement around (wx, wy) from the table; returns true when a hexagon point beats the predictor phase (that moves the centre, :682-724: live)
+                        auto a2_refine = [&](int wx, int wy, int &best, int &bx, int &by, int &bs) {
+                            auto vok = [&](int vx, int vy) { return vx >= dxMin && vy >= nDyMin && vx <= dxMax1 && vy < nDyMax; };
+                            auto cnew = [&](int vx, int vy, const v2u &t) { // pobCheckMV: penalty for new vectors, saturating
+                                int cc = (int)t[0] + ((penaltyNew * (int)t[0]) >> 8);
+                                if (chroma) cc += (int)t[1] + ((penaltyNew * (int)t[1]) >> 8);
+                                return F::sat_add(md(vx, vy), cc);
+                            };
+                            bool won = false;
+                            if (hexLevel) {
+                                if (nSearchParam > 1) {
+#pragma unroll 1
+                                    for (int k = 0; k < 6; k++) {
+                                        const int vx = wx + tab8(HEX2X >> 8, k), vy = wy + tab8(HEX2Y >> 8, k);
+                                        won = won || (vok(vx, vy) && cnew(vx, vy, rd(k)) < best);
+                                    }
+                                }
+#pragma unroll 1
+                                for (int k = 0; k < 8; k++) { // pobExpandingSearch(1, 1) (:636-658)
+                                    const int vx = wx + tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), k), vy = wy + tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), k);
+                                    const v2u t = rd(6 + k);
+                                    const int cc = cnew(vx, vy, t);
+                                    if (vok(vx, vy) && cc < best) { best = cc; bx = vx; by = vy; bs = tot(t); }
+                                }
+                            } else {
+#pragma unroll 1
+                                for (int k = 0; k < 24; k++) { // rings 1 and 2 (:786-791)
+                                    int dx, dy;
+                                    if (k < 8) { dx = tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), k); dy = tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), k); }
+                                    else if (k < 16) { dx = tab8(PACK8(-1, -1, 0, 0, 1, 1, -2, 2), k - 8); dy = tab8(PACK8(-2, 2, -2, 2, -2, 2, -1, -1), k - 8); }
+                                    else { dx = tab8(PACK8(-2, 2, -2, 2, -2, -2, 2, 2), k - 16); dy = tab8(PACK8(0, 0, 1, 1, -2, 2, -2, 2), k - 16); }
+                                    const int vx = wx + dx, vy = wy + dy;
+                                    const v2u t = rd(k);
+                                    const int cc = cnew(vx, vy, t);
+                                    if (vok(vx, vy) && cc < best) { best = cc; bx = vx; by = vy; bs = tot(t); }
+                                }
+                            }
+                            return won;
+                        };
+                        bool staged2 = false;                   // the two-stage row passes ran: the pattern lies around the predictor phase's winner
+                        int pBest = 0, pX_ = 0, pY_ = fieldShift, pSad = 0; // this lane's block: the predictor phase's result
+
                         // ======== A: the SADs of every block of the group, nothing serial in between
                         const int nb = hiE - lo;
                         const bool streamed = chroma && (hexLevel ? STREAM_HEX : STREAM_EXH);
@@ -379,88 +444,94 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                             unsigned long long pbMask = __ballot(act), p3Mask = 0; // blocks evaluated one at a time: every candidate / only ahead, global, hierarchical
 
                             SPROF(1);
-                            // ======== A, row passes: windows of seven columns.  Every pass loads ONE row per lane and load instruction (24 rows: 16 luma,
-                            // 8 of the UV plane), against the window's source strip in LDS.  Strip form (the window's blocks share the up predictor and keep
-                            // the whole pattern inside their limits): lane = (candidate, 16-byte column), eight candidates per pass.  Block form (any
-                            // vectors): lane = (candidate, block, half), four candidates per pass -- neighbouring blocks with similar vectors still read
-                            // neighbouring bytes of the same lines in the same instruction.
+                            // ======== A, row passes: windows of seven columns, in TWO stages.  Every pass loads ONE row per lane and load instruction
+                            // (24 rows: 16 luma, 8 of the UV plane), against the window's source strip in LDS.
+                            //   stage 1, one pass per window: up, ahead, global, hierarchical in block form (lane = (candidate, block, half): any vectors --
+                            //     neighbouring blocks with similar vectors still read neighbouring bytes of the same lines in one instruction) and the zero
+                            //     vector in strip form (lanes 56-63 = the window's eight 16-byte columns);
+                            //   A2a, one lane per block: the predictor phase -> the block's refinement centre W (under the hypothesis left == up);
+                            //   stage 2: the pattern around W.  Strip form where the window's blocks share W and keep the pattern inside their limits
+                            //     (lane = (candidate, column), eight candidates per pass: 2 passes on Hex2 levels, 3 on exhaustive ones); block form
+                            //     elsewhere (four candidates per pass: 4 / 6 passes).
+                            // (the first form evaluated the pattern around UP and gave every block whose predictor phase ended elsewhere to the live
+                            // search: one block in eight one level up from the finest, most blocks of the chains with an odd frame distance there)
                             if constexpr (STRIP_OK) {
                                 if (stripEnabled && stepX == BW / 2) {
                                     const int nw = (nb + SW_BLOCKS - 1) / SW_BLOCKS;
-                                    const bool ok2 = (ux - 2 >= dxMin) & (ux + 2 <= dxMax1) & (uy - 2 >= nDyMin) & (uy + 2 < nDyMax);
-                                    unsigned stripW = 0; // windows in strip form
-                                    for (int w = 0; w < nw; w++) {
-                                        const int f = lo + SW_BLOCKS * w, e = min(f + SW_BLOCKS, hiE);
-                                        const bool inw = (l >= f) & (l < e);
-                                        const int u0 = __builtin_amdgcn_readlane(pkU, f);
-                                        if (e - f >= 2 && __ballot(inw & ((pkU != u0) | !ok2)) == 0) stripW |= 1u << w;
-                                    }
-                                    pbMask = 0;
                                     const int npat = hexLevel ? 14 : 24;
-                                    const int NQS = hexLevel ? 3 : 5;  // strip form: pattern + up + zero in passes of eight, then one block-form pass for ahead / global / hierarchical
-                                    const int NQB = hexLevel ? 5 : 8;  // block form: pattern, up, ahead, zero, global, hierarchical in passes of four
-                                    // lane roles: strip form (candidate l >> 3, column l & 7); block form (candidate l / 14, block (l % 14) >> 1, half l & 1)
-                                    // (the roles are recomputed from an opaque lane number in every pass: values derived from the lane number are loop
-                                    // invariants, the compiler hoists all of them to the top of the level and then has to spill them -- 177 spilled registers)
+                                    pbMask = 0;
+                                    staged2 = true;
+                                    unsigned stripW = 0; // stage 2: windows in strip form
+                                    int pkW = 0;         // this lane's block: the refinement centre
+                                    // lane roles: strip form (candidate l >> 3, column l & 7); block form (candidate l / 14, block (l % 14) >> 1, half l & 1);
+                                    // recomputed from an opaque lane number in every pass (values derived from the lane number are loop invariants: the
+                                    // compiler hoists all of them to the top of the level and then has to spill them)
                                     int lq = l;
                                     asm volatile("" : "+v"(lq));
                                     int gS = lq >> 3, pS = lq & 7;
                                     int gB = lq >= 42 ? 3 : lq >= 28 ? 2 : lq >= 14 ? 1 : 0;
-                                    int rB = lq >= 56 ? lq - 56 : lq - 14 * gB, mB = rB >> 1, hB = rB & 1; // (lanes 56-63 repeat candidate 3 of block 0..3 and write nothing)
-                                    bool idleB = lq >= 56;
+                                    int rB = lq >= 56 ? lq - 56 : lq - 14 * gB, mB = rB >> 1, hB = rB & 1;
+                                    bool tail = lq >= 56; // lanes 56-63: stage 1: the zero vector's strip; stage 2, block form: idle
                                     auto roles = [&]() {
                                         lq = l;
                                         asm volatile("" : "+v"(lq));
                                         gS = lq >> 3; pS = lq & 7;
                                         gB = lq >= 42 ? 3 : lq >= 28 ? 2 : lq >= 14 ? 1 : 0;
                                         rB = lq >= 56 ? lq - 56 : lq - 14 * gB; mB = rB >> 1; hB = rB & 1;
-                                        idleB = lq >= 56;
+                                        tail = lq >= 56;
                                     };
-                                    // this lane's share of pass q of window w: table slot (-1: nothing to write), source column, first reference piece
-                                    auto w_cand = [&](int w, int q, int &slot, int &L, int &srcCol, unsigned &oA, unsigned &oB) {
-                                        const int f = lo + SW_BLOCKS * w;
-                                        L = min(SW_BLOCKS, hiE - f);
-                                        const bool strip = (stripW >> w) & 1;
+                                    // this lane's share of pass q of window w in stage st: table slot (-1: nothing to write), the column it writes, whether its
+                                    // block sum is "column + next column" (strip) or "half + other half" (block), source column, first reference piece
+                                    auto w_cand = [&](int st, int w, int q, int &slot, int &colW, bool &stripLane, int &srcCol, unsigned &oA, unsigned &oB) {
+                                        const int f = lo + SW_BLOCKS * w, L = min(SW_BLOCKS, hiE - f);
                                         const int bxf = hpad + stepX * (c0 + f);
-                                        if (strip && q < NQS - 1) {
-                                            const int sU = __builtin_amdgcn_readlane(pkU, f);
-                                            const int idx = q * 8 + gS;
-                                            const int dd = (int)(sPat >> (8 * q)), dx = (dd << 28) >> 28, dy = (dd << 24) >> 28;
-                                            slot = idx < npat ? idx : idx == npat ? slotUp : idx == npat + 1 ? slotZ : -1;
-                                            const bool isZ = idx == npat + 1;
-                                            const int base = isZ ? pkZ : sU;
-                                            const int vx = upx(base) + dx, vy = upy(base) + dy, vyc = isZ ? 0 : vy;
-                                            const int pe = min(pS, L) * 16; // (columns beyond the run re-read its last one)
-                                            if (pS >= L) slot = -1;
-                                            srcCol = pS;
+                                        const bool stripWin = st == 2 && ((stripW >> w) & 1);
+                                        // the block lanes' vectors come from the lanes that own the blocks: fetched HERE, with every lane active (ds_bpermute returns 0
+                                        // for a source lane that is masked off, and in stage 1 lanes 56-63 take the other branch below)
+                                        const int meB = min(mB, L - 1), colB = f + meB; // (lanes beyond the window repeat its last block)
+                                        int bU = 0, bAh = 0, bG = 0, bH = 0, bW = 0;
+                                        if (st == 1) {
+                                            bU = __builtin_amdgcn_ds_bpermute(colB << 2, pkU); bAh = __builtin_amdgcn_ds_bpermute(colB << 2, pkAh);
+                                            bG = __builtin_amdgcn_ds_bpermute(colB << 2, pkG); bH = __builtin_amdgcn_ds_bpermute(colB << 2, pkH);
+                                        } else if (!stripWin) bW = __builtin_amdgcn_ds_bpermute(colB << 2, pkW);
+                                        if (stripWin || (st == 1 && tail)) { // strip lanes: one vector for the whole window
+                                            const int p = st == 1 ? pS : pS, g = gS;
+                                            int vx, vy, vyc;
+                                            if (st == 1) { vx = 0; vy = fieldShift; vyc = 0; slot = slotZ; } // (the zero candidate's chroma ignores fieldShift, :836-839)
+                                            else {
+                                                const int sW = __builtin_amdgcn_readlane(pkW, f);
+                                                const int idx = q * 8 + g;
+                                                const int dd = (int)(sPat >> (8 * q)), dx = (dd << 28) >> 28, dy = (dd << 24) >> 28;
+                                                vx = upx(sW) + dx; vy = upy(sW) + dy; vyc = vy;
+                                                slot = idx < npat ? idx : -1;
+                                            }
+                                            const int pe = min(p, L) * 16; // (columns beyond the run re-read its last one)
+                                            if (p >= L) slot = -1;
+                                            colW = f + p; stripLane = true; srcCol = p;
                                             oA = luma_off_at(bxf, vx, vy) + (unsigned)pe;
                                             oB = 2 * chroma_off_at(bxf, vx, vyc) + (unsigned)pe;
-                                        } else {
-                                            // block form: candidate list of the window: strip windows: ahead, global, hierarchical; others: pattern 0.., up, ahead, zero, global, hierarchical
-                                            const int ci = strip ? gB : q * 4 + gB;
-                                            const int me = min(mB, L - 1), col = f + me; // (lanes beyond the window repeat its last block)
-                                            const int bU = __builtin_amdgcn_ds_bpermute(col << 2, pkU), bAh = __builtin_amdgcn_ds_bpermute(col << 2, pkAh);
-                                            const int bG = __builtin_amdgcn_ds_bpermute(col << 2, pkG), bH = __builtin_amdgcn_ds_bpermute(col << 2, pkH);
+                                        } else { // block lanes: every block its own vector
+                                            const int me = meB, col = colB;
                                             int base, dx = 0, dy = 0;
-                                            bool isZ = false;
-                                            if (strip) { base = ci == 0 ? bAh : ci == 1 ? bG : bH; slot = ci == 0 ? slotUp + 1 : ci == 1 ? slotZ + 1 : ci == 2 ? slotZ + 2 : -1; }
-                                            else {
+                                            if (st == 1) {
+                                                base = gB == 0 ? bU : gB == 1 ? bAh : gB == 2 ? bG : bH;
+                                                slot = gB == 0 ? slotUp : gB == 1 ? slotUp + 1 : slotZ + gB - 1;
+                                            } else {
+                                                base = bW;
+                                                const int ci = q * 4 + gB;
                                                 const int dd = (int)((q < 4 ? bPat0 : bPat1) >> (8 * (q & 3)));
                                                 dx = (dd << 28) >> 28; dy = (dd << 24) >> 28;
-                                                const int k = ci - npat; // 0 up, 1 ahead, 2 zero, 3 global, 4 hierarchical
-                                                base = k == 1 ? bAh : k == 2 ? pkZ : k == 3 ? bG : k == 4 ? bH : bU;
-                                                isZ = k == 2;
-                                                slot = ci < npat ? ci : k == 0 ? slotUp : k == 1 ? slotUp + 1 : k <= 4 ? slotZ + k - 2 : -1;
+                                                slot = (ci < npat && !tail) ? ci : -1;
                                             }
                                             const int bx0 = hpad + stepX * (c0 + col);
                                             const int xMax = (pw - bx0 - BW - hpad + hps) << logPel, xMin = -((bx0 - hpad + hps) << logPel);
                                             const int cxv = upx(base), cyv = upy(base), tx = cxv + dx, ty = cyv + dy;
                                             const bool ok = (tx >= xMin) & (ty >= nDyMin) & (tx < xMax) & (ty < nDyMax); // (outside the block's limits: the centre instead; A2 never reads the entry)
-                                            const int vx = ok ? tx : cxv, vy = ok ? ty : cyv, vyc = isZ ? 0 : vy;
-                                            if (idleB | (hB != 0) | (mB >= L)) slot = -1;
-                                            srcCol = me + hB;
+                                            const int vx = ok ? tx : cxv, vy = ok ? ty : cyv;
+                                            if ((hB != 0) | (mB >= L)) slot = -1;
+                                            colW = f + me; stripLane = false; srcCol = me + hB;
                                             oA = luma_off_at(bx0, vx, vy) + (unsigned)(hB * 16);
-                                            oB = 2 * chroma_off_at(bx0, vx, vyc) + (unsigned)(hB * 16);
+                                            oB = 2 * chroma_off_at(bx0, vx, vy) + (unsigned)(hB * 16);
                                         }
                                     };
                                     // the source strip of window w: lane = (row l >> 3 of 8, column l & 7); luma rows r and r + 8, UV row r
@@ -478,46 +549,68 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                                     // (a leading-edge prefetch -- one dword of every line a window two ahead will need, four scattered loads per window --
                                     // was measured and removed: 493 -> 544 ms per 2046-chain launch, profiles/r4_spec_prefetch.txt)
                                     auto widx = [&](int i) { return fwd ? i : nw - 1 - i; }; // windows in walk order
-                                    int wi = 0, w = widx(0), q = 0;
-                                    StripPass T;
-                                    int slot, L, srcCol; unsigned oA, oB;
-                                    w_cand(w, q, slot, L, srcCol, oA, oB);
-                                    strip_prime(T, oA, oB);
-                                    stage_issue(w);
-                                    for (;;) {
-                                        // the pass after this one (its loads refill the window of loads while this one is consumed)
+                                    auto npass = [&](int st, int w) { return st == 1 ? 1 : ((stripW >> w) & 1) ? (npat + 7) / 8 : (npat + 3) / 4; };
+                                    // one stage: a stream of passes whose loads stay in flight across passes and windows
+                                    auto run_stage = [&](int st) {
+                                        int wi = 0, w = widx(0), q = 0;
+                                        StripPass T;
+                                        int slot, colW, srcCol; bool stripLane; unsigned oA, oB;
                                         roles();
-                                        const bool stripNow = (stripW >> w) & 1;
-                                        int wn = w, qn = q + 1, win = wi;
-                                        if (qn >= (stripNow ? NQS : NQB)) { qn = 0; win = wi + 1; wn = widx(win); }
-                                        const bool more = win < nw;
-                                        int slotN = -1, LN = 0, srcN = 0; unsigned nA = 0, nB = 0;
-                                        SPROF(2);
-                                        if (more) w_cand(wn, qn, slotN, LN, srcN, nA, nB);
-                                        SPROF(11);
-                                        if (q == 0) { // a new window: its source strip (requested one window ahead)
-                                            __builtin_amdgcn_wave_barrier();
-                                            stage_store();
-                                            if (wi + 1 < nw) stage_issue(widx(wi + 1));
-                                            __builtin_amdgcn_wave_barrier();
-                                        }
-                                        SPROF(12);
-                                        if (more) strip_run<true>(T, srcCol, nA, nB); else strip_run<false>(T, srcCol, 0, 0);
-                                        SPROF(13);
-                                        // strip form: block m = columns m and m + 1; block form: the two halves of a block sit in neighbouring lanes
-                                        const bool stripPass = stripNow && q < NQS - 1;
-                                        const unsigned nL = stripPass ? (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aL, 0x101, 0xf, 0xf, true) : (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aL, 0xB1, 0xf, 0xf, true);
-                                        const unsigned nC = stripPass ? (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aC, 0x101, 0xf, 0xf, true) : (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aC, 0xB1, 0xf, 0xf, true);
-                                        const int colW = lo + SW_BLOCKS * w + (stripPass ? pS : mB);
-                                        if (slot >= 0) *(LDS_AS v2u *)(tab + slot * SPEC_STRIDE + (colW & (SPEC_TB - 1)) * 8) = v2u{T.aL + nL, T.aC + nC};
-                                        SPROF(14);
+                                        w_cand(st, w, q, slot, colW, stripLane, srcCol, oA, oB);
+                                        strip_prime(T, oA, oB);
+                                        stage_issue(w);
+                                        for (;;) {
+                                            roles();
+                                            int wn = w, qn = q + 1, win = wi;
+                                            if (qn >= npass(st, w)) { qn = 0; win = wi + 1; wn = widx(win); }
+                                            const bool more = win < nw;
+                                            int slotN = -1, colN = 0, srcN = 0; bool stripN = false; unsigned nA = 0, nB = 0;
+                                            SPROF(2);
+                                            if (more) w_cand(st, wn, qn, slotN, colN, stripN, srcN, nA, nB); // the pass after this one (its loads refill the window of loads while this one is consumed)
+                                            SPROF(11);
+                                            if (q == 0) { // a new window: its source strip (requested one window ahead)
+                                                __builtin_amdgcn_wave_barrier();
+                                                stage_store();
+                                                if (wi + 1 < nw) stage_issue(widx(wi + 1));
+                                                __builtin_amdgcn_wave_barrier();
+                                            }
+                                            SPROF(12);
+                                            if (more) strip_run<true>(T, srcCol, nA, nB); else strip_run<false>(T, srcCol, 0, 0);
+                                            SPROF(13);
+                                            // strip lanes: block m = columns m and m + 1; block lanes: the two halves of a block sit in neighbouring lanes
+                                            const unsigned sL = (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aL, 0x101, 0xf, 0xf, true), sC = (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aC, 0x101, 0xf, 0xf, true);
+                                            const unsigned hL = (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aL, 0xB1, 0xf, 0xf, true), hC = (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aC, 0xB1, 0xf, 0xf, true);
+                                            if (slot >= 0) *(LDS_AS v2u *)(tab + slot * SPEC_STRIDE + (colW & (SPEC_TB - 1)) * 8) = v2u{T.aL + (stripLane ? sL : hL), T.aC + (stripLane ? sC : hC)};
+                                            SPROF(14);
 #ifdef MVX_SPEC_PROF
-                                        sprof[15] += 1;
+                                            sprof[15] += 1;
 #endif
-                                        if (!more) break;
-                                        w = wn; wi = win; q = qn; slot = slotN; L = LN; srcCol = srcN;
+                                            if (!more) break;
+                                            w = wn; wi = win; q = qn; slot = slotN; colW = colN; stripLane = stripN; srcCol = srcN;
+                                        }
+                                        __builtin_amdgcn_wave_barrier();
+                                    };
+                                    run_stage(1);
+                                    a2_pred(pBest, pX_, pY_, pSad); // the predictor phase of every block of the group
+                                    pkW = pk(pX_, pY_);
+#if MVX_SPEC_ABL == 9
+                                    if (lvl == 1 && act && J.fieldShift == 0 && blky >= 1) { // debug dump of the first chain's predictor phase
+                                        int *o = g_specdbg + ((blky - 1) * 64 + c) * 12;
+                                        const int sUp = hexLevel ? 14 : 24, sZ = hexLevel ? 16 : 26;
+                                        o[0] = pkU; o[1] = pkAh; o[2] = pkG; o[3] = pkH; o[4] = pkW; o[5] = pBest;
+                                        o[6] = tot(rd(sUp)); o[7] = tot(rd(sUp + 1)); o[8] = tot(rd(sZ)); o[9] = tot(rd(sZ + 1)); o[10] = tot(rd(sZ + 2)); o[11] = lam;
                                     }
-                                    __builtin_amdgcn_wave_barrier();
+#endif
+                                    { // windows whose blocks share the centre and keep the whole pattern inside their limits
+                                        const bool ok2 = (pX_ - 2 >= dxMin) & (pX_ + 2 <= dxMax1) & (pY_ - 2 >= nDyMin) & (pY_ + 2 < nDyMax);
+                                        for (int w = 0; w < nw; w++) {
+                                            const int f = lo + SW_BLOCKS * w, e = min(f + SW_BLOCKS, hiE);
+                                            const bool inw = (l >= f) & (l < e);
+                                            const int w0 = __builtin_amdgcn_readlane(pkW, f);
+                                            if (MVX_SPEC_ABL != 7 && e - f >= 2 && __ballot(inw & ((pkW != w0) | !ok2)) == 0) stripW |= 1u << w; // (ABL 7: block form only)
+                                        }
+                                    }
+                                    run_stage(2);
                                 }
                             }
 
@@ -707,61 +800,17 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                         __builtin_amdgcn_wave_barrier();
 
                         SPROF(3);
-                        // ======== A2: one lane per block -- the predictor phase (:832-915) and the refinement (:773-816) under the hypothesis
-                        // left == median == up, costs as pobCheckMV0 / pobCheckMV (:219-261), strict < in the reference's order
+                        // ======== A2: one lane per block -- predictor phase (unless stage 1 already ran it) and refinement
                         {
-                            const int ti8 = (l & (SPEC_TB - 1)) * 8;
-                            auto rd = [&](int slot) { return *(const LDS_AS v2u *)(tab + slot * SPEC_STRIDE + ti8); };
-                            auto tot = [&](const v2u &t) { return (int)t[0] + (chroma ? (int)t[1] : 0); };
-                            auto md = [&](int vx, int vy) { // motion_distortion (:105-114) around the hierarchical predictor
-                                const unsigned dx = (unsigned)(hx - vx), dy = (unsigned)(hy - vy);
-                                const int dist = (int)(dx * dx + dy * dy);
-                                return (int)(((long long)lam * dist) >> 8);
-                            };
-                            const int sUp = hexLevel ? 14 : 24, sZ = hexLevel ? 16 : 26;
-                            const v2u tU = rd(sUp), tA = rd(sUp + 1), tZ = rd(sZ), tG = rd(sZ + 1), tH = rd(sZ + 2);
-                            int best, bx = 0, by = fieldShift, bs;
-                            { const int t = tot(tZ); int cc = t + (int)(((long long)penaltyZero * t) >> 8); cc = F::sat_add(0, cc); best = cc; bs = t; }
-                            { const int t = tot(tG); int cc = t + (int)(((long long)pglobal * t) >> 8); cc = F::sat_add(0, cc); if (cc < best) { best = cc; bx = upx(pkG); by = upy(pkG); bs = t; } }
-                            { const int t = tot(tH); const int cc = F::sat_add(0, t); if (cc < best) { best = cc; bx = hx; by = hy; bs = t; } }
-                            { const int t = tot(tU); const int cc = F::sat_add(md(ux, uy), t); if (cc < best) { best = cc; bx = ux; by = uy; bs = t; } } // median = left = up
-                            { const int t = tot(tA); const int cc = F::sat_add(md(ax, ay), t); if (cc < best) { best = cc; bx = ax; by = ay; bs = t; } }
-                            bool live = !(bx == ux && by == uy); // the pattern was evaluated around up
-                            auto vok = [&](int vx, int vy) { return vx >= dxMin && vy >= nDyMin && vx <= dxMax1 && vy < nDyMax; };
-                            auto cnew = [&](int vx, int vy, const v2u &t) { // pobCheckMV: penalty for new vectors, saturating
-                                int cc = (int)t[0] + ((penaltyNew * (int)t[0]) >> 8);
-                                if (chroma) cc += (int)t[1] + ((penaltyNew * (int)t[1]) >> 8);
-                                return F::sat_add(md(vx, vy), cc);
-                            };
-                            if (hexLevel) {
-                                if (nSearchParam > 1) { // a hexagon point that beats the predictor phase moves the centre (:682-724): left to the live search
-                                    bool won = false;
-#pragma unroll 1
-                                    for (int k = 0; k < 6; k++) {
-                                        const int vx = ux + tab8(HEX2X >> 8, k), vy = uy + tab8(HEX2Y >> 8, k);
-                                        won = won || (vok(vx, vy) && cnew(vx, vy, rd(k)) < best);
-                                    }
-                                    live = live || won;
-                                }
-#pragma unroll 1
-                                for (int k = 0; k < 8; k++) { // pobExpandingSearch(1, 1) around up (:636-658)
-                                    const int vx = ux + tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), k), vy = uy + tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), k);
-                                    const v2u t = rd(6 + k);
-                                    const int cc = cnew(vx, vy, t);
-                                    if (vok(vx, vy) && cc < best) { best = cc; bx = vx; by = vy; bs = tot(t); }
-                                }
+                            bool live = false;
+                            int best = pBest, bx = pX_, by = pY_, bs = pSad;
+                            if (!staged2) {
+                                a2_pred(best, bx, by, bs);
+                                live = !(bx == ux && by == uy); // (one block at a time: the pattern was evaluated around up)
+                                live = a2_refine(ux, uy, best, bx, by, bs) || live;
                             } else {
-#pragma unroll 1
-                                for (int k = 0; k < 24; k++) { // rings 1 and 2 (:786-791)
-                                    int dx, dy;
-                                    if (k < 8) { dx = tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), k); dy = tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), k); }
-                                    else if (k < 16) { dx = tab8(PACK8(-1, -1, 0, 0, 1, 1, -2, 2), k - 8); dy = tab8(PACK8(-2, 2, -2, 2, -2, 2, -1, -1), k - 8); }
-                                    else { dx = tab8(PACK8(-2, 2, -2, 2, -2, -2, 2, 2), k - 16); dy = tab8(PACK8(0, 0, 1, 1, -2, 2, -2, 2), k - 16); }
-                                    const int vx = ux + dx, vy = uy + dy;
-                                    const v2u t = rd(k);
-                                    const int cc = cnew(vx, vy, t);
-                                    if (vok(vx, vy) && cc < best) { best = cc; bx = vx; by = vy; bs = tot(t); }
-                                }
+                                live = a2_refine(pX_, pY_, best, bx, by, bs);
+                                if (MVX_SPEC_ABL == 8) live = live || !(pX_ == ux && pY_ == uy); // (debug: accept only blocks whose centre is up)
                             }
                             // the bad-block rescue (:938-963) is the live search's; a higher badcount later only raises the threshold
                             live = live || (blky * nBlkX + c > 1 && (long long)bs > badSAD + badSAD * badcount / 16);
@@ -944,6 +993,9 @@ __global__ __launch_bounds__(64 * MAXCPW, WPE) void analyse_spec_kernel(const AP
 extern "C" __attribute__((visibility("default"))) int mvx_debug_specprof(unsigned long long *out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_specprof), sizeof(unsigned long long) * SPROF_N) == hipSuccess ? 0 : -1;
 }
+#endif
+#if MVX_SPEC_ABL == 9 && defined(MVX_PROF_EXPORT)
+extern "C" __attribute__((visibility("default"))) int mvx_debug_specdbg(int *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_specdbg), sizeof(int) * 4 * 64 * 12) == hipSuccess ? 0 : -1; }
 #endif
 #if defined(MVX_SPEC_STATS) && defined(MVX_PROF_EXPORT)
 extern "C" __attribute__((visibility("default"))) int mvx_debug_specstats(unsigned long long *out, int reset) {
