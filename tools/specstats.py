@@ -23,7 +23,7 @@ p.step(time_search=True)
 torch.cuda.synchronize()
 assert mv.lib().mvx_debug_specstats(out, 1) == 0
 print("batch %d: search launch %.1f ms (counting build)" % (batch, p.ev[0][0].elapsed_time(p.ev[0][1])))
-print("level: blocks in speculated rows, searched live (share), of them flag clear (centre != up / hexagon won / rescue), rescues")
+print("level: blocks in speculated rows, searched live (share), of them flag clear (hexagon won / rescue), accepted after redoing the predictor phase with the true left / median")
 for lv in range(16):
     b, live, flag, resc = (int(out[lv * 4 + i]) for i in range(4))
     if b:

@@ -332,6 +332,8 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                     int rX = 0, rY = 0, rSad = 0;          // this lane's block: speculative result
                     int pkU = 0, pkAh = 0, pkH = 0, pkG = 0; // this lane's block: clipped up / ahead / hierarchical / global predictors
                     int lam = 0;                             // this lane's block: lambda
+                    bool staged2G = false;                   // the two-stage row passes ran (the predictor phase's outcome below is valid)
+                    int lamG = 0, pBestG = 0, pkWG = 0;      // this lane's block: lambda, the predictor phase's cost and vector under the hypothesis
                     int gEndX = gmvx;
                     if (specRow) {
                         // ======== A1: one lane per block -- limits (:1094-1097) and the predictors that do not depend on the left neighbour (:427-449)
@@ -815,6 +817,7 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                             // the bad-block rescue (:938-963) is the live search's; a higher badcount later only raises the threshold
                             live = live || (blky * nBlkX + c > 1 && (long long)bs > badSAD + badSAD * badcount / 16);
                             rX = bx; rY = by; rSad = bs;
+                            staged2G = staged2; lamG = lam; pBestG = pBest; pkWG = pk(pX_, pY_);
                             // the hypothesis: my left neighbour's (speculative) result, clipped to MY limits, is my up predictor
                             int nb = __builtin_amdgcn_ds_bpermute((l - dir) << 2, pk(bx, by));
                             if (l == (fwd ? lo : hiE - 1)) nb = pk(prevX, prevY);
@@ -847,6 +850,52 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                             if (pos == end) break;
                         }
                         SPROF(5);
+                        // ---- a block whose hypothesis FAILED but whose flag is set: its true left / median vectors differ from up, everything else it needs is in
+                        // the table.  If both vectors are among the five the table holds (they usually are: the left neighbour ended on one of MY predictors), the
+                        // predictor phase is redone here with their costs in their places (:832-915 order: zero, global, hierarchical, MEDIAN, LEFT, up, ahead); when
+                        // it ends on the same vector with the same cost as under the hypothesis, the refinement that was computed for that outcome stands.
+                        if (staged2G && ((flagmask >> pos) & 1)) {
+                            const int li = pos, blkx = c0 + li;
+                            const bool havePrev = fwd ? blkx > 0 : blkx < nBlkX - 1;
+                            const int xb = stepX * blkx;
+                            const int xMin = -((xb + hps) << logPel), xMax1 = ((pw - xb - hpad - BW - hpad + hps) << logPel) - 1;
+                            const int sU = __builtin_amdgcn_readlane(pkU, li), sA = __builtin_amdgcn_readlane(pkAh, li), sG = __builtin_amdgcn_readlane(pkG, li), sH = __builtin_amdgcn_readlane(pkH, li);
+                            const int Lx = min(max(havePrev ? prevX : 0, xMin), xMax1), Ly = this->clipy(havePrev ? prevY : fieldShift);
+                            auto med = [](int a, int b, int c2) { return max(min(a, b), min(max(a, b), c2)); };
+                            const int Mx = med(Lx, upx(sU), upx(sA)), My = med(Ly, upy(sU), upy(sA));
+                            const int slotUpB = hexLevel ? 14 : 24, slotZB = hexLevel ? 16 : 26;
+                            auto find = [&](int vx, int vy) { // the table slot that holds this vector's SADs as a PLAIN vector (the zero candidate's chroma ignores a field shift)
+                                const int v = pk(vx, vy);
+                                return v == sU ? slotUpB : v == sA ? slotUpB + 1 : v == sG ? slotZB + 1 : v == sH ? slotZB + 2 : (v == 0 && fieldShift == 0) ? slotZB : -1;
+                            };
+                            const int fL = find(Lx, Ly), fM = find(Mx, My);
+                            if (fL >= 0 && fM >= 0) {
+                                const lds_u8 *tcol = tab + (li & (SPEC_TB - 1)) * 8;
+                                auto totS = [&](int slot) { const v2u t = *(const LDS_AS v2u *)(tcol + slot * SPEC_STRIDE); return uni((int)t[0] + (chroma ? (int)t[1] : 0)); };
+                                const int lamS = __builtin_amdgcn_readlane(lamG, li);
+                                auto mdS = [&](int vx, int vy) { const unsigned dx = (unsigned)(upx(sH) - vx), dy = (unsigned)(upy(sH) - vy); return (int)(((long long)lamS * (int)(dx * dx + dy * dy)) >> 8); };
+                                int best, wx = 0, wy = fieldShift, ws;
+                                { const int t = totS(slotZB); best = F::sat_add(0, t + (int)(((long long)penaltyZero * t) >> 8)); ws = t; }
+                                { const int t = totS(slotZB + 1); const int cc = F::sat_add(0, t + (int)(((long long)pglobal * t) >> 8)); if (cc < best) { best = cc; wx = upx(sG); wy = upy(sG); ws = t; } }
+                                { const int t = totS(slotZB + 2); const int cc = F::sat_add(0, t); if (cc < best) { best = cc; wx = upx(sH); wy = upy(sH); ws = t; } }
+                                { const int t = totS(fM); const int cc = F::sat_add(mdS(Mx, My), t); if (cc < best) { best = cc; wx = Mx; wy = My; ws = t; } }
+                                { const int t = totS(fL); const int cc = F::sat_add(mdS(Lx, Ly), t); if (cc < best) { best = cc; wx = Lx; wy = Ly; ws = t; } }
+                                { const int t = totS(slotUpB); const int cc = F::sat_add(mdS(upx(sU), upy(sU)), t); if (cc < best) { best = cc; wx = upx(sU); wy = upy(sU); ws = t; } }
+                                { const int t = totS(slotUpB + 1); const int cc = F::sat_add(mdS(upx(sA), upy(sA)), t); if (cc < best) { best = cc; wx = upx(sA); wy = upy(sA); ws = t; } }
+                                if (best == __builtin_amdgcn_readlane(pBestG, li) && pk(wx, wy) == __builtin_amdgcn_readlane(pkWG, li)) { // same centre, same cost to beat: same refinement, same result
+                                    const bool mine = l == li;
+                                    bOut[0] = mine ? (unsigned)rX : bOut[0]; bOut[1] = mine ? (unsigned)rY : bOut[1]; bOut[2] = mine ? (unsigned)rSad : bOut[2];
+                                    prevX = __builtin_amdgcn_readlane(rX, li); prevY = __builtin_amdgcn_readlane(rY, li); prevSad = __builtin_amdgcn_readlane(rSad, li);
+#ifdef MVX_SPEC_STATS
+                                    st0 += 1; st3 += 1;
+#endif
+                                    const int nx = pos + dir; // (the next block's hypothesis was checked against this block's speculative result: that IS its result)
+                                    (void)nx;
+                                    pos += dir;
+                                    continue;
+                                }
+                            }
+                        }
                         { // ---- block `pos` live (the lean kernel's block: predictors :419-463, pobPseudoEPZSearch :819-968)
                             const int li = pos, blkx = c0 + li;
                             A4x32 sb[G::NPF];
@@ -927,7 +976,7 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
             }
         }
 #ifdef MVX_SPEC_STATS
-        if (l == 0) { atomicAdd(&g_specstat[lvl][0], st0); atomicAdd(&g_specstat[lvl][1], st1); atomicAdd(&g_specstat[lvl][2], st2); atomicAdd(&g_specstat[lvl][3], (unsigned long long)badcount); }
+        if (l == 0) { atomicAdd(&g_specstat[lvl][0], st0); atomicAdd(&g_specstat[lvl][1], st1); atomicAdd(&g_specstat[lvl][2], st2); atomicAdd(&g_specstat[lvl][3], st3); }
 #endif
         SPROF(7);
         // vectors[] of this level feed the next level's interpolation / global-MV estimate (other lanes read them)
