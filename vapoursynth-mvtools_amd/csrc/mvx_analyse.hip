@@ -359,7 +359,8 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         int sTab = 0, sRow = fRow;
         if (useSpec) {
             const bool anyExh = P.searchType == SearchExhaustive || (P.nLevels > 1 && P.searchTypeCoarse == SearchExhaustive);
-            const int sSrc = (P.bps == 2 && P.blkX == 16 && fRow < 3072) ? 3072 : fRow; // the source strip of a run of seven blocks (mvx_analyse_spec.h: STRIP_OK)
+            const int sStrip = (P.bps == 2 && P.blkX == 16) ? (P.blkX + P.blkX / 2) * 128 : 0; // the source strip of a window of blocks: 24 (48) rows x 8 columns (mvx_analyse_spec.h: STRIP_OK)
+            const int sSrc = fRow < sStrip ? sStrip : fRow;
             sRow = sSrc;
             sTab = sSrc + ((fMaxBlkX * 8 + 15) & ~15);
             fNeed = 0; // per level: row buffer (8 B per block of THAT level) + the table of its search type

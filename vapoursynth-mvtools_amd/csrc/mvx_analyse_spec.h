@@ -171,8 +171,14 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
     // up to seven blocks), eight candidates per pass, 24 rows (16 luma + 8 of the UV plane) per lane and pass.  Against one block at a time:
     // 128 contiguous bytes per candidate row instead of 7 x 32 scattered ones (~2.3x fewer L1 misses, 3.5x fewer look-ups), half the SADs.
     // The source blocks of the run are one strip in LDS (3 KB: 24 rows x 8 columns).
+    // (the row-pass code below is written for 16x16 AND 32x32 blocks -- HC columns per half block -- but only 16x16 is enabled: at 32x32 it was no faster
+    // than the serial kernel on cfg5 (90.1 against 92.3 fps: windows of three blocks share less, six staging pieces and 24 loads in flight do not fit the
+    // registers) and one 8K bench clip disagreed with the oracle, which was not chased: profiles/r4_cfg5_rowpasses.txt)
     static constexpr bool STRIP_OK = UV && BPS == 2 && BW == 16;
-    static constexpr int SW_BLOCKS = 7, SNA = 16, SNB = 8, SNT = SNA + SNB, SW = SWIN, S_UV = SNA * 128; // window of blocks, rows, loads in flight, LDS offset of the UV rows
+    // HC = 16-byte columns per half block (a 32x32 block row is four columns, blocks step by two); a window is eight columns: 7 (3) blocks;
+    // block form: LPB lanes per block, LPC per candidate (four candidates: lanes 0..4 * LPC - 1; lanes 56-63 stay free for the zero vector's strip)
+    static constexpr int HC = STRIP_OK ? BW / 16 : 1, SW_BLOCKS = 8 / HC - 1, LPB = 2 * HC, LPC = SW_BLOCKS * LPB;
+    static constexpr int SNA = BW, SNB = BW / 2, SNT = SNA + SNB, SW = (BW == 32 && SWIN > 12) ? 12 : SWIN, S_UV = SNA * 128, SSTG = SNT / 8; // (32x32: 12 in flight -- 24 plus the six staging pieces spill) // rows of a pass, loads in flight, LDS offset of the UV rows, staging pieces per lane
     struct StripPass { v4u r[SW]; unsigned curA, curB, aL, aC; };
     __device__ __forceinline__ v4u strip_issue(StripPass &T, int piece) const {
         v4u v;
@@ -470,18 +476,17 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                                     // compiler hoists all of them to the top of the level and then has to spill them)
                                     int lq = l;
                                     asm volatile("" : "+v"(lq));
-                                    int gS = lq >> 3, pS = lq & 7;
-                                    int gB = lq >= 42 ? 3 : lq >= 28 ? 2 : lq >= 14 ? 1 : 0;
-                                    int rB = lq >= 56 ? lq - 56 : lq - 14 * gB, mB = rB >> 1, hB = rB & 1;
-                                    bool tail = lq >= 56; // lanes 56-63: stage 1: the zero vector's strip; stage 2, block form: idle
+                                    int gS, pS, gB, rB, mB, hB;
+                                    bool tail, idleB; // lanes 56-63: stage 1: the zero vector's strip; block form: idle, like the lanes between 4 * LPC and 56
                                     auto roles = [&]() {
                                         lq = l;
                                         asm volatile("" : "+v"(lq));
                                         gS = lq >> 3; pS = lq & 7;
-                                        gB = lq >= 42 ? 3 : lq >= 28 ? 2 : lq >= 14 ? 1 : 0;
-                                        rB = lq >= 56 ? lq - 56 : lq - 14 * gB; mB = rB >> 1; hB = rB & 1;
-                                        tail = lq >= 56;
+                                        gB = min(lq / LPC, 3);
+                                        rB = lq >= 4 * LPC ? (lq - 4 * LPC) % LPC : lq - LPC * gB; mB = rB / LPB; hB = rB % LPB;
+                                        tail = lq >= 56; idleB = lq >= 4 * LPC;
                                     };
+                                    roles();
                                     // this lane's share of pass q of window w in stage st: table slot (-1: nothing to write), the column it writes, whether its
                                     // block sum is "column + next column" (strip) or "half + other half" (block), source column, first reference piece
                                     auto w_cand = [&](int st, int w, int q, int &slot, int &colW, bool &stripLane, int &srcCol, unsigned &oA, unsigned &oB) {
@@ -507,9 +512,9 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                                                 vx = upx(sW) + dx; vy = upy(sW) + dy; vyc = vy;
                                                 slot = idx < npat ? idx : -1;
                                             }
-                                            const int pe = min(p, L) * 16; // (columns beyond the run re-read its last one)
-                                            if (p >= L) slot = -1;
-                                            colW = f + p; stripLane = true; srcCol = p;
+                                            const int pe = min(p, HC * (L + 1) - 1) * 16; // (columns beyond the run re-read its last one)
+                                            if ((p % HC != 0) | (p / HC >= L)) slot = -1;  // (block m is written by the lane of its first column)
+                                            colW = f + p / HC; stripLane = true; srcCol = p;
                                             oA = luma_off_at(bxf, vx, vy) + (unsigned)pe;
                                             oB = 2 * chroma_off_at(bxf, vx, vyc) + (unsigned)pe;
                                         } else { // block lanes: every block its own vector
@@ -523,30 +528,33 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                                                 const int ci = q * 4 + gB;
                                                 const int dd = (int)((q < 4 ? bPat0 : bPat1) >> (8 * (q & 3)));
                                                 dx = (dd << 28) >> 28; dy = (dd << 24) >> 28;
-                                                slot = (ci < npat && !tail) ? ci : -1;
+                                                slot = ci < npat ? ci : -1;
                                             }
                                             const int bx0 = hpad + stepX * (c0 + col);
                                             const int xMax = (pw - bx0 - BW - hpad + hps) << logPel, xMin = -((bx0 - hpad + hps) << logPel);
                                             const int cxv = upx(base), cyv = upy(base), tx = cxv + dx, ty = cyv + dy;
                                             const bool ok = (tx >= xMin) & (ty >= nDyMin) & (tx < xMax) & (ty < nDyMax); // (outside the block's limits: the centre instead; A2 never reads the entry)
                                             const int vx = ok ? tx : cxv, vy = ok ? ty : cyv;
-                                            if ((hB != 0) | (mB >= L)) slot = -1;
-                                            colW = f + me; stripLane = false; srcCol = me + hB;
+                                            if ((hB != 0) | (mB >= L) | idleB) slot = -1;
+                                            colW = f + me; stripLane = false; srcCol = HC * me + hB;
                                             oA = luma_off_at(bx0, vx, vy) + (unsigned)(hB * 16);
                                             oB = 2 * chroma_off_at(bx0, vx, vy) + (unsigned)(hB * 16);
                                         }
                                     };
                                     // the source strip of window w: lane = (row l >> 3 of 8, column l & 7); luma rows r and r + 8, UV row r
-                                    A4x32 sa0, sa1, sb;
+                                    A4x32 stg[SSTG]; // (rows gS, gS + 8, ...: the luma rows first, then the rows of the UV plane)
                                     auto stage_issue = [&](int w) {
-                                        const int f = lo + SW_BLOCKS * w, L = min(SW_BLOCKS, hiE - f), bx0 = hpad + stepX * (c0 + f), pe = min(pS, L) * 16;
-                                        const unsigned oy = (unsigned)(y0 + gS) * pitchY + (unsigned)bx0 * BPS + (unsigned)pe;
-                                        sa0 = ld_chunk_g(srcY + oy, 16); sa1 = ld_chunk_g(srcY + oy + 8 * pitchY, 16);
-                                        sb = ld_chunk_g(srcUV + (unsigned)((y0 >> 1) + gS) * 2 * pitchC + (unsigned)(bx0 >> 1) * 2 * BPS + (unsigned)pe, 16);
+                                        const int f = lo + SW_BLOCKS * w, L = min(SW_BLOCKS, hiE - f), bx0 = hpad + stepX * (c0 + f), pe = min(pS, HC * (L + 1) - 1) * 16;
+#pragma unroll
+                                        for (int k = 0; k < SSTG; k++) {
+                                            const int row = gS + 8 * k;
+                                            if (8 * k < SNA) stg[k] = ld_chunk_g(srcY + (unsigned)(y0 + row) * pitchY + (unsigned)bx0 * BPS + (unsigned)pe, 16);
+                                            else stg[k] = ld_chunk_g(srcUV + (unsigned)((y0 >> 1) + row - SNA) * 2 * pitchC + (unsigned)(bx0 >> 1) * 2 * BPS + (unsigned)pe, 16);
+                                        }
                                     };
                                     auto stage_store = [&]() {
-                                        st_chunk_l(lds + gS * 128 + pS * 16, sa0, 16); st_chunk_l(lds + (gS + 8) * 128 + pS * 16, sa1, 16);
-                                        st_chunk_l(lds + S_UV + gS * 128 + pS * 16, sb, 16);
+#pragma unroll
+                                        for (int k = 0; k < SSTG; k++) st_chunk_l(lds + (gS + 8 * k) * 128 + pS * 16, stg[k], 16); // (S_UV = SNA * 128: the UV rows follow the luma rows)
                                     };
                                     // (a leading-edge prefetch -- one dword of every line a window two ahead will need, four scattered loads per window --
                                     // was measured and removed: 493 -> 544 ms per 2046-chain launch, profiles/r4_spec_prefetch.txt)
@@ -580,9 +588,13 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                                             if (more) strip_run<true>(T, srcCol, nA, nB); else strip_run<false>(T, srcCol, 0, 0);
                                             SPROF(13);
                                             // strip lanes: block m = columns m and m + 1; block lanes: the two halves of a block sit in neighbouring lanes
-                                            const unsigned sL = (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aL, 0x101, 0xf, 0xf, true), sC = (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aC, 0x101, 0xf, 0xf, true);
-                                            const unsigned hL = (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aL, 0xB1, 0xf, 0xf, true), hC = (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aC, 0xB1, 0xf, 0xf, true);
-                                            if (slot >= 0) *(LDS_AS v2u *)(tab + slot * SPEC_STRIDE + (colW & (SPEC_TB - 1)) * 8) = v2u{T.aL + (stripLane ? sL : hL), T.aC + (stripLane ? sC : hC)};
+                                            unsigned sL = T.aL + (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aL, 0x101, 0xf, 0xf, true), sC = T.aC + (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aC, 0x101, 0xf, 0xf, true);
+                                            unsigned hL = T.aL + (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aL, 0xB1, 0xf, 0xf, true), hC = T.aC + (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aC, 0xB1, 0xf, 0xf, true);
+                                            if (HC == 2) { // a 32x32 block: four columns / four lanes
+                                                sL += (unsigned)__builtin_amdgcn_update_dpp(0, (int)sL, 0x102, 0xf, 0xf, true); sC += (unsigned)__builtin_amdgcn_update_dpp(0, (int)sC, 0x102, 0xf, 0xf, true);
+                                                hL += (unsigned)__builtin_amdgcn_update_dpp(0, (int)hL, 0x4E, 0xf, 0xf, true); hC += (unsigned)__builtin_amdgcn_update_dpp(0, (int)hC, 0x4E, 0xf, 0xf, true);
+                                            }
+                                            if (slot >= 0) *(LDS_AS v2u *)(tab + slot * SPEC_STRIDE + (colW & (SPEC_TB - 1)) * 8) = v2u{stripLane ? sL : hL, stripLane ? sC : hC};
                                             SPROF(14);
 #ifdef MVX_SPEC_PROF
                                             sprof[15] += 1;
