@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -x -q -m gpu -k "analyse or golden or full_size_parity_cfg3 or degrain_parity" 2>&1 | tail -5 | tee gpurun_out/r4_twostage_tests.txt
+timeout 900 python -m pytest tests -x -q -m gpu -k "analyse or golden or full_size_parity_cfg3" 2>&1 | tail -5 | tee gpurun_out/r4_twostage_tests.txt
 O=gpurun_out/r4_spec_twostage.txt; : > $O
 run() { echo "== $1" >> $O; shift; env "$@" timeout 400 python bench.py --no-cpu --no-traffic --steps 2 --warmup 1 $EXTRA 2>&1 | tail -1 | python -c "
 import sys,json

@@ -390,7 +390,10 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         if ((long long)perChain * 4 * k <= 160 * 1024) {
             std::stable_sort(hj.begin(), hj.end(), [](const AJob &x, const AJob &y) { return (uintptr_t)x.ref[0] > (uintptr_t)y.ref[0]; }); // (no reference: last)
             int cpw = 4 * k;
-            if (g_dbg.fast_cpw > 0 && g_dbg.fast_cpw < cpw) cpw = g_dbg.fast_cpw;
+            // the speculative kernel's chains wait for each other less in workgroups of FOUR (two per CU) that meet every 128 blocks: 345 ms per
+            // 2046-chain launch against 370 with eight and a barrier per group (profiles/r4_spec_twostage_workgroup_size.txt, ..._barrier_interval.txt)
+            if (useSpecStrips) cpw = 4;
+            if (g_dbg.fast_cpw > 0 && g_dbg.fast_cpw < 4 * k) cpw = g_dbg.fast_cpw;
             // keep the chains that share a reference frame in one workgroup where they fit: a run of the sorted table that would
             // straddle a workgroup boundary starts a new workgroup instead (the skipped slots become padding entries, blob == NULL)
             std::vector<AJob> padded;
@@ -421,6 +424,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
             // 8: 388, 4: 383; 8K16 at two per SIMD: 256: 59.5, 16: 64.6.  8-bit clips (plain layout): 256 stays best (1080p: 2005 against
             // 1953-1970 with 16-64).
             int syncEvery = k >= 2 ? (P.bps == 2 ? 32 : 256) : 0;
+            if (useSpecStrips) syncEvery = 128;
             if (g_dbg.cpw_sync >= 0 && (g_dbg.cpw_sync & (g_dbg.cpw_sync - 1)) == 0) syncEvery = g_dbg.cpw_sync;
             // XCD-contiguous workgroup order: neighbours in the (reference-sorted) job table share an L2 (+0.5 %, 4K16)
             const int flags = (g_dbg.fast_flags >= 0 ? g_dbg.fast_flags : MVX_FAST_XCD_REMAP) | ((P.shadow[1] != 0 && P.chroma) ? MVX_FAST_UV : 0) | (g_dbg.spec == 2 ? MVX_FAST_NOSPEC : 0) | (g_dbg.spec == 3 ? MVX_FAST_NOSTRIP : 0);
