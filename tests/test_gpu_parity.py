@@ -523,6 +523,37 @@ WINDOW_CASES = [
 ])
 @pytest.mark.parametrize("mode", ["default", "everywhere", "no-runs"])
 def test_analyse_speculative_kernel(oracle, mv, dbg, mode, w, h, skw, akw):
+    _speculative_case(oracle, mv, dbg, mode, w, h, 16, skw, akw)
+
+
+# the same kernel on 8-bit clips: row passes over windows of up to fifteen 8x8 blocks overlapping by four (a half block = one dword)
+ROWS8_CASES = [
+    (384, 224, {}, dict(blksize=8, overlap=4)),                                   # cfg2 shape
+    (320, 192, {}, dict(blksize=8, overlap=4, _noise=14)),                        # most hypotheses fail
+    (320, 192, {}, dict(blksize=8, overlap=4, _noise=14, badsad=300, badrange=-3)),
+    (256, 144, {}, dict(blksize=8, overlap=0)),                                   # no row passes: one block at a time / the lean kernel
+    (256, 144, {}, dict(blksize=8, overlap=4, chroma=0)),
+    (256, 144, dict(pel=1), dict(blksize=8, overlap=4)),
+    (256, 144, {}, dict(blksize=8, overlap=4, search=3, searchparam=2, pelsearch=2)),  # exhaustive radius 2 at the finest level too
+    (256, 144, {}, dict(blksize=8, overlap=4, pelsearch=1)),
+    (256, 144, {}, dict(blksize=8, overlap=4, global_=0, pglobal=30, pzero=90)),
+    (256, 144, {}, dict(blksize=8, overlap=4, meander=0, levels=2)),
+    (200, 120, dict(hpad=8, vpad=8), dict(blksize=8, overlap=4)),
+    (136, 96, dict(hpad=4, vpad=4), dict(blksize=8, overlap=4, pglobal=20)),      # tiny padding: candidates reach the very end of a row
+    (1000, 64, {}, dict(blksize=8, overlap=4)),                                   # several 64-block groups per row; a short last group
+    (532, 64, {}, dict(blksize=8, overlap=4, meander=0)),                         # 132 blocks per row: a last group of four
+    (524, 64, {}, dict(blksize=8, overlap=4)),                                    # 130 blocks per row: a last group of two (one block at a time)
+    (640, 360, {}, dict(blksize=8, overlap=4, _noise=0)),                         # a clean clip: long verified runs
+]
+
+
+@pytest.mark.parametrize("w,h,skw,akw", ROWS8_CASES)
+@pytest.mark.parametrize("mode", ["default", "everywhere"])
+def test_analyse_speculative_kernel_8bit(oracle, mv, dbg, mode, w, h, skw, akw):
+    _speculative_case(oracle, mv, dbg, mode, w, h, 8, skw, akw)
+
+
+def _speculative_case(oracle, mv, dbg, mode, w, h, bits, skw, akw):
     """The speculative kernel of the default search (mvx_analyse_spec.h): groups of 32 blocks evaluated ahead of the serial walk under
     the hypothesis left == up (row passes over windows of seven blocks, strip or block form), verified block by block, everything else
     searched live.  Same blobs as the oracle -- forward, backward, with a field shift, with a missing reference; noisy clips (most
@@ -535,10 +566,10 @@ def test_analyse_speculative_kernel(oracle, mv, dbg, mode, w, h, skw, akw):
         dbg("spec", 5)
     if mode == "no-runs":
         dbg("spec", 3)
-    rows_apply = akw.get("blksize", 8) == 16 and akw.get("overlap", 0) == 8 and akw.get("chroma", 1) != 0
-    frames = pl.moving_clip(w, h, 16, 3, seed=17, noise=noise, motion=(5, -2))
-    osup = oracle.Super(w, h, 16, **skw)
-    gsup = mv.Super(w, h, 16, **skw)
+    rows_apply = akw.get("blksize", 8) == bits and akw.get("overlap", 0) == bits // 2 and akw.get("chroma", 1) != 0  # (16-bit 16x16 / 8-bit 8x8, overlapping by half)
+    frames = pl.moving_clip(w, h, bits, 3, seed=17, noise=noise, motion=(5, -2))
+    osup = oracle.Super(w, h, bits, **skw)
+    gsup = mv.Super(w, h, bits, **skw)
     osf = [osup.frame(f) for f in frames]
     gsf = gsup.build([mv.frame_to_device(f) for f in frames])
     info = (C.c_int * 5)()

@@ -353,14 +353,15 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         // The speculative kernel runs where its row passes apply (16-bit 16x16 blocks overlapping by half, with chroma: cfg3 612 against 555 fps);
         // one block at a time it loses to the serial lean kernel (cfg2 2 557 / 2 894, cfg4 17 180 / 18 764, cfg5 76 / 92 fps:
         // profiles/r4_configs_spec_vs_serial.txt), so everything else stays there unless "spec" asks for it (5: wherever it can run).
-        const bool stripShape = P.bps == 2 && P.blkX == 16 && P.chroma && P.ovX == P.blkX / 2;
+        const bool stripShape8 = P.bps == 1 && P.blkX == 8 && P.chroma && P.ovX == 4 && P.shadow[1] != 0; // 8-bit 8x8 blocks overlapping by half, UV-interleaved plane present
+        const bool stripShape = (P.bps == 2 && P.blkX == 16 && P.chroma && P.ovX == P.blkX / 2) || stripShape8;
         const bool useSpec = !useWin && g_dbg.spec != 0 && (stripShape || g_dbg.spec >= 2);
         const bool useSpecStrips = useSpec && g_dbg.spec != 3 && stripShape;
         int sTab = 0, sRow = fRow;
         if (useSpec) {
             const bool anyExh = P.searchType == SearchExhaustive || (P.nLevels > 1 && P.searchTypeCoarse == SearchExhaustive);
             const int sStrip = (P.bps == 2 && P.blkX == 16) ? (P.blkX + P.blkX / 2) * 128 : 0; // the source strip of a window of blocks: 24 (48) rows x 8 columns (mvx_analyse_spec.h: STRIP_OK)
-            const int sSrc = fRow < sStrip ? sStrip : fRow;
+            const int sSrc = stripShape8 ? 16 + 768 : fRow < sStrip ? sStrip : fRow; // (8-bit 8x8: 16 bytes of slack + 12 rows x 64 bytes)
             sRow = sSrc;
             sTab = sSrc + ((fMaxBlkX * 8 + 15) & ~15);
             fNeed = 0; // per level: row buffer (8 B per block of THAT level) + the table of its search type

@@ -214,6 +214,59 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
         }
         T.aL = aL; T.aC = aC;
     }
+    // ---- row passes for 8-bit clips, 8x8 blocks overlapping by half (r4).  A half block is ONE dword: a lane's 16-byte load covers four block steps,
+    // and the SAD of block m is the sum of the dword sums m and m + 1.  A window is 15 blocks = 16 dwords = FOUR lanes per candidate in strip form
+    // (16 candidates per pass: the whole Hex2 pattern in one); in block form a lane is one (candidate, block) and uses the first two dwords of its
+    // load.  12 rows per pass (8 luma + 4 of the UV plane), all in flight; the window's source strip is 12 rows x 64 B in LDS.
+    #ifndef MVX_NO_STRIP8
+    static constexpr bool STRIP8_OK = UV && BPS == 1 && BW == 8;
+#else
+    static constexpr bool STRIP8_OK = false;
+#endif
+    static constexpr int W8_BLOCKS = 15, R8A = 8, R8B = 4, R8T = R8A + R8B;
+    struct Strip8 { v4u r[R8T]; unsigned curA, curB; unsigned aL[4], aC[4]; };
+    __device__ __forceinline__ v4u strip8_issue(Strip8 &T, int piece) const { // (byte-aligned 16-byte loads: 8-bit samples sit anywhere)
+        v4u v;
+        if (piece < R8A) { v = F::template ld_ref<16>(refY + T.curA); T.curA += pitchY; asm volatile("" : "+v"(T.curA) : : "memory"); }
+        else { v = F::template ld_ref<16>(refUV + T.curB); T.curB += 2 * pitchC; asm volatile("" : "+v"(T.curB) : : "memory"); }
+        return v;
+    }
+    __device__ __forceinline__ void strip8_prime(Strip8 &T, unsigned oA, unsigned oB) const {
+        T.curA = oA; T.curB = oB;
+#pragma unroll
+        for (int k = 0; k < R8T; k++) T.r[k] = strip8_issue(T, k);
+    }
+    // A lane never reads past the sixteen dwords of its window / the two of its block when that would cross the end of the row (the last row of a plane
+    // may end the caller's buffer): it starts its sixteen bytes sh dwords EARLIER instead (reference and source alike) and rotates its four sums back.
+    // srcA / srcB: byte offsets of this lane's four source dwords inside a 64-byte strip row (luma rows / UV rows), shifts included
+    static constexpr int S8_BASE = 16; // (a shifted first block reads up to 8 bytes in front of its strip row)
+    template <bool REFILL> __device__ __forceinline__ void strip8_run(Strip8 &T, int srcA, int srcB, int shA, int shB, unsigned nA, unsigned nB) const {
+        const lds_u8 *spA = lds + S8_BASE + srcA, *spB = lds + S8_BASE + srcB;
+        auto src_piece = [&](int k) { // four dwords at a dword-aligned LDS address: two ds_read2_b32
+            const LDS_AS unsigned *q = (const LDS_AS unsigned *)((k < R8A ? spA : spB) + k * 64);
+            return v4u{q[0], q[1], q[2], q[3]};
+        };
+        unsigned aL0 = 0, aL1 = 0, aL2 = 0, aL3 = 0, aC0 = 0, aC1 = 0, aC2 = 0, aC3 = 0;
+        v4u a = src_piece(0);
+#pragma unroll
+        for (int k = 0; k < R8T; k++) {
+            const v4u cur = a;
+            if (k + 1 < R8T) a = src_piece(k + 1);
+            const v4u rr = T.r[k];
+            if (k < R8A) { aL0 = __builtin_amdgcn_sad_u8(cur[0], rr[0], aL0); aL1 = __builtin_amdgcn_sad_u8(cur[1], rr[1], aL1); aL2 = __builtin_amdgcn_sad_u8(cur[2], rr[2], aL2); aL3 = __builtin_amdgcn_sad_u8(cur[3], rr[3], aL3); }
+            else { aC0 = __builtin_amdgcn_sad_u8(cur[0], rr[0], aC0); aC1 = __builtin_amdgcn_sad_u8(cur[1], rr[1], aC1); aC2 = __builtin_amdgcn_sad_u8(cur[2], rr[2], aC2); aC3 = __builtin_amdgcn_sad_u8(cur[3], rr[3], aC3); }
+            asm volatile("" : "+v"(aL0), "+v"(aC0) : : "memory");
+            if (k == 0) { T.curA = nA; T.curB = nB; } // (a whole pass is in flight: every refill belongs to the next pass)
+            if (REFILL) T.r[k] = strip8_issue(T, k);
+        }
+        auto rot = [](unsigned &a0, unsigned &a1, unsigned &a2, unsigned &a3, int sh) { // a'[j] = a[(j + sh) & 3]
+            const bool o = sh & 1, t = sh & 2;
+            const unsigned b0 = o ? a1 : a0, b1 = o ? a2 : a1, b2 = o ? a3 : a2, b3 = o ? a0 : a3;
+            a0 = t ? b2 : b0; a1 = t ? b3 : b1; a2 = t ? b0 : b2; a3 = t ? b1 : b3;
+        };
+        rot(aL0, aL1, aL2, aL3, shA); rot(aC0, aC1, aC2, aC3, shB);
+        T.aL[0] = aL0; T.aL[1] = aL1; T.aL[2] = aL2; T.aL[3] = aL3; T.aC[0] = aC0; T.aC[1] = aC1; T.aC[2] = aC2; T.aC[3] = aC3;
+    }
     // offsets (dx, dy) of pattern point idx in the reference's order: Hex2 levels 0-5 hexagon (:682-687), 6-13 square (:636-658); exhaustive levels rings 1 and 2 (:786-791)
     __device__ __forceinline__ static void pat_delta(bool hex, int idx, int &dx, int &dy) {
         dx = 0; dy = 0;
@@ -292,10 +345,11 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
         // look-up by lane inside the pass loop would keep a dozen 64-bit table constants in vector registers across the whole level
         unsigned sPat = 0, bPat0 = 0, bPat1 = 0;
         {
-            const int gb = l >= 42 ? 3 : l >= 28 ? 2 : l >= 14 ? 1 : 0;
+            // (8-bit row passes: sixteen strip candidates of four lanes per pass, block candidates of fifteen lanes)
+            const int gb = STRIP8_OK ? (l >= 45 ? 3 : l >= 30 ? 2 : l >= 15 ? 1 : 0) : l >= 42 ? 3 : l >= 28 ? 2 : l >= 14 ? 1 : 0;
             for (int q = 0; q < 8; q++) {
                 int dx, dy;
-                if (q < 4) { pat_delta(hexLevel, q * 8 + (l >> 3), dx, dy); sPat |= (unsigned)((dx & 15) | ((dy & 15) << 4)) << (8 * q); }
+                if (q < 4) { pat_delta(hexLevel, STRIP8_OK ? q * 16 + (l >> 2) : q * 8 + (l >> 3), dx, dy); sPat |= (unsigned)((dx & 15) | ((dy & 15) << 4)) << (8 * q); }
                 pat_delta(hexLevel, q * 4 + gb, dx, dy);
                 const unsigned b = (unsigned)((dx & 15) | ((dy & 15) << 4)) << (8 * (q & 3));
                 if (q < 4) bPat0 |= b; else bPat1 |= b;
@@ -622,6 +676,145 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                                             const bool inw = (l >= f) & (l < e);
                                             const int w0 = __builtin_amdgcn_readlane(pkW, f);
                                             if (MVX_SPEC_ABL != 7 && e - f >= 2 && __ballot(inw & ((pkW != w0) | !ok2)) == 0) stripW |= 1u << w; // (ABL 7: block form only)
+                                        }
+                                    }
+                                    run_stage(2);
+                                }
+                            }
+
+                            // ======== A, row passes of 8-bit clips (8x8 blocks overlapping by half): the same two stages, windows of 15 blocks
+                            if constexpr (STRIP8_OK) {
+                                if (stripEnabled && stepX == BW / 2 && nb >= 3) { // (a window has at least four dwords: groups of one or two blocks go one block at a time)
+                                    const int nw = (nb + W8_BLOCKS - 1) / W8_BLOCKS, WL = (nb + nw - 1) / nw; // windows of equal length (32 blocks: 11, 11, 10)
+                                    const int npat = hexLevel ? 14 : 24;
+                                    pbMask = 0;
+                                    staged2 = true;
+                                    unsigned stripW = 0;
+                                    int pkW = 0;
+                                    int lq, gS, qS, gB, mB;
+                                    bool tail;
+                                    auto roles = [&]() { // strip form: candidate l >> 2, lane-in-candidate l & 3; block form: candidate l / 15, block l % 15 (lanes 60-63: stage 1: the zero vector's strip)
+                                        lq = l;
+                                        asm volatile("" : "+v"(lq));
+                                        gS = lq >> 2; qS = lq & 3;
+                                        gB = min(lq / W8_BLOCKS, 3); mB = lq >= 60 ? lq - 60 : lq - W8_BLOCKS * gB;
+                                        tail = lq >= 60;
+                                    };
+                                    roles();
+                                    // this lane's share of pass q of window w in stage st: table slot (-1: nothing), first column it writes, how many consecutive
+                                    // blocks it writes (strip lanes: up to four; block lanes: one), its source dwords, its first reference piece
+                                    auto w_cand = [&](int st, int w, int q, int &slot, int &colW, int &nwr, int &srcA, int &srcB, int &shA, int &shB, unsigned &oA, unsigned &oB) {
+                                        const int f = lo + WL * w, L = min(WL, hiE - f);
+                                        const int bxf = hpad + stepX * (c0 + f);
+                                        const bool stripWin = st == 2 && ((stripW >> w) & 1);
+                                        const int meB = min(mB, L - 1), colB = f + meB;
+                                        int bU = 0, bAh = 0, bG = 0, bH = 0, bW = 0; // (fetched with every lane active: ds_bpermute reads 0 from a masked-off lane)
+                                        if (st == 1) {
+                                            bU = __builtin_amdgcn_ds_bpermute(colB << 2, pkU); bAh = __builtin_amdgcn_ds_bpermute(colB << 2, pkAh);
+                                            bG = __builtin_amdgcn_ds_bpermute(colB << 2, pkG); bH = __builtin_amdgcn_ds_bpermute(colB << 2, pkH);
+                                        } else if (!stripWin) bW = __builtin_amdgcn_ds_bpermute(colB << 2, pkW);
+                                        if (stripWin || (st == 1 && tail)) { // strip lanes: lane qS of its candidate holds dwords 4 qS .. 4 qS + 3 of the window's L + 1
+                                            int vx, vy, vyc;
+                                            if (st == 1) { vx = 0; vy = fieldShift; vyc = 0; slot = slotZ; }
+                                            else {
+                                                const int sW = __builtin_amdgcn_readlane(pkW, f);
+                                                const int idx = q * 16 + gS;
+                                                const int dd = (int)(sPat >> (8 * q)), dx = (dd << 28) >> 28, dy = (dd << 24) >> 28;
+                                                vx = upx(sW) + dx; vy = upy(sW) + dy; vyc = vy;
+                                                slot = idx < npat ? idx : -1;
+                                            }
+                                            // the window is L + 1 dwords: the lane that holds its last ones starts early enough to end with them, lanes beyond repeat it
+                                            const int qe = min(qS, L >> 2), d0 = min(4 * qe, L - 3);
+                                            nwr = max(0, min(4, L - 4 * qS));
+                                            if (nwr == 0) slot = -1;
+                                            colW = f + 4 * qS; srcA = srcB = d0 * 4; shA = shB = 4 * qe - d0;
+                                            oA = luma_off_at(bxf, vx, vy) + (unsigned)(d0 * 4);
+                                            oB = 2 * chroma_off_at(bxf, vx, vyc) + (unsigned)(d0 * 4);
+                                        } else { // block lanes
+                                            int base, dx = 0, dy = 0;
+                                            if (st == 1) {
+                                                base = gB == 0 ? bU : gB == 1 ? bAh : gB == 2 ? bG : bH;
+                                                slot = gB == 0 ? slotUp : gB == 1 ? slotUp + 1 : slotZ + gB - 1;
+                                            } else {
+                                                base = bW;
+                                                const int ci = q * 4 + gB;
+                                                const int dd = (int)((q < 4 ? bPat0 : bPat1) >> (8 * (q & 3)));
+                                                dx = (dd << 28) >> 28; dy = (dd << 24) >> 28;
+                                                slot = ci < npat ? ci : -1;
+                                            }
+                                            const int bx0 = hpad + stepX * (c0 + colB);
+                                            const int xMax = (pw - bx0 - BW - hpad + hps) << logPel, xMin = -((bx0 - hpad + hps) << logPel);
+                                            const int cxv = upx(base), cyv = upy(base), tx = cxv + dx, ty = cyv + dy;
+                                            const bool ok = (tx >= xMin) & (ty >= nDyMin) & (tx < xMax) & (ty < nDyMax);
+                                            const int vx = ok ? tx : cxv, vy = ok ? ty : cyv;
+                                            if ((mB >= L) | tail) slot = -1;
+                                            nwr = 1; colW = colB;
+                                            // sixteen bytes from the block's first sample that would cross the end of the row: the eight in front of the block instead
+                                            const int xl = ((bx0 << logPel) + vx) >> logPel, xc = 2 * ((((bx0 >> 1) << logPel) + ((vx + (vx < 0 ? 1 : 0)) >> 1)) >> logPel);
+                                            shA = xl + 16 > pw ? 2 : 0; shB = xc + 16 > pw ? 2 : 0;
+                                            srcA = (meB - shA) * 4; srcB = (meB - shB) * 4;
+                                            oA = luma_off_at(bx0, vx, vy) - (unsigned)(shA * 4);
+                                            oB = 2 * chroma_off_at(bx0, vx, vy) - (unsigned)(shB * 4);
+                                        }
+                                    };
+                                    // the source strip of window w: 12 rows x 64 bytes, one 16-byte piece per lane (lanes 0-47)
+                                    A4x32 stg;
+                                    auto stage_issue = [&](int w) {
+                                        const int f = lo + WL * w, L = min(WL, hiE - f), bx0 = hpad + stepX * (c0 + f);
+                                        const int row = min(lq >> 2, R8T - 1), pe = min(lq & 3, L >> 2) * 16; // (source blocks end hpad samples before the row does)
+                                        gl_u8 *p8 = row < R8A ? srcY + (unsigned)(y0 + row) * pitchY + (unsigned)bx0 + (unsigned)pe
+                                                              : srcUV + (unsigned)((y0 >> 1) + row - R8A) * 2 * pitchC + (unsigned)(bx0 >> 1) * 2 + (unsigned)pe;
+                                        stg = ld_chunk_g(p8, 16);
+                                    };
+                                    auto stage_store = [&]() { if (lq < 4 * R8T) st_chunk_l(lds + S8_BASE + (lq >> 2) * 64 + (lq & 3) * 16, stg, 16); };
+                                    auto widx = [&](int i) { return fwd ? i : nw - 1 - i; };
+                                    auto npass = [&](int st, int w) { return st == 1 ? 1 : ((stripW >> w) & 1) ? (npat + 15) / 16 : (npat + 3) / 4; };
+                                    auto run_stage = [&](int st) {
+                                        int wi = 0, w = widx(0), q = 0;
+                                        Strip8 T;
+                                        int slot, colW, nwr, srcA, srcB, shA, shB; unsigned oA, oB;
+                                        roles();
+                                        w_cand(st, w, q, slot, colW, nwr, srcA, srcB, shA, shB, oA, oB);
+                                        strip8_prime(T, oA, oB);
+                                        stage_issue(w);
+                                        for (;;) {
+                                            roles();
+                                            int wn = w, qn = q + 1, win = wi;
+                                            if (qn >= npass(st, w)) { qn = 0; win = wi + 1; wn = widx(win); }
+                                            const bool more = win < nw;
+                                            int slotN = -1, colN = 0, nwrN = 0, srcAN = 0, srcBN = 0, shAN = 0, shBN = 0; unsigned nA = 0, nB = 0;
+                                            if (more) w_cand(st, wn, qn, slotN, colN, nwrN, srcAN, srcBN, shAN, shBN, nA, nB);
+                                            if (q == 0) {
+                                                __builtin_amdgcn_wave_barrier();
+                                                stage_store();
+                                                if (wi + 1 < nw) stage_issue(widx(wi + 1));
+                                                __builtin_amdgcn_wave_barrier();
+                                            }
+                                            if (more) strip8_run<true>(T, srcA, srcB, shA, shB, nA, nB); else strip8_run<false>(T, srcA, srcB, shA, shB, 0, 0);
+                                            // block m = dwords m and m + 1; the fourth block of a strip lane needs the next lane's first dword
+                                            const unsigned xL = (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aL[0], 0x101, 0xf, 0xf, true), xC = (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aC[0], 0x101, 0xf, 0xf, true);
+                                            if (slot >= 0) {
+                                                lds_u8 *tp = tab + slot * SPEC_STRIDE;
+                                                *(LDS_AS v2u *)(tp + (colW & (SPEC_TB - 1)) * 8) = v2u{T.aL[0] + T.aL[1], T.aC[0] + T.aC[1]};
+                                                if (nwr > 1) *(LDS_AS v2u *)(tp + ((colW + 1) & (SPEC_TB - 1)) * 8) = v2u{T.aL[1] + T.aL[2], T.aC[1] + T.aC[2]};
+                                                if (nwr > 2) *(LDS_AS v2u *)(tp + ((colW + 2) & (SPEC_TB - 1)) * 8) = v2u{T.aL[2] + T.aL[3], T.aC[2] + T.aC[3]};
+                                                if (nwr > 3) *(LDS_AS v2u *)(tp + ((colW + 3) & (SPEC_TB - 1)) * 8) = v2u{T.aL[3] + xL, T.aC[3] + xC};
+                                            }
+                                            if (!more) break;
+                                            w = wn; wi = win; q = qn; slot = slotN; colW = colN; nwr = nwrN; srcA = srcAN; srcB = srcBN; shA = shAN; shB = shBN;
+                                        }
+                                        __builtin_amdgcn_wave_barrier();
+                                    };
+                                    run_stage(1);
+                                    a2_pred(pBest, pX_, pY_, pSad);
+                                    pkW = pk(pX_, pY_);
+                                    {
+                                        const bool ok2 = (pX_ - 2 >= dxMin) & (pX_ + 2 <= dxMax1) & (pY_ - 2 >= nDyMin) & (pY_ + 2 < nDyMax);
+                                        for (int w = 0; w < nw; w++) {
+                                            const int f = lo + WL * w, e = min(f + WL, hiE);
+                                            const bool inw = (l >= f) & (l < e);
+                                            const int w0 = __builtin_amdgcn_readlane(pkW, f);
+                                            if (e - f >= 2 && __ballot(inw & ((pkW != w0) | !ok2)) == 0) stripW |= 1u << w;
                                         }
                                     }
                                     run_stage(2);
