@@ -531,7 +531,12 @@ ROWS8_CASES = [
     (384, 224, {}, dict(blksize=8, overlap=4)),                                   # cfg2 shape
     (320, 192, {}, dict(blksize=8, overlap=4, _noise=14)),                        # most hypotheses fail
     (320, 192, {}, dict(blksize=8, overlap=4, _noise=14, badsad=300, badrange=-3)),
-    (256, 144, {}, dict(blksize=8, overlap=0)),                                   # no row passes: one block at a time / the lean kernel
+    (256, 144, {}, dict(blksize=8, overlap=0)),                                   # blocks side by side: windows of eight
+    (640, 360, dict(pel=1), dict(blksize=8, overlap=0)),                          # cfg1 shape
+    (320, 192, {}, dict(blksize=8, overlap=0, _noise=14, search=3, searchparam=2, pelsearch=2)),
+    (136, 96, dict(hpad=4, vpad=4), dict(blksize=8, overlap=0, pglobal=20)),
+    (600, 64, {}, dict(blksize=8, overlap=0, meander=0)),                         # 75 blocks per row: a last group of eleven
+    (256, 144, {}, dict(blksize=8, overlap=2)),                                   # another overlap: no row passes (one block at a time / the lean kernel)
     (256, 144, {}, dict(blksize=8, overlap=4, chroma=0)),
     (256, 144, dict(pel=1), dict(blksize=8, overlap=4)),
     (256, 144, {}, dict(blksize=8, overlap=4, search=3, searchparam=2, pelsearch=2)),  # exhaustive radius 2 at the finest level too
@@ -566,7 +571,8 @@ def _speculative_case(oracle, mv, dbg, mode, w, h, bits, skw, akw):
         dbg("spec", 5)
     if mode == "no-runs":
         dbg("spec", 3)
-    rows_apply = akw.get("blksize", 8) == bits and akw.get("overlap", 0) == bits // 2 and akw.get("chroma", 1) != 0  # (16-bit 16x16 / 8-bit 8x8, overlapping by half)
+    blk, ov = akw.get("blksize", 8), akw.get("overlap", 0)  # row passes: 16-bit 16x16 overlapping by half; 8-bit 8x8 overlapping by half or not at all
+    rows_apply = akw.get("chroma", 1) != 0 and ((bits, blk, ov) == (16, 16, 8) or ((bits, blk) == (8, 8) and ov in (4, 0)))
     frames = pl.moving_clip(w, h, bits, 3, seed=17, noise=noise, motion=(5, -2))
     osup = oracle.Super(w, h, bits, **skw)
     gsup = mv.Super(w, h, bits, **skw)

@@ -1,0 +1,21 @@
+#!/bin/bash
+# round 4: the 8-bit row passes, blocks side by side too (cfg1, cfg4): parity tests, then cfg2 / cfg4 / cfg1 against the serial lean kernel
+cd "$(dirname "$0")/../.."
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "speculative_kernel_8bit" 2>&1 | tail -15 > gpurun_out/r4_rows8_tests.txt
+cat gpurun_out/r4_rows8_tests.txt
+O=gpurun_out/r4_rows8_configs.txt; : > $O
+run() { echo "== $1" >> $O; shift; c=$1; shift; env "$@" timeout 400 python bench.py --no-cpu --no-traffic --no-others --steps 2 --warmup 1 --config $c 2>&1 | tail -1 | python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print(round(d['value'],1),'fps', round(d['roofline']['avg_launch_ms'],1),'ms/launch', round(d['ms_per_step'],1), 'ms/step parity', d.get('parity_check',{}).get('identical'), d['config'].get('chains_per_step_per_gpu'))" >> $O; }
+for c in cfg2 cfg4 cfg1; do
+run "$c serial lean kernel" $c MVX_SPEC=0
+run "$c row passes" $c MVX_SPEC=1
+done
+run "cfg2 row passes, barrier every 256" cfg2 MVX_CPW_SYNC=256
+run "cfg2 row passes, barrier every 64" cfg2 MVX_CPW_SYNC=64
+run "cfg2 row passes, 1 chain per SIMD" cfg2 MVX_FAST_K=1
+cat $O

@@ -353,7 +353,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         // The speculative kernel runs where its row passes apply (16-bit 16x16 blocks overlapping by half, with chroma: cfg3 612 against 555 fps);
         // one block at a time it loses to the serial lean kernel (cfg2 2 557 / 2 894, cfg4 17 180 / 18 764, cfg5 76 / 92 fps:
         // profiles/r4_configs_spec_vs_serial.txt), so everything else stays there unless "spec" asks for it (5: wherever it can run).
-        const bool stripShape8 = P.bps == 1 && P.blkX == 8 && P.chroma && P.ovX == 4 && P.shadow[1] != 0; // 8-bit 8x8 blocks overlapping by half, UV-interleaved plane present
+        const bool stripShape8 = P.bps == 1 && P.blkX == 8 && P.chroma && (P.ovX == 4 || P.ovX == 0) && P.shadow[1] != 0; // 8-bit 8x8 blocks overlapping by half or not at all, UV-interleaved plane present
         const bool stripShape = (P.bps == 2 && P.blkX == 16 && P.chroma && P.ovX == P.blkX / 2) || stripShape8;
         const bool useSpec = !useWin && g_dbg.spec != 0 && (stripShape || g_dbg.spec >= 2);
         const bool useSpecStrips = useSpec && g_dbg.spec != 3 && stripShape;
@@ -425,7 +425,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
             // 8: 388, 4: 383; 8K16 at two per SIMD: 256: 59.5, 16: 64.6.  8-bit clips (plain layout): 256 stays best (1080p: 2005 against
             // 1953-1970 with 16-64).
             int syncEvery = k >= 2 ? (P.bps == 2 ? 32 : 256) : 0;
-            if (useSpecStrips) syncEvery = 128;
+            if (useSpecStrips) syncEvery = stripShape8 ? 0 : 128; // (8-bit, 4096 chains: none 330 ms, every 512 blocks 337, 256: 344, 128: 366 -- profiles/r4_rows8_configs2.txt)
             if (g_dbg.cpw_sync >= 0 && (g_dbg.cpw_sync & (g_dbg.cpw_sync - 1)) == 0) syncEvery = g_dbg.cpw_sync;
             // XCD-contiguous workgroup order: neighbours in the (reference-sorted) job table share an L2 (+0.5 %, 4K16)
             const int flags = (g_dbg.fast_flags >= 0 ? g_dbg.fast_flags : MVX_FAST_XCD_REMAP) | ((P.shadow[1] != 0 && P.chroma) ? MVX_FAST_UV : 0) | (g_dbg.spec == 2 ? MVX_FAST_NOSPEC : 0) | (g_dbg.spec == 3 ? MVX_FAST_NOSTRIP : 0);

@@ -24,6 +24,7 @@
 // The first block row of a plane, the first block of every row and the coarsest level (whose cost centre is the median, :858)
 // are always searched live.
 #pragma once
+#include <type_traits>
 #include "mvx_analyse_fast.h"
 
 #define SPEC_TB 32                        // blocks per group (one table column per block)
@@ -346,11 +347,12 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
         unsigned sPat = 0, bPat0 = 0, bPat1 = 0;
         {
             // (8-bit row passes: sixteen strip candidates of four lanes per pass, block candidates of fifteen lanes)
-            const int gb = STRIP8_OK ? (l >= 45 ? 3 : l >= 30 ? 2 : l >= 15 ? 1 : 0) : l >= 42 ? 3 : l >= 28 ? 2 : l >= 14 ? 1 : 0;
+            const bool side8 = STRIP8_OK && stepX == BW; // (blocks side by side: eight block candidates of eight lanes per pass)
+            const int gb = side8 ? l >> 3 : STRIP8_OK ? (l >= 45 ? 3 : l >= 30 ? 2 : l >= 15 ? 1 : 0) : l >= 42 ? 3 : l >= 28 ? 2 : l >= 14 ? 1 : 0;
             for (int q = 0; q < 8; q++) {
                 int dx, dy;
                 if (q < 4) { pat_delta(hexLevel, STRIP8_OK ? q * 16 + (l >> 2) : q * 8 + (l >> 3), dx, dy); sPat |= (unsigned)((dx & 15) | ((dy & 15) << 4)) << (8 * q); }
-                pat_delta(hexLevel, q * 4 + gb, dx, dy);
+                pat_delta(hexLevel, q * (side8 ? 8 : 4) + gb, dx, dy);
                 const unsigned b = (unsigned)((dx & 15) | ((dy & 15) << 4)) << (8 * (q & 3));
                 if (q < 4) bPat0 |= b; else bPat1 |= b;
             }
@@ -682,10 +684,13 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                                 }
                             }
 
-                            // ======== A, row passes of 8-bit clips (8x8 blocks overlapping by half): the same two stages, windows of 15 blocks
+                            // ======== A, row passes of 8-bit clips (8x8 blocks overlapping by half or not at all): the same two stages, windows of up to 15 / 8 blocks
                             if constexpr (STRIP8_OK) {
-                                if (stripEnabled && stepX == BW / 2 && nb >= 3) { // (a window has at least four dwords: groups of one or two blocks go one block at a time)
-                                    const int nw = (nb + W8_BLOCKS - 1) / W8_BLOCKS, WL = (nb + nw - 1) / nw; // windows of equal length (32 blocks: 11, 11, 10)
+                                // (a window has at least four dwords: groups of one or two blocks go one block at a time)
+                                auto rows8 = [&](auto DS2) {
+                                    constexpr bool ds2 = decltype(DS2)::value;    // a block step is two dwords: blocks do not overlap (a compile-time copy each: as a run-time flag it cost cfg2 4 %)
+                                    const int wmax = ds2 ? 8 : W8_BLOCKS;        // sixteen dwords: 15 blocks of two dwords overlapping by one / 8 blocks side by side
+                                    const int nw = (nb + wmax - 1) / wmax, WL = (nb + nw - 1) / nw; // windows of equal length (32 blocks overlapping: 11, 11, 10)
                                     const int npat = hexLevel ? 14 : 24;
                                     pbMask = 0;
                                     staged2 = true;
@@ -693,11 +698,14 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                                     int pkW = 0;
                                     int lq, gS, qS, gB, mB;
                                     bool tail;
-                                    auto roles = [&]() { // strip form: candidate l >> 2, lane-in-candidate l & 3; block form: candidate l / 15, block l % 15 (lanes 60-63: stage 1: the zero vector's strip)
+                                    // strip form: candidate l >> 2, lane-in-candidate l & 3; block form: candidate l / 15, block l % 15 (no overlap: l >> 3, l & 7);
+                                    // lanes 60-63: stage 1: the zero vector's strip
+                                    auto roles = [&]() {
                                         lq = l;
                                         asm volatile("" : "+v"(lq));
                                         gS = lq >> 2; qS = lq & 3;
-                                        gB = min(lq / W8_BLOCKS, 3); mB = lq >= 60 ? lq - 60 : lq - W8_BLOCKS * gB;
+                                        if (ds2) { gB = lq >> 3; mB = lq & 7; }
+                                        else { gB = min(lq / W8_BLOCKS, 3); mB = lq >= 60 ? lq - 60 : lq - W8_BLOCKS * gB; }
                                         tail = lq >= 60;
                                     };
                                     roles();
@@ -713,7 +721,8 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                                             bU = __builtin_amdgcn_ds_bpermute(colB << 2, pkU); bAh = __builtin_amdgcn_ds_bpermute(colB << 2, pkAh);
                                             bG = __builtin_amdgcn_ds_bpermute(colB << 2, pkG); bH = __builtin_amdgcn_ds_bpermute(colB << 2, pkH);
                                         } else if (!stripWin) bW = __builtin_amdgcn_ds_bpermute(colB << 2, pkW);
-                                        if (stripWin || (st == 1 && tail)) { // strip lanes: lane qS of its candidate holds dwords 4 qS .. 4 qS + 3 of the window's L + 1
+                                        const int nd = ds2 ? 2 * L : L + 1; // the window's dwords
+                                        if (stripWin || (st == 1 && tail)) { // strip lanes: lane qS of its candidate holds dwords 4 qS .. 4 qS + 3 of the window
                                             int vx, vy, vyc;
                                             if (st == 1) { vx = 0; vy = fieldShift; vyc = 0; slot = slotZ; }
                                             else {
@@ -723,11 +732,11 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                                                 vx = upx(sW) + dx; vy = upy(sW) + dy; vyc = vy;
                                                 slot = idx < npat ? idx : -1;
                                             }
-                                            // the window is L + 1 dwords: the lane that holds its last ones starts early enough to end with them, lanes beyond repeat it
-                                            const int qe = min(qS, L >> 2), d0 = min(4 * qe, L - 3);
-                                            nwr = max(0, min(4, L - 4 * qS));
+                                            // the lane that holds the window's last dwords starts early enough to end with them, lanes beyond repeat it
+                                            const int qe = min(qS, (nd - 1) >> 2), d0 = min(4 * qe, nd - 4);
+                                            nwr = ds2 ? max(0, min(2, L - 2 * qS)) : max(0, min(4, L - 4 * qS));
                                             if (nwr == 0) slot = -1;
-                                            colW = f + 4 * qS; srcA = srcB = d0 * 4; shA = shB = 4 * qe - d0;
+                                            colW = f + (ds2 ? 2 : 4) * qS; srcA = srcB = d0 * 4; shA = shB = 4 * qe - d0;
                                             oA = luma_off_at(bxf, vx, vy) + (unsigned)(d0 * 4);
                                             oB = 2 * chroma_off_at(bxf, vx, vyc) + (unsigned)(d0 * 4);
                                         } else { // block lanes
@@ -737,7 +746,7 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                                                 slot = gB == 0 ? slotUp : gB == 1 ? slotUp + 1 : slotZ + gB - 1;
                                             } else {
                                                 base = bW;
-                                                const int ci = q * 4 + gB;
+                                                const int ci = q * (ds2 ? 8 : 4) + gB;
                                                 const int dd = (int)((q < 4 ? bPat0 : bPat1) >> (8 * (q & 3)));
                                                 dx = (dd << 28) >> 28; dy = (dd << 24) >> 28;
                                                 slot = ci < npat ? ci : -1;
@@ -747,12 +756,13 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                                             const int cxv = upx(base), cyv = upy(base), tx = cxv + dx, ty = cyv + dy;
                                             const bool ok = (tx >= xMin) & (ty >= nDyMin) & (tx < xMax) & (ty < nDyMax);
                                             const int vx = ok ? tx : cxv, vy = ok ? ty : cyv;
-                                            if ((mB >= L) | tail) slot = -1;
+                                            if ((mB >= L) | (st == 1 ? gB >= 4 : !ds2 & tail)) slot = -1;
                                             nwr = 1; colW = colB;
                                             // sixteen bytes from the block's first sample that would cross the end of the row: the eight in front of the block instead
                                             const int xl = ((bx0 << logPel) + vx) >> logPel, xc = 2 * ((((bx0 >> 1) << logPel) + ((vx + (vx < 0 ? 1 : 0)) >> 1)) >> logPel);
                                             shA = xl + 16 > pw ? 2 : 0; shB = xc + 16 > pw ? 2 : 0;
-                                            srcA = (meB - shA) * 4; srcB = (meB - shB) * 4;
+                                            const int dB = ds2 ? 2 * meB : meB; // the block's first dword in the window
+                                            srcA = (dB - shA) * 4; srcB = (dB - shB) * 4;
                                             oA = luma_off_at(bx0, vx, vy) - (unsigned)(shA * 4);
                                             oB = 2 * chroma_off_at(bx0, vx, vy) - (unsigned)(shB * 4);
                                         }
@@ -761,14 +771,14 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                                     A4x32 stg;
                                     auto stage_issue = [&](int w) {
                                         const int f = lo + WL * w, L = min(WL, hiE - f), bx0 = hpad + stepX * (c0 + f);
-                                        const int row = min(lq >> 2, R8T - 1), pe = min(lq & 3, L >> 2) * 16; // (source blocks end hpad samples before the row does)
+                                        const int row = min(lq >> 2, R8T - 1), pe = min(lq & 3, ((ds2 ? 2 * L : L + 1) - 1) >> 2) * 16; // (a source block ends hpad samples before its row and vpad rows before its plane)
                                         gl_u8 *p8 = row < R8A ? srcY + (unsigned)(y0 + row) * pitchY + (unsigned)bx0 + (unsigned)pe
                                                               : srcUV + (unsigned)((y0 >> 1) + row - R8A) * 2 * pitchC + (unsigned)(bx0 >> 1) * 2 + (unsigned)pe;
                                         stg = ld_chunk_g(p8, 16);
                                     };
                                     auto stage_store = [&]() { if (lq < 4 * R8T) st_chunk_l(lds + S8_BASE + (lq >> 2) * 64 + (lq & 3) * 16, stg, 16); };
                                     auto widx = [&](int i) { return fwd ? i : nw - 1 - i; };
-                                    auto npass = [&](int st, int w) { return st == 1 ? 1 : ((stripW >> w) & 1) ? (npat + 15) / 16 : (npat + 3) / 4; };
+                                    auto npass = [&](int st, int w) { return st == 1 ? 1 : ((stripW >> w) & 1) ? (npat + 15) / 16 : ds2 ? (npat + 7) / 8 : (npat + 3) / 4; };
                                     auto run_stage = [&](int st) {
                                         int wi = 0, w = widx(0), q = 0;
                                         Strip8 T;
@@ -791,14 +801,19 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                                                 __builtin_amdgcn_wave_barrier();
                                             }
                                             if (more) strip8_run<true>(T, srcA, srcB, shA, shB, nA, nB); else strip8_run<false>(T, srcA, srcB, shA, shB, 0, 0);
-                                            // block m = dwords m and m + 1; the fourth block of a strip lane needs the next lane's first dword
+                                            // overlapping blocks: block m = dwords m and m + 1, the fourth block of a strip lane needs the next lane's first dword;
+                                            // blocks side by side: block m = dwords 2 m and 2 m + 1
                                             const unsigned xL = (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aL[0], 0x101, 0xf, 0xf, true), xC = (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aC[0], 0x101, 0xf, 0xf, true);
                                             if (slot >= 0) {
                                                 lds_u8 *tp = tab + slot * SPEC_STRIDE;
                                                 *(LDS_AS v2u *)(tp + (colW & (SPEC_TB - 1)) * 8) = v2u{T.aL[0] + T.aL[1], T.aC[0] + T.aC[1]};
-                                                if (nwr > 1) *(LDS_AS v2u *)(tp + ((colW + 1) & (SPEC_TB - 1)) * 8) = v2u{T.aL[1] + T.aL[2], T.aC[1] + T.aC[2]};
-                                                if (nwr > 2) *(LDS_AS v2u *)(tp + ((colW + 2) & (SPEC_TB - 1)) * 8) = v2u{T.aL[2] + T.aL[3], T.aC[2] + T.aC[3]};
-                                                if (nwr > 3) *(LDS_AS v2u *)(tp + ((colW + 3) & (SPEC_TB - 1)) * 8) = v2u{T.aL[3] + xL, T.aC[3] + xC};
+                                                if (ds2) {
+                                                    if (nwr > 1) *(LDS_AS v2u *)(tp + ((colW + 1) & (SPEC_TB - 1)) * 8) = v2u{T.aL[2] + T.aL[3], T.aC[2] + T.aC[3]};
+                                                } else {
+                                                    if (nwr > 1) *(LDS_AS v2u *)(tp + ((colW + 1) & (SPEC_TB - 1)) * 8) = v2u{T.aL[1] + T.aL[2], T.aC[1] + T.aC[2]};
+                                                    if (nwr > 2) *(LDS_AS v2u *)(tp + ((colW + 2) & (SPEC_TB - 1)) * 8) = v2u{T.aL[2] + T.aL[3], T.aC[2] + T.aC[3]};
+                                                    if (nwr > 3) *(LDS_AS v2u *)(tp + ((colW + 3) & (SPEC_TB - 1)) * 8) = v2u{T.aL[3] + xL, T.aC[3] + xC};
+                                                }
                                             }
                                             if (!more) break;
                                             w = wn; wi = win; q = qn; slot = slotN; colW = colN; nwr = nwrN; srcA = srcAN; srcB = srcBN; shA = shAN; shB = shBN;
@@ -818,6 +833,10 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                                         }
                                     }
                                     run_stage(2);
+                                };
+                                if (stripEnabled && nb >= 3) {
+                                    if (stepX == BW / 2) rows8(std::false_type());
+                                    else if (stepX == BW) rows8(std::true_type());
                                 }
                             }
 
