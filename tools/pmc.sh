@@ -20,7 +20,11 @@ for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         n[(k, r['Counter_Name'])] += 1
 print('## group:', g)
 for k in acc:
-    if 'analyse' not in k and 'degrain_kernel' not in k and 'super_level0' not in k: continue
+    import os, re
+    flt = os.environ.get('PMC_FILTER')  # regex over kernel names (default: the search, the per-sample Degrain gather, the level-0 Super kernel)
+    if flt:
+        if not re.search(flt, k): continue
+    elif 'analyse' not in k and 'degrain_kernel' not in k and 'super_level0' not in k: continue
     for c, v in acc[k].items():
         print(f'{k:60s} {c:36s} total {v:.6g} dispatches {n[(k,c)]} per-dispatch {v/n[(k,c)]:.6g}')
 PY
