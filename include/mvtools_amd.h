@@ -201,6 +201,11 @@ int mvx_degrain_create(const mvx_degrain_args *args, const mvx_analysis_data *ve
                        const mvx_super *super_clip, const ptrdiff_t src_pitch[3], const ptrdiff_t super_pitch[3],
                        const ptrdiff_t dst_pitch[3], mvx_degrain **out, char *err);
 void mvx_degrain_destroy(mvx_degrain *d);
+/* The caller promises that every reference super frame of every job carries the shifted copy of its luma plane at plane[0] +
+ * copy_stride[0] (mvx_super_shadow_frames; clips of more than 8 bits); NULL or zero: none (the default).  Blocks that start at an odd
+ * sample are then read from the copy, at dword-aligned addresses.  Only changes which addresses are loaded, never a result.
+ * (no reference counterpart: memory layout only) */
+int mvx_degrain_set_ref_shadow(mvx_degrain *d, const ptrdiff_t copy_stride[3]);
 
 typedef struct mvx_degrain_job {
     const void *src[3];          /* clip frame n */

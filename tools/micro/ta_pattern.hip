@@ -33,6 +33,16 @@ __device__ __forceinline__ long long lane_off(int pat, int l, bool &active) {
     case 13: return (long long)(l >> 1) * 128 + (l & 1) * 16;                          // row pitch 128 B: one row per line, neighbouring lines
     case 14: return (long long)(l >> 2) * PITCH + (l & 3) * 16;                        // 16 rows x 64 B, 16-byte aligned (7 is its 2-byte-aligned form)
     case 15: return (long long)(l >> 1) * 32 + (l & 1) * 16;                           // row pitch 32 B = pattern 0 written as rows (control)
+    // r4: which alignment does a 16-byte piece need?  (the search's row passes read 128-byte strips at dword-aligned addresses -- shadow planes --,
+    // Degrain 16-byte rows at 2-byte-aligned ones)
+    case 16: return (long long)(l >> 3) * PITCH + (l & 7) * 16 + 4;                    // 8 rows x 128 B, dword-aligned
+    case 17: return (long long)(l >> 3) * PITCH + (l & 7) * 16 + 2;                    // 8 rows x 128 B, 2-byte-aligned
+    case 18: return (long long)(l >> 3) * PITCH + (l & 7) * 16 + 8;                    // 8 rows x 128 B, 8-byte-aligned
+    case 19: return (long long)(l >> 1) * PITCH + (l & 1) * 16 + 4;                    // 32 rows x 32 B, dword-aligned
+    case 20: return (long long)(l >> 1) * PITCH + (l & 1) * 16 + 8;                    // 32 rows x 32 B, 8-byte-aligned
+    case 21: return (long long)l * 16 + 4;                                             // contiguous, dword-aligned
+    case 22: return (long long)l * 16 + 2;                                             // contiguous, 2-byte-aligned
+    case 23: return (long long)(l >> 3) * PITCH + (l & 7) * 16 + 64;                   // 8 rows x 128 B starting in the middle of a line (aligned, two lines per row)
     default: return 0;
     }
 }
@@ -71,9 +81,11 @@ int main() {
     const int iters = 2000, NIF = 4;
     const char *names[] = {"0 coalesced 64x16B contiguous (8 lines)", "1 32 rows x 32B aligned", "2 32 rows x 32B, 2B-aligned", "3 64 rows x 16B", "4 16 cand x2 rows on 4 rows (non-neighbour merge)",
                            "5 pattern 2, lanes 32-63 off", "6 pattern 2, alternate lane pairs off", "7 16 rows x 64B", "8 8 rows x 128B (full lines)", "9 8 cand on the same 4 rows", "10 pattern 2 rows, candidate-major order",
-                           "11 32 rows x 32B, row pitch 64B (2 rows per line)", "12 same, block at byte 16 of its rows", "13 32 rows x 32B, row pitch 128B", "14 16 rows x 64B aligned", "15 32 rows x 32B, row pitch 32B (= 0)"};
+                           "11 32 rows x 32B, row pitch 64B (2 rows per line)", "12 same, block at byte 16 of its rows", "13 32 rows x 32B, row pitch 128B", "14 16 rows x 64B aligned", "15 32 rows x 32B, row pitch 32B (= 0)",
+                           "16 8 rows x 128B, dword-aligned (+4)", "17 8 rows x 128B, 2-byte-aligned (+2)", "18 8 rows x 128B, 8-byte-aligned (+8)", "19 32 rows x 32B, dword-aligned (+4)",
+                           "20 32 rows x 32B, 8-byte-aligned (+8)", "21 contiguous, dword-aligned (+4)", "22 contiguous, 2-byte-aligned (+2)", "23 8 rows x 128B from the middle of a line (+64)"};
     for (int blocks : {256, 512}) { // one / two workgroups of four waves per CU
-        for (int pat = 0; pat <= 15; pat++) {
+        for (int pat = 0; pat <= 23; pat++) {
             for (int rep = 0; rep < 2; rep++) { hipLaunchKernelGGL(k<NIF>, dim3(blocks), dim3(256), 0, 0, buf, d, pat, iters, waveStride); hipDeviceSynchronize(); }
             std::vector<unsigned long long> h(blocks * 4);
             hipMemcpy(h.data(), d, 8 * blocks * 4, hipMemcpyDeviceToHost);

@@ -38,6 +38,7 @@ struct MvxDebug {
     int pad_runs = -1;   // lean kernel: 1 = pad the job table so that the chains of one reference frame never straddle two workgroups
     int shadow_planes = 3; // 1 = luma only, 2 = chroma only uses the shadow copies
     int degrain_xcd = -1;  // Degrain cell kernels: XCD-contiguous tile order (1 / 0), -1 = default
+    int degrain_shadow = 1; // Degrain: 0 = never read the shifted luma copies (takes effect at mvx_degrain_set_ref_shadow)
     int cpw_sync = -1; // barrier interval inside a workgroup (power of two, 0 = none)
     int lds_min = -1;  // LDS floor of the one-chain launches
     int spec = 1;      // default search: 1 = the speculative kernel (mvx_analyse_spec.h), 0 = the lean serial kernel (mvx_analyse_fast.h), 2 = the speculative kernel's code with speculation off (every block live), 3 = speculative without runs (every block's candidates loaded on their own), 5 = speculative for every shape it can run (by default only where its row passes apply)
@@ -47,7 +48,7 @@ struct MvxDebug {
 };
 static MvxDebug g_dbg;
 extern "C" __attribute__((visibility("default"))) int mvx_debug_option(const char *name, int value) {
-    struct { const char *n; int *p; } tab[] = { { "general", &g_dbg.general }, { "fast_wpe", &g_dbg.fast_wpe }, { "cpw1", &g_dbg.cpw1 }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "fast_cpw", &g_dbg.fast_cpw }, { "fast_k", &g_dbg.fast_k }, { "fast_lds_min", &g_dbg.fast_lds_min }, { "fast_flags", &g_dbg.fast_flags }, { "pad_runs", &g_dbg.pad_runs }, { "shadow_planes", &g_dbg.shadow_planes }, { "degrain_xcd", &g_dbg.degrain_xcd }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min }, { "super_rows_off", &g_dbg.super_rows_off }, { "win", &g_dbg.win }, { "spec", &g_dbg.spec },
+    struct { const char *n; int *p; } tab[] = { { "general", &g_dbg.general }, { "fast_wpe", &g_dbg.fast_wpe }, { "cpw1", &g_dbg.cpw1 }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "fast_cpw", &g_dbg.fast_cpw }, { "fast_k", &g_dbg.fast_k }, { "fast_lds_min", &g_dbg.fast_lds_min }, { "fast_flags", &g_dbg.fast_flags }, { "pad_runs", &g_dbg.pad_runs }, { "shadow_planes", &g_dbg.shadow_planes }, { "degrain_xcd", &g_dbg.degrain_xcd }, { "degrain_shadow", &g_dbg.degrain_shadow }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min }, { "super_rows_off", &g_dbg.super_rows_off }, { "win", &g_dbg.win }, { "spec", &g_dbg.spec },
 #ifdef MVX_LAB
         { "ablate", &g_dbg.ablate },
 #endif
@@ -68,6 +69,7 @@ extern "C" __attribute__((visibility("default"))) void mvx_debug_last_launch(int
 int mvx_debug_value(const char *name, int def) {
     if (!strcmp(name, "degrain_xcd")) return g_dbg.degrain_xcd >= 0 ? g_dbg.degrain_xcd : def;
     if (!strcmp(name, "super_rows_off")) return g_dbg.super_rows_off;
+    if (!strcmp(name, "degrain_shadow")) return g_dbg.degrain_shadow;
     return def;
 }
 

@@ -85,6 +85,7 @@ struct PlaneG { // one plane of the clip / of level 0 of the super frame
     int thIdx;               // 0 luma threshold, 1 chroma threshold
     int process;
     int limit;
+    long long shadow;        // 16-bit luma: byte distance to the copy of the super plane shifted left by one sample (mvx_degrain_set_ref_shadow), 0 = none
 };
 
 struct DGParams {
@@ -181,6 +182,10 @@ __global__ __launch_bounds__(256) void degrain_plan_kernel(const DGParams *Pp, c
             if (us[r]) { // MVDegrains.h:192-200 useBlock; block origin Fakery.c:31-32
                 const int blx = ((bx * P.pl[0].stepX) << P.logPel) + vx[r], bly = ((by * P.pl[0].stepY) << P.logPel) + vy[r];
                 rec.off[r] = sup_offset(g, P.pel, P.logPel, P.bps, c ? blx >> g.subX : blx, c ? bly >> g.subY : bly);
+                // a block that starts at an odd sample is read from the shifted copy, where it starts at a dword-aligned address: same samples, but a
+                // wave's 16-byte loads at 2-byte-aligned addresses cost the texture addresser 64 cycles instead of 16 (tools/micro/ta_pattern.hip, patterns
+                // 21 / 22), and these loads keep it busy 78 % of the kernel's run time (profiles/r4_stream_kernel_counters.txt)
+                if (g.shadow && (rec.off[r] & 2u)) rec.off[r] = (rec.off[r] & ~3u) + (unsigned)g.shadow;
                 W[r] = degrain_weight(P.thSAD[g.thIdx], sad[r]);
             }
             WSum += W[r];
@@ -611,6 +616,7 @@ static int fill_common(DGCommon *h, const mvx_analysis_data *ad, const mvx_super
         g.supPlaneStride = g.supPitch * (long long)((si.height >> sy) + 2 * (si.vpad >> sy));
         g.thIdx = p ? 1 : 0;
         g.process = 1; g.limit = (1 << si.bits) - 1;
+        g.shadow = 0;
     }
     if (si.num_planes > 1 && super_pitch[1] != super_pitch[2]) DFAIL("U and V super planes must share one pitch.");
     h->nWinClasses = si.num_planes > 1 ? 2 : 1;
@@ -708,6 +714,20 @@ extern "C" __attribute__((visibility("default"))) int mvx_degrain_create(const m
 }
 
 extern "C" __attribute__((visibility("default"))) void mvx_degrain_destroy(mvx_degrain *d) { delete d; }
+
+// The caller promises that every reference super frame of every job carries, behind its luma plane at + copy_stride[0], the plane shifted left by
+// one sample (mvx_super_shadow_frames).  Only changes which addresses the kernels load from.
+extern "C" __attribute__((visibility("default"))) int mvx_degrain_set_ref_shadow(mvx_degrain *d, const ptrdiff_t copy_stride[3]) {
+    const long long v = copy_stride ? (long long)copy_stride[0] : 0;
+    const PlaneG &g0 = d->P.pl[0];
+    if (v < 0 || v % 16) { mvx_set_error("mvx_degrain_set_ref_shadow: copy strides must be non-negative multiples of 16 bytes"); return MVX_E_ARG; }
+    // (plan records hold 32-bit byte offsets into a super plane: the copy must lie inside that range)
+    if (v && v + g0.supPlaneStride * d->P.pel * d->P.pel >= 0xffffffffLL) { mvx_set_error("mvx_degrain_set_ref_shadow: the shifted copy lies beyond 4 GiB of the plane"); return MVX_E_ARG; }
+    std::lock_guard<std::mutex> lk(d->guard.mu);
+    d->P.pl[0].shadow = (d->P.bps == 2 && mvx_debug_value("degrain_shadow", 1)) ? v : 0;
+    if (d->dP) HIP_CHECK(hipMemcpy(d->dP, &d->P, sizeof(DGParams), hipMemcpyHostToDevice));
+    return MVX_OK;
+}
 
 template <typename T> static void launch_degrain(int nr, dim3 grid, hipStream_t st, const DGParams *dP, const DGJob *dJ, const void *plan) {
 #define DG(N) hipLaunchKernelGGL((degrain_kernel<T, N>), grid, dim3(256), 0, st, dP, dJ, (const PlanRecT<N> *)plan)

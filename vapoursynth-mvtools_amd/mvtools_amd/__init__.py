@@ -134,6 +134,7 @@ def lib():
         L.mvx_super_shadow_bytes.restype = None
         L.mvx_super_shadow_frames.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p), P(C.c_ssize_t), P(C.c_ssize_t), C.c_void_p]
         L.mvx_analyse_set_ref_shadow.argtypes = [C.c_void_p, P(C.c_ssize_t)]
+        L.mvx_degrain_set_ref_shadow.argtypes = [C.c_void_p, P(C.c_ssize_t)]
         L.mvx_super_frames_shadow.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p), P(C.c_ssize_t), P(C.c_void_p), P(C.c_ssize_t), P(C.c_ssize_t), C.c_void_p]
         L.mvx_debug_option.argtypes = [C.c_char_p, C.c_int]
         L.mvx_analyse_create.argtypes = [P(AnalyseArgs), C.c_void_p, C.c_int, P(C.c_ssize_t), P(C.c_void_p), C.c_char_p]
@@ -170,7 +171,7 @@ def lib():
         # developer / test switches: the library itself never reads the environment (mvx_debug_option is its one hook);
         # this TEST binding forwards the MVX_* variables the tools/ scripts use
         for env, opt in (("MVX_GENERAL", "general"), ("MVX_FAST_WPE", "fast_wpe"), ("MVX_NO_WPE2", "no_wpe2"),
-                         ("MVX_NO_WPE3", "no_wpe3"), ("MVX_WPE3", "wpe3_u16"), ("MVX_FAST_CPW", "fast_cpw"), ("MVX_FAST_FLAGS", "fast_flags"), ("MVX_PAD_RUNS", "pad_runs"), ("MVX_SHADOW_PLANES", "shadow_planes"), ("MVX_DEGRAIN_XCD", "degrain_xcd"), ("MVX_CPW_SYNC", "cpw_sync"), ("MVX_LDS_MIN", "lds_min"), ("MVX_SUPER_ROWS_OFF", "super_rows_off"), ("MVX_ABLATE", "ablate"), ("MVX_WIN", "win"), ("MVX_FAST_K", "fast_k"), ("MVX_SPEC", "spec"), ("MVX_FAST_LDS_MIN", "fast_lds_min")):
+                         ("MVX_NO_WPE3", "no_wpe3"), ("MVX_WPE3", "wpe3_u16"), ("MVX_FAST_CPW", "fast_cpw"), ("MVX_FAST_FLAGS", "fast_flags"), ("MVX_PAD_RUNS", "pad_runs"), ("MVX_SHADOW_PLANES", "shadow_planes"), ("MVX_DEGRAIN_XCD", "degrain_xcd"), ("MVX_DEGRAIN_SHADOW", "degrain_shadow"), ("MVX_CPW_SYNC", "cpw_sync"), ("MVX_LDS_MIN", "lds_min"), ("MVX_SUPER_ROWS_OFF", "super_rows_off"), ("MVX_ABLATE", "ablate"), ("MVX_WIN", "win"), ("MVX_FAST_K", "fast_k"), ("MVX_SPEC", "spec"), ("MVX_FAST_LDS_MIN", "fast_lds_min")):
             if os.environ.get(env) is not None:
                 L.mvx_debug_option(opt.encode(), int(os.environ[env]))
         if os.environ.get("MVX_CPW") == "1":
@@ -489,6 +490,8 @@ class Degrain:
         err = C.create_string_buffer(ERRLEN)
         _check(lib().mvx_degrain_create(C.byref(a), C.byref(ad), sup.h, pad(src_pitch), pad(sup.pitch), pad(dst_pitch), C.byref(self.h), err), err)
         self.src_pitch, self.dst_pitch = list(src_pitch), list(dst_pitch)
+        if sup.shadow and sup.slots[0] > 1:  # super frames from sup.alloc / sup.build carry the shifted copy of their luma plane (clips of more than 8 bits)
+            _check(lib().mvx_degrain_set_ref_shadow(self.h, (C.c_ssize_t * 3)(*(sup.shadow_stride + [0] * (3 - len(sup.shadow_stride))))))
 
     def __del__(self):
         try:

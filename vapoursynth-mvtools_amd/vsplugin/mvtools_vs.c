@@ -1630,6 +1630,7 @@ static void VS_CC degrainCreate(const VSMap *in, VSMap *out, void *user, VSCore 
         }
         char lerr[MVX_ERRLEN];
         if (mvx_degrain_create(&a, &d->ad[0], d->sup, d->pitch, d->geo.pitch, d->pitch, &d->dg, lerr)) snprintf(err, sizeof(err), "%s", lerr);
+        else if (d->geo.copies > 1) mvx_degrain_set_ref_shadow(d->dg, d->geo.shadowStride); /* every device super frame of this shell carries its copies */
     }
     if (!err[0]) d->blobSize = mvx_vectors_size(&d->ad[0]);
     if (err[0]) {
