@@ -623,10 +623,12 @@ def test_analyse_window_kernel(oracle, mv, dbg, w, h, skw, akw):
 @pytest.mark.parametrize("bits,akw,per_simd", [(8, dict(blksize=8, overlap=4), 3), (8, dict(blksize=8, overlap=4), 4), (16, dict(blksize=16, overlap=8), 3),
                                                (16, dict(blksize=16, overlap=8), 4), (8, dict(blksize=16, overlap=8), 4), (16, dict(blksize=32, overlap=16), 3),
                                                (16, dict(blksize=8, overlap=4), 4)])
-def test_analyse_many_chains_per_simd(oracle, mv, bits, akw, per_simd):
+def test_analyse_many_chains_per_simd(oracle, mv, dbg, bits, akw, per_simd):
     """launches with more than two (three) chains per SIMD take the lean kernel's 168- (128-) register builds, workgroups of twelve
-    (sixteen) chains: every result must still be the oracle's, whatever the order the chains were given in"""
+    (sixteen) chains: every result must still be the oracle's, whatever the order the chains were given in.  ("spec" = 0: the shapes
+    the speculative kernel's row passes cover would otherwise run there, at two per SIMD.)"""
     import torch
+    dbg("spec", 0)
     frames, osup, gsup, osf, gsrc, gsf = _pipeline(oracle, mv, 96, 64, bits, 1, {}, akw, nframes=3)
     oan = oracle.Analyse(osup, isb=0, **akw)
     gan = mv.Analyse(gsup, isb=0, **akw)
@@ -829,7 +831,8 @@ def _fullsize_parity(mv, oracle, w, h, bits, tr, akw, nout, replicas, want_k, la
     torch.cuda.synchronize()
     info = (C.c_int * 5)()
     mv.lib().mvx_debug_last_launch(info)
-    assert info[0] == want_k and info[2] > 0 and info[3] == len(jobs), label + ": the batch did not take the %d-per-SIMD build with a barrier interval (%s)" % (want_k, list(info))
+    # (8-bit clips through the speculative kernel -- info[4] == 2 -- run without a barrier between a workgroup's chains)
+    assert info[0] == want_k and (info[2] > 0 or (bits == 8 and info[4] == 2)) and info[3] == len(jobs), label + ": the batch did not take the %d-per-SIMD build with a barrier interval (%s)" % (want_k, list(info))
     with ThreadPoolExecutor(16) as ex:
         osf = list(ex.map(osup.frame, frames))
         oblobs = list(ex.map(lambda c: oan[(abs(c[1] - c[0]), 1 if c[1] > c[0] else 0)].frame(osf[c[0]], osf[c[1]]), chains))
@@ -855,8 +858,8 @@ def test_full_size_parity_cfg3(mv, oracle):
 
 
 def test_full_size_parity_cfg2(mv, oracle):
-    """BASELINE cfg2 (1080p YUV420P8 Degrain1 blk 8 ov 4 pel 2 search 4), full size, inside a 3 078-chain launch (four per SIMD)"""
-    _fullsize_parity(mv, oracle, 1920, 1080, 8, 1, dict(blksize=8, overlap=4, search=4), nout=3, replicas=513, want_k=4, label="cfg2")
+    """BASELINE cfg2 (1080p YUV420P8 Degrain1 blk 8 ov 4 pel 2 search 4), full size, inside a 2 046-chain launch (the speculative kernel, two per SIMD)"""
+    _fullsize_parity(mv, oracle, 1920, 1080, 8, 1, dict(blksize=8, overlap=4, search=4), nout=3, replicas=341, want_k=2, label="cfg2")  # (2046 chains: the speculative kernel's two per SIMD in one round)
 
 
 def test_full_size_parity_cfg5(mv, oracle):
