@@ -17,6 +17,9 @@ struct __attribute__((packed, aligned(4))) GVecD { int x, y; long long sad; };
 // level-0 vectors of a MVTools_vectors blob: skip size + validity, then every coarser plane by ITS OWN size header -- the
 // reference's reader does exactly this, which is what makes clips produced with divide (an extra array of half-size
 // blocks after the finest estimated plane, whose geometry the level formula does not describe) readable
+// pointers that come out of job tables are generic ("flat") to the compiler: loads through them are slower and each is waited for on its own
+#define DG_GL __attribute__((address_space(1)))
+__device__ __forceinline__ DG_GL const unsigned char *dg_gl(const void *p) { return (DG_GL const unsigned char *)(unsigned long long)p; }
 __device__ __forceinline__ const GVecD *mvx_level0(const unsigned char *blob, int nLvCount) {
     const unsigned char *p = blob + 8;
     for (int i = nLvCount - 1; i >= 1; i--) p += *(const int *)p;
@@ -160,18 +163,26 @@ __global__ __launch_bounds__(256) void degrain_plan_kernel(const DGParams *Pp, c
     const DGParams &P = *Pp;
     const int f = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P.nBlk) return;
-    const int by = i / P.nBlkX, bx = i - by * P.nBlkX;
     const DGJob &J = jobs[f];
     constexpr int n = NR; // (= P.nRefs)
+    // where level 0 starts inside each blob: found once per workgroup (a walk over the per-level size headers: nLvCount - 1 dependent loads), not
+    // once per thread and reference (r4); the vectors themselves through global-address-space pointers, all requested before the first is used
+    __shared__ unsigned lv0[NR];
+    if (threadIdx.x < NR) lv0[threadIdx.x] = usable[f * 12 + threadIdx.x] ? (unsigned)((const unsigned char *)mvx_level0(J.blobs[threadIdx.x], P.nLvCount) - J.blobs[threadIdx.x]) : 0u;
+    __syncthreads();
+    if (i >= P.nBlk) return;
+    const int by = i / P.nBlkX, bx = i - by * P.nBlkX;
     int vx[NR], vy[NR]; long long sad[NR]; int us[NR];
+    typedef unsigned pl_v4 __attribute__((ext_vector_type(4), aligned(4)));
+    pl_v4 vv[NR];
+#pragma unroll
     for (int r = 0; r < n; r++) {
         us[r] = usable[f * 12 + r];
-        if (us[r]) {
-            const GVecD *v = mvx_level0(J.blobs[r], P.nLvCount);
-            vx[r] = v[i].x; vy[r] = v[i].y; sad[r] = v[i].sad;
-        }
+        vv[r] = pl_v4{0, 0, 0, 0};
+        if (us[r]) vv[r] = *(DG_GL const pl_v4 *)(dg_gl(J.blobs[r]) + lv0[r] + (size_t)i * sizeof(GVecD)); // (a reference that is not usable may have no blob at all)
     }
+#pragma unroll
+    for (int r = 0; r < n; r++) { vx[r] = (int)vv[r][0]; vy[r] = (int)vv[r][1]; sad[r] = (long long)(((unsigned long long)vv[r][3] << 32) | vv[r][2]); }
     const int ncls = P.nplanes > 1 ? 2 : 1;
     for (int c = 0; c < ncls; c++) {
         const PlaneG &g = P.pl[c];
@@ -270,8 +281,6 @@ __global__ __launch_bounds__(256) void degrain_kernel(const DGParams *Pp, const 
 // Same arithmetic per sample as degrain_kernel (Degrain_C + overlaps_c + ToPixels + LimitChanges).
 // Pointers that come out of the job tables are generic ("flat") to the compiler; flat loads are slower and every one of them is waited
 // for with vmcnt(0) lgkmcnt(0).  The vector helpers therefore take global-address-space pointers (dg_gl casts).
-#define DG_GL __attribute__((address_space(1)))
-__device__ __forceinline__ DG_GL const unsigned char *dg_gl(const void *p) { return (DG_GL const unsigned char *)(unsigned long long)p; }
 __device__ __forceinline__ DG_GL unsigned char *dg_glw(void *p) { return (DG_GL unsigned char *)(unsigned long long)p; }
 typedef unsigned dg_uv4 __attribute__((ext_vector_type(4), aligned(1)));
 typedef unsigned dg_uv2 __attribute__((ext_vector_type(2), aligned(1)));
@@ -309,6 +318,16 @@ template <typename T, int W> __device__ __forceinline__ DgRaw<T, W> dg_load_raw(
 }
 template <typename T, int W> __device__ __forceinline__ int dg_sample(const DgRaw<T, W> &r, int i) {
     return sizeof(T) == 2 ? (int)((r.d[i >> 1] >> (16 * (i & 1))) & 0xffffu) : (int)((r.d[i >> 2] >> (8 * (i & 3))) & 0xffu);
+}
+// N consecutive ints (dword-aligned address)
+typedef int dg_iv4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef int dg_iv2 __attribute__((ext_vector_type(2), aligned(4)));
+template <int N> __device__ __forceinline__ void dg_load_ints(DG_GL const unsigned char *p, int *o) {
+    if (N >= 4) {
+#pragma unroll
+        for (int k = 0; k < N / 4; k++) { const dg_iv4 t = *(DG_GL const dg_iv4 *)(p + 16 * k); o[4 * k] = t[0]; o[4 * k + 1] = t[1]; o[4 * k + 2] = t[2]; o[4 * k + 3] = t[3]; }
+    } else if (N == 2) { const dg_iv2 t = *(DG_GL const dg_iv2 *)p; o[0] = t[0]; o[1] = t[1]; }
+    else o[0] = *(DG_GL const int *)p;
 }
 template <typename T, int W> __device__ __forceinline__ void dg_store(DG_GL unsigned char *p, const int *v) {
     constexpr int BYTES = W * (int)sizeof(T);
@@ -1151,18 +1170,31 @@ __global__ __launch_bounds__(256) void blockfps_rows_kernel(const DGParams *Pp, 
 #pragma unroll
     for (int i = 0; i < CW; i++) { mF[i] = 0; mB[i] = 0; mO[i] = 0; }
     if (mode >= 3) {
-        const unsigned char *m = masks + (size_t)f * 3 * B.XP * B.YP;
-        const int wb = B.vW[c][y], wt = 16384 - wb;
-        const int rowOff = B.vOff[c][y] * B.XP;
-        const int o0 = B.hOff[c][x];
+        DG_GL const unsigned char *m = dg_gl(masks + (size_t)f * 3 * B.XP * B.YP);
+        // (r4: the resize tables and the mask bytes through global-address-space pointers and as vectors -- the table pointers sit in a struct, so the
+        // compiler emitted one FLAT load per table entry, each waited for on its own, and six byte loads per mask: 45 loads per thread, now 15)
+        const int wb = *(DG_GL const int *)dg_gl(B.vW[c] + y), wt = 16384 - wb;
+        const int rowOff = *(DG_GL const int *)dg_gl(B.vOff[c] + y) * B.XP;
+        int hO[CW], hWr[CW];
+        if (x + CW <= g.W) {
+            dg_load_ints<CW>(dg_gl(B.hOff[c] + x), hO);
+            dg_load_ints<CW>(dg_gl(B.hW[c] + x), hWr);
+        } else {
+#pragma unroll
+            for (int i = 0; i < CW; i++) { const int xi = x + i < g.W ? x + i : g.W - 1; hO[i] = *(DG_GL const int *)dg_gl(B.hOff[c] + xi); hWr[i] = *(DG_GL const int *)dg_gl(B.hW[c] + xi); }
+        }
+        const int o0 = hO[0];
         // vertically interpolated values of up to three mask columns; columns further right (upsizing by less than CW) are done on demand
-        auto vcol = [&](const unsigned char *mm, int o) { return (int)(unsigned char)((mm[rowOff + o] * wt + mm[rowOff + B.XP + o] * wb + 8192) >> 14); };
-        auto upsize = [&](const unsigned char *mm, int *dst) {
+        auto vcol = [&](DG_GL const unsigned char *mm, int o) { return (int)(unsigned char)((mm[rowOff + o] * wt + mm[rowOff + B.XP + o] * wb + 8192) >> 14); };
+        auto upsize = [&](DG_GL const unsigned char *mm, int *dst) {
             // (the third column is only used when a sample's left neighbour is o0 + 1; at the plane's right edge it does not exist: read o0 + 1 again)
-            const int a0 = vcol(mm, o0), a1 = vcol(mm, o0 + 1), a2 = vcol(mm, o0 + 2 < B.XP ? o0 + 2 : o0 + 1);
+            // the bytes o0 .. o0 + 3 of the two mask rows as ONE unaligned dword each (the mask buffer has four bytes of slack behind its last row)
+            const unsigned r0 = *(DG_GL const dg_uv1 *)(mm + rowOff + o0), r1 = *(DG_GL const dg_uv1 *)(mm + rowOff + B.XP + o0);
+            auto vc = [&](int k) { return (int)(unsigned char)((((r0 >> (8 * k)) & 0xffu) * wt + ((r1 >> (8 * k)) & 0xffu) * wb + 8192) >> 14); };
+            const int a0 = vc(0), a1 = vc(1), a2 = o0 + 2 < B.XP ? vc(2) : a1;
 #pragma unroll
             for (int i = 0; i < CW; i++) {
-                const int o = B.hOff[c][x + i], wr = B.hW[c][x + i], wl = 16384 - wr, k = o - o0;
+                const int o = hO[i], wr = hWr[i], wl = 16384 - wr, k = o - o0;
                 int a, b;
                 if (k == 0) { a = a0; b = a1; } else if (k == 1) { a = a1; b = a2; } else { a = vcol(mm, o); b = vcol(mm, o + 1); }
                 dst[i] = (int)(unsigned char)((a * wl + b * wr + 8192) >> 14);
@@ -1342,7 +1374,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_blockfps_frames(mvx_bl
         if (b->dMasks) (void)hipFree(b->dMasks);
         b->maskCap = (size_t)nframes * 2;
         HIP_CHECK(hipMalloc((void **)&b->dSmall, b->maskCap * 2 * cells * sizeof(int)));
-        HIP_CHECK(hipMalloc((void **)&b->dMasks, b->maskCap * 3 * cells));
+        HIP_CHECK(hipMalloc((void **)&b->dMasks, b->maskCap * 3 * cells + 16)); // (+ slack: the row kernels read mask bytes four at a time)
     }
     std::vector<BFJob> hj(nframes);
     for (int f = 0; f < nframes; f++) {
