@@ -466,32 +466,43 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                                 return F::sat_add(md(vx, vy), cc);
                             };
                             bool won = false;
+                            // (the table entries of the whole pattern are read up front: one after the other inside the loops below, each look-up's LDS latency was
+                            // exposed -- the loops stay rolled for the registers the row passes need, the reads do not depend on them)
                             if (hexLevel) {
+                                v2u tt[14];
+#pragma unroll
+                                for (int k = 0; k < 14; k++) tt[k] = rd(k);
                                 if (nSearchParam > 1) {
-#pragma unroll 1
+#pragma unroll
                                     for (int k = 0; k < 6; k++) {
                                         const int vx = wx + tab8(HEX2X >> 8, k), vy = wy + tab8(HEX2Y >> 8, k);
-                                        won = won || (vok(vx, vy) && cnew(vx, vy, rd(k)) < best);
+                                        won = won || (vok(vx, vy) && cnew(vx, vy, tt[k]) < best);
                                     }
                                 }
-#pragma unroll 1
+#pragma unroll
                                 for (int k = 0; k < 8; k++) { // pobExpandingSearch(1, 1) (:636-658)
                                     const int vx = wx + tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), k), vy = wy + tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), k);
-                                    const v2u t = rd(6 + k);
+                                    const v2u t = tt[6 + k];
                                     const int cc = cnew(vx, vy, t);
                                     if (vok(vx, vy) && cc < best) { best = cc; bx = vx; by = vy; bs = tot(t); }
                                 }
                             } else {
 #pragma unroll 1
-                                for (int k = 0; k < 24; k++) { // rings 1 and 2 (:786-791)
-                                    int dx, dy;
-                                    if (k < 8) { dx = tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), k); dy = tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), k); }
-                                    else if (k < 16) { dx = tab8(PACK8(-1, -1, 0, 0, 1, 1, -2, 2), k - 8); dy = tab8(PACK8(-2, 2, -2, 2, -2, 2, -1, -1), k - 8); }
-                                    else { dx = tab8(PACK8(-2, 2, -2, 2, -2, -2, 2, 2), k - 16); dy = tab8(PACK8(0, 0, 1, 1, -2, 2, -2, 2), k - 16); }
-                                    const int vx = wx + dx, vy = wy + dy;
-                                    const v2u t = rd(k);
-                                    const int cc = cnew(vx, vy, t);
-                                    if (vok(vx, vy) && cc < best) { best = cc; bx = vx; by = vy; bs = tot(t); }
+                                for (int k0 = 0; k0 < 24; k0 += 8) { // rings 1 and 2 (:786-791), eight entries at a time
+                                    v2u tt[8];
+#pragma unroll
+                                    for (int k = 0; k < 8; k++) tt[k] = rd(k0 + k);
+#pragma unroll
+                                    for (int k = 0; k < 8; k++) {
+                                        int dx, dy;
+                                        if (k0 == 0) { dx = tab8(PACK8(0, 0, -1, 1, -1, -1, 1, 1), k); dy = tab8(PACK8(-1, 1, 0, 0, -1, 1, -1, 1), k); }
+                                        else if (k0 == 8) { dx = tab8(PACK8(-1, -1, 0, 0, 1, 1, -2, 2), k); dy = tab8(PACK8(-2, 2, -2, 2, -2, 2, -1, -1), k); }
+                                        else { dx = tab8(PACK8(-2, 2, -2, 2, -2, -2, 2, 2), k); dy = tab8(PACK8(0, 0, 1, 1, -2, 2, -2, 2), k); }
+                                        const int vx = wx + dx, vy = wy + dy;
+                                        const v2u t = tt[k];
+                                        const int cc = cnew(vx, vy, t);
+                                        if (vok(vx, vy) && cc < best) { best = cc; bx = vx; by = vy; bs = tot(t); }
+                                    }
                                 }
                             }
                             return won;
