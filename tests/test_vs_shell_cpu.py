@@ -50,6 +50,9 @@ def _oracle_degrain(oracle, frames, w, h, bits, radius, blksize, overlap):
     (16, 2, 16, {"MVX_VS_LOOKAHEAD": "4", "MVX_VS_LOOKAHEAD_DEPTH": "3"}),       # more threads than a window has frames, three windows ahead
     (8, 2, 8, {"MVX_VS_LOOKAHEAD": "8", "MVX_FAKEDEV_MEM": str(3 << 20)}),       # a "device" so small that cached super frames are evicted all the time
     (16, 1, 8, {"MVX_VS_LOOKAHEAD": "0"}),                                       # the per-frame path with its combining queue
+    (16, 3, 8, {"MVX_VS_LOOKAHEAD": "8", "MVX_VS_SUPER_LAZY": "1"}),             # r4 opt-in: super frames whose pixels never leave the device
+    (8, 2, 8, {"MVX_VS_LOOKAHEAD": "8", "MVX_VS_SUPER_LAZY": "1", "MVX_FAKEDEV_MEM": str(3 << 20)}),  # ... with evictions: consumers rebuild them from the embedded source
+    (16, 1, 4, {"MVX_VS_LOOKAHEAD": "0", "MVX_VS_SUPER_LAZY": "1"}),             # ... on the per-frame path
 ])
 def test_shell_reproduces_the_oracle_without_a_gpu(tmp_path, oracle, fakedev, bits, radius, threads, env):
     w, h, n = 160, 96, 37

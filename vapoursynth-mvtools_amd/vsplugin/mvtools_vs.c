@@ -289,6 +289,15 @@ static void cache_unpin(DevFrame *e) {
 /* a super frame on the device for the duration of one getFrame: from the cache or uploaded into a temporary arena */
 typedef struct DevRef { DevFrame *cached; void *temp; void *plane[3]; } DevRef;
 
+/* MVX_VS_SUPER_LAZY=1 (opt-in, r4): mv.Super hands out frames whose super pixels were never downloaded -- 138 MB per 4K16 frame, three quarters
+ * of what the shell moves over PCIe per output frame.  Such a frame carries the SOURCE planes in the top-left corner of its planes (a host copy)
+ * and the property MVX_super_lazy; the device copy lives in the cache, and a consumer that does not find it there rebuilds it on the device from
+ * the embedded source with the mv.Super instance's own handle.  Only this plugin's filters understand such frames: any other consumer of the
+ * super clip would see the source picture in a corner of an otherwise undefined frame -- hence opt-in. */
+#define PROP_SUPER_LAZY "MVX_super_lazy"
+static int super_lazy(void) { static int v = -1; if (v < 0) { const char *e = getenv("MVX_VS_SUPER_LAZY"); v = e && atoi(e) != 0; } return v; }
+static int super_rebuild_lazy(DevRef *r, const VSFrame *f, int64_t id, uint64_t print, const VSAPI *vs);
+
 static int super_to_device(DevRef *r, const VSFrame *f, const SuperGeo *g, const VSAPI *vs) {
     memset(r, 0, sizeof(*r));
     int err = 0;
@@ -297,6 +306,10 @@ static int super_to_device(DevRef *r, const VSFrame *f, const SuperGeo *g, const
     if (!err && (r->cached = cache_find(id, print)) != NULL) {
         for (int p = 0; p < 3; p++) r->plane[p] = r->cached->plane[p];
         return 0;
+    }
+    {
+        int lerr = 0;
+        if (!err && vs->mapGetInt(vs->getFramePropertiesRO(f), PROP_SUPER_LAZY, 0, &lerr) == 1 && !lerr) return super_rebuild_lazy(r, f, id, print, vs);
     }
     void *arena = shell_alloc(g->bytes);
     if (!arena) return MVX_E_NOMEM;
@@ -502,6 +515,60 @@ static SuperData *super_lookup(VSNode *out) {
     pthread_mutex_unlock(&g_lock);
     return d;
 }
+static SuperData *super_by_instance(int64_t instance) {
+    SuperData *d = NULL;
+    pthread_mutex_lock(&g_lock);
+    for (int i = 0; i < SUPER_REG_MAX; i++) if (g_supers[i].d && g_supers[i].d->instance == instance) d = g_supers[i].d;
+    pthread_mutex_unlock(&g_lock);
+    return d;
+}
+/* lazy super frames (MVX_VS_SUPER_LAZY): the source picture in the top-left corner of every plane; the rows the fingerprint samples are defined */
+static void lazy_fill(VSFrame *dst, const VSFrame *src, const SuperGeo *g, const VSAPI *vs) {
+    for (int p = 0; p < g->si.num_planes; p++) {
+        const int H = g->si.plane_height[p];
+        const size_t rb = (size_t)g->si.plane_width[p] * g->bps;
+        const int rows[5] = { 0, H / 5, H / 2, (int)((int64_t)H * 4 / 5), H - 1 }; /* (= frame_print's) */
+        uint8_t *dp = vs->getWritePtr(dst, p);
+        const ptrdiff_t ds = vs->getStride(dst, p), ss = vs->getStride(src, p);
+        for (int k = 0; k < 5; k++) memset(dp + (ptrdiff_t)rows[k] * ds, 0, rb);
+        const uint8_t *sp = vs->getReadPtr(src, p);
+        const size_t wb = (size_t)vs->getFrameWidth(src, p) * g->bps;
+        const int h = vs->getFrameHeight(src, p);
+        for (int y = 0; y < h; y++) memcpy(dp + (ptrdiff_t)y * ds, sp + (ptrdiff_t)y * ss, wb);
+    }
+    vs->mapSetInt(vs->getFramePropertiesRW(dst), PROP_SUPER_LAZY, 1, maReplace);
+}
+/* a consumer found no device copy of a lazy frame: rebuild it from the embedded source with the handle of the mv.Super instance that made it */
+static int super_rebuild_lazy(DevRef *r, const VSFrame *f, int64_t id, uint64_t print, const VSAPI *vs) {
+    SuperData *sd = super_by_instance(id >> 32);
+    if (!sd || sd->pelMode) return MVX_E_ARG; /* (its mv.Super instance is gone: cannot happen while a consumer holds the node) */
+    const SuperGeo *g = &sd->geo;
+    size_t off[3], total = 0;
+    int w[3], h[3];
+    for (int p = 0; p < g->si.num_planes; p++) {
+        w[p] = p ? g->si.width / g->si.xRatioUV : g->si.width; h[p] = p ? g->si.height / g->si.yRatioUV : g->si.height;
+        off[p] = total; total += (size_t)sd->srcPitch[p] * (size_t)h[p];
+    }
+    void *srcArena = shell_alloc(total), *arena = shell_alloc(g->bytes), *dsrc[3] = { NULL, NULL, NULL };
+    int rc = (!srcArena || !arena) ? MVX_E_NOMEM : 0;
+    void *st = thread_stream();
+    if (!rc) rc = mvx_dev_memset(arena, 0, g->bytes, st);
+    for (int p = 0; p < g->si.num_planes && !rc; p++) {
+        dsrc[p] = (char *)srcArena + off[p];
+        rc = timed_upload(dsrc[p], sd->srcPitch[p], vs->getReadPtr(f, p), vs->getStride(f, p), (size_t)w[p] * g->bps, (size_t)h[p]);
+        r->plane[p] = (char *)arena + g->off[p];
+    }
+    if (!rc) {
+        if (g->copies > 1) rc = mvx_super_frames_shadow(sd->sup, 1, (const void *const *)dsrc, sd->srcPitch, (void *const *)r->plane, g->pitch, g->shadowStride, st);
+        else rc = mvx_super_frames(sd->sup, 1, (const void *const *)dsrc, sd->srcPitch, (void *const *)r->plane, g->pitch, st);
+    }
+    if (!rc) rc = mvx_stream_sync(st); else (void)mvx_stream_sync(st);
+    if (srcArena) mvx_dev_free(srcArena);
+    if (rc) { shell_quiesce(rc); if (arena) mvx_dev_free(arena); memset(r, 0, sizeof(*r)); return rc; }
+    if ((r->cached = cache_insert(id, print, arena, g, 0)) != NULL) return 0;
+    r->temp = arena;
+    return 0;
+}
 /* builds the device super frames of `n` SOURCE frames in one batch (uploads, then one mvx_super_frames_shadow call) and hands them
  * to the cache, pinned; frames that are cached already are only pinned.  out[i] = the pinned entry of frame nums[i].  One builder at a
  * time: six vector clips ask for the same frames.  Returns 0 or an MVX_E_* code (entries pinned so far are released on failure). */
@@ -615,7 +682,8 @@ static const VSFrame *VS_CC superGetFrame(int n, int reason, void *inst, void **
     if (have) {
         int rc2 = 0;
         VSFrame *dst2 = vs->newVideoFrame(&d->vi.format, d->vi.width, d->vi.height, src, core);
-        for (int p = 0; p < g->si.num_planes && !rc2; p++)
+        if (super_lazy()) lazy_fill(dst2, src, g, vs); /* (the pixels stay on the device) */
+        else for (int p = 0; p < g->si.num_planes && !rc2; p++)
             rc2 = timed_download_on(download_stream(), vs->getWritePtr(dst2, p), vs->getStride(dst2, p), have->plane[p], g->pitch[p], (size_t)g->si.plane_width[p] * g->bps, (size_t)g->si.plane_height[p]);
         vs->freeFrame(src);
         if (rc2) { cache_unpin(have); vs->freeFrame(dst2); vs->setFilterError(mvx_last_error(), ctx); return NULL; }
@@ -651,9 +719,12 @@ static const VSFrame *VS_CC superGetFrame(int n, int reason, void *inst, void **
     VSFrame *dst = NULL;
     if (!rc) {
         dst = vs->newVideoFrame(&d->vi.format, d->vi.width, d->vi.height, src, core);
-        for (int p = 0; p < g->si.num_planes && !rc; p++)
-            rc = timed_download(vs->getWritePtr(dst, p), vs->getStride(dst, p), ddst[p], g->pitch[p], (size_t)g->si.plane_width[p] * g->bps, (size_t)g->si.plane_height[p]);
-        if (!rc) rc = mvx_stream_sync(st);
+        if (super_lazy() && !d->pelMode) lazy_fill(dst, src, g, vs);
+        else {
+            for (int p = 0; p < g->si.num_planes && !rc; p++)
+                rc = timed_download(vs->getWritePtr(dst, p), vs->getStride(dst, p), ddst[p], g->pitch[p], (size_t)g->si.plane_width[p] * g->bps, (size_t)g->si.plane_height[p]);
+            if (!rc) rc = mvx_stream_sync(st);
+        }
     }
     shell_quiesce(rc);
     if (srcArena) mvx_dev_free(srcArena);
