@@ -722,8 +722,7 @@ static const VSFrame *VS_CC superGetFrame(int n, int reason, void *inst, void **
         if (super_lazy() && !d->pelMode) lazy_fill(dst, src, g, vs);
         else {
             for (int p = 0; p < g->si.num_planes && !rc; p++)
-                rc = timed_download(vs->getWritePtr(dst, p), vs->getStride(dst, p), ddst[p], g->pitch[p], (size_t)g->si.plane_width[p] * g->bps, (size_t)g->si.plane_height[p]);
-            if (!rc) rc = mvx_stream_sync(st);
+                rc = timed_download_on(download_stream(), vs->getWritePtr(dst, p), vs->getStride(dst, p), ddst[p], g->pitch[p], (size_t)g->si.plane_width[p] * g->bps, (size_t)g->si.plane_height[p]);
         }
     }
     shell_quiesce(rc);
@@ -1155,7 +1154,8 @@ static const VSFrame *VS_CC analyseGetFrame(int n, int reason, void *inst, void 
             VSFrame *dst = NULL;
             char *blob = rc ? NULL : (char *)malloc((size_t)d->blobSize);
             if (!rc && !blob) rc = MVX_E_NOMEM;
-            if (!rc) rc = timed_download(blob, d->blobSize, (const char *)s->dblobs + s->dstride * (size_t)(n - s->first), d->blobSize, (size_t)d->blobSize, 1);
+            /* (r4: the window's search was waited for; on the download stream the copy does not queue behind other threads' uploads -- PCIe is full duplex) */
+            if (!rc) rc = timed_download_on(download_stream(), blob, d->blobSize, (const char *)s->dblobs + s->dstride * (size_t)(n - s->first), d->blobSize, (size_t)d->blobSize, 1);
             if (!rc && src) { /* src/MVAnalyse.c:224-239 */
                 dst = vs->copyFrame(src, core);
                 VSMap *props = vs->getFramePropertiesRW(dst);
@@ -1616,9 +1616,8 @@ static const VSFrame *VS_CC degrainGetFrame(int n, int reason, void *inst, void 
     VSFrame *dst = NULL;
     if (!rc) {
         dst = vs->newVideoFrame(&d->vi->format, d->vi->width, d->vi->height, src, core);
-        for (int p = 0; p < np && !rc; p++)
-            rc = timed_download(vs->getWritePtr(dst, p), vs->getStride(dst, p), job.dst[p], d->pitch[p], (size_t)vs->getFrameWidth(dst, p) * bps, (size_t)vs->getFrameHeight(dst, p));
-        if (!rc) rc = mvx_stream_sync(thread_stream());
+        for (int p = 0; p < np && !rc; p++) /* (the kernels were waited for above: the download stream, beside the other threads' uploads) */
+            rc = timed_download_on(download_stream(), vs->getWritePtr(dst, p), vs->getStride(dst, p), job.dst[p], d->pitch[p], (size_t)vs->getFrameWidth(dst, p) * bps, (size_t)vs->getFrameHeight(dst, p));
     }
     shell_quiesce(rc);
     for (int r = 0; r < nr; r++) { dev_release(&refs[r]); if (blobArena[r]) mvx_dev_free(blobArena[r]); }
