@@ -75,13 +75,32 @@ static void la_trace(const void *inst, int w, const char *what, double dur) {
     if (g_trace_on) fprintf(stderr, "mvtools_vs trace %8.3f  analyse %p window %d %s (%.3f s)\n", prof_now() - g_trace_t0, inst, w, what, dur);
 }
 static void prof_add_locked_ok(int k, double t0) { prof_add(k, t0); } /* (g_lock is a different mutex than the callers hold) */
+/* The per-frame work of a worker thread (its uploads, its Super / Degrain / ... kernels) runs on ONE stream of a small pool
+ * (MVX_VS_FRAME_STREAMS, default 4; r3 had ONE for all threads: a thread's kernel then waited behind every other thread's uploads), chosen per
+ * thread the first time it asks.  Every getFrame waits for its own stream before it publishes or releases anything, so the streams need no
+ * ordering among each other.  640 4K16 frames, lazy super frames: 405 fps with one stream, 481 with four, 508 with eight
+ * (profiles/r4_vs_shell_frame_streams.txt); the default mode is bound by its super-frame downloads and does not change. */
+#define FRAME_STREAMS_MAX 8
+static void *g_frame_streams[FRAME_STREAMS_MAX];
+static int g_frame_nstreams, g_frame_next;
+static __thread int t_frame_stream = -1;
 static void *thread_stream(void) {
     if (!__atomic_load_n(&g_frame_stream_tried, __ATOMIC_ACQUIRE)) {
         pthread_mutex_lock(&g_lock);
-        if (!g_frame_stream_tried) { g_frame_stream = mvx_stream_create_priority(1); __atomic_store_n(&g_frame_stream_tried, 1, __ATOMIC_RELEASE); }
+        if (!g_frame_stream_tried) {
+            const char *e = getenv("MVX_VS_FRAME_STREAMS");
+            int n = e ? atoi(e) : 4;
+            n = n < 1 ? 1 : n > FRAME_STREAMS_MAX ? FRAME_STREAMS_MAX : n;
+            for (int i = 0; i < n; i++) g_frame_streams[i] = mvx_stream_create_priority(1);
+            g_frame_stream = g_frame_streams[0];
+            g_frame_nstreams = n;
+            __atomic_store_n(&g_frame_stream_tried, 1, __ATOMIC_RELEASE);
+        }
         pthread_mutex_unlock(&g_lock);
     }
-    return g_frame_stream;
+    if (g_frame_nstreams <= 1) return g_frame_stream;
+    if (t_frame_stream < 0) t_frame_stream = __atomic_fetch_add(&g_frame_next, 1, __ATOMIC_RELAXED) % g_frame_nstreams;
+    return g_frame_streams[t_frame_stream] ? g_frame_streams[t_frame_stream] : g_frame_stream;
 }
 /* the 131 MB downloads of finished super frames (mv.Super's host frames) run on a stream of their own: they only depend on kernels that
  * were waited for already, and on their own stream they overlap the other threads' uploads (PCIe is full duplex) instead of queueing
