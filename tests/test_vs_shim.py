@@ -466,3 +466,25 @@ def test_lookahead_serves_windows_and_is_bit_identical(shell, tmp_path, bits, pi
     assert len(stats) == 1, r1.stderr
     kv = {k: int(v) for k, v in (t.split("=") for t in stats[0].split()[2:])}
     assert kv["jobs"] == n * kv["instances"] and kv["launches"] * 10 <= kv["jobs"] and kv["largest_batch"] == 128, stats[0]
+
+
+@pytest.mark.parametrize("bits,pipeline,extra,env", [
+    (16, "degrain3", ("a.blksize=16", "a.overlap=8"), {}),
+    (8, "degrain1", ("a.blksize=8", "a.overlap=4"), {"MVX_VS_LOOKAHEAD": "0", "MVX_VS_CACHE_FRAMES": "6"}),  # per-frame path, a cache so small that consumers rebuild super frames from the embedded source
+    (16, "compensate", ("a.blksize=16", "a.overlap=8"), {"MVX_VS_LOOKAHEAD": "8"}),             # short look-ahead windows
+])
+def test_lazy_super_frames_are_bit_identical(shell, tmp_path, bits, pipeline, extra, env):
+    """MVX_VS_SUPER_LAZY=1 (opt-in, r4): mv.Super's frames carry the source picture instead of the super pixels, which stay on the device; a
+    consumer that finds no device copy rebuilds it from that picture with the mv.Super instance's own handle.  Every filter of the plugin
+    takes its super frames through that path, so the output clip must be the default mode's, byte for byte."""
+    w, h, n = 192, 112, 70
+    frames = pl.moving_clip(w, h, bits, n, seed=23, noise=3)
+    src, ref, lazy = str(tmp_path / "in.raw"), str(tmp_path / "ref.raw"), str(tmp_path / "lazy.raw")
+    _write_clip(src, frames)
+    args = [str(a) for a in ("run", pipeline, src, w, h, bits, n)]
+    r0 = subprocess.run([HOST, PLUGIN] + args + [ref] + list(extra) + ["x.threads=8"], capture_output=True, text=True, timeout=900, env=proc_env(**env))
+    assert r0.returncode == 0 and "DONE" in r0.stdout, r0.stdout + r0.stderr
+    r1 = subprocess.run([HOST, PLUGIN] + args + [lazy] + list(extra) + ["x.threads=8", "x.order=frame"], capture_output=True, text=True, timeout=900,
+                        env=proc_env(MVX_VS_SUPER_LAZY="1", **env))
+    assert r1.returncode == 0 and "DONE" in r1.stdout, r1.stdout + r1.stderr
+    assert open(ref, "rb").read() == open(lazy, "rb").read()
