@@ -594,11 +594,11 @@ static int super_rebuild_lazy(DevRef *r, const VSFrame *f, int64_t id, uint64_t 
 static pthread_mutex_t g_build_mu = PTHREAD_MUTEX_INITIALIZER;
 #define BUILD_THREADS 8
 static long env_long_early(const char *name, long def) { const char *e = getenv(name); return e ? atol(e) : def; }
-typedef struct BuildJob { SuperData *sd; const VSAPI *vs; const int *miss; int nmiss; const VSFrame *const *srcs; void **srcArena, **arena; const void **sp; void **dp; int next, rc; pthread_mutex_t mu; } BuildJob;
+typedef struct BuildJob { SuperData *sd; const VSAPI *vs; const int *miss; int nmiss; const VSFrame *const *srcs; void **srcArena, **arena; const void **sp; void **dp; int next, rc; pthread_mutex_t mu; void *st; } BuildJob;
 static void *build_worker(void *arg) { /* uploads source frames and prepares their (zero-filled) super arenas, one frame at a time */
     BuildJob *j = (BuildJob *)arg;
     const SuperGeo *g = &j->sd->geo;
-    void *st = thread_stream();
+    void *st = j->st; /* the BUILDER's stream: the arenas' memsets must be ordered before the super kernels it launches there (a helper thread's own stream of the pool is not) */
     for (;;) {
         pthread_mutex_lock(&j->mu);
         const int k = (j->rc || j->next >= j->nmiss) ? -1 : j->next++;
@@ -638,7 +638,7 @@ static int super_build_device(SuperData *sd, int n, const int *nums, const VSFra
     const double tp = prof_now();
     if (!rc && nmiss) { /* the uploads (a host memcpy into pinned staging + a DMA each) are spread over a few helper threads: a window of 64 4K16
                          * frames is 1.6 GB, which one thread moves in ~0.4 s -- as long as it takes to consume the window */
-        BuildJob job = { sd, vs, miss, nmiss, srcs, srcArena, arena, sp, dp, 0, 0, PTHREAD_MUTEX_INITIALIZER };
+        BuildJob job = { sd, vs, miss, nmiss, srcs, srcArena, arena, sp, dp, 0, 0, PTHREAD_MUTEX_INITIALIZER, st };
         pthread_t th[BUILD_THREADS];
         int want = (int)env_long_early("MVX_VS_BUILD_THREADS", 4);
         if (want < 1) want = 1;
