@@ -92,8 +92,16 @@ def synth_clip_device(torch, width, height, bits, nframes, seed, device):
     return frames
 
 
+def _order_behind_caller(torch, stream, device):
+    """A pipeline computes on its own HIP stream, which torch creates non-blocking: NOT ordered behind the stream the caller
+    allocated, zero-filled and generated the clip on.  Everything the caller has enqueued so far (clip generation, the zero fill of the
+    super / blob arenas, a new `src`) must be ahead of the pipeline's kernels: one event wait, no host synchronisation."""
+    stream.wait_stream(torch.cuda.current_stream(device))
+
+
 class Pipeline:
-    """Super -> Analyse x 2tr -> DegrainN over a resident batch, all on the current HIP stream."""
+    """Super -> Analyse x 2tr -> DegrainN over a resident batch, on the pipeline's own HIP stream (ordered behind the caller's
+    stream at construction and at every step; the caller synchronises -- or waits on `stream` -- before it reads the results)."""
 
     def __init__(self, mv, torch, cfg, batch, device, seed, src=None, plan=None):
         (self.w, self.h, self.bits, self.tr, akw, skw, _, self.label) = cfg
@@ -119,8 +127,10 @@ class Pipeline:
         self.dg = mv.Degrain(tr, self.sup, a0.ad, [p.stride(0) for p in self.src[0]])
         self.out = mv.arena_frames(batch, [tuple(p.shape) for p in self.src[0]], device, zero=False)
         self.ev = []  # (start, end) events around the search launches
+        _order_behind_caller(torch, self.stream, device)
 
     def step(self, time_search=False, src=None):
+        _order_behind_caller(self.torch, self.stream, self.device)
         with self.torch.cuda.stream(self.stream):
             self._step(time_search, self.src if src is None else src)
 
@@ -201,8 +211,10 @@ class PipelineFPS:
         self.fps_out = mv.arena_frames(self.nout, shapes, device, zero=False)
         self.ev = []
         self.frames_per_step = self.nout
+        _order_behind_caller(torch, self.stream, device)
 
     def step(self, time_search=False):
+        _order_behind_caller(self.torch, self.stream, self.device)
         with self.torch.cuda.stream(self.stream):
             torch, n = self.torch, self.n
             self.sup.build(self.src, out=self.supers)

@@ -356,7 +356,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         // one block at a time it loses to the serial lean kernel (cfg2 2 557 / 2 894, cfg4 17 180 / 18 764, cfg5 76 / 92 fps:
         // profiles/r4_configs_spec_vs_serial.txt), so everything else stays there unless "spec" asks for it (5: wherever it can run).
         const bool stripShape8 = P.bps == 1 && P.blkX == 8 && P.chroma && (P.ovX == 4 || P.ovX == 0) && P.shadow[1] != 0; // 8-bit 8x8 blocks overlapping by half or not at all, UV-interleaved plane present
-        const bool stripShape = (P.bps == 2 && P.blkX == 16 && P.chroma && P.ovX == P.blkX / 2) || stripShape8;
+        const bool stripShape = (P.bps == 2 && P.blkX == 16 && P.chroma && P.ovX == P.blkX / 2 && P.shadow[1] != 0) || stripShape8; // (the row passes read the UV-interleaved plane: STRIP_OK)
         const bool useSpec = !useWin && g_dbg.spec != 0 && (stripShape || g_dbg.spec >= 2);
         const bool useSpecStrips = useSpec && g_dbg.spec != 3 && stripShape;
         int sTab = 0, sRow = fRow;

@@ -25,9 +25,7 @@
 // de-duplication, the hexagon pass without its speculative square) were measured one switch at a time: DESIGN.md 4.2.3,
 // profiles/r3_lean_kernel_trims_ab.txt, r3_lean_kernel_dedup_nospec_ab.txt.
 #define MVX_SRC_AHEAD 2 // the source block's LDS pieces are read this many pieces ahead of their use (a read right before its use costs the wave an LDS round trip per piece)
-#ifndef MVX_STREAM_MAX
-#define MVX_STREAM_MAX 12 // a candidate's pieces per lane up to which luma + chroma are ONE stream of loads (the serial kernel: longer streams measured slower; the speculative kernel's translation units set 48)
-#endif
+#define MVX_STREAM_MAX 12 // a candidate's pieces per lane up to which luma + chroma are ONE stream of loads (the serial kernel: longer streams measured slower).  The default of FastSearcher's STREAM_MAX parameter; the speculative kernel instantiates its base class with 48
 #ifndef MVX_INFLIGHT
 #define MVX_INFLIGHT 12 // reference loads a lane keeps in flight while it evaluates a candidate: all twelve of a hexagon-pass candidate
 #endif
@@ -110,7 +108,7 @@ static inline bool mvx_fast_eligible(const AParams &P) {
 }
 
 // UV: chroma is read from the UV-interleaved shadow plane (compile-time: the two chroma paths must not share a register allocation)
-template <int BPS, int BW, bool UV> struct FastSearcher {
+template <int BPS, int BW, bool UV, int STREAM_MAX = MVX_STREAM_MAX> struct FastSearcher {
     typedef FGeo<BPS, BW> G;
     const AParams &P;
     const AJob &J;
@@ -307,7 +305,7 @@ template <int BPS, int BW, bool UV> struct FastSearcher {
     // partial SADs (this lane's share) of candidate (vx, vy); vyc = the vertical component the chroma planes use (:836-839)
     template <int LOGG> __device__ __forceinline__ void eval(int s, int vx, int vy, int vyc, unsigned &aL, unsigned &aC) const {
         constexpr int GG = 1 << LOGG;
-        constexpr bool STREAM = UV && G::LT >= GG && G::UVT >= GG && GG >= (1 << G::LLOGC) && GG >= (1 << G::UVLOGC) && (G::LT + G::UVT) / GG >= 2 && (G::LT + G::UVT) / GG <= MVX_STREAM_MAX;
+        constexpr bool STREAM = UV && G::LT >= GG && G::UVT >= GG && GG >= (1 << G::LLOGC) && GG >= (1 << G::UVLOGC) && (G::LT + G::UVT) / GG >= 2 && (G::LT + G::UVT) / GG <= STREAM_MAX;
         if constexpr (STREAM) { // (region2 does not exist for shapes with fewer pieces than lanes)
             if (chroma) {
                 const unsigned co = ref_chroma_off(vx, vyc);

@@ -64,8 +64,10 @@ static __device__ unsigned long long g_specstat[MVX_MAX_LEVELS][4]; // per level
 #endif
 
 // SWIN: row loads a lane keeps in flight in the row passes (12 = half a pass; 24 = a whole pass: the builds with 256 registers)
-template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSearcher<BPS, BW, UV> {
-    typedef FastSearcher<BPS, BW, UV> F;
+// (pass A has nothing else to wait for: whole candidates as one stream of loads -- FastSearcher's STREAM_MAX = 48; a template argument, so the serial
+// kernel's FastSearcher<.., 12> and this one are different types whatever translation unit instantiates them)
+template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSearcher<BPS, BW, UV, 48> {
+    typedef FastSearcher<BPS, BW, UV, 48> F;
     typedef FGeo<BPS, BW> G;
     using F::P; using F::J; using F::lds; using F::ldsRow; using F::ldsHist; using F::histBins;
     using F::nBlkX; using F::nBlkY; using F::pel; using F::logPel; using F::pw; using F::ph; using F::hpad; using F::vpad;

@@ -1,5 +1,4 @@
 // 8-bit builds of the speculative default search (mvx_analyse_spec.h): S.L.fast = chains per SIMD it is launched at
-#define MVX_STREAM_MAX 48 // pass A has nothing else to wait for: whole candidates as one stream of loads, twelve in flight
 #include "mvx_analyse_kernel.h"
 #include "mvx_analyse_spec.h"
 int mvx_analyse_launch_spec_u8(const AParams &P, const ASpecLaunch &S) {

@@ -181,7 +181,7 @@ bool stage_acquire_n(Stage **out, int n) {
 void stage_release(Stage *s) {
     if (!s) return;
     { std::lock_guard<std::mutex> g(g_stage_mu); s->busy = false; }
-    g_stage_cv.notify_one();
+    g_stage_cv.notify_all(); // (waiters need one OR two buffers: a single wake-up may go to one that cannot proceed)
 }
 // rows of a transfer that fit one staging buffer (device pitch dp; the last row of a chunk needs row_bytes only)
 size_t chunk_rows(ptrdiff_t dp, size_t row_bytes) { const size_t n = (kStageBytes - row_bytes) / (size_t)dp + 1; return n ? n : 1; }

@@ -490,7 +490,8 @@ class Degrain:
         err = C.create_string_buffer(ERRLEN)
         _check(lib().mvx_degrain_create(C.byref(a), C.byref(ad), sup.h, pad(src_pitch), pad(sup.pitch), pad(dst_pitch), C.byref(self.h), err), err)
         self.src_pitch, self.dst_pitch = list(src_pitch), list(dst_pitch)
-        if sup.shadow and sup.slots[0] > 1:  # super frames from sup.alloc / sup.build carry the shifted copy of their luma plane (clips of more than 8 bits)
+        self.ref_shadow = bool(sup.shadow and sup.slots[0] > 1)
+        if self.ref_shadow:  # super frames from sup.alloc / sup.build carry the shifted copy of their luma plane (clips of more than 8 bits)
             _check(lib().mvx_degrain_set_ref_shadow(self.h, (C.c_ssize_t * 3)(*(sup.shadow_stride + [0] * (3 - len(sup.shadow_stride))))))
 
     def __del__(self):
@@ -507,6 +508,8 @@ class Degrain:
         if out is None:
             out = [[torch.empty_like(p) for p in j[0]] for j in jobs]
         arr = (DegrainJob * n)()
+        if self.ref_shadow:  # (blocks at odd sample positions are read from the shifted luma copy BEHIND every reference plane: a plain tensor would be over-run)
+            self.sup.check_room([r for _, refs, _ in jobs for r in refs], "Degrain reference")
         for i, (src, refs, blobs) in enumerate(jobs):
             for p in range(self.sup.nplanes):
                 assert src[p].stride(0) == self.src_pitch[p] and out[i][p].stride(0) == self.dst_pitch[p]

@@ -481,6 +481,9 @@ int main(int argc, char **argv) {
     if (argc < 3) { fprintf(stderr, "usage: see minihost.c\n"); return 2; }
     g_start = now_s();
     init_api();
+    /* host-side setting: the plugin hands its search launches to a pool of 12 streams, and the HIP runtime maps streams onto
+     * GPU_MAX_HW_QUEUES hardware queues (read once, when the runtime initialises).  The host owns its environment, so it is set here */
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     void *h = dlopen(argv[1], RTLD_NOW | RTLD_GLOBAL);
     if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
     VSInitPlugin init = (VSInitPlugin)dlsym(h, "VapourSynthPluginInit2");

@@ -315,7 +315,7 @@ typedef struct DevRef { DevFrame *cached; void *temp; void *plane[3]; } DevRef;
  * super clip would see the source picture in a corner of an otherwise undefined frame -- hence opt-in. */
 #define PROP_SUPER_LAZY "MVX_super_lazy"
 static int super_lazy(void) { static int v = -1; if (v < 0) { const char *e = getenv("MVX_VS_SUPER_LAZY"); v = e && atoi(e) != 0; } return v; }
-static int super_rebuild_lazy(DevRef *r, const VSFrame *f, int64_t id, uint64_t print, const VSAPI *vs);
+static int super_rebuild_lazy(DevRef *r, const VSFrame *f, int64_t id, uint64_t print, const SuperGeo *want, const VSAPI *vs);
 
 static int super_to_device(DevRef *r, const VSFrame *f, const SuperGeo *g, const VSAPI *vs) {
     memset(r, 0, sizeof(*r));
@@ -328,7 +328,7 @@ static int super_to_device(DevRef *r, const VSFrame *f, const SuperGeo *g, const
     }
     {
         int lerr = 0;
-        if (!err && vs->mapGetInt(vs->getFramePropertiesRO(f), PROP_SUPER_LAZY, 0, &lerr) == 1 && !lerr) return super_rebuild_lazy(r, f, id, print, vs);
+        if (!err && vs->mapGetInt(vs->getFramePropertiesRO(f), PROP_SUPER_LAZY, 0, &lerr) == 1 && !lerr) return super_rebuild_lazy(r, f, id, print, g, vs);
     }
     void *arena = shell_alloc(g->bytes);
     if (!arena) return MVX_E_NOMEM;
@@ -549,7 +549,10 @@ static void lazy_fill(VSFrame *dst, const VSFrame *src, const SuperGeo *g, const
         const int rows[5] = { 0, H / 5, H / 2, (int)((int64_t)H * 4 / 5), H - 1 }; /* (= frame_print's) */
         uint8_t *dp = vs->getWritePtr(dst, p);
         const ptrdiff_t ds = vs->getStride(dst, p), ss = vs->getStride(src, p);
-        for (int k = 0; k < 5; k++) memset(dp + (ptrdiff_t)rows[k] * ds, 0, rb);
+        /* the whole plane is defined (zero outside the embedded source): newVideoFrame hands out uninitialised heap, and a consumer that is
+         * not this plugin must neither see stale memory nor a frame that differs from run to run */
+        for (int y = 0; y < H; y++) memset(dp + (ptrdiff_t)y * ds, 0, rb);
+        (void)rows;
         const uint8_t *sp = vs->getReadPtr(src, p);
         const size_t wb = (size_t)vs->getFrameWidth(src, p) * g->bps;
         const int h = vs->getFrameHeight(src, p);
@@ -558,10 +561,16 @@ static void lazy_fill(VSFrame *dst, const VSFrame *src, const SuperGeo *g, const
     vs->mapSetInt(vs->getFramePropertiesRW(dst), PROP_SUPER_LAZY, 1, maReplace);
 }
 /* a consumer found no device copy of a lazy frame: rebuild it from the embedded source with the handle of the mv.Super instance that made it */
-static int super_rebuild_lazy(DevRef *r, const VSFrame *f, int64_t id, uint64_t print, const VSAPI *vs) {
+static int super_rebuild_lazy(DevRef *r, const VSFrame *f, int64_t id, uint64_t print, const SuperGeo *want, const VSAPI *vs) {
     SuperData *sd = super_by_instance(id >> 32);
     if (!sd || sd->pelMode) return MVX_E_ARG; /* (its mv.Super instance is gone: cannot happen while a consumer holds the node) */
     const SuperGeo *g = &sd->geo;
+    /* the id comes from frame properties: a stale or foreign one may name a live instance with ANOTHER layout -- the planes built below must be the
+     * ones the consumer's kernels will address */
+    if (g->bytes != want->bytes || g->copies != want->copies || g->bps != want->bps || g->si.num_planes != want->si.num_planes) return MVX_E_ARG;
+    for (int p = 0; p < g->si.num_planes; p++)
+        if (g->pitch[p] != want->pitch[p] || g->off[p] != want->off[p] || g->shadowStride[p] != want->shadowStride[p] ||
+            g->si.plane_width[p] != want->si.plane_width[p] || g->si.plane_height[p] != want->si.plane_height[p]) return MVX_E_ARG;
     size_t off[3], total = 0;
     int w[3], h[3];
     for (int p = 0; p < g->si.num_planes; p++) {
@@ -890,8 +899,8 @@ __attribute__((destructor)) static void print_stats(void) {
 /* Streams of the search launches, shared by every mv.Analyse instance and handed out round robin.  The runtime maps streams onto a few
  * hardware queues per priority level, in creation order, and launches that share a queue run one after the other: with four streams per
  * instance the six instances of a Degrain3 graph put the six searches of a window on the SAME queue (traced: 128-chain launches enqueued
- * together finished 0.6 s apart, two at a time).  One pool makes consecutive launches land on different queues; plugin init raises the
- * number of queues (GPU_MAX_HW_QUEUES, unless the user set it) to SEARCH_STREAMS.  Priority: MVX_VS_SEARCH_PRIO (-1 lowest = default, 0, 1);
+ * together finished 0.6 s apart, two at a time).  One pool makes consecutive launches land on different queues; the HOST should run with
+ * GPU_MAX_HW_QUEUES >= SEARCH_STREAMS (the mini host sets 16 unless the user chose a value).  Priority: MVX_VS_SEARCH_PRIO (-1 lowest = default, 0, 1);
  * a NULL entry (the default stream) still works, it only serialises. */
 #define SEARCH_STREAMS 12
 static void *g_search_stream[SEARCH_STREAMS];
@@ -2048,9 +2057,9 @@ static void VS_CC fpsCreate(const VSMap *in, VSMap *out, void *user, VSCore *cor
 
 /* replaces src/EntryPoint.c:28-52 for the filters of the hot path */
 VS_EXTERNAL_API(void) VapourSynthPluginInit2(VSPlugin *plugin, const VSPLUGINAPI *vspapi) {
-    /* hardware queues for the search streams (see search_stream_next); read by the HIP runtime when it initialises, i.e. at this plugin's
-     * first device call -- no effect, and no harm, if the process has used the runtime before or the user has set the variable */
-    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    /* (the search streams want GPU_MAX_HW_QUEUES >= 12 -- see search_stream_next.  That is a setting of the HOST PROCESS, read once when the HIP
+     * runtime initialises: a plugin must not change the process environment behind its host's back, so it is documented in INTEGRATION.md and set
+     * by the mini host / the launch scripts, not here) */
     vspapi->configPlugin("com.nodame.mvtools", "mv", "MVTools v24", VS_MAKE_VERSION(24, 0), VS_MAKE_VERSION(VAPOURSYNTH_API_MAJOR, VAPOURSYNTH_API_MINOR), 0, plugin);
     vspapi->registerFunction("Super",
                              "clip:vnode;hpad:int:opt;vpad:int:opt;pel:int:opt;levels:int:opt;chroma:int:opt;sharp:int:opt;rfilter:int:opt;pelclip:vnode:opt;opt:int:opt;",
