@@ -41,20 +41,25 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_MEASURED_GBS = 6290.0  # the same guide's measured copy ceiling
 
 
-def synth_clip_device(torch, width, height, bits, nframes, seed, device):
+def synth_clip_device(torch, width, height, bits, nframes, seed, device, first_frame=0, total_frames=None):
     """Textured 4:2:0 clip generated on the device: band-limited texture + 8x8 checker translating (+3,-1) px/frame,
-    a rectangle of different texture moving (-2,+2), +-2 LSB (8-bit scale) noise.  SURVEY.md 8(d)."""
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
+    a rectangle of different texture moving (-2,+2), +-2 LSB (8-bit scale) noise.  SURVEY.md 8(d).
+    Frame f of the result is frame first_frame + f of ONE clip of total_frames frames: texture, rectangle and noise are functions of the
+    GLOBAL frame index (and the seed) only, so every rank of a sharded run generates identical bytes for the frames it shares with its
+    neighbours (its tr-frame halo) -- r5; checked across ranks by main()'s shard_check."""
+    total = nframes if total_frames is None else total_frames
     scale = 1 << (bits - 8)
     pm = (1 << bits) - 1
-    margin = 32 + 4 * nframes
-    H, W = height + 2 * margin, width + 2 * margin
-    yy = torch.arange(H, device=device, dtype=torch.float32)[:, None]
-    xx = torch.arange(W, device=device, dtype=torch.float32)[None, :]
-    tex = (40 * torch.sin(xx * 0.21 + yy * 0.07) + 30 * torch.sin(xx * 0.05 - yy * 0.13) + 20 * torch.sin(xx * 0.33 + 1.3) * torch.cos(yy * 0.27)
-           + 25 * (((xx.long() // 8) + (yy.long() // 8)) & 1).float() + 120)
-    texc = [20 * torch.sin(xx * 0.11 + yy * 0.05 + k) + 128 for k in (0.3, 1.7)]
+    margin = 32 + 4 * total
+
+    def tex(p, y0, x0, h, w, s):
+        """plane p's texture at canvas rows y0, y0 + s, ... / columns x0, x0 + s, ... (an analytic function of the canvas position)"""
+        yy = torch.arange(y0, y0 + h * s, s, device=device, dtype=torch.float32)[:, None]
+        xx = torch.arange(x0, x0 + w * s, s, device=device, dtype=torch.float32)[None, :]
+        if p == 0:
+            return (40 * torch.sin(xx * 0.21 + yy * 0.07) + 30 * torch.sin(xx * 0.05 - yy * 0.13) + 20 * torch.sin(xx * 0.33 + 1.3) * torch.cos(yy * 0.27)
+                    + 25 * (((xx.long() // 8) + (yy.long() // 8)) & 1).float() + 120)
+        return 20 * torch.sin(xx * 0.11 + yy * 0.05 + (0.3, 1.7)[p - 1]) + 128
     import mvtools_amd as mv
     shapes = []
     for p in range(3):
@@ -62,26 +67,28 @@ def synth_clip_device(torch, width, height, bits, nframes, seed, device):
         rowbytes = (width // s_) * (2 if bits > 8 else 1)
         shapes.append((height // s_, (rowbytes + 255) // 256 * 256))
     arena = mv.arena_frames(nframes, shapes, device)  # one allocation for the whole clip (see Super.alloc)
+    g = torch.Generator(device=device)
     frames = []
-    for f in range(nframes):
+    for fl in range(nframes):
+        f = first_frame + fl
+        g.manual_seed(seed * 1000003 + f)               # the frame's noise depends on its global index only
         ox, oy = margin + 3 * f, margin - 1 * f
         planes = []
         for p in range(3):
             s = 2 if p else 1
-            base = tex if p == 0 else texc[p - 1]
-            img = base[oy:oy + height:s, ox:ox + width:s].clone()
-            h, w = img.shape
+            h, w = height // s, width // s
+            img = tex(p, oy, ox, h, w, s)
             per = max(8, min(height * 5 // 24, width // 4) - 8)   # the rectangle bounces so that long clips keep it inside
             fb = f % (2 * per)
             fb = fb if fb < per else 2 * per - fb
             rx, ry = (width // 2 - 2 * fb) // s, (height // 3 + 2 * fb) // s
             rw, rh = (width // 4) // s, (height // 4) // s
-            img[ry:ry + rh, rx:rx + rw] = base[8:8 + rh * s:s, 8:8 + rw * s:s] * 0.8 + (35 if p == 0 else 10)
+            img[ry:ry + rh, rx:rx + rw] = tex(p, 8, 8, rh, rw, s) * 0.8 + (35 if p == 0 else 10)
             img = img + torch.randint(-2, 3, img.shape, generator=g, device=device).float()
             v = torch.clamp(torch.round(img * scale), 0, pm).to(torch.int32)
             rowbytes = w * (2 if bits > 8 else 1)
             pitch = (rowbytes + 255) // 256 * 256
-            t = arena[f][p]
+            t = arena[fl][p]
             assert t.shape == (h, pitch)
             if bits > 8:
                 t[:, :rowbytes] = torch.stack([(v & 0xFF), (v >> 8)], dim=-1).to(torch.uint8).reshape(h, rowbytes)
@@ -96,6 +103,8 @@ def _order_behind_caller(torch, stream, device):
     """A pipeline computes on its own HIP stream, which torch creates non-blocking: NOT ordered behind the stream the caller
     allocated, zero-filled and generated the clip on.  Everything the caller has enqueued so far (clip generation, the zero fill of the
     super / blob arenas, a new `src`) must be ahead of the pipeline's kernels: one event wait, no host synchronisation."""
+    if os.environ.get("MVX_BENCH_NO_STREAM_ORDER") == "1":  # evidence only (tools/stress_sharding.py): round 4's behaviour, which raced
+        return
     stream.wait_stream(torch.cuda.current_stream(device))
 
 
@@ -114,7 +123,8 @@ class Pipeline:
         self.n = self.plan.held[1] - self.plan.held[0]
         # `src` lets a second pipeline slot (own filter handles, own super / vector / output buffers, own stream) share
         # the read-only input clip
-        self.src = src if src is not None else synth_clip_device(torch, self.w, self.h, self.bits, self.n, seed, device)
+        self.src = src if src is not None else synth_clip_device(torch, self.w, self.h, self.bits, self.n, seed, device,
+                                                                 first_frame=self.plan.held[0], total_frames=self.plan.num_frames)
         self.stream = torch.cuda.Stream(device=device)
         self.sup = mv.Super(self.w, self.h, self.bits, **skw)
         self.supers = self.sup.alloc(self.n, device=device)
@@ -196,7 +206,10 @@ class PipelineFPS:
         self.mv, self.torch, self.B, self.device = mv, torch, batch, device
         self.tr = 1
         self.n = batch + 1
-        self.src = src if src is not None else synth_clip_device(torch, self.w, self.h, self.bits, self.n, seed, device)
+        self.plan = plan
+        self.src = src if src is not None else synth_clip_device(torch, self.w, self.h, self.bits, self.n, seed, device,
+                                                                 first_frame=plan.held[0] if plan is not None else 0,
+                                                                 total_frames=plan.num_frames if plan is not None else None)
         self.stream = torch.cuda.Stream(device=device)
         self.sup = mv.Super(self.w, self.h, self.bits, **skw)
         self.supers = self.sup.alloc(self.n, device=device)
@@ -240,7 +253,58 @@ def _frame_to_numpy(mv, frame, w, h, bits):
     return [mv.plane_to_numpy(frame[p], w >> (1 if p else 0), dt) for p in range(3)]
 
 
-def oracle_leg(mv, torch, cfg, pipe, threads, F):
+def shard_payload(mv, torch, cfg, pipe, plan, rank, threads, oracle=True):
+    """One rank's contribution to shard_check: checksums of the source frames at both ends of the range it holds -- the frames it shares with its
+    neighbours -- and, on ranks 0 and 1, the comparison of ONE output frame at the shard boundary with the oracle (rank 0: its last output frame,
+    rank 1: its first; both need the halo)."""
+    res = {"rank": rank, "held": list(plan.held), "out": list(plan.out), "sums": {}, "parity": None}
+    try:
+        tr = max(plan.tr, 1)
+        lo, hi = plan.held
+        for n in sorted(set(range(lo, min(hi, lo + 2 * tr))) | set(range(max(lo, hi - 2 * tr), hi))):
+            acc = []
+            for t in pipe.src[n - lo]:
+                x = t.reshape(-1).to(torch.int64)
+                acc += [int(x.sum().item()), int((x * (torch.arange(x.numel(), device=x.device, dtype=torch.int64) % 65521 + 1)).sum().item())]
+            res["sums"][n] = acc
+        if oracle and rank in (0, 1) and len(plan.outputs()) > 0:
+            _, par = oracle_leg(mv, torch, cfg, pipe, threads, 1, i0=(pipe.B - 1 if rank == 0 else 0))
+            res["parity"] = {"rank": rank, "global_frame": plan.out[1] - 1 if rank == 0 else plan.out[0], "identical": par["identical"], "mismatches": par.get("mismatches")}
+    except Exception as e:  # (a failed side check must neither cost the headline line nor leave the other ranks waiting in the gather)
+        res["error"] = "%s: %s" % (type(e).__name__, e)
+    return res
+
+
+def shard_verdict(gathered):
+    """rank 0: every global frame index that two ranks hold must carry identical bytes on both; the output ranges must partition the job"""
+    seen, compared, bad = {}, 0, []
+    for g in gathered:
+        for n, v in g["sums"].items():
+            if n in seen:
+                compared += 1
+                if seen[n][1] != v:
+                    bad.append("frame %d: ranks %d and %d hold different bytes" % (n, seen[n][0], g["rank"]))
+            else:
+                seen[n] = (g["rank"], v)
+    covered = sorted(n for g in gathered for n in range(g["out"][0], g["out"][1]))
+    res = {"shared_source_frames_compared": compared, "shared_source_frames_identical": not bad, "mismatches": bad[:8],
+           "output_ranges_partition_the_job": bool(covered) and covered == list(range(covered[0], covered[0] + len(covered))),
+           "boundary_frames_vs_oracle": [g["parity"] for g in gathered if g.get("parity") is not None]}
+    errs = [g["error"] for g in gathered if g.get("error")]
+    if errs:
+        res["errors"] = errs[:4]
+    return res
+
+
+def shard_check(mv, torch, dist, cfg, pipe, plan, rank, world, threads):
+    """--gpus N > 1, outside the timed region, control plane only (all_gather_object; no data-path collective).  Returns the dict rank 0 puts
+    into the JSON line (None elsewhere)."""
+    gathered = [None] * world
+    dist.all_gather_object(gathered, shard_payload(mv, torch, cfg, pipe, plan, rank, threads))
+    return shard_verdict(gathered) if rank == 0 else None
+
+
+def oracle_leg(mv, torch, cfg, pipe, threads, F, i0=None):
     """The CPU oracle (scalar C restatement of the reference, kind 'port') on F output frames OF THE TIMED STEP: the clip
     frames they need are downloaded from the device clip, the oracle runs Super / Analyse x 2tr / DegrainN on them with
     `threads` worker threads each owning whole frames (VapourSynth fmParallel style; the wall time of this part is the CPU
@@ -253,7 +317,8 @@ def oracle_leg(mv, torch, cfg, pipe, threads, F):
     (w, h, bits, tr, akw, skw, _, label) = cfg
     B = pipe.B
     F = max(1, min(F, B))
-    i0 = max(0, B // 2 - F // 2)                       # F consecutive output frames from the middle of the batch
+    if i0 is None:
+        i0 = max(0, B // 2 - F // 2)                   # F consecutive output frames from the middle of the batch (i0 given: from there)
     dgs = pipe.plan.degrains()[i0:i0 + F]              # (local frame, local refs per vector clip, blob index)
     need = sorted({n for n, refs, _ in dgs} | {r for _, refs, _ in dgs for r in refs if r is not None})
     torch.cuda.synchronize()
@@ -346,7 +411,7 @@ def search_kernel_name(mv):
     import ctypes as C
     info = (C.c_int * 5)()
     mv.lib().mvx_debug_last_launch(info)
-    return "analyse_spec_kernel, %d chains per SIMD" % info[0] if info[4] == 2 else "analyse_win_kernel" if info[4] == 1 else "analyse_fast_kernel, %d chains per SIMD" % info[0] if info[0] else "analyse_kernel"
+    return "analyse_spec_kernel, %d chains per SIMD" % info[0] if info[4] == 2 else "analyse_spec_kernel (team form: %d waves per chain)" % info[1] if info[4] == 3 else "analyse_win_kernel" if info[4] == 1 else "analyse_fast_kernel, %d chains per SIMD" % info[0] if info[0] else "analyse_kernel"
 
 
 def other_configs():
@@ -367,6 +432,102 @@ def other_configs():
         except Exception as e:  # (a failed side run must not cost the headline line)
             res[c] = {"error": "%s: %s" % (type(e).__name__, e)}
     return res
+
+
+def vs_shell_leg(frames=640, threads=32):
+    """The drop-in boundary in the driver's record (r5): the VapourSynth filter shell (libmvtools_vs.so) in the mini host, the cfg3 graph -- mv.Super ->
+    mv.Analyse x 6 -> mv.Degrain3, blksize 16, overlap 8 -- over `frames` 4K16 frames with `threads` request threads asking for OUTPUT frames in frame
+    order, in a child process of its own (this function IS that child: `bench.py --vs-shell-leg`).  The clip is generated on the device and written to a
+    raw file the host reads; `fps_all_inclusive` = frames / wall clock from "clip in host memory" to "last output frame delivered": graph construction
+    (which starts the first look-ahead windows), every upload / download over PCIe, and the shell's per-frame work included; `fps_steady` = frames / the
+    request phase alone.  The result file is compared plane by plane with the same graph through the batched C ABI (bench.Pipeline over the whole
+    clip, missing references at the clip ends exactly as the filters see them).  Modes: the default, and MVX_VS_SUPER_LAZY=1 (mv.Super's pixels stay on
+    the device; opt-in).  Prints one JSON object."""
+    import re
+    import subprocess
+    import tempfile
+    import numpy as np
+    import torch
+    import mvtools_amd as mv
+    from mvtools_amd import shard
+    cfg = CONFIGS["cfg3"]
+    (w, h, bits, tr, akw, skw, _, label) = cfg
+    here = os.path.join(ROOT, "vapoursynth-mvtools_amd")
+    host, plugin = os.path.join(here, "mvx_vs_host"), os.path.join(here, "libmvtools_vs.so")
+    if not (os.path.exists(host) and os.path.exists(plugin)):
+        return {"error": "mvx_vs_host / libmvtools_vs.so not built"}
+    device = torch.device("cuda", 0)
+    tmp = tempfile.mkdtemp(prefix="mvx_vs_", dir=os.environ.get("TMPDIR", "/tmp"))
+    src, outp = os.path.join(tmp, "in.raw"), os.path.join(tmp, "out.raw")
+    res = {"workload": label + " through VapourSynthPluginInit2 / getFrame", "frames": frames, "threads": threads}
+    try:
+        plan = shard.RankPlan(frames, 0, 1, tr)   # the whole clip, no lead-in: references beyond its ends are missing (MVAnalyse.c:120-129)
+        pipe = Pipeline(mv, torch, cfg, frames, device, seed=1000, plan=plan)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        with open(src, "wb") as f:
+            for fr in pipe.src:
+                for p, t in enumerate(fr):
+                    f.write(t[:, :(w >> (1 if p else 0)) * 2].contiguous().cpu().numpy().tobytes())
+        res["clip_file_s"] = round(time.time() - t0, 1)
+        pipe.step()                                 # the reference result: the batched C ABI over the same clip (the host runs after it: both need the HBM)
+        torch.cuda.synchronize()
+        want = [[t[:, :(w >> (1 if p else 0)) * 2].contiguous().cpu().numpy().view(np.uint16) for p, t in enumerate(fr)] for fr in pipe.out]
+        pipe.__dict__.clear()
+        del pipe
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+
+        def run(extra_env, key):
+            env = dict(os.environ, MVX_HOST_TIMES="1", GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES", "16"), **extra_env)
+            t0 = time.time()
+            r = subprocess.run([host, plugin, "run", "degrain3", src, str(w), str(h), str(bits), str(frames), outp, "a.blksize=16", "a.overlap=8",
+                                "x.threads=%d" % threads, "x.order=frame"], capture_output=True, text=True, env=env, timeout=600)
+            d = {"process_wall_s": round(time.time() - t0, 2), "rc": r.returncode}
+            if r.returncode != 0 or "DONE" not in r.stdout:
+                d["error"] = (r.stderr or r.stdout)[-300:]
+                return d
+            g = lambda pat: float(re.search(pat, r.stderr).group(1))
+            loaded, built, req = g(r"clip loaded at ([0-9.]+) s"), g(r"graph built at ([0-9.]+) s"), g(r"output clip \(frame order\) ([0-9.]+) s")
+            d.update({"mode": key, "graph_construction_s": round(built - loaded, 2), "request_phase_s": req,
+                      "fps_all_inclusive": frames / (built - loaded + req), "fps_steady": frames / req})
+            got = np.fromfile(outp, dtype=np.uint16)
+            per = w * h + 2 * (w // 2) * (h // 2)
+            bad = 0
+            if got.size != per * frames:
+                bad = -1
+            else:
+                for n in range(frames):
+                    o = n * per
+                    for p in range(3):
+                        pw, ph = (w, h) if p == 0 else (w // 2, h // 2)
+                        if not np.array_equal(got[o:o + pw * ph].reshape(ph, pw), want[n][p]):
+                            bad += 1
+                        o += pw * ph
+            d["identical_to_c_abi"] = bad == 0
+            if bad:
+                d["planes_that_differ"] = bad
+            return d
+        first = run({}, "default (mv.Super delivers its frames to the host)")
+        res.update(first)
+        res["lazy_super"] = run({"MVX_VS_SUPER_LAZY": "1"}, "MVX_VS_SUPER_LAZY=1 (mv.Super's pixels stay on the device; opt-in)")
+    except Exception as e:  # (a failed side run must not cost the headline line)
+        res["error"] = "%s: %s" % (type(e).__name__, e)
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    return res
+
+
+def vs_shell():
+    """child run of vs_shell_leg (the parent has released its device memory); {"error": ...} on any failure"""
+    import subprocess
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--vs-shell-leg"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=900)
+        return json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 def measure_traffic(args, B):
@@ -491,11 +652,17 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="with --no-cpu: skip the oracle comparison of the timed step too")
     ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure the search launch's HBM traffic")
     ap.add_argument("--no-others", action="store_true", help="default cfg3 run: do not add the short runs of cfg2 / cfg4 / cfg5 (`other_configs` of the JSON line)")
+    ap.add_argument("--no-vs", action="store_true", help="default cfg3 run: do not add the run of the graph through the VapourSynth filter shell (`vs_shell` of the JSON line)")
+    ap.add_argument("--vs-shell-leg", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--vs-frames", type=int, default=640)
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--ingest", action="store_true", help="also measure the step with its source frames arriving from / its output frames leaving to pinned host memory "
                     "(secondary metric `ingest_inclusive` of the JSON line; `value` stays the resident-input number)")
     args = ap.parse_args()
 
+    if args.vs_shell_leg:
+        print(json.dumps(vs_shell_leg(args.vs_frames)))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank, local_rank, world = world_from_env(args.gpus)
@@ -521,8 +688,10 @@ def main():
     PipeT = PipelineFPS if fpsconv else Pipeline
     # the job: world*B output frames of one clip with a tr-frame lead-in / lead-out; this rank's contiguous share + halo
     plan = shard.RankPlan(world * B + 2 * max(tr, 1), rank, world, max(tr, 1), first_out=max(tr, 1), last_out=world * B + max(tr, 1))
-    pipe = PipeT(mv, torch, cfg, B, device, seed=1000 + rank, plan=plan)  # (synthetic content is generated per rank for the frames it holds)
-    pipes = [pipe] + [PipeT(mv, torch, cfg, B, device, seed=1000 + rank, src=pipe.src, plan=plan) for _ in range(max(1, args.slots) - 1)]
+    # ONE clip for the whole job: every rank generates the frames it holds (its share + the tr-frame halo) from the same seed; the content of a
+    # frame is a function of its global index, so neighbouring ranks hold identical copies of the frames they share (shard_check below)
+    pipe = PipeT(mv, torch, cfg, B, device, seed=1000, plan=plan)
+    pipes = [pipe] + [PipeT(mv, torch, cfg, B, device, seed=1000, src=pipe.src, plan=plan) for _ in range(max(1, args.slots) - 1)]
     units = pipe.frames_per_step if fpsconv else B  # frames a step delivers
     torch.cuda.synchronize()
 
@@ -546,6 +715,12 @@ def main():
         dt = float(t.item())
 
     rc = 0
+    shard = None
+    if dist is not None and not fpsconv and not args.no_parity:  # every rank takes part (control-plane gather, after the timed region)
+        try:
+            shard = shard_check(mv, torch, dist, cfg, pipes[(args.steps - 1) % len(pipes)] if args.steps else pipe, plan, rank, world, max(1, min((os.cpu_count() or 8) // world, 16)))
+        except Exception as e:
+            shard = {"error": "%s: %s" % (type(e).__name__, e)} if rank == 0 else None
     if rank == 0:
         search_ms = [a.elapsed_time(b) for pp in pipes for a, b in pp.ev]
         avg_launch_ms = sum(search_ms) / len(search_ms)
@@ -584,6 +759,10 @@ def main():
             out["parity_check"] = parity
             if not parity["identical"]:
                 rc = 3
+        if shard is not None:
+            out["shard_check"] = shard
+            if shard.get("shared_source_frames_identical") is False or any(b.get("identical") is False for b in shard.get("boundary_frames_vs_oracle", [])):
+                rc = 3  # (a definite mismatch; an error of the side check itself is reported in the line only)
         traffic, traffic_note = None, "not measured (--no-traffic)" if args.no_traffic else "not measured at more than one rank"
         if world == 1 and not args.no_traffic:
             for pp in pipes:  # the profiled child needs the HBM this process holds
@@ -600,6 +779,8 @@ def main():
                                                                "several x this figure on 8-bit clips (reference AVX2 SAD ~16x, overlap-add ~5-6x the scalar port per kernel)")
         if world == 1 and args.config == "cfg3" and not args.no_others and not args.no_cpu and not args.no_traffic and not args.batch:
             out["other_configs"] = other_configs()
+            if not args.no_vs:
+                out["vs_shell"] = vs_shell()
         print(json.dumps(out))
         if rc:
             sys.stderr.write("bench.py: the timed step's results differ from the oracle: %s\n" % out["parity_check"].get("mismatches"))

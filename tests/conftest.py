@@ -16,7 +16,7 @@ def pytest_configure(config):
 def pytest_collection_modifyitems(config, items):
     """Order of the GPU run: the parity suite first, then the filter shell (tests/test_vs_shim.py), the one-GPU sharding case LAST -- with
     `-x` a failure of a late file must not hide the cases of another (round 4: 31 shell cases were never reached behind a sharding failure)."""
-    last = [it for it in items if "test_rank_plans_on_one_gpu" in it.nodeid]
+    last = [it for it in items if "test_sharding.py" in it.nodeid and it.get_closest_marker("gpu") is not None]
     if last:
         items[:] = [it for it in items if it not in last] + last
 

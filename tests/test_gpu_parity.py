@@ -184,7 +184,7 @@ def dbg(mv):
         used.append(name)
     yield set_
     for name in used:
-        mv.debug_option(name, -1 if name in ("cpw_sync", "lds_min") else 1 if name == "spec" else 0)
+        mv.debug_option(name, -1 if name in ("cpw_sync", "lds_min", "team") else 1 if name == "spec" else 0)
 
 
 ANALYSE_CASES = [
@@ -521,7 +521,7 @@ WINDOW_CASES = [
     (320, 192, {}, dict(blksize=16, overlap=8, _noise=14, badsad=400, badrange=6)),  # UMH rescue between verified runs
     (520, 96, dict(hpad=4, vpad=4), dict(blksize=16, overlap=8, pglobal=20)),     # tiny padding: the global predictor is clipped block by block
 ])
-@pytest.mark.parametrize("mode", ["default", "everywhere", "no-runs"])
+@pytest.mark.parametrize("mode", ["default", "everywhere", "no-runs", "team"])
 def test_analyse_speculative_kernel(oracle, mv, dbg, mode, w, h, skw, akw):
     _speculative_case(oracle, mv, dbg, mode, w, h, 16, skw, akw)
 
@@ -553,9 +553,38 @@ ROWS8_CASES = [
 
 
 @pytest.mark.parametrize("w,h,skw,akw", ROWS8_CASES)
-@pytest.mark.parametrize("mode", ["default", "everywhere"])
+@pytest.mark.parametrize("mode", ["default", "everywhere", "team"])
 def test_analyse_speculative_kernel_8bit(oracle, mv, dbg, mode, w, h, skw, akw):
     _speculative_case(oracle, mv, dbg, mode, w, h, 8, skw, akw)
+
+
+@pytest.mark.parametrize("nw", [2, 3, 5, 8])
+@pytest.mark.parametrize("w,h,bits,skw,akw", [
+    (1000, 96, 16, {}, dict(blksize=16, overlap=8)),                              # four groups per row, meander: the turn-around waits for the token
+    (1000, 96, 16, {}, dict(blksize=16, overlap=8, meander=0, _noise=14)),        # always left to right; most hypotheses fail
+    (1000, 64, 8, {}, dict(blksize=8, overlap=4)),
+    (320, 192, 16, {}, dict(blksize=16, overlap=8, _noise=14, badsad=400, badrange=6)),  # rescues: badcount travels with the token
+    (512, 288, 16, {}, dict(blksize=32, overlap=16)),                             # one group per row (cfg5 shape)
+])
+def test_analyse_team_sizes(oracle, mv, dbg, nw, w, h, bits, skw, akw):
+
+    """The team form of the speculative kernel (mvx_analyse_spec.h, TEAM: the nw waves of a workgroup walk one chain, the token passes from group to
+    group) with 2, 3, 5 and 8 waves per chain: same blobs as the oracle whatever the number of waves."""
+    _speculative_case(oracle, mv, dbg, "team%d" % nw, w, h, bits, skw, akw)
+
+
+@pytest.mark.parametrize("w,h,bits,skw,akw", [
+    (384, 224, 16, {}, dict(blksize=16, overlap=8)),      # cfg3 shape: a launch of two chains leaves the GPU empty -> teams of four
+    (384, 224, 8, {}, dict(blksize=8, overlap=4)),        # cfg2 shape
+    (512, 288, 16, {}, dict(blksize=32, overlap=16)),     # no row passes: the serial lean kernel, no team
+])
+def test_analyse_team_is_the_librarys_choice_for_small_launches(oracle, mv, dbg, w, h, bits, skw, akw):
+    """With nothing forced, a launch that would leave wave slots empty at one wave per chain runs as teams (mvx_analyse.hip: mvx_team_default)."""
+    _speculative_case(oracle, mv, dbg, "auto", w, h, bits, skw, akw)
+    info = (C.c_int * 5)()
+    mv.lib().mvx_debug_last_launch(info)
+    if (bits, akw["blksize"]) in ((16, 16), (8, 8)):
+        assert info[4] == 3 and info[1] == 4, list(info)
 
 
 def _speculative_case(oracle, mv, dbg, mode, w, h, bits, skw, akw):
@@ -571,6 +600,11 @@ def _speculative_case(oracle, mv, dbg, mode, w, h, bits, skw, akw):
         dbg("spec", 5)
     if mode == "no-runs":
         dbg("spec", 3)
+    if mode.startswith("team"):  # the team form, forced for every shape the speculative kernel can run
+        dbg("spec", 5)
+        dbg("team", int(mode[4:] or 4))
+    elif mode != "auto":         # one wave per chain (the library itself picks the team form for launches this small: "auto")
+        dbg("team", 0)
     blk, ov = akw.get("blksize", 8), akw.get("overlap", 0)  # row passes: 16-bit 16x16 overlapping by half; 8-bit 8x8 overlapping by half or not at all
     rows_apply = akw.get("chroma", 1) != 0 and ((bits, blk, ov) == (16, 16, 8) or ((bits, blk) == (8, 8) and ov in (4, 0)))
     frames = pl.moving_clip(w, h, bits, 3, seed=17, noise=noise, motion=(5, -2))
@@ -585,7 +619,7 @@ def _speculative_case(oracle, mv, dbg, mode, w, h, bits, skw, akw):
         ref = 2 if isb else 0
         got = gan.run([(gsf[1], gsf[ref]), (gsf[1], None)])
         mv.lib().mvx_debug_last_launch(info)
-        assert info[4] == (2 if (mode != "default" or rows_apply) else 0), "not the kernel this case is meant to cover (%s)" % list(info)
+        assert info[4] == (3 if (mode.startswith("team") or (mode == "auto" and rows_apply)) else 2 if (mode not in ("default", "auto") or rows_apply) else 0), "not the kernel this case is meant to cover (%s)" % list(info)
         assert np.array_equal(got[0].cpu().numpy(), oan.frame(osf[1], osf[ref]))
         assert np.array_equal(got[1].cpu().numpy(), oan.frame(osf[1], None))
         if skw.get("pel", 2) == 2:

@@ -25,7 +25,7 @@ def test_frame_ranges_partition():
     assert shard.ref_index(0, 1, 0, 10) is None and shard.ref_index(0, 1, 1, 10) == 1 and shard.ref_index(9, 2, 1, 10) is None
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, N=9, tr=2):
     sys.path[:0] = [os.path.join(ROOT, "oracle"), os.path.join(ROOT, "vapoursynth-mvtools_amd"), os.path.join(ROOT, "tests")]
     import torch.distributed as dist
     import mvoracle as mo
@@ -34,7 +34,7 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    N, tr, w, h = 9, 2, 96, 64
+    w, h = 96, 64
     clip = pl.moving_clip(w, h, 8, N, seed=4)           # the "file" every rank can read
     plan = shard.RankPlan(N, rank, world, tr)           # the same planner bench.py's Pipeline builds its job tables from
     lo, hi = plan.held
@@ -44,6 +44,8 @@ def _worker(rank, world, port, q):
     kw = dict(blksize=8, overlap=4)
     ans = {(d, isb): mo.Analyse(sup, isb=isb, delta=d, num_frames=N, **kw) for d, isb in plan.clips}
     dg = mo.Degrain(tr, sup, ans[(1, 1)].ad)
+    if lo == hi:  # more ranks than frames: this rank owns nothing (it still takes part in the gather)
+        supers = []
     blobs = {key: [ans[key].frame(supers[n], supers[nref] if nref is not None else None) for n, nref in pairs]
              for key, pairs in plan.searches().items()}
     out = {}
@@ -55,6 +57,39 @@ def _worker(rank, world, port, q):
     if rank == 0:
         q.put(gathered)
     dist.destroy_process_group()
+
+
+def _run_worlds(worlds, N, tr):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    res = {}
+    for world in worlds:
+        q = ctx.Queue()
+        port = 29500 + (os.getpid() * 7 + world * 13 + N) % 2000
+        procs = [ctx.Process(target=_worker, args=(r, world, port, q, N, tr)) for r in range(world)]
+        for p in procs:
+            p.start()
+        gathered = q.get(timeout=280)
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+        merged = {}
+        for part in gathered:
+            assert not (set(part) & set(merged))
+            merged.update(part)
+        res[world] = merged
+    return res
+
+
+@pytest.mark.timeout(600)
+def test_uneven_sharding_radius_6_worlds_3_and_8():
+    """r5: a clip whose length does not divide by the world size (11 frames over 3 and over 8 ranks: shares of 4+4+3 and of 2+2+2+1+1+1+1+1), temporal
+    radius 6 (Degrain6: the halo is longer than any share, every rank holds most of the clip, references beyond the clip ends are missing exactly as in
+    the single-process run): the gathered result equals the world-1 result frame for frame."""
+    N, tr = 11, 6
+    res = _run_worlds((1, 3, 8), N, tr)
+    assert sorted(res[1]) == list(range(N)) == sorted(res[3]) == sorted(res[8])
+    assert res[1] == res[3] == res[8]
 
 
 @pytest.mark.timeout(300)
@@ -138,6 +173,7 @@ def test_rank_plans_on_one_gpu_match_the_single_rank_run(world):
     N = total + 2 * tr
     dev = torch.device("cuda", 0)
     clip = bench.synth_clip_device(torch, w, h, bits, N, seed=5, device=dev)
+    torch.cuda.synchronize()
 
     def run(rank, nranks):
         plan = shard.RankPlan(N, rank, nranks, tr, first_out=tr, last_out=N - tr)
@@ -164,3 +200,42 @@ def test_rank_plans_on_one_gpu_match_the_single_rank_run(world):
             assert torch.equal(a[:, :rb], b[:, :rb]), "Degrain output of frame %d differs between the world-1 and the world-%d run" % (n, world)
         for k in whole[n][1]:
             assert torch.equal(whole[n][1][k], union[n][1][k]), "vectors of frame %d, clip %s differ" % (n, k)
+
+
+@pytest.mark.gpu
+def test_ranks_generate_identical_shared_frames_and_the_shard_check_sees_a_difference():
+    """bench.py --gpus N as far as one GPU allows (r5): every rank generates the frames it holds from the clip's seed and the GLOBAL frame index, so
+    the frames two neighbouring ranks share (the halo) are identical bytes; bench.shard_payload / shard_verdict (what main() runs over
+    all_gather_object at N > 1) confirm it, check one output frame on either side of the shard boundary against the oracle, and report a
+    corrupted halo frame."""
+    import torch
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "vapoursynth-mvtools_amd")]
+    import bench
+    import mvtools_amd as mv
+    from mvtools_amd import shard
+    w, h, bits, tr, B, world = 320, 192, 16, 2, 5, 2
+    cfg = (w, h, bits, tr, dict(blksize=16, overlap=8), dict(pel=2), 0, "shard check test clip")
+    N = world * B + 2 * tr
+    dev = torch.device("cuda", 0)
+    whole = bench.synth_clip_device(torch, w, h, bits, N, seed=1000, device=dev)
+    pipes, plans = [], []
+    for r in range(world):
+        plan = shard.RankPlan(N, r, world, tr, first_out=tr, last_out=N - tr)
+        p = bench.Pipeline(mv, torch, cfg, B, dev, seed=1000, plan=plan)      # generates plan.held from the global index, like main()
+        for k, n in enumerate(range(*plan.held)):
+            for a, b in zip(p.src[k], whole[n]):
+                assert torch.equal(a, b), "rank %d: frame %d differs from the whole clip's" % (r, n)
+        p.step()
+        torch.cuda.synchronize()
+        pipes.append(p)
+        plans.append(plan)
+    gathered = [bench.shard_payload(mv, torch, cfg, pipes[r], plans[r], r, 4) for r in range(world)]
+    v = bench.shard_verdict(gathered)
+    assert v["shared_source_frames_compared"] == 2 * tr and v["shared_source_frames_identical"] and v["output_ranges_partition_the_job"], v
+    assert [b["identical"] for b in v["boundary_frames_vs_oracle"]] == [True, True] and "errors" not in v, v
+    assert [b["global_frame"] for b in v["boundary_frames_vs_oracle"]] == [tr + B - 1, tr + B]
+    pipes[1].src[0][0][3, 5] += 1                                             # rank 1's copy of a frame rank 0 holds too
+    torch.cuda.synchronize()
+    gathered[1] = bench.shard_payload(mv, torch, cfg, pipes[1], plans[1], 1, 4, oracle=False)
+    v = bench.shard_verdict(gathered)
+    assert not v["shared_source_frames_identical"] and "frame %d" % plans[1].held[0] in v["mismatches"][0], v

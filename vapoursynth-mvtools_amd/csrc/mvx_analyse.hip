@@ -42,13 +42,14 @@ struct MvxDebug {
     int cpw_sync = -1; // barrier interval inside a workgroup (power of two, 0 = none)
     int lds_min = -1;  // LDS floor of the one-chain launches
     int spec = 1;      // default search: 1 = the speculative kernel (mvx_analyse_spec.h), 0 = the lean serial kernel (mvx_analyse_fast.h), 2 = the speculative kernel's code with speculation off (every block live), 3 = speculative without runs (every block's candidates loaded on their own), 5 = speculative for every shape it can run (by default only where its row passes apply)
+    int team = -1;     // waves per chain of the speculative kernel's team form (mvx_analyse_spec.h: TEAM): 0 = never, 2..8 = always that many, -1 = the library's choice
     int win = 0;       // 1: the LDS-window kernel of the default search (mvx_analyse_win.h) where it applies: bit-exact, measured slower
     int super_rows_off = 0; // 1: mv.Super level 0 / first reduction through the LDS-tile / per-sample kernels only
     int ablate = 0;
 };
 static MvxDebug g_dbg;
 extern "C" __attribute__((visibility("default"))) int mvx_debug_option(const char *name, int value) {
-    struct { const char *n; int *p; } tab[] = { { "general", &g_dbg.general }, { "fast_wpe", &g_dbg.fast_wpe }, { "cpw1", &g_dbg.cpw1 }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "fast_cpw", &g_dbg.fast_cpw }, { "fast_k", &g_dbg.fast_k }, { "fast_lds_min", &g_dbg.fast_lds_min }, { "fast_flags", &g_dbg.fast_flags }, { "pad_runs", &g_dbg.pad_runs }, { "shadow_planes", &g_dbg.shadow_planes }, { "degrain_xcd", &g_dbg.degrain_xcd }, { "degrain_shadow", &g_dbg.degrain_shadow }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min }, { "super_rows_off", &g_dbg.super_rows_off }, { "win", &g_dbg.win }, { "spec", &g_dbg.spec },
+    struct { const char *n; int *p; } tab[] = { { "general", &g_dbg.general }, { "fast_wpe", &g_dbg.fast_wpe }, { "cpw1", &g_dbg.cpw1 }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "fast_cpw", &g_dbg.fast_cpw }, { "fast_k", &g_dbg.fast_k }, { "fast_lds_min", &g_dbg.fast_lds_min }, { "fast_flags", &g_dbg.fast_flags }, { "pad_runs", &g_dbg.pad_runs }, { "shadow_planes", &g_dbg.shadow_planes }, { "degrain_xcd", &g_dbg.degrain_xcd }, { "degrain_shadow", &g_dbg.degrain_shadow }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min }, { "super_rows_off", &g_dbg.super_rows_off }, { "win", &g_dbg.win }, { "spec", &g_dbg.spec }, { "team", &g_dbg.team },
 #ifdef MVX_LAB
         { "ablate", &g_dbg.ablate },
 #endif
@@ -292,6 +293,22 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_set_ref_shadow
 extern "C" __attribute__((visibility("default"))) void mvx_analyse_get_data(const mvx_analyse *a, mvx_analysis_data *out) { *out = a->adOut; }
 extern "C" __attribute__((visibility("default"))) int mvx_analyse_blob_size(const mvx_analyse *a) { return a->P.blobSize; }
 
+// Waves per chain the speculative kernel is launched with when the caller does not say (mvx_debug_option "team"): 0 = one wave per chain.
+// Measured r5 on cfg3 (profiles/r5_team_first_bench.txt, r5_team_batch_sweep.txt; ms per launch, one wave / team of 2 / 4 / 8):
+//   132 chains 191 / - / 71 / 69,   258: 201 / - / 76 / 90,   516: 205 / - / 145 / 141,   768: 209 / 165 / 200 / -,   1020: 226 / 226 / - / -,
+//   2046: 342 / 461 / 421 / 473.
+// A launch that leaves wave slots empty with one wave per chain (two per SIMD fit) finishes sooner as teams; one that fills the GPU anyway does
+// not: four chains of a workgroup that share a reference frame and walk in step fetch each line once for all of them, a team's chains do not
+// (2 444 against 1 302 GB of line traffic per 2046-chain launch, L2 hit rate 43 against 62 %), and the token makes a team wave wait for its
+// predecessors' verification (40 % of a wave's time on a chain with many live blocks: profiles/r5_team_phase_cycles.txt).
+static int mvx_team_default(int njobs, int simds, bool strips) {
+    if (!strips) return 0; // (measured for the shapes with row passes only)
+    const long long slots = 2LL * simds; // waves the 256-register build keeps resident
+    if (njobs * 4LL <= slots * 11 / 10) return 4;
+    if (njobs * 2LL <= slots * 9 / 10) return 2;
+    return 0;
+}
+
 extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_analyse *a, int njobs, const mvx_analyse_job *jobs, void *stream) {
     if (njobs <= 0) return MVX_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -359,7 +376,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         const bool stripShape = (P.bps == 2 && P.blkX == 16 && P.chroma && P.ovX == P.blkX / 2 && P.shadow[1] != 0) || stripShape8; // (the row passes read the UV-interleaved plane: STRIP_OK)
         const bool useSpec = !useWin && g_dbg.spec != 0 && (stripShape || g_dbg.spec >= 2);
         const bool useSpecStrips = useSpec && g_dbg.spec != 3 && stripShape;
-        int sTab = 0, sRow = fRow;
+        int sTab = 0, sRow = fRow, sTabMax = 0; // (sTabMax: the largest SAD table of any level)
         if (useSpec) {
             const bool anyExh = P.searchType == SearchExhaustive || (P.nLevels > 1 && P.searchTypeCoarse == SearchExhaustive);
             const int sStrip = (P.bps == 2 && P.blkX == 16) ? (P.blkX + P.blkX / 2) * 128 : 0; // the source strip of a window of blocks: 24 (48) rows x 8 columns (mvx_analyse_spec.h: STRIP_OK)
@@ -372,6 +389,8 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
                 const int st = smallest ? (P.nLevels == 1 ? P.searchType : P.searchTypeCoarse) : (i == 0 ? P.searchType : P.searchTypeCoarse);
                 const int need = sSrc + ((P.lv[i].nBlkX * 8 + 15) & ~15) + (st == SearchHex2 ? SPEC_SLOTS_HEX : SPEC_SLOTS_EXH) * SPEC_STRIDE;
                 if (need > fNeed) fNeed = need;
+                const int tabB = (st == SearchHex2 ? SPEC_SLOTS_HEX : SPEC_SLOTS_EXH) * SPEC_STRIDE;
+                if (tabB > sTabMax) sTabMax = tabB;
             }
             if (fNeed < sRow + fBins * 4) fNeed = sRow + fBins * 4;
         }
@@ -434,7 +453,36 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
             ALaunch L = { ntab, fNeed, useSpec ? sRow : fRow, useSpec ? sRow : fRow, fBins, fNeed, simds, cpw, k, syncEvery, k, flags, st, a->dP, S.d };
             L.ldsBytes = g_dbg.fast_lds_min; // (floor of the workgroup's LDS request, 0 = none)
             int rc;
-            if (useSpec) { const ASpecLaunch SL = { L, sTab }; rc = P.bps == 1 ? mvx_analyse_launch_spec_u8(P, SL) : mvx_analyse_launch_spec_u16(P, SL); }
+            // TEAM form (r5): the nw waves of a workgroup walk ONE chain.  A chain finishes ~nw times sooner and a launch keeps nw times fewer chains resident
+            // per wave slot, so it is the form for launches that do not fill the GPU with one wave per chain (a frame server's look-ahead window); for
+            // big batches the choice is measured.  LDS: [64 B control words | row buffer] shared + per wave [source strip | SAD table]
+            int team = 0;
+            if (useSpec) {
+                team = g_dbg.team >= 0 ? g_dbg.team : mvx_team_default(njobs, simds, useSpecStrips);
+                if (team == 1 || team > 8) team = 0;
+            }
+            if (team) {
+                const int shared = (64 + fMaxBlkX * 8 + 255) & ~255;
+                int perWave = sRow + sTabMax; // [source strip / block | SAD table]; the histogram of the global-motion estimate lies over the table
+                if (perWave < sRow + fBins * 4) perWave = sRow + fBins * 4;
+                perWave = (perWave + 255) & ~255;
+                while (team > 1 && shared + perWave * team > 160 * 1024) team--;
+                if (team > 1) {
+                    ALaunch TL = L;
+                    TL.ldsRow = shared; TL.ldsNeed = perWave; TL.ldsHist = sRow; TL.syncEvery = 0; TL.fast = 2; TL.cpw = 1;
+                    // the table of the job list is NOT padded for this form (one chain per workgroup); padding entries are skipped by the kernel
+                    const ASpecLaunch SL = { TL, sRow, team };
+                    rc = P.bps == 1 ? mvx_analyse_launch_spec_u8(P, SL) : mvx_analyse_launch_spec_u16(P, SL);
+                    if (rc == MVX_OK) {
+                        g_lastLaunch[0] = 2; g_lastLaunch[1] = team; g_lastLaunch[2] = 0; g_lastLaunch[3] = ntab; g_lastLaunch[4] = 3;
+                        if (P.divide) hipLaunchKernelGGL(analyse_divide_kernel, dim3((P.lv[0].nBlkX * P.lv[0].nBlkY + 255) / 256, ntab), dim3(256), 0, st, a->dP, S.d);
+                        HIP_CHECK(hipGetLastError());
+                        return MVX_OK;
+                    }
+                    if (rc != 1) return rc;
+                }
+            }
+            if (useSpec) { const ASpecLaunch SL = { L, sTab, 0 }; rc = P.bps == 1 ? mvx_analyse_launch_spec_u8(P, SL) : mvx_analyse_launch_spec_u16(P, SL); }
             else rc = useWin ? mvx_analyse_launch_win(P, L) : P.bps == 1 ? mvx_analyse_launch_fast_u8(P, L) : mvx_analyse_launch_fast_u16(P, L);
             if (rc == MVX_OK) {
                 g_lastLaunch[0] = k; g_lastLaunch[1] = cpw; g_lastLaunch[2] = syncEvery; g_lastLaunch[3] = ntab; g_lastLaunch[4] = useWin ? 1 : useSpec ? 2 : 0;

@@ -575,11 +575,12 @@ template <int BPS, int BW, bool UV, int STREAM_MAX = MVX_STREAM_MAX> struct Fast
     __device__ static void st_vec(GL_AS GVec *p, const Vec &v) { p->x = v.x; p->y = v.y; p->sad = v.sad; }
 
     // pobInterpolatePrediction (:1447-1514) straight into vectors[], or zero (pobInit :355)
-    __device__ __forceinline__ void interpolate(GL_AS const GVec *coarse, int coarseBlkX, int coarseBlkY, int coarseLogPel) {
-        const int l = lane_id();
+    // (first / stride: the share of this wave when several waves of a workgroup fill one plane -- the team form of the speculative kernel)
+    __device__ __forceinline__ void interpolate(GL_AS const GVec *coarse, int coarseBlkX, int coarseBlkY, int coarseLogPel, int first = -1, int stride = WAVE) {
+        const int l = first < 0 ? lane_id() : first;
         const int nBlk = nBlkX * nBlkY;
         if (!coarse) {
-            for (int i = l; i < nBlk; i += WAVE) { Vec z; z.x = 0; z.y = 0; z.sad = 0; st_vec(&vectors[i], z); }
+            for (int i = l; i < nBlk; i += stride) { Vec z; z.x = 0; z.y = 0; z.sad = 0; st_vec(&vectors[i], z); }
             return;
         }
         int normFactor = 3 - logPel + coarseLogPel;
@@ -589,7 +590,7 @@ template <int BPS, int BW, bool UV, int STREAM_MAX = MVX_STREAM_MAX> struct Fast
         const int aoddx = P.blkX * 3 - P.ovX * 2, aevenx = P.blkX * 3 - P.ovX * 4;
         const int aoddy = P.blkY * 3 - P.ovY * 2, aeveny = P.blkY * 3 - P.ovY * 4;
         const double scaleov = 1.0 / normov;
-        for (int index = l; index < nBlk; index += WAVE) {
+        for (int index = l; index < nBlk; index += stride) {
             const int ly = index / nBlkX, k = index - ly * nBlkX;
             int i = k, j = ly;
             if (i >= 2 * coarseBlkX) i = 2 * coarseBlkX - 1;

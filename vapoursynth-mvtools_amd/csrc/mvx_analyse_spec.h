@@ -45,14 +45,14 @@
 #endif
 // -DMVX_SPEC_PROF (tools/specprof.py): cycles of ONE chain per phase of the group loop (s_memtime; a stamp waits for the scalar counter only)
 #ifdef MVX_SPEC_PROF
-#define SPROF_N 16
+#define SPROF_N 20 // (16: TEAM, waiting for the previous block row; 17: TEAM, waiting for the token)
 static __device__ unsigned long long g_specprof[SPROF_N];
 #define SPROF(i) do { const long long t1_ = (long long)__builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" : : "s"(t1_) : "memory"); sprof[i] += t1_ - sprofT; sprofT = t1_; } while (0)
 #else
 #define SPROF(i) ((void)0)
 #endif
 #ifdef MVX_SPEC_PROF
-#define SPEC_PROF_DUMP_() do { if (l == 0 && chain == 5) for (int i = 0; i < SPROF_N; i++) g_specprof[i] = (unsigned long long)S.sprof[i]; } while (0)
+#define SPEC_PROF_DUMP_() do { if (l == 0 && chain == 5 && S.role == 1) for (int i = 0; i < SPROF_N; i++) g_specprof[i] = (unsigned long long)S.sprof[i]; } while (0)
 #else
 #define SPEC_PROF_DUMP_() ((void)0)
 #endif
@@ -66,7 +66,15 @@ static __device__ unsigned long long g_specstat[MVX_MAX_LEVELS][4]; // per level
 // SWIN: row loads a lane keeps in flight in the row passes (12 = half a pass; 24 = a whole pass: the builds with 256 registers)
 // (pass A has nothing else to wait for: whole candidates as one stream of loads -- FastSearcher's STREAM_MAX = 48; a template argument, so the serial
 // kernel's FastSearcher<.., 12> and this one are different types whatever translation unit instantiates them)
-template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSearcher<BPS, BW, UV, 48> {
+//
+// TEAM (round 5): ONE chain is walked by the nw waves of a workgroup.  The groups of a level are dealt out round robin; a wave runs phases A1 / A / A2 of
+// its group with nothing to wait for but the previous block row's results of the same columns, then waits for the TOKEN -- the count of groups whose
+// results are written -- to reach its group, takes the true left neighbour (prevX / prevY / prevSad) and badcount from the workgroup's control words,
+// runs phase B exactly as the single-wave form does, writes the group's results and passes the token on.  The serial part of the walk (B) stays serial
+// and in reference order; the SAD work of nw groups overlaps.  A chain finishes ~nw times sooner, so a launch keeps nw times fewer chains resident for
+// the same number of waves: their live reference rows share the L2 / the Infinity Cache among fewer chains, and small launches (a frame server's
+// look-ahead window) fill the GPU.  Results are those of the single-wave form by construction: every decision in A2 / B is taken with the same inputs.
+template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct SpecSearcher : FastSearcher<BPS, BW, UV, 48> {
     typedef FastSearcher<BPS, BW, UV, 48> F;
     typedef FGeo<BPS, BW> G;
     using F::P; using F::J; using F::lds; using F::ldsRow; using F::ldsHist; using F::histBins;
@@ -78,6 +86,39 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
     using F::x0; using F::y0; using F::blkIdx; using F::nDxMin; using F::nDyMin; using F::nDxMax; using F::nDyMax;
     using F::predX; using F::predY; using F::pX; using F::pY; using F::nLambda; using F::bestX; using F::bestY; using F::bestSad;
     int ldsTab; // byte offset of the SAD table inside the chain's LDS
+    // TEAM: this wave's number inside the workgroup and the workgroup's waves; the previous block row's results (shared); control words: [0] token = groups
+    // of this level whose results are written, [1..3] the last block's result (x, y, sad), [4] badcount
+    int role, nw;
+    lds_u8 *shRow;
+    LDS_AS int *ctl;
+    // the running global predictor after the blocks lo..hiE-1 of the 64-column chunk at c0, in walk order (:859: every block clips the running value
+    // with its own limits).  The limits are monotonic along a row: a value that neither the first nor the last block of the group clips passes them all
+    __device__ __forceinline__ int team_advance(int g, int c0, int lo, int hiE, bool fwd, int stepX, int hps) const {
+        auto clampAt = [&](int v, int li) { const int xb = stepX * (c0 + li); return min(max(v, -((xb + hps) << logPel)), ((pw - xb - hpad - BW - hpad + hps) << logPel) - 1); };
+        if (clampAt(g, lo) == g && clampAt(g, hiE - 1) == g) return g;
+        for (int i = 0; i < hiE - lo; i++) g = clampAt(g, fwd ? lo + i : hiE - 1 - i);
+        return g;
+    }
+    __device__ __forceinline__ void team_wait_ge(int need) const { // until the results of the first `need` groups of this level are written
+        while (uni(__hip_atomic_load(ctl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(2);
+    }
+    __device__ __forceinline__ void team_acquire(int myG, int &px, int &py, int &ps) { // the token reaches group myG: the walk's state behind group myG - 1
+        team_wait_ge(myG);
+        px = uni(__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        py = uni(__hip_atomic_load(ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        ps = uni(__hip_atomic_load(ctl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        badcount = uni(__hip_atomic_load(ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    }
+    __device__ __forceinline__ void team_release(int done, int px, int py, int ps) const { // this group's results (vectors[], the row buffer) are written
+        if (lane_id() == 0) {
+            __hip_atomic_store(ctl + 1, px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(ctl + 2, py, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(ctl + 3, ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(ctl + 4, badcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane_id() == 0) __hip_atomic_store(ctl, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
 #ifdef MVX_SPEC_PROF
     long long sprof[SPROF_N], sprofT; // 0 barrier, 1 fetch + A1, 2 row passes, 3 one-block passes, 4 A2, 5 verification, 6 live blocks, 7 results, 8 level prologue, 9 groups, 10 live blocks counted
 #endif
@@ -299,9 +340,12 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
         srcUV = uptr(J.src[1] + P.shadow[1] + 2 * L.off[1]); refUV = uptr((J.ref[1] ? J.ref[1] : J.src[1]) + P.shadow[1] + 2 * L.off[1]);
         unsigned char *rec = (unsigned char *)(unsigned long long)uni((long long)(unsigned long long)(J.blob + L.blobOff));
         vectors = (GL_AS GVec *)(rec + 4);
-        if (l == 0) *(int *)rec = 4 + nBlkX * nBlkY * 16; // pobWriteHeaderToArray :413-416
+        if (l == 0 && (!TEAM || role == 0)) *(int *)rec = 4 + nBlkX * nBlkY * 16; // pobWriteHeaderToArray :413-416
         const bool smallestPlane = lvl == P.nLevels - 1;
-        this->interpolate(coarse, coarseBlkX, coarseBlkY, coarseLogPel);
+        if constexpr (TEAM) {
+            if (role == 0 && l < 8) ctl[l] = 0; // (every wave passed the previous level's closing barrier: nobody reads the control words now)
+            this->interpolate(coarse, coarseBlkX, coarseBlkY, coarseLogPel, l + 64 * role, 64 * nw);
+        } else this->interpolate(coarse, coarseBlkX, coarseBlkY, coarseLogPel);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         __builtin_amdgcn_s_barrier();
@@ -322,8 +366,8 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
         const int stepX = uni(P.blkX - P.ovX), stepY = uni(P.blkY - P.ovY);
         const int hps = hpad >> lvl, vps = vpad >> lvl; // :1091-1092
         const bool meander = uni(P.meander) != 0;
-        LDS_AS v2u *rowbuf = (LDS_AS v2u *)(lds + ldsRow); // the previous block row's results, 8 bytes per block: (x | y << 16, sad)
-        lds_u8 *tab = lds + ldsRow + ((nBlkX * 8 + 15) & ~15); // the group's SAD table follows the row buffer of THIS level (the host sizes the chain's LDS for the worst level)
+        LDS_AS v2u *rowbuf = (LDS_AS v2u *)(TEAM ? shRow : lds + ldsRow); // the previous block row's results, 8 bytes per block: (x | y << 16, sad)
+        lds_u8 *tab = TEAM ? lds + ldsTab : lds + ldsRow + ((nBlkX * 8 + 15) & ~15); // the group's SAD table follows the row buffer of THIS level (the host sizes the chain's LDS for the worst level); TEAM: in the wave's own area
         this->pf_setup();
         SPROF(8);
         auto lambda_of = [&](int predSad) { // :456-462, fp64 as the reference
@@ -366,12 +410,15 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
         int prevX = 0, prevY = 0, prevSad = 0;
         int syncCount = 0;
         if (syncEvery > 0 && syncEvery < 32) syncEvery = 32; // (a group is the unit)
+        int Gc = 0;                                 // groups of this level so far, in walk order (TEAM: the token's unit)
+        const int nGrpRow = (nBlkX + SPEC_TB - 1) / SPEC_TB;
         for (int blky = 0; blky < nBlkY; blky++) {
             const bool fwd = (blky & 1) == 0 || !meander;
             const int dir = fwd ? 1 : -1;
             y0 = vpad + stepY * blky;
             nDyMax = (ph - y0 - BW - vpad + vps) << logPel; // :1094-1097 (the vertical limits are the row's)
             nDyMin = -((y0 - vpad + vps) << logPel);
+            if constexpr (TEAM) gmvy = this->clipy(gmvy); // (every wave follows the running global predictor through the groups it does not own; the row's clip is idempotent)
             const bool specRow = specLevel && blky > 0;
             const int ngrp = (nBlkX + 63) >> 6;
             for (int gi = 0; gi < ngrp; gi++) {
@@ -388,6 +435,26 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                     const int h = fwd ? hi : 1 - hi;
                     const int lo = h * SPEC_TB, hiE = min(lo + SPEC_TB, ncol);
                     if (lo >= ncol) continue;
+                    const int myG = Gc++;
+                    bool teamHeld = false; // TEAM: this wave holds the token (prevX / prevY / prevSad / badcount are the walk's)
+                    if constexpr (TEAM) {
+                        if (uni(myG % nw) != role) { // another wave's group: only the running global predictor moves on (:859)
+                            gmvx = team_advance(gmvx, c0, lo, hiE, fwd, stepX, hps);
+                            continue;
+                        }
+                        if (specRow) {
+                            // phase A1 reads the previous block row's results of this group's columns (in the last block row also of the column ahead, :441-447):
+                            // they are written when the token has passed the group(s) of the previous row that cover them
+                            const int j = (c0 >> 5) + h;
+                            const bool fwdPrev = ((blky - 1) & 1) == 0 || !meander;
+                            auto idxPrev = [&](int jj) { return fwdPrev ? jj : nGrpRow - 1 - jj; };
+                            int need = (blky - 1) * nGrpRow + idxPrev(j) + 1;
+                            if (blky == nBlkY - 1) { const int j2 = j + dir; if (j2 >= 0 && j2 < nGrpRow) need = max(need, (blky - 1) * nGrpRow + idxPrev(j2) + 1); }
+                            SPROF(7);
+                            team_wait_ge(need);
+                            SPROF(16);
+                        }
+                    }
                     SPROF(7);
                     if (syncEvery && (syncCount++ & ((syncEvery >> 5) - 1)) == 0) __builtin_amdgcn_s_barrier(); // keeps the chains of a workgroup on neighbouring blocks (shared reference lines): every syncEvery / 32 groups
                     SPROF(0);
@@ -1051,6 +1118,8 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                                 live = a2_refine(pX_, pY_, best, bx, by, bs);
                                 if (MVX_SPEC_ABL == 8) live = live || !(pX_ == ux && pY_ == uy); // (debug: accept only blocks whose centre is up)
                             }
+                            // TEAM: everything above was independent of the walk; from here on the group needs the walk's state behind its left neighbour
+                            if constexpr (TEAM) { SPROF(4); team_acquire(myG, prevX, prevY, prevSad); teamHeld = true; SPROF(17); }
                             // the bad-block rescue (:938-963) is the live search's; a higher badcount later only raises the threshold
                             live = live || (blky * nBlkX + c > 1 && (long long)bs > badSAD + badSAD * badcount / 16);
                             rX = bx; rY = by; rSad = bs;
@@ -1067,6 +1136,7 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                     }
 
                     SPROF(4);
+                    if constexpr (TEAM) { if (!teamHeld) { team_acquire(myG, prevX, prevY, prevSad); SPROF(17); } } // (rows that are not speculated: every block is searched live, in turn)
                     // ======== B: verification in walk order; whatever does not verify is searched live with its true predictors
                     int pos = fwd ? lo : hiE - 1;
                     const int end = fwd ? hiE : lo - 1;
@@ -1198,13 +1268,22 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
                         }
                     }
                     if (specRow) gmvx = gEndX;
+                    if constexpr (TEAM) { // the group's results (:967, :1106), then the token moves on
+                        if (act) {
+                            typedef unsigned a4v __attribute__((ext_vector_type(4), aligned(4)));
+                            const a4v t = {bOut[0], bOut[1], bOut[2], 0u};
+                            *(GL_AS a4v *)&vectors[blky * nBlkX + c] = t;
+                            rowbuf[c] = v2u{(unsigned)pk((int)bOut[0], (int)bOut[1]), bOut[2]};
+                        }
+                        team_release(myG + 1, prevX, prevY, prevSad);
+                    }
                     SPROF(5);
 #ifdef MVX_SPEC_PROF
                     sprof[9] += 1;
 #endif
                 }
                 // ---- results of the 64 columns (:967, :1106)
-                if (in) {
+                if (!TEAM && in) {
                     typedef unsigned a4v __attribute__((ext_vector_type(4), aligned(4)));
                     const a4v t = {bOut[0], bOut[1], bOut[2], 0u}; // (block SADs are non-negative and < 2^31)
                     *(GL_AS a4v *)&vectors[blky * nBlkX + c] = t;
@@ -1224,22 +1303,26 @@ template <int BPS, int BW, bool UV, int SWIN = 12> struct SpecSearcher : FastSea
 };
 
 // The launch shape is analyse_fast_kernel's: workgroups of 4 * WPE chains that are consecutive entries of the (reference-sorted) job table.
-template <int BPS, int BW, int WPE, int MAXCPW, bool UV>
+// TEAM: the workgroup's waves walk ONE chain (blockDim.x / 64 of them; workgroup b = entry b of the job table).  LDS: [control words 64 B | the previous block
+// row's results | one area of ldsChain bytes per wave: source strip / block, SAD table]; ldsRow carries the size of the shared part
+template <int BPS, int BW, int WPE, int MAXCPW, bool UV, bool TEAM = false>
 __global__ __launch_bounds__(64 * MAXCPW, WPE) void analyse_spec_kernel(const AParams *Pp, const AJob *jobs, int njobs, int ldsChain, int syncEvery, int ldsRow, int ldsHist, int histBins, int ldsTab, int flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const AParams &P = *Pp;
-    const int cpw = (int)(blockDim.x >> 6);
+    const int cpw = TEAM ? 1 : (int)(blockDim.x >> 6);
     int wg = (int)blockIdx.x;
     if (flags & MVX_FAST_XCD_REMAP) { // workgroup b runs on XCD b % 8 (round-robin dispatch): give every XCD a contiguous range of the table
         const int n = (int)gridDim.x, x = wg & 7, slot = wg >> 3;
         wg = x * (n >> 3) + min(x, n & 7) + slot;
     }
-    const int chain = uni(wg * cpw + (int)(threadIdx.x >> 6));
+    const int wave = uni((int)(threadIdx.x >> 6));
+    const int chain = uni(TEAM ? wg : wg * cpw + wave);
     if (chain >= njobs) return; // (a finished wave no longer counts for the workgroup's barriers)
     const AJob &J = jobs[chain];
     if (!J.blob) return;        // padding entry of the job table
     const int l = lane_id();
     int *hdr = (int *)J.blob;
+    if (TEAM && wave != 0 && !J.valid) return;
     if (!J.valid) { // gopWriteDefaultToArray GroupOfPlanes.c:150-164, pobWriteDefaultToArray PlaneOfBlocks.cpp:1529-1556
         if (l == 0) { hdr[0] = P.blobSize; hdr[1] = 0; }
         for (int lvl = P.nLevels - 1; lvl >= 0; lvl--) {
@@ -1252,10 +1335,11 @@ __global__ __launch_bounds__(64 * MAXCPW, WPE) void analyse_spec_kernel(const AP
         }
         return;
     }
-    if (l == 0) { hdr[0] = P.blobSize; hdr[1] = 1; } // GroupOfPlanes.c:77-85
-    SpecSearcher<BPS, BW, UV, (WPE <= 2 ? 24 : MVX_SPEC_SW3)> S(P, J);
-    S.lds = (lds_u8 *)smem + uni((int)(threadIdx.x >> 6)) * ldsChain;
+    if (l == 0 && (!TEAM || wave == 0)) { hdr[0] = P.blobSize; hdr[1] = 1; } // GroupOfPlanes.c:77-85
+    SpecSearcher<BPS, BW, UV, (WPE <= 2 ? 24 : MVX_SPEC_SW3), TEAM> S(P, J);
+    S.lds = (lds_u8 *)smem + (TEAM ? ldsRow : 0) + wave * ldsChain;
     S.ldsRow = ldsRow; S.ldsHist = ldsHist; S.histBins = histBins; S.ldsTab = ldsTab;
+    S.role = wave; S.nw = uni((int)(blockDim.x >> 6)); S.ctl = (LDS_AS int *)((lds_u8 *)smem); S.shRow = (lds_u8 *)smem + 64;
 #ifdef MVX_SPEC_PROF
     for (int i = 0; i < SPROF_N; i++) S.sprof[i] = 0;
     S.sprofT = (long long)__builtin_amdgcn_s_memtime();
@@ -1265,7 +1349,7 @@ __global__ __launch_bounds__(64 * MAXCPW, WPE) void analyse_spec_kernel(const AP
     int cbx = 0, cby = 0, clp = 0;
     for (int lvl = P.nLevels - 1; lvl >= 0; lvl--) {
         if (coarse && P.global) S.estimate_global(coarse, cbx * cby, 8192 * P.lv[lvl + 1].pel, &gx, &gy);
-        S.search_level_spec(lvl, gx, gy, coarse, cbx, cby, clp, cpw > 1 ? syncEvery : 0, !(flags & MVX_FAST_NOSPEC), !(flags & MVX_FAST_NOSTRIP));
+        S.search_level_spec(lvl, gx, gy, coarse, cbx, cby, clp, (cpw > 1 && !TEAM) ? syncEvery : 0, !(flags & MVX_FAST_NOSPEC), !(flags & MVX_FAST_NOSTRIP));
         coarse = S.vectors; cbx = P.lv[lvl].nBlkX; cby = P.lv[lvl].nBlkY; clp = P.lv[lvl].logPel;
     }
     SPEC_PROF_DUMP_();
@@ -1293,7 +1377,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_debug_specstats(unsign
 
 // L.ldsRow = offset of the row buffer (8 bytes per block), L.ldsHist = offset of the histogram (lies over row buffer and table: it is
 // only used between levels), L.ldsBytes = offset of the table when L.ldsNeed carries the chain's total
-struct ASpecLaunch { ALaunch L; int ldsTab; };
+struct ASpecLaunch { ALaunch L; int ldsTab; int team; }; // team: 0 = one wave per chain, n = the workgroup's n waves walk one chain
 template <int BPS, int BW, int WPE, int MAXCPW, bool UV> static int launch_analyse_spec_uv(const ASpecLaunch &S) {
     const ALaunch &L = S.L;
     const int perChain = (L.ldsNeed + 255) & ~255;
@@ -1309,4 +1393,22 @@ template <int BPS, int BW, int WPE, int MAXCPW, bool UV> static int launch_analy
 template <int BPS, int BW, int WPE, int MAXCPW> static int launch_analyse_spec(const ASpecLaunch &S) {
     if (S.L.flags & MVX_FAST_UV) return launch_analyse_spec_uv<BPS, BW, WPE, MAXCPW, true>(S);
     return launch_analyse_spec_uv<BPS, BW, WPE, MAXCPW, false>(S);
+}
+// TEAM: S.team waves per chain, one chain per workgroup; S.L.ldsRow = the shared part (control words + row buffer), S.L.ldsNeed = one wave's own area,
+// S.ldsTab / S.L.ldsHist = offsets of the SAD table / the histogram inside a wave's area
+template <int BPS, int BW, int WPE, int MAXCPW, bool UV> static int launch_analyse_spec_team_uv(const ASpecLaunch &S) {
+    const ALaunch &L = S.L;
+    const int nw = S.team < MAXCPW ? S.team : MAXCPW;
+    const int perWave = (L.ldsNeed + 255) & ~255;
+    int lds = L.ldsRow + perWave * nw;
+    if (L.ldsBytes > lds && L.ldsBytes <= 160 * 1024) lds = L.ldsBytes;
+    if (lds > 64 * 1024)
+        HIP_CHECK(hipFuncSetAttribute((const void *)analyse_spec_kernel<BPS, BW, WPE, MAXCPW, UV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((analyse_spec_kernel<BPS, BW, WPE, MAXCPW, UV, true>), dim3(L.njobs), dim3(64 * nw), lds, L.st, L.dP, L.dJobs,
+                       L.njobs, perWave, 0, L.ldsRow, L.ldsHist, L.histBins, S.ldsTab, L.flags);
+    return MVX_OK;
+}
+template <int BPS, int BW, int WPE, int MAXCPW> static int launch_analyse_spec_team(const ASpecLaunch &S) {
+    if (S.L.flags & MVX_FAST_UV) return launch_analyse_spec_team_uv<BPS, BW, WPE, MAXCPW, true>(S);
+    return launch_analyse_spec_team_uv<BPS, BW, WPE, MAXCPW, false>(S);
 }

@@ -4,6 +4,12 @@
 #include "mvx_analyse_spec.h"
 int mvx_analyse_launch_spec_u16(const AParams &P, const ASpecLaunch &S) {
     const int k = S.L.fast;
+    if (S.team) { // the team form: 256-register builds, up to eight waves per chain
+        if (P.blkX == 16) return launch_analyse_spec_team<2, 16, 2, 8>(S);
+        if (P.blkX == 32) return launch_analyse_spec_team<2, 32, 2, 8>(S);
+        if (P.blkX == 8) return launch_analyse_spec_team<2, 8, 2, 8>(S);
+        return 1;
+    }
     if (P.blkX == 16) {
         if (k == 4) return launch_analyse_spec<2, 16, 4, 16>(S);
         if (k == 3) return launch_analyse_spec<2, 16, 3, 12>(S);

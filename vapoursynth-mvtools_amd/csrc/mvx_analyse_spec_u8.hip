@@ -3,6 +3,11 @@
 #include "mvx_analyse_spec.h"
 int mvx_analyse_launch_spec_u8(const AParams &P, const ASpecLaunch &S) {
     const int k = S.L.fast;
+    if (S.team) { // the team form: 256-register builds, up to eight waves per chain
+        if (P.blkX == 8) return launch_analyse_spec_team<1, 8, 2, 8>(S);
+        if (P.blkX == 16) return launch_analyse_spec_team<1, 16, 2, 8>(S);
+        return 1;
+    }
     if (P.blkX == 8) {
         if (k == 4) return launch_analyse_spec<1, 8, 4, 16>(S);
         if (k == 3) return launch_analyse_spec<1, 8, 3, 12>(S);

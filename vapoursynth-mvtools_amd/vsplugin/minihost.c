@@ -542,6 +542,7 @@ int main(int argc, char **argv) {
     for (int i = 0; i < nextra; i++) if (!strncmp(extra[i], "x.threads=", 10)) threads = atoi(extra[i] + 10);
     for (int i = 0; i < nextra; i++) if (!strncmp(extra[i], "x.cache=", 8)) g_cache_limit = atoi(extra[i] + 8);
     VSNode *clip = source_clip(inPath, w, hh, bits, nframes);
+    if (getenv("MVX_HOST_TIMES")) fprintf(stderr, "minihost: clip loaded at %.2f s after start\n", now_s() - g_start); /* (graph construction starts here) */
     FILE *fo = fopen(outPath, "wb");
     if (!fo) { fprintf(stderr, "cannot write %s\n", outPath); return 2; }
 
