@@ -485,6 +485,8 @@ def vs_shell_leg(frames=640, threads=32):
             r = subprocess.run([host, plugin, "run", "degrain3", src, str(w), str(h), str(bits), str(frames), outp, "a.blksize=16", "a.overlap=8",
                                 "x.threads=%d" % threads, "x.order=frame"], capture_output=True, text=True, env=env, timeout=600)
             d = {"process_wall_s": round(time.time() - t0, 2), "rc": r.returncode}
+            if os.environ.get("MVX_VS_KEEP_STDERR"):  # developer: the shell's statistics / window trace (MVX_VS_STATS=1, MVX_VS_TRACE=1) of this run
+                open(os.path.join(os.environ["MVX_VS_KEEP_STDERR"], "vs_shell_stderr_%s.txt" % ("lazy" if extra_env else "default")), "w").write(r.stderr)
             if r.returncode != 0 or "DONE" not in r.stdout:
                 d["error"] = (r.stderr or r.stdout)[-300:]
                 return d
@@ -549,7 +551,9 @@ def measure_traffic(args, B):
         cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
                "--no-cpu", "--no-parity", "--no-traffic", "--steps", "1", "--warmup", "0", "--config", args.config, "--batch", str(B), "--slots", str(args.slots)]
         try:
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+            pr = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
+            if pr.returncode != 0:
+                return None, "not measured: rocprofv3 --pmc %s pass exited with %d: %s" % (c, pr.returncode, pr.stderr.decode(errors="replace")[-400:].replace("\n", " | "))
             tot, n = 0.0, 0
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 with open(f) as fh:

@@ -70,7 +70,12 @@ def test_shell_reproduces_the_oracle_without_a_gpu(tmp_path, oracle, fakedev, bi
     assert stats["jobs"] >= n * 2 * radius  # every vector frame was searched (a window may be searched again after its slot was recycled)
     if la:
         windows = -(-n // la)
-        assert stats["launches"] >= windows * 2 * radius and stats["launches"] * (la // 2) <= stats["jobs"] + la * 2 * radius, stats
+        assert stats["launches"] >= windows * 2 * radius, stats
+        # launches are window-sized on average -- unless the "device" is so small that windows run out of memory: a window that does degrades to the
+        # per-frame path (one launch per handful of requests), and how many do depends on how the request threads interleave (r5: this bound was
+        # asserted for those configurations too and failed one run in four, with the output bit-identical)
+        if "MVX_FAKEDEV_MEM" not in env:
+            assert stats["launches"] * (la // 2) <= stats["jobs"] + la * 2 * radius, stats
 
 
 def test_vector_clip_through_the_shell_equals_the_oracle(tmp_path, oracle, fakedev):

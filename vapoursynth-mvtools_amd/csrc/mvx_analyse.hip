@@ -301,11 +301,12 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_blob_size(cons
 // not: four chains of a workgroup that share a reference frame and walk in step fetch each line once for all of them, a team's chains do not
 // (2 444 against 1 302 GB of line traffic per 2046-chain launch, L2 hit rate 43 against 62 %), and the token makes a team wave wait for its
 // predecessors' verification (40 % of a wave's time on a chain with many live blocks: profiles/r5_team_phase_cycles.txt).
-static int mvx_team_default(int njobs, int simds, bool strips) {
+// 8-bit 8x8 (cfg2, profiles/r5_team_cfg2_sweep.txt): 128 chains 118 / - / 50 / 46,   512: 120 / 77 / 63 / -,   1024: 121 / 94 / - / -,   2048: 164 (one wave).
+static int mvx_team_default(int njobs, int simds, bool strips, int bps) {
     if (!strips) return 0; // (measured for the shapes with row passes only)
     const long long slots = 2LL * simds; // waves the 256-register build keeps resident
     if (njobs * 4LL <= slots * 11 / 10) return 4;
-    if (njobs * 2LL <= slots * 9 / 10) return 2;
+    if (njobs * 2LL <= (bps == 1 ? slots : slots * 9 / 10)) return 2;
     return 0;
 }
 
@@ -373,13 +374,13 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         // one block at a time it loses to the serial lean kernel (cfg2 2 557 / 2 894, cfg4 17 180 / 18 764, cfg5 76 / 92 fps:
         // profiles/r4_configs_spec_vs_serial.txt), so everything else stays there unless "spec" asks for it (5: wherever it can run).
         const bool stripShape8 = P.bps == 1 && P.blkX == 8 && P.chroma && (P.ovX == 4 || P.ovX == 0) && P.shadow[1] != 0; // 8-bit 8x8 blocks overlapping by half or not at all, UV-interleaved plane present
-        const bool stripShape = (P.bps == 2 && P.blkX == 16 && P.chroma && P.ovX == P.blkX / 2 && P.shadow[1] != 0) || stripShape8; // (the row passes read the UV-interleaved plane: STRIP_OK)
+        const bool stripShape = (P.bps == 2 && (P.blkX == 16 || (MVX_STRIP32 && P.blkX == 32)) && P.chroma && P.ovX == P.blkX / 2 && P.shadow[1] != 0) || stripShape8; // (the row passes read the UV-interleaved plane: STRIP_OK)
         const bool useSpec = !useWin && g_dbg.spec != 0 && (stripShape || g_dbg.spec >= 2);
         const bool useSpecStrips = useSpec && g_dbg.spec != 3 && stripShape;
         int sTab = 0, sRow = fRow, sTabMax = 0; // (sTabMax: the largest SAD table of any level)
         if (useSpec) {
             const bool anyExh = P.searchType == SearchExhaustive || (P.nLevels > 1 && P.searchTypeCoarse == SearchExhaustive);
-            const int sStrip = (P.bps == 2 && P.blkX == 16) ? (P.blkX + P.blkX / 2) * 128 : 0; // the source strip of a window of blocks: 24 (48) rows x 8 columns (mvx_analyse_spec.h: STRIP_OK)
+            const int sStrip = (P.bps == 2 && (P.blkX == 16 || (MVX_STRIP32 && P.blkX == 32))) ? (P.blkX + P.blkX / 2) * 128 : 0; // the source strip of a window of blocks: 24 (48) rows x 8 columns (mvx_analyse_spec.h: STRIP_OK)
             const int sSrc = stripShape8 ? 16 + 768 : fRow < sStrip ? sStrip : fRow; // (8-bit 8x8: 16 bytes of slack + 12 rows x 64 bytes)
             sRow = sSrc;
             sTab = sSrc + ((fMaxBlkX * 8 + 15) & ~15);
@@ -458,7 +459,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
             // big batches the choice is measured.  LDS: [64 B control words | row buffer] shared + per wave [source strip | SAD table]
             int team = 0;
             if (useSpec) {
-                team = g_dbg.team >= 0 ? g_dbg.team : mvx_team_default(njobs, simds, useSpecStrips);
+                team = g_dbg.team >= 0 ? g_dbg.team : mvx_team_default(njobs, simds, useSpecStrips, P.bps);
                 if (team == 1 || team > 8) team = 0;
             }
             if (team) {

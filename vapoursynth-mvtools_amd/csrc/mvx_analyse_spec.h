@@ -56,8 +56,11 @@ static __device__ unsigned long long g_specprof[SPROF_N];
 #else
 #define SPEC_PROF_DUMP_() ((void)0)
 #endif
-#if MVX_SPEC_ABL == 9
-static __device__ int g_specdbg[4 * 64 * 12];
+#if MVX_SPEC_ABL == 9 // debug build: what the kernel knew about the 64 columns at (level, block row, first column) = g_specdbgAt (mvx_debug_specdbg_at)
+#define SPECDBG_N 24
+static __device__ int g_specdbg[64 * SPECDBG_N];
+static __device__ int g_specdbgAt[3];
+#define SPECDBG_HERE() (lvl == g_specdbgAt[0] && blky == g_specdbgAt[1] && c0 == g_specdbgAt[2])
 #endif
 #ifdef MVX_SPEC_STATS
 static __device__ unsigned long long g_specstat[MVX_MAX_LEVELS][4]; // per level: blocks in speculated rows, of them searched live, live because the flag was clear, rescues
@@ -218,7 +221,10 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
     // (the row-pass code below is written for 16x16 AND 32x32 blocks -- HC columns per half block -- but only 16x16 is enabled: at 32x32 it was no faster
     // than the serial kernel on cfg5 (90.1 against 92.3 fps: windows of three blocks share less, six staging pieces and 24 loads in flight do not fit the
     // registers) and one 8K bench clip disagreed with the oracle, which was not chased: profiles/r4_cfg5_rowpasses.txt)
-    static constexpr bool STRIP_OK = UV && BPS == 2 && BW == 16;
+#ifndef MVX_STRIP32
+#define MVX_STRIP32 0 // developer builds (-DMVX_STRIP32=1, mvx_analyse.hip AND mvx_analyse_spec_u16.hip): row passes for 32x32 blocks too
+#endif
+    static constexpr bool STRIP_OK = UV && BPS == 2 && (BW == 16 || (MVX_STRIP32 && BW == 32));
     // HC = 16-byte columns per half block (a 32x32 block row is four columns, blocks step by two); a window is eight columns: 7 (3) blocks;
     // block form: LPB lanes per block, LPC per candidate (four candidates: lanes 0..4 * LPC - 1; lanes 56-63 stay free for the zero vector's strip)
     static constexpr int HC = STRIP_OK ? BW / 16 : 1, SW_BLOCKS = 8 / HC - 1, LPB = 2 * HC, LPC = SW_BLOCKS * LPB;
@@ -394,7 +400,10 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
         {
             // (8-bit row passes: sixteen strip candidates of four lanes per pass, block candidates of fifteen lanes)
             const bool side8 = STRIP8_OK && stepX == BW; // (blocks side by side: eight block candidates of eight lanes per pass)
-            const int gb = side8 ? l >> 3 : STRIP8_OK ? (l >= 45 ? 3 : l >= 30 ? 2 : l >= 15 ? 1 : 0) : l >= 42 ? 3 : l >= 28 ? 2 : l >= 14 ? 1 : 0;
+            // (16-bit: LPC lanes per block-form candidate -- 14 for 16x16 blocks.  r4 had the 14 written out here, which made the block-form stage 2 of a 32x32 build
+            // (LPC = 12) mix two pattern points in the blocks of lanes 12-13, 24-27 and 36-41: the "8K clip that disagreed with the oracle" of r4 -- one block in
+            // 128 851, profiles/r5_strip32_mismatch_found.txt)
+            const int gb = side8 ? l >> 3 : STRIP8_OK ? (l >= 45 ? 3 : l >= 30 ? 2 : l >= 15 ? 1 : 0) : min(l / LPC, 3);
             for (int q = 0; q < 8; q++) {
                 int dx, dy;
                 if (q < 4) { pat_delta(hexLevel, STRIP8_OK ? q * 16 + (l >> 2) : q * 8 + (l >> 3), dx, dy); sPat |= (unsigned)((dx & 15) | ((dy & 15) << 4)) << (8 * q); }
@@ -744,8 +753,8 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
                                     a2_pred(pBest, pX_, pY_, pSad); // the predictor phase of every block of the group
                                     pkW = pk(pX_, pY_);
 #if MVX_SPEC_ABL == 9
-                                    if (lvl == 1 && act && J.fieldShift == 0 && blky >= 1) { // debug dump of the first chain's predictor phase
-                                        int *o = g_specdbg + ((blky - 1) * 64 + c) * 12;
+                                    if (SPECDBG_HERE() && act) { // the predictor phase of this lane's block
+                                        int *o = g_specdbg + l * SPECDBG_N;
                                         const int sUp = hexLevel ? 14 : 24, sZ = hexLevel ? 16 : 26;
                                         o[0] = pkU; o[1] = pkAh; o[2] = pkG; o[3] = pkH; o[4] = pkW; o[5] = pBest;
                                         o[6] = tot(rd(sUp)); o[7] = tot(rd(sUp + 1)); o[8] = tot(rd(sZ)); o[9] = tot(rd(sZ + 1)); o[10] = tot(rd(sZ + 2)); o[11] = lam;
@@ -1132,6 +1141,9 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
                             flagmask = __ballot(act && !live && !rowStart);
                             okmask = flagmask & __ballot(hyp);
                             if (MVX_SPEC_ABL == 3) okmask = flagmask = __ballot(act);
+#if MVX_SPEC_ABL == 9
+                            if (SPECDBG_HERE() && act) { int *o = g_specdbg + l * SPECDBG_N; o[12] = rX; o[13] = rY; o[14] = rSad; o[15] = (int)((flagmask >> l) & 1) | ((int)((okmask >> l) & 1) << 1) | (staged2 ? 4 : 0) | (live ? 8 : 0); o[16] = pk(prevX, prevY); o[17] = best; }
+#endif
                         }
                     }
 
@@ -1150,6 +1162,9 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
                             bOut[0] = mine ? (unsigned)rX : bOut[0]; bOut[1] = mine ? (unsigned)rY : bOut[1]; bOut[2] = mine ? (unsigned)rSad : bOut[2];
                             const int last = fwd ? a + run - 1 : a;
                             prevX = __builtin_amdgcn_readlane(rX, last); prevY = __builtin_amdgcn_readlane(rY, last); prevSad = __builtin_amdgcn_readlane(rSad, last);
+#if MVX_SPEC_ABL == 9
+                            if (SPECDBG_HERE() && mine) g_specdbg[l * SPECDBG_N + 18] = 1;
+#endif
                             pos += dir * run;
 #ifdef MVX_SPEC_STATS
                             st0 += run;
@@ -1193,6 +1208,9 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
                                     const bool mine = l == li;
                                     bOut[0] = mine ? (unsigned)rX : bOut[0]; bOut[1] = mine ? (unsigned)rY : bOut[1]; bOut[2] = mine ? (unsigned)rSad : bOut[2];
                                     prevX = __builtin_amdgcn_readlane(rX, li); prevY = __builtin_amdgcn_readlane(rY, li); prevSad = __builtin_amdgcn_readlane(rSad, li);
+#if MVX_SPEC_ABL == 9
+                                    if (SPECDBG_HERE() && l == 0) { int *o = g_specdbg + li * SPECDBG_N; o[18] = 2; o[19] = pk(Lx, Ly); o[20] = pk(Mx, My); o[21] = fL | (fM << 8); o[22] = best; o[23] = pk(wx, wy); }
+#endif
 #ifdef MVX_SPEC_STATS
                                     st0 += 1; st3 += 1;
 #endif
@@ -1247,6 +1265,9 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
                             __builtin_amdgcn_wave_barrier();
                             { const bool mine = l == li; bOut[0] = mine ? (unsigned)bestX : bOut[0]; bOut[1] = mine ? (unsigned)bestY : bOut[1]; bOut[2] = mine ? (unsigned)bestSad : bOut[2]; }
                             prevX = bestX; prevY = bestY; prevSad = bestSad;
+#if MVX_SPEC_ABL == 9
+                            if (SPECDBG_HERE() && l == 0) { int *o = g_specdbg + li * SPECDBG_N; o[18] = 3; o[19] = pk(pX[1], pY[1]); o[20] = pk(pX[0], pY[0]); o[22] = bestSad; o[23] = pk(bestX, bestY); }
+#endif
 #ifdef MVX_SPEC_STATS
                             if (specRow) { st0 += 1; st1 += 1; st2 += !((flagmask >> li) & 1); }
 #endif
@@ -1365,7 +1386,8 @@ extern "C" __attribute__((visibility("default"))) int mvx_debug_specprof(unsigne
 }
 #endif
 #if MVX_SPEC_ABL == 9 && defined(MVX_PROF_EXPORT)
-extern "C" __attribute__((visibility("default"))) int mvx_debug_specdbg(int *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_specdbg), sizeof(int) * 4 * 64 * 12) == hipSuccess ? 0 : -1; }
+extern "C" __attribute__((visibility("default"))) int mvx_debug_specdbg(int *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_specdbg), sizeof(int) * 64 * SPECDBG_N) == hipSuccess ? 0 : -1; }
+extern "C" __attribute__((visibility("default"))) int mvx_debug_specdbg_at(int lvl, int blky, int c0) { const int v[3] = { lvl, blky, c0 }; return hipMemcpyToSymbol(HIP_SYMBOL(g_specdbgAt), v, sizeof(v)) == hipSuccess ? 0 : -1; }
 #endif
 #if defined(MVX_SPEC_STATS) && defined(MVX_PROF_EXPORT)
 extern "C" __attribute__((visibility("default"))) int mvx_debug_specstats(unsigned long long *out, int reset) {
