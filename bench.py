@@ -411,7 +411,7 @@ def search_kernel_name(mv):
     import ctypes as C
     info = (C.c_int * 5)()
     mv.lib().mvx_debug_last_launch(info)
-    return "analyse_spec_kernel, %d chains per SIMD" % info[0] if info[4] == 2 else "analyse_spec_kernel (team form: %d waves per chain)" % info[1] if info[4] == 3 else "analyse_win_kernel" if info[4] == 1 else "analyse_fast_kernel, %d chains per SIMD" % info[0] if info[0] else "analyse_kernel"
+    return "analyse_spec_kernel, %d chains per SIMD" % info[0] if info[4] == 2 else "analyse_spec_kernel (team form: %d waves per chain)" % info[1] if info[4] == 3 else "analyse_fast_kernel, %d chains per SIMD" % info[0] if info[0] else "analyse_kernel"
 
 
 def other_configs():

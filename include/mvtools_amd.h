@@ -304,8 +304,9 @@ int mvx_vectors_size(const mvx_analysis_data *ad);
  * environment; a production host never needs this call. */
 int mvx_debug_option(const char *name, int value);
 /* the last search launch of this process: out[0] = chains per SIMD of the default-search kernel (0: the general kernel ran), out[1] = chains
- * per workgroup, out[2] = barrier interval in blocks, out[3] = job-table entries, out[4] = 1 when the LDS-window kernel of the default search
- * ran.  Tests use it to assert which build a batch took. */
+ * per workgroup (team form: waves per chain), out[2] = barrier interval in blocks, out[3] = job-table entries, out[4] = which default-search kernel:
+ * 0 the serial lean kernel (or the general one), 2 the speculative kernel with one wave per chain, 3 its team form (the waves of a workgroup walk one
+ * chain; the library's choice for launches that leave wave slots empty).  Tests use it to assert which build a batch took. */
 void mvx_debug_last_launch(int out[5]);
 
 /* ---- small device-memory helpers so that a C host (e.g. the VapourSynth shell) needs no HIP headers */

@@ -627,33 +627,6 @@ def _speculative_case(oracle, mv, dbg, mode, w, h, bits, skw, akw):
                 assert np.array_equal(gan.run([(gsf[1], gsf[ref])], field_shift=fs)[0].cpu().numpy(), oan.frame(osf[1], osf[ref], field_shift=fs))
 
 
-@pytest.mark.parametrize("w,h,skw,akw", WINDOW_CASES)
-def test_analyse_window_kernel(oracle, mv, dbg, w, h, skw, akw):
-    """The LDS-window kernel of the default search (mvx_analyse_win.h; opt-in, "win" = 1): candidates served from LDS windows that
-    LDS-DMA fills once per block.  Same blobs as the oracle -- forward, backward, with a field shift, with a missing reference."""
-    akw = dict(akw)
-    noise = akw.pop("_noise", 3)
-    dbg("win", 1)
-    frames = pl.moving_clip(w, h, 16, 3, seed=17, noise=noise, motion=(5, -2))
-    osup = oracle.Super(w, h, 16, **skw)
-    gsup = mv.Super(w, h, 16, **skw)
-    osf = [osup.frame(f) for f in frames]
-    gsf = gsup.build([mv.frame_to_device(f) for f in frames])
-    info = (C.c_int * 5)()
-    for isb in (1, 0):
-        oan = oracle.Analyse(osup, isb=isb, **akw)
-        gan = mv.Analyse(gsup, isb=isb, **akw)
-        ref = 2 if isb else 0
-        got = gan.run([(gsf[1], gsf[ref]), (gsf[1], None)])
-        mv.lib().mvx_debug_last_launch(info)
-        assert info[4] == 1, "the window kernel did not run (%s)" % list(info)
-        assert np.array_equal(got[0].cpu().numpy(), oan.frame(osf[1], osf[ref]))
-        assert np.array_equal(got[1].cpu().numpy(), oan.frame(osf[1], None))
-        if skw.get("pel", 2) == 2:
-            for fs in (1, -1):  # fields: the zero candidate's luma is shifted, its chroma is not (PlaneOfBlocks.cpp:836-839)
-                assert np.array_equal(gan.run([(gsf[1], gsf[ref])], field_shift=fs)[0].cpu().numpy(), oan.frame(osf[1], osf[ref], field_shift=fs))
-
-
 @pytest.mark.parametrize("bits,akw,per_simd", [(8, dict(blksize=8, overlap=4), 3), (8, dict(blksize=8, overlap=4), 4), (16, dict(blksize=16, overlap=8), 3),
                                                (16, dict(blksize=16, overlap=8), 4), (8, dict(blksize=16, overlap=8), 4), (16, dict(blksize=32, overlap=16), 3),
                                                (16, dict(blksize=8, overlap=4), 4)])

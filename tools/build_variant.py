@@ -3,7 +3,7 @@
 with MVX_LIB=tools/variants/<name>.so).  Only the named translation units are recompiled with the extra -D switches; the others are
 taken from the default build's objects.
 
-    python tools/build_variant.py <name> "<DEF1> <DEF2=..>" mvx_analyse_win.hip [more.hip ...]
+    python tools/build_variant.py <name> "<DEF1> <DEF2=..>" mvx_analyse_spec_u16.hip [more.hip ...]
 """
 import os
 import subprocess

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmvtools_amd.so")
-SOURCES = ["mvx_api.hip", "mvx_super.hip", "mvx_analyse.hip", "mvx_analyse_any.hip", "mvx_analyse_u8.hip", "mvx_analyse_u16.hip", "mvx_analyse_win.hip", "mvx_analyse_spec_u8.hip", "mvx_analyse_spec_u16.hip", "mvx_degrain.hip"]
+SOURCES = ["mvx_api.hip", "mvx_super.hip", "mvx_analyse.hip", "mvx_analyse_any.hip", "mvx_analyse_u8.hip", "mvx_analyse_u16.hip", "mvx_analyse_spec_u8.hip", "mvx_analyse_spec_u16.hip", "mvx_degrain.hip"]
 # -ffp-contract=off: the reference's double arithmetic (lambda scaling, predictor interpolation, degrain weights) must
 # not be fused into FMAs; no fast-math anywhere.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-inline-asm",

@@ -6,7 +6,6 @@
 #include <algorithm>
 #include "mvx_analyse_kernel.h"
 #include "mvx_analyse_fast.h"
-#include "mvx_analyse_win.h"
 #include "mvx_analyse_spec.h"
 int mvx_analyse_launch_spec_u8(const AParams &P, const ASpecLaunch &S);
 int mvx_analyse_launch_spec_u16(const AParams &P, const ASpecLaunch &S);
@@ -43,13 +42,12 @@ struct MvxDebug {
     int lds_min = -1;  // LDS floor of the one-chain launches
     int spec = 1;      // default search: 1 = the speculative kernel (mvx_analyse_spec.h), 0 = the lean serial kernel (mvx_analyse_fast.h), 2 = the speculative kernel's code with speculation off (every block live), 3 = speculative without runs (every block's candidates loaded on their own), 5 = speculative for every shape it can run (by default only where its row passes apply)
     int team = -1;     // waves per chain of the speculative kernel's team form (mvx_analyse_spec.h: TEAM): 0 = never, 2..8 = always that many, -1 = the library's choice
-    int win = 0;       // 1: the LDS-window kernel of the default search (mvx_analyse_win.h) where it applies: bit-exact, measured slower
     int super_rows_off = 0; // 1: mv.Super level 0 / first reduction through the LDS-tile / per-sample kernels only
     int ablate = 0;
 };
 static MvxDebug g_dbg;
 extern "C" __attribute__((visibility("default"))) int mvx_debug_option(const char *name, int value) {
-    struct { const char *n; int *p; } tab[] = { { "general", &g_dbg.general }, { "fast_wpe", &g_dbg.fast_wpe }, { "cpw1", &g_dbg.cpw1 }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "fast_cpw", &g_dbg.fast_cpw }, { "fast_k", &g_dbg.fast_k }, { "fast_lds_min", &g_dbg.fast_lds_min }, { "fast_flags", &g_dbg.fast_flags }, { "pad_runs", &g_dbg.pad_runs }, { "shadow_planes", &g_dbg.shadow_planes }, { "degrain_xcd", &g_dbg.degrain_xcd }, { "degrain_shadow", &g_dbg.degrain_shadow }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min }, { "super_rows_off", &g_dbg.super_rows_off }, { "win", &g_dbg.win }, { "spec", &g_dbg.spec }, { "team", &g_dbg.team },
+    struct { const char *n; int *p; } tab[] = { { "general", &g_dbg.general }, { "fast_wpe", &g_dbg.fast_wpe }, { "cpw1", &g_dbg.cpw1 }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "fast_cpw", &g_dbg.fast_cpw }, { "fast_k", &g_dbg.fast_k }, { "fast_lds_min", &g_dbg.fast_lds_min }, { "fast_flags", &g_dbg.fast_flags }, { "pad_runs", &g_dbg.pad_runs }, { "shadow_planes", &g_dbg.shadow_planes }, { "degrain_xcd", &g_dbg.degrain_xcd }, { "degrain_shadow", &g_dbg.degrain_shadow }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min }, { "super_rows_off", &g_dbg.super_rows_off }, { "spec", &g_dbg.spec }, { "team", &g_dbg.team },
 #ifdef MVX_LAB
         { "ablate", &g_dbg.ablate },
 #endif
@@ -366,8 +364,6 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         const int fBins = 1024;
         int fNeed = fRow + fMaxBlkX * 16;
         if (fNeed < fRow + fBins * 4) fNeed = fRow + fBins * 4;
-        // 16-bit 16x16 blocks: the LDS-window kernel (mvx_analyse_win.h) -- its own LDS layout, builds for one to three chains per SIMD
-        const bool useWin = g_dbg.win && mvx_win_eligible(P);
         // the speculative kernel (mvx_analyse_spec.h): [source block | previous row's results, 8 B per block | SAD table of a 32-block group];
         // the histogram lies over row buffer and table
         // The speculative kernel runs where its row passes apply (16-bit 16x16 blocks overlapping by half, with chroma: cfg3 612 against 555 fps);
@@ -375,7 +371,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         // profiles/r4_configs_spec_vs_serial.txt), so everything else stays there unless "spec" asks for it (5: wherever it can run).
         const bool stripShape8 = P.bps == 1 && P.blkX == 8 && P.chroma && (P.ovX == 4 || P.ovX == 0) && P.shadow[1] != 0; // 8-bit 8x8 blocks overlapping by half or not at all, UV-interleaved plane present
         const bool stripShape = (P.bps == 2 && (P.blkX == 16 || (MVX_STRIP32 && P.blkX == 32)) && P.chroma && P.ovX == P.blkX / 2 && P.shadow[1] != 0) || stripShape8; // (the row passes read the UV-interleaved plane: STRIP_OK)
-        const bool useSpec = !useWin && g_dbg.spec != 0 && (stripShape || g_dbg.spec >= 2);
+        const bool useSpec = g_dbg.spec != 0 && (stripShape || g_dbg.spec >= 2);
         const bool useSpecStrips = useSpec && g_dbg.spec != 3 && stripShape;
         int sTab = 0, sRow = fRow, sTabMax = 0; // (sTabMax: the largest SAD table of any level)
         if (useSpec) {
@@ -395,10 +391,9 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
             }
             if (fNeed < sRow + fBins * 4) fNeed = sRow + fBins * 4;
         }
-        const int perChain = useWin ? WG16::TOTAL : (fNeed + 255) & ~255;
+        const int perChain = (fNeed + 255) & ~255;
         // builds per (sample size, block size): chains per SIMD that exist (mvx_analyse_u8.hip / _u16.hip)
         auto have = [&](int k) {
-            if (useWin) return k >= 1 && k <= 3;
             if (P.bps == 2 && P.blkX == 8) return k == 1 || k == 2 || k == 4;
             if (P.bps == 2 && P.blkX == 32) return k >= 1 && k <= 3;
             return k >= 1 && k <= 4;
@@ -484,9 +479,9 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
                 }
             }
             if (useSpec) { const ASpecLaunch SL = { L, sTab, 0 }; rc = P.bps == 1 ? mvx_analyse_launch_spec_u8(P, SL) : mvx_analyse_launch_spec_u16(P, SL); }
-            else rc = useWin ? mvx_analyse_launch_win(P, L) : P.bps == 1 ? mvx_analyse_launch_fast_u8(P, L) : mvx_analyse_launch_fast_u16(P, L);
+            else rc = P.bps == 1 ? mvx_analyse_launch_fast_u8(P, L) : mvx_analyse_launch_fast_u16(P, L);
             if (rc == MVX_OK) {
-                g_lastLaunch[0] = k; g_lastLaunch[1] = cpw; g_lastLaunch[2] = syncEvery; g_lastLaunch[3] = ntab; g_lastLaunch[4] = useWin ? 1 : useSpec ? 2 : 0;
+                g_lastLaunch[0] = k; g_lastLaunch[1] = cpw; g_lastLaunch[2] = syncEvery; g_lastLaunch[3] = ntab; g_lastLaunch[4] = useSpec ? 2 : 0;
                 if (P.divide) hipLaunchKernelGGL(analyse_divide_kernel, dim3((P.lv[0].nBlkX * P.lv[0].nBlkY + 255) / 256, ntab), dim3(256), 0, st, a->dP, S.d);
                 HIP_CHECK(hipGetLastError());
                 return MVX_OK;

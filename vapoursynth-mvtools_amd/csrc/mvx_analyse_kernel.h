@@ -1887,4 +1887,3 @@ int mvx_analyse_launch_u8(const AParams &P, const ALaunch &L);
 int mvx_analyse_launch_u16(const AParams &P, const ALaunch &L);
 int mvx_analyse_launch_fast_u8(const AParams &P, const ALaunch &L);
 int mvx_analyse_launch_fast_u16(const AParams &P, const ALaunch &L);
-int mvx_analyse_launch_win(const AParams &P, const ALaunch &L);
