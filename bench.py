@@ -34,6 +34,8 @@ CONFIGS = {
     "cfg2": (1920, 1080, 8, 1, dict(blksize=8, overlap=4, search=4), dict(pel=2), 2048, "1080p YUV420P8 Degrain1 blksize=8 overlap=4 pel=2 search=4"),
     "cfg3": (3840, 2160, 16, 3, dict(blksize=16, overlap=8), dict(pel=2), 341, "4K YUV420P16 Degrain3 blksize=16 overlap=8 pel=2"),
     "cfg5": (7680, 4320, 16, 6, dict(blksize=32, overlap=16), dict(pel=2), 168, "8K YUV420P16 Degrain6 blksize=32 overlap=16 pel=2"),
+    # (not a BASELINE configuration: the common HD setting of the reference's users -- 8-bit, 16x16 blocks overlapping by half; r5, `other_configs`)
+    "hd16": (1920, 1080, 8, 1, dict(blksize=16, overlap=8), dict(pel=2), 2048, "1080p YUV420P8 Degrain1 blksize=16 overlap=8 pel=2"),
     # BASELINE config 4: frame-rate conversion instead of denoising (radius field = 0 selects PipelineFPS)
     "cfg4": (1920, 1080, 8, 0, dict(blksize=8), dict(pel=2), 2047, "1080p YUV420P8 Compensate + BlockFPS 24->60 blksize=8 pel=2"),
 }
@@ -137,6 +139,10 @@ class Pipeline:
         self.dg = mv.Degrain(tr, self.sup, a0.ad, [p.stride(0) for p in self.src[0]])
         self.out = mv.arena_frames(batch, [tuple(p.shape) for p in self.src[0]], device, zero=False)
         self.ev = []  # (start, end) events around the search launches
+        # several batches in flight (--slots): the search launches run ONE AFTER THE OTHER (a launch fills the GPU's wave slots: two at once only share
+        # them), while Super of the next batch and Degrain of the previous one run under the search of the current one on their own streams
+        self.search_after = None   # the pipeline slot whose last search this slot's next search waits for
+        self.search_done = None    # event: this slot's last search launch has finished
         _order_behind_caller(torch, self.stream, device)
 
     def step(self, time_search=False, src=None):
@@ -153,6 +159,8 @@ class Pipeline:
         for key, pairs in self.plan.searches().items():
             jobs += [(self.supers[n], self.supers[nref] if nref is not None else None) for n, nref in pairs]
             blobs += self.blobs[key]
+        if self.search_after is not None and self.search_after.search_done is not None:
+            torch.cuda.current_stream().wait_event(self.search_after.search_done)
         if time_search:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -160,6 +168,9 @@ class Pipeline:
         if time_search:
             e1.record()
             self.ev.append((e0, e1))
+        if self.search_after is not None:
+            self.search_done = torch.cuda.Event()
+            self.search_done.record()
         djobs = []
         for n, refs, i in self.plan.degrains():
             djobs.append((src[n], [self.supers[r] if r is not None else None for r in refs], [self.blobs[key][i] for key in self.plan.clips]))
@@ -419,7 +430,7 @@ def other_configs():
     own two-frame comparison against the oracle; the parent has released its device memory): {"cfg2": {...}, ...}.  Outside every timed region."""
     import subprocess
     res = {}
-    for c in ("cfg2", "cfg4", "cfg5"):
+    for c in ("cfg2", "cfg4", "cfg5", "hd16"):
         cmd = [sys.executable, os.path.abspath(__file__), "--config", c, "--steps", "2", "--warmup", "1", "--no-cpu", "--no-traffic", "--no-others"]
         try:
             p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=420)
@@ -650,8 +661,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0)
-    ap.add_argument("--slots", type=int, default=1, help="batches in flight: slot i owns its buffers and HIP stream, so the Super / "
-                    "Degrain kernels of one batch run under the (latency-bound) search kernel of the other")
+    ap.add_argument("--slots", type=int, default=0, help="batches in flight: slot i owns its buffers and HIP stream; the search launches are chained (one at a time), so "
+                    "the Super kernels of the next batch and the Degrain kernels of the previous one run under the (latency-bound) search of the current one.  "
+                    "Default: 2 for cfg3 (+5.7 %%, profiles/r5_batches_in_flight_chained_searches.txt; 2 x 107 GB of the 288 GB), 1 elsewhere (cfg2: no gain; cfg5: no room)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline (a two-frame parity check of the timed step still runs)")
     ap.add_argument("--no-parity", action="store_true", help="with --no-cpu: skip the oracle comparison of the timed step too")
     ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure the search launch's HBM traffic")
@@ -686,6 +698,8 @@ def main():
     device = torch.device("cuda", local_rank)
 
     cfg = CONFIGS[args.config]
+    if args.slots <= 0:
+        args.slots = 2 if args.config == "cfg3" else 1
     B = args.batch or cfg[6]
     tr = cfg[3]
     fpsconv = tr == 0  # cfg4: Compensate + BlockFPS instead of DegrainN
@@ -696,6 +710,9 @@ def main():
     # frame is a function of its global index, so neighbouring ranks hold identical copies of the frames they share (shard_check below)
     pipe = PipeT(mv, torch, cfg, B, device, seed=1000, plan=plan)
     pipes = [pipe] + [PipeT(mv, torch, cfg, B, device, seed=1000, src=pipe.src, plan=plan) for _ in range(max(1, args.slots) - 1)]
+    if len(pipes) > 1 and not fpsconv:
+        for i, pp in enumerate(pipes):
+            pp.search_after = pipes[i - 1]
     units = pipe.frames_per_step if fpsconv else B  # frames a step delivers
     torch.cuda.synchronize()
 

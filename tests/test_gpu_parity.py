@@ -576,15 +576,15 @@ def test_analyse_team_sizes(oracle, mv, dbg, nw, w, h, bits, skw, akw):
 @pytest.mark.parametrize("w,h,bits,skw,akw", [
     (384, 224, 16, {}, dict(blksize=16, overlap=8)),      # cfg3 shape: a launch of two chains leaves the GPU empty -> teams of four
     (384, 224, 8, {}, dict(blksize=8, overlap=4)),        # cfg2 shape
-    (512, 288, 16, {}, dict(blksize=32, overlap=16)),     # no row passes: the serial lean kernel, no team
+    (512, 288, 16, {}, dict(blksize=32, overlap=16)),     # no row passes: still teams (the speculative kernel one block at a time beats the serial walk of a lone chain)
+    (256, 144, 8, {}, dict(blksize=16, overlap=8)),       # the common HD shape, likewise
 ])
 def test_analyse_team_is_the_librarys_choice_for_small_launches(oracle, mv, dbg, w, h, bits, skw, akw):
     """With nothing forced, a launch that would leave wave slots empty at one wave per chain runs as teams (mvx_analyse.hip: mvx_team_default)."""
     _speculative_case(oracle, mv, dbg, "auto", w, h, bits, skw, akw)
     info = (C.c_int * 5)()
     mv.lib().mvx_debug_last_launch(info)
-    if (bits, akw["blksize"]) in ((16, 16), (8, 8)):
-        assert info[4] == 3 and info[1] == 4, list(info)
+    assert info[4] == 3 and info[1] == 4, list(info)
 
 
 def _speculative_case(oracle, mv, dbg, mode, w, h, bits, skw, akw):
@@ -619,7 +619,7 @@ def _speculative_case(oracle, mv, dbg, mode, w, h, bits, skw, akw):
         ref = 2 if isb else 0
         got = gan.run([(gsf[1], gsf[ref]), (gsf[1], None)])
         mv.lib().mvx_debug_last_launch(info)
-        assert info[4] == (3 if (mode.startswith("team") or (mode == "auto" and rows_apply)) else 2 if (mode not in ("default", "auto") or rows_apply) else 0), "not the kernel this case is meant to cover (%s)" % list(info)
+        assert info[4] == (3 if (mode.startswith("team") or mode == "auto") else 2 if (mode != "default" or rows_apply) else 0), "not the kernel this case is meant to cover (%s)" % list(info)
         assert np.array_equal(got[0].cpu().numpy(), oan.frame(osf[1], osf[ref]))
         assert np.array_equal(got[1].cpu().numpy(), oan.frame(osf[1], None))
         if skw.get("pel", 2) == 2:

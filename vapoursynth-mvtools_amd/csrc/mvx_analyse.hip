@@ -301,9 +301,9 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_blob_size(cons
 // predecessors' verification (40 % of a wave's time on a chain with many live blocks: profiles/r5_team_phase_cycles.txt).
 // 8-bit 8x8 (cfg2, profiles/r5_team_cfg2_sweep.txt): 128 chains 118 / - / 50 / 46,   512: 120 / 77 / 63 / -,   1024: 121 / 94 / - / -,   2048: 164 (one wave).
 static int mvx_team_default(int njobs, int simds, bool strips, int bps) {
-    if (!strips) return 0; // (measured for the shapes with row passes only)
     const long long slots = 2LL * simds; // waves the 256-register build keeps resident
     if (njobs * 4LL <= slots * 11 / 10) return 4;
+    if (!strips) return 0; // (shapes without row passes: teams of two do not beat the serial kernel)
     if (njobs * 2LL <= (bps == 1 ? slots : slots * 9 / 10)) return 2;
     return 0;
 }
@@ -371,7 +371,11 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         // profiles/r4_configs_spec_vs_serial.txt), so everything else stays there unless "spec" asks for it (5: wherever it can run).
         const bool stripShape8 = P.bps == 1 && P.blkX == 8 && P.chroma && (P.ovX == 4 || P.ovX == 0) && P.shadow[1] != 0; // 8-bit 8x8 blocks overlapping by half or not at all, UV-interleaved plane present
         const bool stripShape = (P.bps == 2 && (P.blkX == 16 || (MVX_STRIP32 && P.blkX == 32)) && P.chroma && P.ovX == P.blkX / 2 && P.shadow[1] != 0) || stripShape8; // (the row passes read the UV-interleaved plane: STRIP_OK)
-        const bool useSpec = g_dbg.spec != 0 && (stripShape || g_dbg.spec >= 2);
+        // ... except as TEAMS in a launch that leaves the GPU's wave slots empty (r5): there the speculative kernel wins for every shape it can run, row passes or
+        // not (132 chains of cfg5: 974 ms serial, 352 ms as teams of four; 128 chains of 8-bit 16x16 blocks: 140 / 43 ms; at ~512 chains it is a tie:
+        // profiles/r5_team_other_shapes.txt).  The library's own choice only: any forced "spec" / "team" value keeps its meaning.
+        const bool teamAnyShape = g_dbg.spec == 1 && g_dbg.team < 0 && mvx_team_default(njobs, simds, false, P.bps) > 0;
+        const bool useSpec = g_dbg.spec != 0 && (stripShape || g_dbg.spec >= 2 || teamAnyShape);
         const bool useSpecStrips = useSpec && g_dbg.spec != 3 && stripShape;
         int sTab = 0, sRow = fRow, sTabMax = 0; // (sTabMax: the largest SAD table of any level)
         if (useSpec) {
