@@ -559,7 +559,9 @@ def measure_traffic(args, B):
     vals = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="mvx_pmc_", dir="/tmp")
-        cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+        # (counters for the search kernels only: with every torch kernel of the clip generator instrumented too, rocprofv3 7.2 crashed -- SIGSEGV inside a torch
+        # multiply -- in two of two r5 runs; the bytes this function reports are the search launch's anyway)
+        cmd = [exe, "--pmc", c, "--kernel-trace", "--kernel-include-regex", "analyse_", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
                "--no-cpu", "--no-parity", "--no-traffic", "--steps", "1", "--warmup", "0", "--config", args.config, "--batch", str(B), "--slots", str(args.slots)]
         try:
             pr = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)

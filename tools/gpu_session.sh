@@ -14,7 +14,7 @@
 #         vs                       the VapourSynth shell on a 4K16 clip (tools/vs_4k_run.py)
 #         sh <file>                a one-off script
 export TMPDIR=/tmp
-TAG=${TAG:-r3}
+TAG=${TAG:-r5}
 out=$PWD/gpurun_out; mkdir -p $out
 root=$PWD
 line() { python -c "import sys,json
@@ -40,7 +40,7 @@ while [ $# -gt 0 ]; do
       f=$(find /tmp/kt -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $out/${TAG}_kernel_stats.csv && head -12 $out/${TAG}_kernel_stats.csv || tail -5 /tmp/kt.log ;;
     traffic)
       for c in FETCH_SIZE WRITE_SIZE; do
-        (cd /tmp && rm -rf /tmp/pmc_$c && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $root/bench.py --no-cpu --no-parity --no-traffic --steps 1 --warmup 0 $BENCH_ARGS > /tmp/pmc_$c.log 2>&1)
+        (cd /tmp && rm -rf /tmp/pmc_$c && timeout 600 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "${PMC_KERNELS:-analyse_|degrain|super_|compensate|blockfps|bf_|usable}" --output-format csv -d /tmp/pmc_$c -o p -- python $root/bench.py --no-cpu --no-parity --no-traffic --steps 1 --warmup 0 $BENCH_ARGS > /tmp/pmc_$c.log 2>&1)
       done
       python3 tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE "$BENCH_ARGS" > $out/${TAG}_pmc_traffic.json; head -c 1200 $out/${TAG}_pmc_traffic.json ;;
     sq)

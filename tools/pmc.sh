@@ -8,7 +8,7 @@ out=/root/repo/gpurun_out; mkdir -p $out; : > $out/pmc_summary.txt
 i=0
 for g in "${groups[@]}"; do
   d=/tmp/pmc_$i; rm -rf $d
-  (cd /root/repo && timeout 600 rocprofv3 --pmc $g --kernel-trace --output-format csv -d $d -o p -- "$@" > /tmp/pmc_$i.log 2>&1)
+  (cd /root/repo && timeout 600 rocprofv3 --pmc $g --kernel-trace --kernel-include-regex "${PMC_KERNELS:-analyse_|degrain|super_|compensate|blockfps|bf_|usable}" --output-format csv -d $d -o p -- "$@" > /tmp/pmc_$i.log 2>&1)
   python3 - $d "$g" >> $out/pmc_summary.txt <<'PY'
 import sys, csv, glob, collections
 d, g = sys.argv[1], sys.argv[2]
