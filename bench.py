@@ -176,6 +176,23 @@ class Pipeline:
             djobs.append((src[n], [self.supers[r] if r is not None else None for r in refs], [self.blobs[key][i] for key in self.plan.clips]))
         self.dg.run(djobs, out=self.out)
 
+    def search_alone(self):
+        """ONE search launch of this slot with nothing else on the GPU, by HIP events (after the timed region: with several batches in flight the launches of
+        the timed steps run with the neighbours' Super / Degrain kernels beside them and take longer): milliseconds"""
+        torch = self.torch
+        torch.cuda.synchronize()
+        with torch.cuda.stream(self.stream):
+            jobs, blobs = [], []
+            for key, pairs in self.plan.searches().items():
+                jobs += [(self.supers[n], self.supers[nref] if nref is not None else None) for n, nref in pairs]
+                blobs += self.blobs[key]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.an[(1, 1)].run(jobs, blobs=blobs)
+            e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+
     def level_grids(self):
         """[(nBlkX, nBlkY)] of every level of the search, finest first (GroupOfPlanes.c:25-56)"""
         ad = self.an[(1, 1)].ad
@@ -768,6 +785,11 @@ def main():
                          # the search is a serial chain per (frame, direction) -- its own yardstick is block steps per second
                          "blocks_per_chain": nblk, "chain_steps_per_s": chains * nblk / (avg_launch_ms * 1e-3)},
         }
+        if len(pipes) > 1 and not fpsconv:
+            # the launches of the timed steps ran beside the other slot's Super / Degrain kernels; the same launch with the GPU to itself (same clip, same result):
+            alone_ms = pipes[(args.steps - 1) % len(pipes)].search_alone()
+            out["roofline"]["launch_alone"] = {"avg_launch_ms": alone_ms, "achieved": bytes_chain * chains / (alone_ms * 1e-3) / 1e9, "frac": bytes_chain * chains / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                               "note": "one search launch after the timed region, nothing else on the GPU; `frac` above is the timed region's (launches overlapped by the neighbouring batches' Super / Degrain kernels)"}
         if args.ingest and world == 1 and not fpsconv:
             sps, up_b, down_b = ingest_run(torch, pipe, max(2, min(args.steps, 4)), 1)
             out["ingest_inclusive"] = {"value": units / sps, "unit": "fps", "ms_per_step": sps * 1e3, "h2d_bytes_per_step": up_b, "d2h_bytes_per_step": down_b,

@@ -558,6 +558,18 @@ def test_analyse_speculative_kernel_8bit(oracle, mv, dbg, mode, w, h, skw, akw):
     _speculative_case(oracle, mv, dbg, mode, w, h, 8, skw, akw)
 
 
+@pytest.mark.parametrize("w,h,skw,akw", WINDOW_CASES + [
+    (1000, 96, {}, dict(blksize=16, overlap=8, meander=0)),
+    (640, 360, {}, dict(blksize=16, overlap=8, _noise=0)),
+    (520, 96, dict(hpad=4, vpad=4), dict(blksize=16, overlap=8, pglobal=20)),     # tiny padding: candidates reach the very end of a row (8-byte loads, no over-read)
+    (1920, 64, {}, dict(blksize=16, overlap=8)),                                  # a 1080p row of blocks: 239 per row
+])
+@pytest.mark.parametrize("mode", ["default", "everywhere", "team"])
+def test_analyse_speculative_kernel_8bit_16x16(oracle, mv, dbg, mode, w, h, skw, akw):
+    """r5: 8-bit clips, 16x16 blocks overlapping by 8 (the common HD setting) through the row passes of the 16-bit form with 8-byte columns."""
+    _speculative_case(oracle, mv, dbg, mode, w, h, 8, skw, akw)
+
+
 @pytest.mark.parametrize("nw", [2, 3, 5, 8])
 @pytest.mark.parametrize("w,h,bits,skw,akw", [
     (1000, 96, 16, {}, dict(blksize=16, overlap=8)),                              # four groups per row, meander: the turn-around waits for the token
@@ -606,7 +618,7 @@ def _speculative_case(oracle, mv, dbg, mode, w, h, bits, skw, akw):
     elif mode != "auto":         # one wave per chain (the library itself picks the team form for launches this small: "auto")
         dbg("team", 0)
     blk, ov = akw.get("blksize", 8), akw.get("overlap", 0)  # row passes: 16-bit 16x16 overlapping by half; 8-bit 8x8 overlapping by half or not at all
-    rows_apply = akw.get("chroma", 1) != 0 and ((bits, blk, ov) == (16, 16, 8) or ((bits, blk) == (8, 8) and ov in (4, 0)))
+    rows_apply = akw.get("chroma", 1) != 0 and ((bits, blk, ov) in ((16, 16, 8), (8, 16, 8)) or ((bits, blk) == (8, 8) and ov in (4, 0)))
     frames = pl.moving_clip(w, h, bits, 3, seed=17, noise=noise, motion=(5, -2))
     osup = oracle.Super(w, h, bits, **skw)
     gsup = mv.Super(w, h, bits, **skw)

@@ -370,7 +370,8 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         // one block at a time it loses to the serial lean kernel (cfg2 2 557 / 2 894, cfg4 17 180 / 18 764, cfg5 76 / 92 fps:
         // profiles/r4_configs_spec_vs_serial.txt), so everything else stays there unless "spec" asks for it (5: wherever it can run).
         const bool stripShape8 = P.bps == 1 && P.blkX == 8 && P.chroma && (P.ovX == 4 || P.ovX == 0) && P.shadow[1] != 0; // 8-bit 8x8 blocks overlapping by half or not at all, UV-interleaved plane present
-        const bool stripShape = (P.bps == 2 && (P.blkX == 16 || (MVX_STRIP32 && P.blkX == 32)) && P.chroma && P.ovX == P.blkX / 2 && P.shadow[1] != 0) || stripShape8; // (the row passes read the UV-interleaved plane: STRIP_OK)
+        const bool stripShape16 = P.bps == 1 && P.blkX == 16 && P.chroma && P.ovX == 8 && P.shadow[1] != 0; // r5: 8-bit 16x16 blocks overlapping by half (the 16-bit form with 8-byte columns)
+        const bool stripShape = (P.bps == 2 && (P.blkX == 16 || (MVX_STRIP32 && P.blkX == 32)) && P.chroma && P.ovX == P.blkX / 2 && P.shadow[1] != 0) || stripShape8 || stripShape16; // (the row passes read the UV-interleaved plane: STRIP_OK)
         // ... except as TEAMS in a launch that leaves the GPU's wave slots empty (r5): there the speculative kernel wins for every shape it can run, row passes or
         // not (132 chains of cfg5: 974 ms serial, 352 ms as teams of four; 128 chains of 8-bit 16x16 blocks: 140 / 43 ms; at ~512 chains it is a tie:
         // profiles/r5_team_other_shapes.txt).  The library's own choice only: any forced "spec" / "team" value keeps its meaning.
@@ -380,7 +381,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         int sTab = 0, sRow = fRow, sTabMax = 0; // (sTabMax: the largest SAD table of any level)
         if (useSpec) {
             const bool anyExh = P.searchType == SearchExhaustive || (P.nLevels > 1 && P.searchTypeCoarse == SearchExhaustive);
-            const int sStrip = (P.bps == 2 && (P.blkX == 16 || (MVX_STRIP32 && P.blkX == 32))) ? (P.blkX + P.blkX / 2) * 128 : 0; // the source strip of a window of blocks: 24 (48) rows x 8 columns (mvx_analyse_spec.h: STRIP_OK)
+            const int sStrip = (P.bps == 2 && (P.blkX == 16 || (MVX_STRIP32 && P.blkX == 32))) ? (P.blkX + P.blkX / 2) * 128 : (P.bps == 1 && P.blkX == 16) ? 24 * 64 : 0; // the source strip of a window of blocks: 24 (48) rows x 8 columns (mvx_analyse_spec.h: STRIP_OK)
             const int sSrc = stripShape8 ? 16 + 768 : fRow < sStrip ? sStrip : fRow; // (8-bit 8x8: 16 bytes of slack + 12 rows x 64 bytes)
             sRow = sSrc;
             sTab = sSrc + ((fMaxBlkX * 8 + 15) & ~15);
@@ -446,7 +447,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
             // 8: 388, 4: 383; 8K16 at two per SIMD: 256: 59.5, 16: 64.6.  8-bit clips (plain layout): 256 stays best (1080p: 2005 against
             // 1953-1970 with 16-64).
             int syncEvery = k >= 2 ? (P.bps == 2 ? 32 : 256) : 0;
-            if (useSpecStrips) syncEvery = stripShape8 ? 0 : 128; // (8-bit, 4096 chains: none 330 ms, every 512 blocks 337, 256: 344, 128: 366 -- profiles/r4_rows8_configs2.txt)
+            if (useSpecStrips) syncEvery = (stripShape8 || stripShape16) ? 0 : 128; // (8-bit 16x16, 4096 chains: none 144 ms, every 128 blocks 147: profiles/r5_hd16_bench.txt) // (8-bit, 4096 chains: none 330 ms, every 512 blocks 337, 256: 344, 128: 366 -- profiles/r4_rows8_configs2.txt)
             if (g_dbg.cpw_sync >= 0 && (g_dbg.cpw_sync & (g_dbg.cpw_sync - 1)) == 0) syncEvery = g_dbg.cpw_sync;
             // XCD-contiguous workgroup order: neighbours in the (reference-sorted) job table share an L2 (+0.5 %, 4K16)
             const int flags = (g_dbg.fast_flags >= 0 ? g_dbg.fast_flags : MVX_FAST_XCD_REMAP) | ((P.shadow[1] != 0 && P.chroma) ? MVX_FAST_UV : 0) | (g_dbg.spec == 2 ? MVX_FAST_NOSPEC : 0) | (g_dbg.spec == 3 ? MVX_FAST_NOSTRIP : 0);

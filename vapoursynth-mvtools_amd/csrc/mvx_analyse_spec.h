@@ -224,16 +224,19 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
 #ifndef MVX_STRIP32
 #define MVX_STRIP32 0 // developer builds (-DMVX_STRIP32=1, mvx_analyse.hip AND mvx_analyse_spec_u16.hip): row passes for 32x32 blocks too
 #endif
-    static constexpr bool STRIP_OK = UV && BPS == 2 && (BW == 16 || (MVX_STRIP32 && BW == 32));
+    // (r5: 8-bit 16x16 blocks overlapping by 8 -- the common HD setting -- take the same code with 8-byte columns: a half block is 8 samples = COLB bytes, a window row
+    // 8 * COLB = 64 bytes; loads are 8 bytes per lane, at any byte address -- 8-bit super frames have no shifted copies)
+    static constexpr bool STRIP_OK = UV && ((BPS == 2 && (BW == 16 || (MVX_STRIP32 && BW == 32))) || (BPS == 1 && BW == 16));
+    static constexpr int COLB = BPS == 2 ? 16 : 8, ROWB = 8 * COLB; // bytes of a strip column / of a strip row (eight columns)
     // HC = 16-byte columns per half block (a 32x32 block row is four columns, blocks step by two); a window is eight columns: 7 (3) blocks;
     // block form: LPB lanes per block, LPC per candidate (four candidates: lanes 0..4 * LPC - 1; lanes 56-63 stay free for the zero vector's strip)
     static constexpr int HC = STRIP_OK ? BW / 16 : 1, SW_BLOCKS = 8 / HC - 1, LPB = 2 * HC, LPC = SW_BLOCKS * LPB;
-    static constexpr int SNA = BW, SNB = BW / 2, SNT = SNA + SNB, SW = (BW == 32 && SWIN > 12) ? 12 : SWIN, S_UV = SNA * 128, SSTG = SNT / 8; // (32x32: 12 in flight -- 24 plus the six staging pieces spill) // rows of a pass, loads in flight, LDS offset of the UV rows, staging pieces per lane
+    static constexpr int SNA = BW, SNB = BW / 2, SNT = SNA + SNB, SW = (BW == 32 && SWIN > 12) ? 12 : SWIN, S_UV = SNA * ROWB, SSTG = SNT / 8; // (32x32: 12 in flight -- 24 plus the six staging pieces spill) // rows of a pass, loads in flight, LDS offset of the UV rows, staging pieces per lane
     struct StripPass { v4u r[SW]; unsigned curA, curB, aL, aC; };
     __device__ __forceinline__ v4u strip_issue(StripPass &T, int piece) const {
         v4u v;
-        if (piece < SNA) { v = F::template ld_ref<16>(refY + T.curA); T.curA += pitchY; asm volatile("" : "+v"(T.curA) : : "memory"); }
-        else { v = F::template ld_ref<16>(refUV + T.curB); T.curB += 2 * pitchC; asm volatile("" : "+v"(T.curB) : : "memory"); }
+        if (piece < SNA) { v = F::template ld_ref<COLB>(refY + T.curA); T.curA += pitchY; asm volatile("" : "+v"(T.curA) : : "memory"); }
+        else { v = F::template ld_ref<COLB>(refUV + T.curB); T.curB += 2 * pitchC; asm volatile("" : "+v"(T.curB) : : "memory"); }
         return v;
     }
     __device__ __forceinline__ void strip_prime(StripPass &T, unsigned oA, unsigned oB) const {
@@ -242,8 +245,8 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
         for (int k = 0; k < SW; k++) T.r[k] = strip_issue(T, k);
     }
     template <bool REFILL> __device__ __forceinline__ void strip_run(StripPass &T, int p, unsigned nA, unsigned nB) const {
-        const lds_u8 *sp = lds + p * 16;
-        auto src_piece = [&](int k) { return F::template lds_piece<16>(sp + (k < SNA ? k * 128 : S_UV + (k - SNA) * 128)); };
+        const lds_u8 *sp = lds + p * COLB;
+        auto src_piece = [&](int k) { return F::template lds_piece<COLB>(sp + (k < SNA ? k * ROWB : S_UV + (k - SNA) * ROWB)); };
         constexpr int D = MVX_SRC_AHEAD;
         v4u a[D];
 #pragma unroll
@@ -254,8 +257,8 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
             const v4u cur = a[k % D];
             if (MVX_SPEC_ABL != 4 && k + D < SNT) a[k % D] = src_piece(k + D);
             if (MVX_SPEC_ABL != 6) {
-                if (k < SNA) aL = F::template sad_regs<16>(cur, T.r[k % SW], aL);
-                else aC = F::template sad_regs<16>(cur, T.r[k % SW], aC);
+                if (k < SNA) aL = F::template sad_regs<COLB>(cur, T.r[k % SW], aL);
+                else aC = F::template sad_regs<COLB>(cur, T.r[k % SW], aC);
             } else { aL += cur[0] + T.r[k % SW][0]; }
             asm volatile("" : "+v"(aL), "+v"(aC) : : "memory");
             const int kk = k + SW;
@@ -657,7 +660,7 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
                                                 vx = upx(sW) + dx; vy = upy(sW) + dy; vyc = vy;
                                                 slot = idx < npat ? idx : -1;
                                             }
-                                            const int pe = min(p, HC * (L + 1) - 1) * 16; // (columns beyond the run re-read its last one)
+                                            const int pe = min(p, HC * (L + 1) - 1) * COLB; // (columns beyond the run re-read its last one)
                                             if ((p % HC != 0) | (p / HC >= L)) slot = -1;  // (block m is written by the lane of its first column)
                                             colW = f + p / HC; stripLane = true; srcCol = p;
                                             oA = luma_off_at(bxf, vx, vy) + (unsigned)pe;
@@ -682,24 +685,24 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
                                             const int vx = ok ? tx : cxv, vy = ok ? ty : cyv;
                                             if ((hB != 0) | (mB >= L) | idleB) slot = -1;
                                             colW = f + me; stripLane = false; srcCol = HC * me + hB;
-                                            oA = luma_off_at(bx0, vx, vy) + (unsigned)(hB * 16);
-                                            oB = 2 * chroma_off_at(bx0, vx, vy) + (unsigned)(hB * 16);
+                                            oA = luma_off_at(bx0, vx, vy) + (unsigned)(hB * COLB);
+                                            oB = 2 * chroma_off_at(bx0, vx, vy) + (unsigned)(hB * COLB);
                                         }
                                     };
                                     // the source strip of window w: lane = (row l >> 3 of 8, column l & 7); luma rows r and r + 8, UV row r
                                     A4x32 stg[SSTG]; // (rows gS, gS + 8, ...: the luma rows first, then the rows of the UV plane)
                                     auto stage_issue = [&](int w) {
-                                        const int f = lo + SW_BLOCKS * w, L = min(SW_BLOCKS, hiE - f), bx0 = hpad + stepX * (c0 + f), pe = min(pS, HC * (L + 1) - 1) * 16;
+                                        const int f = lo + SW_BLOCKS * w, L = min(SW_BLOCKS, hiE - f), bx0 = hpad + stepX * (c0 + f), pe = min(pS, HC * (L + 1) - 1) * COLB;
 #pragma unroll
                                         for (int k = 0; k < SSTG; k++) {
                                             const int row = gS + 8 * k;
-                                            if (8 * k < SNA) stg[k] = ld_chunk_g(srcY + (unsigned)(y0 + row) * pitchY + (unsigned)bx0 * BPS + (unsigned)pe, 16);
-                                            else stg[k] = ld_chunk_g(srcUV + (unsigned)((y0 >> 1) + row - SNA) * 2 * pitchC + (unsigned)(bx0 >> 1) * 2 * BPS + (unsigned)pe, 16);
+                                            if (8 * k < SNA) stg[k] = ld_chunk_g(srcY + (unsigned)(y0 + row) * pitchY + (unsigned)bx0 * BPS + (unsigned)pe, COLB);
+                                            else stg[k] = ld_chunk_g(srcUV + (unsigned)((y0 >> 1) + row - SNA) * 2 * pitchC + (unsigned)(bx0 >> 1) * 2 * BPS + (unsigned)pe, COLB);
                                         }
                                     };
                                     auto stage_store = [&]() {
 #pragma unroll
-                                        for (int k = 0; k < SSTG; k++) st_chunk_l(lds + (gS + 8 * k) * 128 + pS * 16, stg[k], 16); // (S_UV = SNA * 128: the UV rows follow the luma rows)
+                                        for (int k = 0; k < SSTG; k++) st_chunk_l(lds + (gS + 8 * k) * ROWB + pS * COLB, stg[k], COLB); // (S_UV = SNA * ROWB: the UV rows follow the luma rows)
                                     };
                                     // (a leading-edge prefetch -- one dword of every line a window two ahead will need, four scattered loads per window --
                                     // was measured and removed: 493 -> 544 ms per 2046-chain launch, profiles/r4_spec_prefetch.txt)
