@@ -226,6 +226,18 @@ PY
     grep "trace" $out/vs_team/vs_shell_stderr_default.txt | head -70
 }
 
+r5_side16() {
+    # 16x16 blocks side by side (overlap 0) through the row passes: parity, the bench line against the serial kernel, and cfg3 must not have moved
+    timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "speculative or analyse_parity or golden or team" 2>&1 | tail -8 | tee $out/r5_side16_tests.txt
+    if grep -q "failed\|error" $out/r5_side16_tests.txt; then echo "not green: no timing"; return 1; fi
+    {
+    timeout 400 python bench.py --config hd16s --no-cpu --no-traffic --no-others --steps 2 --warmup 1 2>&1 | tail -1 | line "hd16s (1080p8 16x16 overlap 0) row passes"
+    MVX_SPEC=0 timeout 400 python bench.py --config hd16s --no-cpu --no-traffic --no-others --steps 2 --warmup 1 2>&1 | tail -1 | line "hd16s serial lean kernel"
+    timeout 400 python bench.py --no-cpu --no-traffic --no-others --steps 3 --warmup 1 --slots 1 2>&1 | tail -1 | line "cfg3 one batch in flight (must not have moved: 345 ms)"
+    timeout 400 python bench.py --config hd16 --no-cpu --no-traffic --no-others --steps 2 --warmup 1 2>&1 | tail -1 | line "hd16 (must not have moved: 144 ms)"
+    } 2>&1 | tee $out/r5_side16_bench.txt
+}
+
 s=$1; shift
 case "$s" in
   col) r5_col "$@" ;;
@@ -242,5 +254,6 @@ case "$s" in
   team_shapes) r5_team_shapes "$@" ;;
   uni) r5_uni "$@" ;;
   vs_trace) r5_vs_trace "$@" ;;
+  side16) r5_side16 "$@" ;;
   *) echo "unknown session: $s"; exit 2 ;;
 esac

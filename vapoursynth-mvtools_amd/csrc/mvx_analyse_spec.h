@@ -406,7 +406,8 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
             // (16-bit: LPC lanes per block-form candidate -- 14 for 16x16 blocks.  r4 had the 14 written out here, which made the block-form stage 2 of a 32x32 build
             // (LPC = 12) mix two pattern points in the blocks of lanes 12-13, 24-27 and 36-41: the "8K clip that disagreed with the oracle" of r4 -- one block in
             // 128 851, profiles/r5_strip32_mismatch_found.txt)
-            const int gb = side8 ? l >> 3 : STRIP8_OK ? (l >= 45 ? 3 : l >= 30 ? 2 : l >= 15 ? 1 : 0) : min(l / LPC, 3);
+            const bool side16 = STRIP_OK && HC == 1 && stepX == BW; // (16x16 blocks side by side: four blocks per window, eight lanes per block-form candidate)
+            const int gb = side8 ? l >> 3 : STRIP8_OK ? (l >= 45 ? 3 : l >= 30 ? 2 : l >= 15 ? 1 : 0) : side16 ? min(l >> 3, 3) : min(l / LPC, 3);
             for (int q = 0; q < 8; q++) {
                 int dx, dy;
                 if (q < 4) { pat_delta(hexLevel, STRIP8_OK ? q * 16 + (l >> 2) : q * 8 + (l >> 3), dx, dy); sPat |= (unsigned)((dx & 15) | ((dy & 15) << 4)) << (8 * q); }
@@ -612,8 +613,12 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
                             // (the first form evaluated the pattern around UP and gave every block whose predictor phase ended elsewhere to the live
                             // search: one block in eight one level up from the finest, most blocks of the chains with an odd frame distance there)
                             if constexpr (STRIP_OK) {
-                                if (stripEnabled && stepX == BW / 2) {
-                                    const int nw = (nb + SW_BLOCKS - 1) / SW_BLOCKS;
+                                // (r5: 16x16 blocks SIDE BY SIDE -- overlap 0, the reference's default -- take the same passes: a block is two columns and steps by TC = two,
+                                // a window holds four; no column sum is shared, the strips stay contiguous)
+                                const bool side = HC == 1 && stepX == BW;
+                                if (stripEnabled && (stepX == BW / 2 || side)) {
+                                    const int TC = side ? 2 : HC, SWB = side ? 4 : SW_BLOCKS, LPCr = SWB * LPB; // columns per block step, blocks per window, lanes per block-form candidate
+                                    const int nw = (nb + SWB - 1) / SWB;
                                     const int npat = hexLevel ? 14 : 24;
                                     pbMask = 0;
                                     staged2 = true;
@@ -630,15 +635,15 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
                                         lq = l;
                                         asm volatile("" : "+v"(lq));
                                         gS = lq >> 3; pS = lq & 7;
-                                        gB = min(lq / LPC, 3);
-                                        rB = lq >= 4 * LPC ? (lq - 4 * LPC) % LPC : lq - LPC * gB; mB = rB / LPB; hB = rB % LPB;
-                                        tail = lq >= 56; idleB = lq >= 4 * LPC;
+                                        gB = side ? min(lq >> 3, 3) : min(lq / LPC, 3);
+                                        rB = side ? (lq & 7) : lq >= 4 * LPC ? (lq - 4 * LPC) % LPC : lq - LPC * gB; mB = rB / LPB; hB = rB % LPB;
+                                        tail = lq >= 56; idleB = lq >= 4 * LPCr;
                                     };
                                     roles();
                                     // this lane's share of pass q of window w in stage st: table slot (-1: nothing to write), the column it writes, whether its
                                     // block sum is "column + next column" (strip) or "half + other half" (block), source column, first reference piece
                                     auto w_cand = [&](int st, int w, int q, int &slot, int &colW, bool &stripLane, int &srcCol, unsigned &oA, unsigned &oB) {
-                                        const int f = lo + SW_BLOCKS * w, L = min(SW_BLOCKS, hiE - f);
+                                        const int f = lo + SWB * w, L = min(SWB, hiE - f);
                                         const int bxf = hpad + stepX * (c0 + f);
                                         const bool stripWin = st == 2 && ((stripW >> w) & 1);
                                         // the block lanes' vectors come from the lanes that own the blocks: fetched HERE, with every lane active (ds_bpermute returns 0
@@ -660,9 +665,9 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
                                                 vx = upx(sW) + dx; vy = upy(sW) + dy; vyc = vy;
                                                 slot = idx < npat ? idx : -1;
                                             }
-                                            const int pe = min(p, HC * (L + 1) - 1) * COLB; // (columns beyond the run re-read its last one)
-                                            if ((p % HC != 0) | (p / HC >= L)) slot = -1;  // (block m is written by the lane of its first column)
-                                            colW = f + p / HC; stripLane = true; srcCol = p;
+                                            const int pe = min(p, TC * (L - 1) + 2 * HC - 1) * COLB; // (columns beyond the run re-read its last one)
+                                            if ((p % TC != 0) | (p / TC >= L)) slot = -1;  // (block m is written by the lane of its first column)
+                                            colW = f + p / TC; stripLane = true; srcCol = p;
                                             oA = luma_off_at(bxf, vx, vy) + (unsigned)pe;
                                             oB = 2 * chroma_off_at(bxf, vx, vyc) + (unsigned)pe;
                                         } else { // block lanes: every block its own vector
@@ -684,7 +689,7 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
                                             const bool ok = (tx >= xMin) & (ty >= nDyMin) & (tx < xMax) & (ty < nDyMax); // (outside the block's limits: the centre instead; A2 never reads the entry)
                                             const int vx = ok ? tx : cxv, vy = ok ? ty : cyv;
                                             if ((hB != 0) | (mB >= L) | idleB) slot = -1;
-                                            colW = f + me; stripLane = false; srcCol = HC * me + hB;
+                                            colW = f + me; stripLane = false; srcCol = TC * me + hB;
                                             oA = luma_off_at(bx0, vx, vy) + (unsigned)(hB * COLB);
                                             oB = 2 * chroma_off_at(bx0, vx, vy) + (unsigned)(hB * COLB);
                                         }
@@ -692,7 +697,7 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
                                     // the source strip of window w: lane = (row l >> 3 of 8, column l & 7); luma rows r and r + 8, UV row r
                                     A4x32 stg[SSTG]; // (rows gS, gS + 8, ...: the luma rows first, then the rows of the UV plane)
                                     auto stage_issue = [&](int w) {
-                                        const int f = lo + SW_BLOCKS * w, L = min(SW_BLOCKS, hiE - f), bx0 = hpad + stepX * (c0 + f), pe = min(pS, HC * (L + 1) - 1) * COLB;
+                                        const int f = lo + SWB * w, L = min(SWB, hiE - f), bx0 = hpad + stepX * (c0 + f), pe = min(pS, TC * (L - 1) + 2 * HC - 1) * COLB;
 #pragma unroll
                                         for (int k = 0; k < SSTG; k++) {
                                             const int row = gS + 8 * k;
@@ -766,7 +771,7 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
                                     { // windows whose blocks share the centre and keep the whole pattern inside their limits
                                         const bool ok2 = (pX_ - 2 >= dxMin) & (pX_ + 2 <= dxMax1) & (pY_ - 2 >= nDyMin) & (pY_ + 2 < nDyMax);
                                         for (int w = 0; w < nw; w++) {
-                                            const int f = lo + SW_BLOCKS * w, e = min(f + SW_BLOCKS, hiE);
+                                            const int f = lo + SWB * w, e = min(f + SWB, hiE);
                                             const bool inw = (l >= f) & (l < e);
                                             const int w0 = __builtin_amdgcn_readlane(pkW, f);
                                             if (MVX_SPEC_ABL != 7 && e - f >= 2 && __ballot(inw & ((pkW != w0) | !ok2)) == 0) stripW |= 1u << w; // (ABL 7: block form only)
