@@ -36,6 +36,7 @@ CONFIGS = {
     "cfg5": (7680, 4320, 16, 6, dict(blksize=32, overlap=16), dict(pel=2), 168, "8K YUV420P16 Degrain6 blksize=32 overlap=16 pel=2"),
     # (not a BASELINE configuration: the common HD setting of the reference's users -- 8-bit, 16x16 blocks overlapping by half; r5, `other_configs`)
     "hd16": (1920, 1080, 8, 1, dict(blksize=16, overlap=8), dict(pel=2), 2048, "1080p YUV420P8 Degrain1 blksize=16 overlap=8 pel=2"),
+    "hd16l": (1920, 1080, 8, 1, dict(blksize=16, overlap=8, chroma=0), dict(pel=2), 2048, "1080p YUV420P8 Degrain1 blksize=16 overlap=8 pel=2, luma-only search (chroma=0)"),
     "hd16s": (1920, 1080, 8, 1, dict(blksize=16), dict(pel=2), 2048, "1080p YUV420P8 Degrain1 blksize=16 overlap=0 pel=2"),  # (blocks side by side: the reference's default overlap)
     # BASELINE config 4: frame-rate conversion instead of denoising (radius field = 0 selects PipelineFPS)
     "cfg4": (1920, 1080, 8, 0, dict(blksize=8), dict(pel=2), 2047, "1080p YUV420P8 Compensate + BlockFPS 24->60 blksize=8 pel=2"),

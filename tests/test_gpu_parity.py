@@ -517,6 +517,8 @@ WINDOW_CASES = [
 
 @pytest.mark.parametrize("w,h,skw,akw", WINDOW_CASES + [
     (1000, 96, {}, dict(blksize=16, overlap=8, meander=0)),                       # several groups per row, always left to right
+    (1000, 96, {}, dict(blksize=16, overlap=8, chroma=0)),                        # r5: a luma-only search through the row passes (no UV rows), several groups per row
+    (330, 192, {}, dict(blksize=16, overlap=0, chroma=0, _noise=14)),
     (1000, 96, {}, dict(blksize=16, overlap=0)),                                  # r5: blocks side by side (windows of four), several groups per row
     (330, 192, {}, dict(blksize=16, overlap=0, _noise=14, badsad=400, badrange=6)),  # ... a ragged last window, rescues
     (640, 360, {}, dict(blksize=16, overlap=8, _noise=0)),                        # a clean clip: long verified runs
@@ -567,6 +569,7 @@ def test_analyse_speculative_kernel_8bit(oracle, mv, dbg, mode, w, h, skw, akw):
     (1920, 64, {}, dict(blksize=16, overlap=8)),                                  # a 1080p row of blocks: 239 per row
     (1000, 96, {}, dict(blksize=16, overlap=0)),                                  # blocks side by side
     (330, 192, {}, dict(blksize=16, overlap=0, _noise=14, pelsearch=1)),
+    (1000, 96, {}, dict(blksize=16, overlap=8, chroma=0, _noise=14)),             # luma-only
 ])
 @pytest.mark.parametrize("mode", ["default", "everywhere", "team"])
 def test_analyse_speculative_kernel_8bit_16x16(oracle, mv, dbg, mode, w, h, skw, akw):
@@ -622,7 +625,7 @@ def _speculative_case(oracle, mv, dbg, mode, w, h, bits, skw, akw):
     elif mode != "auto":         # one wave per chain (the library itself picks the team form for launches this small: "auto")
         dbg("team", 0)
     blk, ov = akw.get("blksize", 8), akw.get("overlap", 0)  # row passes: 16-bit 16x16 overlapping by half; 8-bit 8x8 overlapping by half or not at all
-    rows_apply = akw.get("chroma", 1) != 0 and ((blk == 16 and ov in (8, 0)) or ((bits, blk) == (8, 8) and ov in (4, 0)))
+    rows_apply = (blk == 16 and ov in (8, 0)) or (akw.get("chroma", 1) != 0 and (bits, blk) == (8, 8) and ov in (4, 0))  # (16x16: luma-only searches too, r5)
     frames = pl.moving_clip(w, h, bits, 3, seed=17, noise=noise, motion=(5, -2))
     osup = oracle.Super(w, h, bits, **skw)
     gsup = mv.Super(w, h, bits, **skw)

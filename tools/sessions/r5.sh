@@ -238,6 +238,17 @@ r5_side16() {
     } 2>&1 | tee $out/r5_side16_bench.txt
 }
 
+r5_lumaonly() {
+    # luma-only searches (chroma = 0) of 16x16 blocks through the row passes (no UV rows): parity, the bench line against the serial kernel, cfg3 must not have moved
+    timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "speculative or analyse_parity or golden or team" 2>&1 | tail -8 | tee $out/r5_lumaonly_tests.txt
+    if grep -q "failed\|error" $out/r5_lumaonly_tests.txt; then echo "not green: no timing"; return 1; fi
+    {
+    timeout 400 python bench.py --config hd16l --no-cpu --no-traffic --no-others --steps 2 --warmup 1 2>&1 | tail -1 | line "hd16l (1080p8 16x16 overlap 8, chroma=0) row passes"
+    MVX_SPEC=0 timeout 400 python bench.py --config hd16l --no-cpu --no-traffic --no-others --steps 2 --warmup 1 2>&1 | tail -1 | line "hd16l serial lean kernel"
+    timeout 400 python bench.py --no-cpu --no-traffic --no-others --steps 3 --warmup 1 --slots 1 2>&1 | tail -1 | line "cfg3 one batch in flight (must not have moved: 345 ms)"
+    } 2>&1 | tee $out/r5_lumaonly_bench.txt
+}
+
 s=$1; shift
 case "$s" in
   col) r5_col "$@" ;;
@@ -255,5 +266,6 @@ case "$s" in
   uni) r5_uni "$@" ;;
   vs_trace) r5_vs_trace "$@" ;;
   side16) r5_side16 "$@" ;;
+  lumaonly) r5_lumaonly "$@" ;;
   *) echo "unknown session: $s"; exit 2 ;;
 esac

@@ -370,8 +370,9 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         // one block at a time it loses to the serial lean kernel (cfg2 2 557 / 2 894, cfg4 17 180 / 18 764, cfg5 76 / 92 fps:
         // profiles/r4_configs_spec_vs_serial.txt), so everything else stays there unless "spec" asks for it (5: wherever it can run).
         const bool stripShape8 = P.bps == 1 && P.blkX == 8 && P.chroma && (P.ovX == 4 || P.ovX == 0) && P.shadow[1] != 0; // 8-bit 8x8 blocks overlapping by half or not at all, UV-interleaved plane present
-        const bool stripShape16 = P.bps == 1 && P.blkX == 16 && P.chroma && (P.ovX == 8 || P.ovX == 0) && P.shadow[1] != 0; // r5: 8-bit 16x16 blocks overlapping by half (the 16-bit form with 8-byte columns)
-        const bool stripShape = (P.bps == 2 && (P.blkX == 16 || (MVX_STRIP32 && P.blkX == 32)) && P.chroma && (P.ovX == P.blkX / 2 || (P.blkX == 16 && P.ovX == 0)) && P.shadow[1] != 0) || stripShape8 || stripShape16; // (16x16 side by side: r5) // (the row passes read the UV-interleaved plane: STRIP_OK)
+        const bool uvOrLumaOnly = P.chroma ? P.shadow[1] != 0 : true; // the row passes read chroma from the UV-interleaved plane; a luma-only search (chroma = 0) needs none (r5)
+        const bool stripShape16 = P.bps == 1 && P.blkX == 16 && uvOrLumaOnly && (P.ovX == 8 || P.ovX == 0); // r5: 8-bit 16x16 blocks overlapping by half (the 16-bit form with 8-byte columns)
+        const bool stripShape = (P.bps == 2 && (P.blkX == 16 || (MVX_STRIP32 && P.blkX == 32)) && uvOrLumaOnly && (P.ovX == P.blkX / 2 || (P.blkX == 16 && P.ovX == 0))) || stripShape8 || stripShape16; // (16x16 side by side: r5) // (the row passes read the UV-interleaved plane: STRIP_OK)
         // ... except as TEAMS in a launch that leaves the GPU's wave slots empty (r5): there the speculative kernel wins for every shape it can run, row passes or
         // not (132 chains of cfg5: 974 ms serial, 352 ms as teams of four; 128 chains of 8-bit 16x16 blocks: 140 / 43 ms; at ~512 chains it is a tie:
         // profiles/r5_team_other_shapes.txt).  The library's own choice only: any forced "spec" / "team" value keeps its meaning.

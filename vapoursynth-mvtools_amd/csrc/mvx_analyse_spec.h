@@ -226,12 +226,14 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
 #endif
     // (r5: 8-bit 16x16 blocks overlapping by 8 -- the common HD setting -- take the same code with 8-byte columns: a half block is 8 samples = COLB bytes, a window row
     // 8 * COLB = 64 bytes; loads are 8 bytes per lane, at any byte address -- 8-bit super frames have no shifted copies)
-    static constexpr bool STRIP_OK = UV && ((BPS == 2 && (BW == 16 || (MVX_STRIP32 && BW == 32))) || (BPS == 1 && BW == 16));
+    // (r5: the builds WITHOUT the UV plane run the same passes for luma-only searches -- chroma = 0: 16 rows per pass, no UV rows; with chroma on they have no row passes)
+    static constexpr bool STRIP_OK = (BPS == 2 && (BW == 16 || (MVX_STRIP32 && BW == 32))) || (BPS == 1 && BW == 16);
     static constexpr int COLB = BPS == 2 ? 16 : 8, ROWB = 8 * COLB; // bytes of a strip column / of a strip row (eight columns)
     // HC = 16-byte columns per half block (a 32x32 block row is four columns, blocks step by two); a window is eight columns: 7 (3) blocks;
     // block form: LPB lanes per block, LPC per candidate (four candidates: lanes 0..4 * LPC - 1; lanes 56-63 stay free for the zero vector's strip)
     static constexpr int HC = STRIP_OK ? BW / 16 : 1, SW_BLOCKS = 8 / HC - 1, LPB = 2 * HC, LPC = SW_BLOCKS * LPB;
-    static constexpr int SNA = BW, SNB = BW / 2, SNT = SNA + SNB, SW = (BW == 32 && SWIN > 12) ? 12 : SWIN, S_UV = SNA * ROWB, SSTG = SNT / 8; // (32x32: 12 in flight -- 24 plus the six staging pieces spill) // rows of a pass, loads in flight, LDS offset of the UV rows, staging pieces per lane
+    static constexpr int pickSW(int nt, int w) { return w <= 1 ? 1 : (w <= nt && nt % w == 0) ? w : pickSW(nt, w - 1); } // rows in flight: a divisor of the rows of a pass
+    static constexpr int SNA = BW, SNB = UV ? BW / 2 : 0, SNT = SNA + SNB, SW = pickSW(SNT, (BW == 32 && SWIN > 12) ? 12 : SWIN), S_UV = SNA * ROWB, SSTG = SNT / 8; // (32x32: 12 in flight -- 24 plus the six staging pieces spill) // rows of a pass, loads in flight, LDS offset of the UV rows, staging pieces per lane
     struct StripPass { v4u r[SW]; unsigned curA, curB, aL, aC; };
     __device__ __forceinline__ v4u strip_issue(StripPass &T, int piece) const {
         v4u v;
@@ -594,7 +596,8 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
 
                         // ======== A: the SADs of every block of the group, nothing serial in between
                         const int nb = hiE - lo;
-                        const bool streamed = chroma && (hexLevel ? STREAM_HEX : STREAM_EXH);
+                        const bool lumaStrips = STRIP_OK && !UV && !chroma && stripEnabled && (stepX == BW / 2 || (BW == 16 && stepX == BW)); // luma-only search: row passes without UV rows
+                        const bool streamed = (chroma && (hexLevel ? STREAM_HEX : STREAM_EXH)) || lumaStrips;
                         if (streamed) {
                             const int pkZ = pk(0, fieldShift);
                             const int slotUp = hexLevel ? 14 : 24, slotZ = hexLevel ? 16 : 26; // (ahead = slotUp + 1, global / hierarchical = slotZ + 1 / + 2)
@@ -616,7 +619,7 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
                                 // (r5: 16x16 blocks SIDE BY SIDE -- overlap 0, the reference's default -- take the same passes: a block is two columns and steps by TC = two,
                                 // a window holds four; no column sum is shared, the strips stay contiguous)
                                 const bool side = HC == 1 && stepX == BW;
-                                if (stripEnabled && (stepX == BW / 2 || side)) {
+                                if (stripEnabled && (stepX == BW / 2 || side) && (UV ? chroma != 0 : chroma == 0)) {
                                     const int TC = side ? 2 : HC, SWB = side ? 4 : SW_BLOCKS, LPCr = SWB * LPB; // columns per block step, blocks per window, lanes per block-form candidate
                                     const int nw = (nb + SWB - 1) / SWB;
                                     const int npat = hexLevel ? 14 : 24;
