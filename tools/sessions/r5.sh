@@ -249,6 +249,17 @@ r5_lumaonly() {
     } 2>&1 | tee $out/r5_lumaonly_bench.txt
 }
 
+r5_degrain_side() {
+    # Degrain of blocks side by side (overlap 0) through the cell kernel instead of the per-sample gather: parity, hd16s and cfg1 bench lines
+    timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_vs_shim.py -x -q -m gpu -k "degrain or golden or full_size or device" 2>&1 | tail -8 | tee $out/r5_degrain_side_tests.txt
+    if grep -q "failed\|error" $out/r5_degrain_side_tests.txt; then echo "not green: no timing"; return 1; fi
+    {
+    timeout 400 python bench.py --config hd16s --no-cpu --no-traffic --no-others --steps 3 --warmup 1 2>&1 | tail -1 | line "hd16s (was 135.0 ms/step, Degrain gather 42 ms)"
+    timeout 400 python bench.py --config cfg1 --no-cpu --no-traffic --no-others --steps 3 --warmup 1 2>&1 | tail -1 | line "cfg1 (r4: 66 700 fps)"
+    timeout 400 python bench.py --config cfg4 --no-cpu --no-traffic --no-others --steps 3 --warmup 1 2>&1 | tail -1 | line "cfg4 (unchanged path)"
+    } 2>&1 | tee $out/r5_degrain_side_bench.txt
+}
+
 s=$1; shift
 case "$s" in
   col) r5_col "$@" ;;
@@ -267,5 +278,6 @@ case "$s" in
   vs_trace) r5_vs_trace "$@" ;;
   side16) r5_side16 "$@" ;;
   lumaonly) r5_lumaonly "$@" ;;
+  degrain_side) r5_degrain_side "$@" ;;
   *) echo "unknown session: $s"; exit 2 ;;
 esac

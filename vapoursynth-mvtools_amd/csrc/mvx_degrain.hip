@@ -379,7 +379,39 @@ __global__ __launch_bounds__(256) void degrain_cell_kernel(const DGParams *Pp, c
     int out[W];
 #pragma unroll
     for (int i = 0; i < W; i++) out[i] = s[i];
-    if (g.process && x0 < g.WB && y < g.HB) { // MVDegrains.cpp:211-214,238-249,290-298: uncovered strips keep the source
+    if (g.process && x0 < g.WB && y < g.HB && !P.overlap) {
+        // r5: blocks side by side (MVDegrains.cpp:238-249: Degrain_C straight into the frame, no windows).  W divides the block width, so the cell lies in ONE
+        // block: one plan record, one vector load per reference -- the per-sample gather this replaces took 42 of the 135 ms of a 2048-frame 1080p step
+        const PlanRec &R = (plan + ((size_t)f * 2 + (p ? 1 : 0)) * P.nBlk)[(y / g.blkH) * P.nBlkX + x0 / g.blkW];
+        const int px = x0 % g.blkW, py = y % g.blkH;
+        const unsigned char *safe = nullptr;
+#pragma unroll
+        for (int r = 0; r < NR; r++) if (J.refs[r][p]) safe = J.refs[r][p];
+        const long long rowOff = safe ? (long long)py * g.supPitch + (long long)px * sizeof(T) : 0;
+        DgRaw<T, W> raw[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) raw[r] = dg_load_raw<T, W>(dg_gl((J.refs[r][p] ? J.refs[r][p] : (safe ? safe : J.src[p])) + R.off[r] + rowOff)); // (weight 0: any valid address)
+        const int wsrc = R.wsrc, pm = (1 << P.bits) - 1;
+        int sum[W];
+#pragma unroll
+        for (int i = 0; i < W; i++) sum[i] = 128 + s[i] * wsrc;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int w = R.w[r];
+#pragma unroll
+            for (int i = 0; i < W; i++) sum[i] += dg_sample<T, W>(raw[r], i) * w;
+        }
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            int o = (T)(sum[i] >> 8);
+            if (g.limit < pm) { // MVDegrains.h:163-181
+                const int lo = s[i] - g.limit, hi = s[i] + g.limit;
+                o = o < lo ? lo : o;
+                o = o > hi ? hi : o;
+            }
+            out[i] = o;
+        }
+    } else if (g.process && x0 < g.WB && y < g.HB) { // MVDegrains.cpp:211-214,238-249,290-298: uncovered strips keep the source
         const PlanRec *pl = plan + ((size_t)f * 2 + (p ? 1 : 0)) * P.nBlk;
         int bx1 = c; if (bx1 > P.nBlkX - 1) bx1 = P.nBlkX - 1;
         const int bx0 = x0 - g.blkW + 1 <= 0 ? 0 : (x0 - g.blkW + g.stepX) / g.stepX;
@@ -798,7 +830,8 @@ extern "C" __attribute__((visibility("default"))) int mvx_degrain_frames(mvx_deg
     }
     // overlapped blocks with a power-of-two step: vectorised cell kernel, one launch per plane class; otherwise the
     // per-sample gather
-    auto cellW = [&](int p) { const int w = P.pl[p].stepX; return (P.overlap && (w == 2 || w == 4 || w == 8 || w == 16)) ? w : 0; };
+    // (r5: blocks side by side take the cell kernel too -- a cell of 8 (4) samples inside one block)
+    auto cellW = [&](int p) { const int w = P.pl[p].stepX; return P.overlap ? ((w == 2 || w == 4 || w == 8 || w == 16) ? w : 0) : (P.pl[p].blkW % 8 == 0 ? 8 : P.pl[p].blkW % 4 == 0 ? 4 : 0); };
     const bool cells = cellW(0) && (P.nplanes == 1 || (cellW(1) && P.pl[1].stepX == P.pl[2].stepX));
     if (cells) {
         for (int cls = 0; cls < (P.nplanes > 1 ? 2 : 1); cls++) {
