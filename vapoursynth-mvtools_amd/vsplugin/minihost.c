@@ -542,15 +542,16 @@ int main(int argc, char **argv) {
     for (int i = 0; i < nextra; i++) if (!strncmp(extra[i], "x.threads=", 10)) threads = atoi(extra[i] + 10);
     for (int i = 0; i < nextra; i++) if (!strncmp(extra[i], "x.cache=", 8)) g_cache_limit = atoi(extra[i] + 8);
     VSNode *clip = source_clip(inPath, w, hh, bits, nframes);
-    if (getenv("MVX_HOST_TIMES")) fprintf(stderr, "minihost: clip loaded at %.2f s after start\n", now_s() - g_start); /* (graph construction starts here) */
-    FILE *fo = fopen(outPath, "wb");
+    FILE *fo = fopen(outPath, "wb"); /* (before the time mark: truncating a previous run's multi-gigabyte result file takes a second) */
     if (!fo) { fprintf(stderr, "cannot write %s\n", outPath); return 2; }
+    if (getenv("MVX_HOST_TIMES")) fprintf(stderr, "minihost: clip loaded at %.2f s after start\n", now_s() - g_start); /* (graph construction starts here) */
 
     VSMap *sm = createMap(); mapSetNode(sm, "clip", clip, maReplace); add_args(sm, 's', nextra, extra);
     VSNode *pelclip = pelclip_from_args(nextra, extra, bits, nframes);
     if (pelclip) mapSetNode(sm, "pelclip", pelclip, maReplace);
     VSNode *sup = invoke("Super", sm, err, sizeof(err));
     if (!sup) die("Super", err);
+    if (getenv("MVX_HOST_TIMES")) fprintf(stderr, "minihost: mv.Super created at %.2f s after start\n", now_s() - g_start);
     if (!strcmp(pipeline, "super")) {
         for (int n = 0; n < nframes; n++) {
             const VSFrame *f = eval_frame(n, sup, err, sizeof(err));
@@ -577,6 +578,7 @@ int main(int argc, char **argv) {
             mapSetInt(am, "isb", isb, maReplace); mapSetInt(am, "delta", r + 1, maReplace);
             amaps[2 * r + (isb ? 0 : 1)] = am;
             vec[2 * r + (isb ? 0 : 1)] = invoke("Analyse", am, err, sizeof(err));
+            if (getenv("MVX_HOST_TIMES")) fprintf(stderr, "minihost: mv.Analyse delta %d isb %d created at %.2f s after start\n", r + 1, isb, now_s() - g_start);
             if (!vec[2 * r + (isb ? 0 : 1)]) die("Analyse", err);
         }
     if (!strcmp(pipeline, "analyse")) {
