@@ -155,12 +155,7 @@ class Pipeline:
     def _step(self, time_search, src):
         torch, tr, B = self.torch, self.tr, self.B
         self.sup.build(src, out=self.supers)
-        # all 2*tr vector clips share one parameter block (delta / isb only pick the reference frame), so every chain
-        # of the step goes into ONE launch: 2*tr*B chains resident at once
-        jobs, blobs = [], []
-        for key, pairs in self.plan.searches().items():
-            jobs += [(self.supers[n], self.supers[nref] if nref is not None else None) for n, nref in pairs]
-            blobs += self.blobs[key]
+        jobs, blobs = self._search_jobs()
         if self.search_after is not None and self.search_after.search_done is not None:
             torch.cuda.current_stream().wait_event(self.search_after.search_done)
         if time_search:
@@ -178,16 +173,22 @@ class Pipeline:
             djobs.append((src[n], [self.supers[r] if r is not None else None for r in refs], [self.blobs[key][i] for key in self.plan.clips]))
         self.dg.run(djobs, out=self.out)
 
+    def _search_jobs(self):
+        """all 2*tr vector clips share one parameter block (delta / isb only pick the reference frame), so every chain of the step goes into ONE
+        launch: 2*tr*B chains resident at once.  -> (jobs, blobs) of that launch"""
+        jobs, blobs = [], []
+        for key, pairs in self.plan.searches().items():
+            jobs += [(self.supers[n], self.supers[nref] if nref is not None else None) for n, nref in pairs]
+            blobs += self.blobs[key]
+        return jobs, blobs
+
     def search_alone(self):
         """ONE search launch of this slot with nothing else on the GPU, by HIP events (after the timed region: with several batches in flight the launches of
         the timed steps run with the neighbours' Super / Degrain kernels beside them and take longer): milliseconds"""
         torch = self.torch
         torch.cuda.synchronize()
         with torch.cuda.stream(self.stream):
-            jobs, blobs = [], []
-            for key, pairs in self.plan.searches().items():
-                jobs += [(self.supers[n], self.supers[nref] if nref is not None else None) for n, nref in pairs]
-                blobs += self.blobs[key]
+            jobs, blobs = self._search_jobs()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             self.an[(1, 1)].run(jobs, blobs=blobs)
@@ -379,7 +380,8 @@ def oracle_leg(mv, torch, cfg, pipe, threads, F, i0=None):
               "first_output_frame_in_batch": i0}
     if bad:
         parity["mismatches"] = bad[:8]
-    sample = "%d output frames of %s taken from the timed step's own clip (%d Super + %d Analyse + %d Degrain%d), %d threads each owning whole frames, %.1f s wall; scalar C oracle (-O2 -mavx2), not the reference's SIMD build (BASELINE.md 4)" % (
+    sample = ("%d output frames of %s taken from the timed step's own clip (%d Super + %d Analyse + %d Degrain%d), %d threads each owning whole frames, "
+              "%.1f s wall; scalar C oracle (-O2 -mavx2), not the reference's SIMD build (BASELINE.md 4)") % (
         len(dgs), label, len(need), 2 * tr * len(dgs), len(dgs), tr, threads, dt)
     return {"value": len(dgs) / dt, "unit": "fps", "cores": threads, "kind": "port", "sample": sample}, parity
 
@@ -431,7 +433,8 @@ def oracle_leg_fps(mv, torch, cfg, pipe, threads, F):
               "against": "oracle/ (CPU restatement) on the same clip frames, downloaded from the device clip of the timed step"}
     if bad:
         parity["mismatches"] = bad[:8]
-    sample = "%d input frames of %s taken from the timed step's own clip -> %d interpolated + %d compensated frames, %d threads each owning whole frames, %.1f s wall; scalar C oracle (-O2 -mavx2), not the reference's SIMD build (BASELINE.md 4)" % (
+    sample = ("%d input frames of %s taken from the timed step's own clip -> %d interpolated + %d compensated frames, %d threads each owning whole frames, "
+              "%.1f s wall; scalar C oracle (-O2 -mavx2), not the reference's SIMD build (BASELINE.md 4)") % (
         n, label, fps.num_frames, F, threads, dt)
     return {"value": fps.num_frames / dt, "unit": "fps", "cores": threads, "kind": "port", "sample": sample}, parity
 
@@ -441,7 +444,11 @@ def search_kernel_name(mv):
     import ctypes as C
     info = (C.c_int * 5)()
     mv.lib().mvx_debug_last_launch(info)
-    return "analyse_spec_kernel, %d chains per SIMD" % info[0] if info[4] == 2 else "analyse_spec_kernel (team form: %d waves per chain)" % info[1] if info[4] == 3 else "analyse_fast_kernel, %d chains per SIMD" % info[0] if info[0] else "analyse_kernel"
+    if info[4] == 2:
+        return "analyse_spec_kernel, %d chains per SIMD" % info[0]
+    if info[4] == 3:
+        return "analyse_spec_kernel (team form: %d waves per chain)" % info[1]
+    return "analyse_fast_kernel, %d chains per SIMD" % info[0] if info[0] else "analyse_kernel"
 
 
 def other_configs():
@@ -823,8 +830,11 @@ def main():
         if len(pipes) > 1 and not fpsconv:
             # the launches of the timed steps ran beside the other slot's Super / Degrain kernels; the same launch with the GPU to itself (same clip, same result):
             alone_ms = pipes[(args.steps - 1) % len(pipes)].search_alone()
-            out["roofline"]["launch_alone"] = {"avg_launch_ms": alone_ms, "achieved": bytes_chain * chains / (alone_ms * 1e-3) / 1e9, "frac": bytes_chain * chains / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                               "note": "one search launch after the timed region, nothing else on the GPU; `frac` above is the timed region's (launches overlapped by the neighbouring batches' Super / Degrain kernels)"}
+            alone_gbs = bytes_chain * chains / (alone_ms * 1e-3) / 1e9
+            out["roofline"]["launch_alone"] = {
+                "avg_launch_ms": alone_ms, "achieved": alone_gbs, "frac": alone_gbs / HBM_PEAK_GBS,
+                "note": "one search launch after the timed region, nothing else on the GPU; `frac` above is the timed region's "
+                        "(launches overlapped by the neighbouring batches' Super / Degrain kernels)"}
         if args.ingest and world == 1 and not fpsconv:
             sps, up_b, down_b = ingest_run(torch, pipe, max(2, min(args.steps, 4)), 1)
             out["ingest_inclusive"] = {"value": units / sps, "unit": "fps", "ms_per_step": sps * 1e3, "h2d_bytes_per_step": up_b, "d2h_bytes_per_step": down_b,
