@@ -866,6 +866,13 @@ def _fullsize_parity(mv, oracle, w, h, bits, tr, akw, nout, replicas, want_k, la
     want = [torch.from_numpy(b).to(blobs[0].device) for b in oblobs]
     for i, b in enumerate(blobs):
         assert torch.equal(b, want[i % nc]), label + ": vectors of chain %s differ from the oracle (copy %d of %d)" % (chains[i % nc], i // nc, replicas)
+    # r5: the same chains as a SMALL launch -- the library runs it as teams (the waves of a workgroup walk one chain) -- must give the same blobs
+    small = gan.run([(gsf[a], gsf[b]) for a, b in chains])
+    torch.cuda.synchronize()
+    mv.lib().mvx_debug_last_launch(info)
+    assert info[4] == 3 and info[1] == 4, label + ": the small launch did not take the team form (%s)" % list(info)
+    for i, b in enumerate(small):
+        assert torch.equal(b, want[i]), label + ": vectors of chain %s differ from the oracle in the team form" % (chains[i],)
     gdg = mv.Degrain(tr, gsup, gan.ad, [p.stride(0) for p in gsrc[0]])
     odg = oracle.Degrain(tr, osup, oan[clips[0]].ad)
     for k, f in enumerate(range(tr, tr + nout)):
