@@ -319,6 +319,36 @@ template <typename T, int W> __device__ __forceinline__ DgRaw<T, W> dg_load_raw(
 template <typename T, int W> __device__ __forceinline__ int dg_sample(const DgRaw<T, W> &r, int i) {
     return sizeof(T) == 2 ? (int)((r.d[i >> 1] >> (16 * (i & 1))) & 0xffffu) : (int)((r.d[i >> 2] >> (8 * (i & 3))) & 0xffu);
 }
+// r5: the weighted sum of TWO references per instruction for 16-bit samples (MVDegrains.h:31-53: sum += ref * W, all terms non-negative and < 2^24):
+// v_perm_b32 pairs sample i of reference a with sample i of reference b, v_dot2_u32_u16 multiplies the pair by the two weights and adds.  Per sample and pair of
+// references 2 instructions instead of 4 (two shifts / masks + two multiply-adds); same integers.
+typedef unsigned short dg_us2 __attribute__((ext_vector_type(2)));
+template <int W> __device__ __forceinline__ void dg_mad_pair_u16(const DgRaw<unsigned short, W> &a, const DgRaw<unsigned short, W> &b, int wa, int wb, int *sum) {
+    const dg_us2 w = { (unsigned short)wa, (unsigned short)wb };
+#pragma unroll
+    for (int j = 0; j < (W + 1) / 2; j++) {
+        const unsigned lo = __builtin_amdgcn_perm(b.d[j], a.d[j], 0x05040100u); // (a[2j], b[2j])
+        sum[2 * j] = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(dg_us2, lo), w, (unsigned)sum[2 * j], false);
+        if (2 * j + 1 < W) {
+            const unsigned hi = __builtin_amdgcn_perm(b.d[j], a.d[j], 0x07060302u); // (a[2j + 1], b[2j + 1])
+            sum[2 * j + 1] = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(dg_us2, hi), w, (unsigned)sum[2 * j + 1], false);
+        }
+    }
+}
+// the weighted references of one block into sum[]: pairs of references for 16-bit samples (NR is even: 2 x radius), one at a time otherwise
+template <typename T, int NR, int W, typename REC> __device__ __forceinline__ void dg_mad_refs(const DgRaw<T, W> *raw, const REC &R, int *sum) {
+    if constexpr (sizeof(T) == 2 && NR % 2 == 0) {
+#pragma unroll
+        for (int r = 0; r < NR; r += 2) dg_mad_pair_u16<W>(raw[r], raw[r + 1], R.w[r], R.w[r + 1], sum);
+    } else {
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int w = R.w[r];
+#pragma unroll
+            for (int i = 0; i < W; i++) sum[i] += dg_sample<T, W>(raw[r], i) * w;
+        }
+    }
+}
 // N consecutive ints (dword-aligned address)
 typedef int dg_iv4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef int dg_iv2 __attribute__((ext_vector_type(2), aligned(4)));
@@ -395,12 +425,7 @@ __global__ __launch_bounds__(256) void degrain_cell_kernel(const DGParams *Pp, c
         int sum[W];
 #pragma unroll
         for (int i = 0; i < W; i++) sum[i] = 128 + s[i] * wsrc;
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            const int w = R.w[r];
-#pragma unroll
-            for (int i = 0; i < W; i++) sum[i] += dg_sample<T, W>(raw[r], i) * w;
-        }
+        dg_mad_refs<T, NR, W>(raw, R, sum);
 #pragma unroll
         for (int i = 0; i < W; i++) {
             int o = (T)(sum[i] >> 8);
@@ -451,12 +476,7 @@ __global__ __launch_bounds__(256) void degrain_cell_kernel(const DGParams *Pp, c
 #pragma unroll
                     for (int r = 0; r < NR; r++) raw[r] = dg_load_raw<T, W>(dg_gl(refp[r] + R.off[r] + rowOff));
                     dg_load<unsigned short, W>(dg_gl((const unsigned char *)wrow), wv);
-#pragma unroll
-                    for (int r = 0; r < NR; r++) {
-                        const int w = R.w[r];
-#pragma unroll
-                        for (int i = 0; i < W; i++) sum[i] += dg_sample<T, W>(raw[r], i) * w;
-                    }
+                    dg_mad_refs<T, NR, W>(raw, R, sum);
                 } else { // partially covered (overlap != block/2): per-sample loads of the covered samples only
 #pragma unroll
                     for (int r = 0; r < NR; r++) {
