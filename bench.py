@@ -141,10 +141,9 @@ class Pipeline:
         self.dg = mv.Degrain(tr, self.sup, a0.ad, [p.stride(0) for p in self.src[0]])
         self.out = mv.arena_frames(batch, [tuple(p.shape) for p in self.src[0]], device, zero=False)
         self.ev = []  # (start, end) events around the search launches
-        # several batches in flight (--slots): the search launches run ONE AFTER THE OTHER (a launch fills the GPU's wave slots: two at once only share
-        # them), while Super of the next batch and Degrain of the previous one run under the search of the current one on their own streams
-        self.search_after = None   # the pipeline slot whose last search this slot's next search waits for
-        self.search_done = None    # event: this slot's last search launch has finished
+        # several batches in flight (--slots): every slot has its own stream.  A search launch of 2046 chains fills the GPU's wave slots (two waves per SIMD at 256
+        # registers), so the next slot's launch is dispatched chain by chain as the current one's chains finish -- its tail is filled --, while Super of the
+        # next batch and Degrain of the previous one run under the running search
         _order_behind_caller(torch, self.stream, device)
 
     def step(self, time_search=False, src=None):
@@ -156,8 +155,6 @@ class Pipeline:
         torch, tr, B = self.torch, self.tr, self.B
         self.sup.build(src, out=self.supers)
         jobs, blobs = self._search_jobs()
-        if self.search_after is not None and self.search_after.search_done is not None:
-            torch.cuda.current_stream().wait_event(self.search_after.search_done)
         if time_search:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -165,9 +162,6 @@ class Pipeline:
         if time_search:
             e1.record()
             self.ev.append((e0, e1))
-        if self.search_after is not None:
-            self.search_done = torch.cuda.Event()
-            self.search_done.record()
         djobs = []
         for n, refs, i in self.plan.degrains():
             djobs.append((src[n], [self.supers[r] if r is not None else None for r in refs], [self.blobs[key][i] for key in self.plan.clips]))
@@ -722,9 +716,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0)
-    ap.add_argument("--slots", type=int, default=0, help="batches in flight: slot i owns its buffers and HIP stream; the search launches are chained (one at a time), so "
-                    "the Super kernels of the next batch and the Degrain kernels of the previous one run under the (latency-bound) search of the current one.  "
-                    "Default: 2 for cfg3 (+5.7 %%, profiles/r5_batches_in_flight_chained_searches.txt; 2 x 107 GB of the 288 GB), 1 elsewhere (cfg2: no gain; cfg5: no room)")
+    ap.add_argument("--slots", type=int, default=0, help="batches in flight: slot i owns its buffers and HIP stream, so the Super kernels of the next batch and the "
+                    "Degrain kernels of the previous one run under the (latency-bound) search of the current one, and the next search launch fills the wave slots "
+                    "the current one's finishing chains free.  Default: 2 for cfg3 (+10 %%: profiles/r5_batches_in_flight_unchained.txt; 2 x 107 GB of the 288 GB), "
+                    "1 elsewhere (cfg2: +0.4 %%; cfg5: no room)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline (a two-frame parity check of the timed step still runs)")
     ap.add_argument("--no-parity", action="store_true", help="with --no-cpu: skip the oracle comparison of the timed step too")
     ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure the search launch's HBM traffic")
@@ -771,9 +766,6 @@ def main():
     # frame is a function of its global index, so neighbouring ranks hold identical copies of the frames they share (shard_check below)
     pipe = PipeT(mv, torch, cfg, B, device, seed=1000, plan=plan)
     pipes = [pipe] + [PipeT(mv, torch, cfg, B, device, seed=1000, src=pipe.src, plan=plan) for _ in range(max(1, args.slots) - 1)]
-    if len(pipes) > 1 and not fpsconv:
-        for i, pp in enumerate(pipes):
-            pp.search_after = pipes[i - 1]
     units = pipe.frames_per_step if fpsconv else B  # frames a step delivers
     torch.cuda.synchronize()
 
@@ -806,6 +798,23 @@ def main():
     if rank == 0:
         search_ms = [a.elapsed_time(b) for pp in pipes for a, b in pp.ev]
         avg_launch_ms = sum(search_ms) / len(search_ms)
+        # with several batches in flight consecutive search launches OVERLAP (the next one fills the slots the current one frees): their event-to-event durations add
+        # up to more than the time the GPU spent searching.  The kernel's time per launch is then the length of the UNION of the launches' intervals / launches
+        evs = [e for pp in pipes for e in pp.ev]
+        iv = sorted((evs[0][0].elapsed_time(a), evs[0][0].elapsed_time(b)) for a, b in evs)
+        busy, cur_s, cur_e = 0.0, iv[0][0], iv[0][1]
+        for s_, e_ in iv[1:]:
+            if s_ > cur_e:
+                busy += cur_e - cur_s
+                cur_s, cur_e = s_, e_
+            else:
+                cur_e = max(cur_e, e_)
+        busy += cur_e - cur_s
+        busy_launch_ms = busy / len(evs)
+        overlapped = len(pipes) > 1 and busy_launch_ms < 0.98 * avg_launch_ms
+        event_launch_ms = avg_launch_ms
+        if overlapped:
+            avg_launch_ms = busy_launch_ms
         bytes_chain, full = pipe.algorithmic_bytes_per_chain()
         chains = 2 * (B + 1) if fpsconv else 2 * cfg[3] * B
         achieved = bytes_chain * chains / (avg_launch_ms * 1e-3) / 1e9
@@ -822,7 +831,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "%s (the motion search; one launch = %d chains)" % (search_kernel_name(mv), chains), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                          "peak_measured": HBM_MEASURED_GBS, "frac_of_measured_peak": achieved / HBM_MEASURED_GBS,
-                         "algorithmic_bytes_per_launch": bytes_chain * chains, "avg_launch_ms": avg_launch_ms,
+                         "algorithmic_bytes_per_launch": bytes_chain * chains, "avg_launch_ms": avg_launch_ms, "avg_launch_event_ms": event_launch_ms,
+                         "launch_time_basis": ("union of the launches' HIP-event intervals / launches: consecutive launches overlap (avg_launch_event_ms is the mean "
+                                               "event-to-event duration of one launch, which counts the overlaps twice)") if overlapped else "mean HIP-event duration of a launch",
                          "search_share_of_step": sum(search_ms) / (dt * 1e3),
                          # the search is a serial chain per (frame, direction) -- its own yardstick is block steps per second
                          "blocks_per_chain": nblk, "chain_steps_per_s": chains * nblk / (avg_launch_ms * 1e-3)},
@@ -834,7 +845,7 @@ def main():
             out["roofline"]["launch_alone"] = {
                 "avg_launch_ms": alone_ms, "achieved": alone_gbs, "frac": alone_gbs / HBM_PEAK_GBS,
                 "note": "one search launch after the timed region, nothing else on the GPU; `frac` above is the timed region's "
-                        "(launches overlapped by the neighbouring batches' Super / Degrain kernels)"}
+                        "(launches beside the neighbouring batches' Super / Degrain kernels and each other's tails)"}
         if args.ingest and world == 1 and not fpsconv:
             sps, up_b, down_b = ingest_run(torch, pipe, max(2, min(args.steps, 4)), 1)
             out["ingest_inclusive"] = {"value": units / sps, "unit": "fps", "ms_per_step": sps * 1e3, "h2d_bytes_per_step": up_b, "d2h_bytes_per_step": down_b,

@@ -123,11 +123,14 @@ r5_shadow_ab() {
 }
 
 r5_slots() {
-    # r5: two batches in flight with the searches chained (one launch at a time), Super / Degrain of the neighbouring batches under the running search
+    # r5: batches in flight, each on its own stream: Super / Degrain of the neighbouring batches under the running search, and the next search launch in the wave slots
+    # the current one frees.  (The first form of this chained the search launches by events -- profiles/r5_batches_in_flight_chained_searches.txt, 878 fps; not chaining
+    # them is 922: profiles/r5_batches_in_flight_unchained.txt.)
     {
     timeout 400 python bench.py --no-cpu --no-traffic --no-others --steps 8 --warmup 2 --slots 1 2>&1 | tail -1 | line "cfg3 one batch in flight"
-    timeout 400 python bench.py --no-cpu --no-traffic --no-others --steps 8 --warmup 2 --slots 2 2>&1 | tail -1 | line "cfg3 two batches in flight, searches chained"
-    timeout 400 python bench.py --no-cpu --no-traffic --no-others --steps 9 --warmup 3 --slots 3 --batch 256 2>&1 | tail -1 | line "cfg3 three batches of 256 in flight, searches chained"
+    timeout 400 python bench.py --no-cpu --no-traffic --no-others --steps 8 --warmup 2 --slots 2 2>&1 | tail -1 | line "cfg3 two batches in flight"
+    timeout 400 python bench.py --no-cpu --no-traffic --no-others --steps 9 --warmup 3 --slots 3 --batch 256 2>&1 | tail -1 | line "cfg3 three batches of 256 in flight"
+    timeout 400 python bench.py --no-cpu --no-traffic --no-others --steps 8 --warmup 4 --slots 4 --batch 170 2>&1 | tail -1 | line "cfg3 four batches of 170 in flight"
     timeout 400 python bench.py --config cfg2 --no-cpu --no-traffic --no-others --steps 8 --warmup 2 --slots 2 2>&1 | tail -1 | line "cfg2 two batches in flight"
     timeout 400 python bench.py --config cfg2 --no-cpu --no-traffic --no-others --steps 8 --warmup 2 --slots 1 2>&1 | tail -1 | line "cfg2 one batch in flight"
     } 2>&1 | tee $out/r5_batches_in_flight.txt
