@@ -718,8 +718,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--slots", type=int, default=0, help="batches in flight: slot i owns its buffers and HIP stream, so the Super kernels of the next batch and the "
                     "Degrain kernels of the previous one run under the (latency-bound) search of the current one, and the next search launch fills the wave slots "
-                    "the current one's finishing chains free.  Default: 2 for cfg3 (+10 %%: profiles/r5_batches_in_flight_unchained.txt; 2 x 107 GB of the 288 GB), "
-                    "1 elsewhere (cfg2: +0.4 %%; cfg5: no room)")
+                    "the current one's finishing chains free.  Default: 2 (cfg3 +11 %%: profiles/r5_batches_in_flight_unchained.txt, 2 x 107 GB of the 288 GB; "
+                    "cfg2 / cfg4 / hd16 +3 %%: their chains finish together, there is little tail to fill), 1 for cfg5 (no room).  Stream priorities change nothing "
+                    "(profiles/r5_batches_in_flight_other_configs.txt)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline (a two-frame parity check of the timed step still runs)")
     ap.add_argument("--no-parity", action="store_true", help="with --no-cpu: skip the oracle comparison of the timed step too")
     ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure the search launch's HBM traffic")
@@ -755,7 +756,7 @@ def main():
 
     cfg = CONFIGS[args.config]
     if args.slots <= 0:
-        args.slots = 2 if args.config == "cfg3" else 1
+        args.slots = 1 if args.config == "cfg5" else 2
     B = args.batch or cfg[6]
     tr = cfg[3]
     fpsconv = tr == 0  # cfg4: Compensate + BlockFPS instead of DegrainN
@@ -834,7 +835,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_chain * chains, "avg_launch_ms": avg_launch_ms, "avg_launch_event_ms": event_launch_ms,
                          "launch_time_basis": ("union of the launches' HIP-event intervals / launches: consecutive launches overlap (avg_launch_event_ms is the mean "
                                                "event-to-event duration of one launch, which counts the overlaps twice)") if overlapped else "mean HIP-event duration of a launch",
-                         "search_share_of_step": sum(search_ms) / (dt * 1e3),
+                         "search_share_of_step": avg_launch_ms * len(search_ms) / (dt * 1e3),
                          # the search is a serial chain per (frame, direction) -- its own yardstick is block steps per second
                          "blocks_per_chain": nblk, "chain_steps_per_s": chains * nblk / (avg_launch_ms * 1e-3)},
         }
