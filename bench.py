@@ -446,12 +446,12 @@ def search_kernel_name(mv):
 
 
 def other_configs():
-    """The other BASELINE configurations that run on one GPU, each as a short child run of this script (2 timed steps after 1 warm-up, its
+    """The other BASELINE configurations that run on one GPU, each as a short child run of this script (4 timed steps after 2 warm-ups -- one per batch in flight --, its
     own two-frame comparison against the oracle; the parent has released its device memory): {"cfg2": {...}, ...}.  Outside every timed region."""
     import subprocess
     res = {}
     for c in ("cfg2", "cfg4", "cfg5", "hd16"):
-        cmd = [sys.executable, os.path.abspath(__file__), "--config", c, "--steps", "2", "--warmup", "1", "--no-cpu", "--no-traffic", "--no-others"]
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", c, "--steps", "4", "--warmup", "2", "--no-cpu", "--no-traffic", "--no-others"]
         try:
             p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=420)
             line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1]

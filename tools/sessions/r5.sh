@@ -24,6 +24,17 @@ for u in 1 0; do
     } 2>&1 | tee $out/r5_column_passes_ab.txt
 }
 
+r5_final_light() {
+    # r5: the whole GPU suite, smoke() and the driver's bench command on the last commit that touches bench.py (the profiler passes of `final` are not repeated:
+    # the library is unchanged)
+    timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -12 | tee $out/r5_tests_gpu_final.txt
+    timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $out/r5_smoke.txt
+    t0=$(date +%s)
+    timeout 1500 python bench.py --steps 20 --warmup 5 > $out/r5_bench_default.json 2> $out/r5_bench_default.err || tail -5 $out/r5_bench_default.err
+    echo "bench.py --steps 20 --warmup 5 wall: $(( $(date +%s) - t0 )) s"
+    tail -1 $out/r5_bench_default.json | cut -c1-300
+}
+
 r5_final() {
     # r5 final state: the whole GPU suite, the driver's bench command (20 steps like the driver), rocprofv3 kernel stats of the same command, per-kernel HBM traffic,
     # SQ / TCP / TCC counters of the search kernel
@@ -267,6 +278,7 @@ s=$1; shift
 case "$s" in
   col) r5_col "$@" ;;
   final) r5_final "$@" ;;
+  final_light) r5_final_light "$@" ;;
   first) r5_first "$@" ;;
   full) r5_full "$@" ;;
   full2) r5_full2 "$@" ;;
