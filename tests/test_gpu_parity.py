@@ -323,6 +323,13 @@ DEGRAIN_CASES = [
     (640, 512, 8, 1, {}, dict(blksize=128, overlap=64), {}),
     (256, 144, 16, 1, {}, dict(blksize=32, blksizev=16, overlap=0), {}),
     (256, 144, 8, 1, {}, dict(blksize=16, blksizev=2, overlap=8, overlapv=0), {}),
+    # blocks side by side through the cell kernel (r5) beyond the two plain cases above: several v_dot2 pairs on 16 bit with 16x16 blocks
+    # (chroma cell W = 8), the limits, a luma-only run, unusable references (the `safe` pointer) -- ADVICE r5
+    (192, 112, 16, 3, {}, dict(blksize=16, overlap=0), {}),
+    (128, 96, 8, 1, {}, dict(blksize=8, overlap=0), dict(limit=3, limitc=5)),
+    (128, 96, 16, 2, {}, dict(blksize=16, overlap=0), dict(limit=2, limitc=4)),
+    (128, 96, 16, 1, {}, dict(blksize=16, overlap=0), dict(plane=0)),
+    (128, 96, 8, 1, {}, dict(blksize=16, overlap=0), dict(thscd1=20, thscd2=10)),
 ]
 
 
