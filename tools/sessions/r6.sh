@@ -17,4 +17,60 @@ r6_formats() {
     timeout 600 python bench.py --no-cpu --no-traffic --no-others --no-vs --steps 5 --warmup 2 2>&1 | tail -1 | tee $out/r6_start_bench.json | line "cfg3 start of r6"
 }
 
+r6_ab() {
+    # A/B of library builds on cfg3, one batch in flight, with the in-run traffic passes: r6.sh ab <tests -k expression or ""> <lib> [<lib> ...]   (lib "default" = the tree's build)
+    k=$1; shift
+    for lib in "$@"; do
+        if [ "$lib" != default ]; then export MVX_LIB=$PWD/$lib; else unset MVX_LIB; fi
+        if [ -n "$k" ]; then timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "$k" 2>&1 | tail -3 | sed "s|^|$lib: |"; fi
+        timeout 600 python bench.py --no-cpu --no-others --no-vs --slots 1 --steps 3 --warmup 1 $BENCH_ARGS 2>/dev/null | tail -1 > $out/r6_ab_$(basename $lib .so).json
+        python - $out/r6_ab_$(basename $lib .so).json $lib <<'PY'
+import sys, json
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = d['roofline']
+print(sys.argv[2], round(d['value'], 1), 'fps', round(r['avg_launch_ms'], 1), 'ms/launch', round(d['ms_per_step'], 1), 'ms/step traffic', r.get('traffic'), 'parity', d.get('parity_check', {}).get('identical'))
+PY
+    done 2>&1 | tee $out/r6_ab_${TAG:-last}.txt
+}
+
+r6_suite() {
+    timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -6 | tee $out/r6_tests_gpu_${TAG:-last}.txt
+}
+
+r6_cfg2pmc() {
+    # name the bound of the 8-bit search.  Counters of analyse_spec_kernel<1, 8, 2, 8, true> on cfg2 (one launch of 4096 chains), then the phase cycles of one chain
+    # (specprof variant), then the same two for hd16 and cfg3 for comparison
+    for c in cfg2 hd16; do
+        PMC_FILTER=analyse_spec bash tools/pmc.sh "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM_RD SQ_LDS_BANK_CONFLICT" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_BUSY_avr" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE" -- python bench.py --config $c --no-cpu --no-parity --no-traffic --steps 1 --warmup 0 --slots 1 > /dev/null 2>&1
+        cp $out/pmc_summary.txt $out/r6_${c}_search_counters.txt
+    done
+    for c in cfg2 hd16 cfg3; do
+        echo "== $c"; MVX_LIB=$PWD/tools/variants/specprof.so timeout 300 python tools/specprof.py $c 2>&1 | grep -v amdgpu.ids
+    done | tee $out/r6_spec_phase_cycles.txt
+}
+
+r6_shadow8() {
+    # r6 experiment: three byte-shifted copies of every 8-bit luma plane (every reference load of the 8-bit row passes dword-aligned: 16 instead of 64 texture-path cycles)
+    MVX_SHADOW8=1 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "speculative_kernel_8bit or analyse_parity or degrain_parity or golden or full_size_parity_cfg2" 2>&1 | tail -4
+    for c in cfg2 cfg4 hd16; do
+        for s8 in 0 1; do
+            MVX_SHADOW8=$s8 timeout 600 python bench.py --config $c --no-cpu --no-traffic --slots 1 --steps 3 --warmup 1 2>/dev/null | tail -1 | line "$c shadow8=$s8"
+        done
+    done 2>&1 | tee $out/r6_shadow8_ab.txt
+}
+
+r6_stats() {
+    # strip / block windows of stage 2 per level (specstats variant), phase cycles of one chain (specprof variant)
+    MVX_LIB=$PWD/tools/variants/specstats.so timeout 300 python tools/specstats.py cfg3 341 2>&1 | grep -v amdgpu.ids | tee $out/r6_spec_window_stats.txt
+    MVX_LIB=$PWD/tools/variants/specprof.so timeout 300 python tools/specprof.py cfg3 2>&1 | grep -v amdgpu.ids | tee $out/r6_spec_phase_cycles_cfg3.txt
+}
+
+r6_k34() {
+    # chains per SIMD of the 8-bit row-pass builds: 2 (256 registers, the default), 3 (168), 4 (128)
+    for c in cfg2 cfg4 hd16; do
+        for k in 0 3 4; do
+            MVX_FAST_K=$k timeout 600 python bench.py --config $c --no-cpu --no-traffic --slots 1 --steps 3 --warmup 1 2>/dev/null | tail -1 | line "$c fast_k=$k"
+        done
+    done 2>&1 | tee $out/r6_8bit_chains_per_simd.txt
+}
+
 "r6_$1" "${@:2}"

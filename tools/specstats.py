@@ -15,7 +15,7 @@ import mvtools_amd as mv  # noqa: E402
 cfg = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "cfg3"]
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 p = bench.Pipeline(mv, torch, cfg, batch, torch.device("cuda", 0), 1)
-out = (C.c_ulonglong * (16 * 4))()
+out = (C.c_ulonglong * (24 * 8))()  # MVX_MAX_LEVELS x 8
 p.step()
 torch.cuda.synchronize()
 assert mv.lib().mvx_debug_specstats(out, 1) == 0
@@ -25,6 +25,9 @@ assert mv.lib().mvx_debug_specstats(out, 1) == 0
 print("batch %d: search launch %.1f ms (counting build)" % (batch, p.ev[0][0].elapsed_time(p.ev[0][1])))
 print("level: blocks in speculated rows, searched live (share), of them flag clear (hexagon won / rescue), accepted after redoing the predictor phase with the true left / median")
 for lv in range(16):
-    b, live, flag, resc = (int(out[lv * 4 + i]) for i in range(4))
+    b, live, flag, resc, ws, wb, dev, lim = (int(out[lv * 8 + i]) for i in range(8))
     if b:
         print("%5d: %12d %12d (%5.2f %%) %12d %10d" % (lv, b, live, 100.0 * live / b, flag, resc))
+        if ws + wb:
+            print("       stage-2 windows (16x16 row passes): strip form %d (%.1f %%), block form %d -- %.2f blocks per block-form window whose centre differs from the window's first block, %d block-form windows for the limits alone" % (
+                ws, 100.0 * ws / (ws + wb), wb, dev / max(wb, 1), lim))

@@ -43,11 +43,12 @@ struct MvxDebug {
     int spec = 1;      // default search: 1 = the speculative kernel (mvx_analyse_spec.h), 0 = the lean serial kernel (mvx_analyse_fast.h), 2 = the speculative kernel's code with speculation off (every block live), 3 = speculative without runs (every block's candidates loaded on their own), 5 = speculative for every shape it can run (by default only where its row passes apply)
     int team = -1;     // waves per chain of the speculative kernel's team form (mvx_analyse_spec.h: TEAM): 0 = never, 2..8 = always that many, -1 = the library's choice
     int super_rows_off = 0; // 1: mv.Super level 0 / first reduction through the LDS-tile / per-sample kernels only
+    int shadow8 = 0;   // r6 experiment: 8-bit clips keep THREE byte-shifted copies of their luma planes too (takes effect at mvx_super_shadow_bytes / the Super calls / mvx_analyse_set_ref_shadow)
     int ablate = 0;
 };
 static MvxDebug g_dbg;
 extern "C" __attribute__((visibility("default"))) int mvx_debug_option(const char *name, int value) {
-    struct { const char *n; int *p; } tab[] = { { "general", &g_dbg.general }, { "fast_wpe", &g_dbg.fast_wpe }, { "cpw1", &g_dbg.cpw1 }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "fast_cpw", &g_dbg.fast_cpw }, { "fast_k", &g_dbg.fast_k }, { "fast_lds_min", &g_dbg.fast_lds_min }, { "fast_flags", &g_dbg.fast_flags }, { "pad_runs", &g_dbg.pad_runs }, { "shadow_planes", &g_dbg.shadow_planes }, { "degrain_xcd", &g_dbg.degrain_xcd }, { "degrain_shadow", &g_dbg.degrain_shadow }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min }, { "super_rows_off", &g_dbg.super_rows_off }, { "spec", &g_dbg.spec }, { "team", &g_dbg.team },
+    struct { const char *n; int *p; } tab[] = { { "general", &g_dbg.general }, { "fast_wpe", &g_dbg.fast_wpe }, { "cpw1", &g_dbg.cpw1 }, { "no_wpe2", &g_dbg.no_wpe2 }, { "no_wpe3", &g_dbg.no_wpe3 }, { "wpe3_u16", &g_dbg.wpe3_u16 }, { "fast_cpw", &g_dbg.fast_cpw }, { "fast_k", &g_dbg.fast_k }, { "fast_lds_min", &g_dbg.fast_lds_min }, { "fast_flags", &g_dbg.fast_flags }, { "pad_runs", &g_dbg.pad_runs }, { "shadow_planes", &g_dbg.shadow_planes }, { "degrain_xcd", &g_dbg.degrain_xcd }, { "degrain_shadow", &g_dbg.degrain_shadow }, { "cpw_sync", &g_dbg.cpw_sync }, { "lds_min", &g_dbg.lds_min }, { "super_rows_off", &g_dbg.super_rows_off }, { "spec", &g_dbg.spec }, { "team", &g_dbg.team }, { "shadow8", &g_dbg.shadow8 },
 #ifdef MVX_LAB
         { "ablate", &g_dbg.ablate },
 #endif
@@ -68,6 +69,7 @@ extern "C" __attribute__((visibility("default"))) void mvx_debug_last_launch(int
 int mvx_debug_value(const char *name, int def) {
     if (!strcmp(name, "degrain_xcd")) return g_dbg.degrain_xcd >= 0 ? g_dbg.degrain_xcd : def;
     if (!strcmp(name, "super_rows_off")) return g_dbg.super_rows_off;
+    if (!strcmp(name, "shadow8")) return g_dbg.shadow8;
     if (!strcmp(name, "degrain_shadow")) return g_dbg.degrain_shadow;
     return def;
 }
@@ -282,7 +284,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_set_ref_shadow
         const long long v = copy_stride ? (long long)copy_stride[p] : 0;
         if (v < 0 || v % 16) { mvx_set_error("mvx_analyse_set_ref_shadow: copy strides must be non-negative multiples of 16 bytes"); return MVX_E_ARG; }
         a->P.shadow[p] = ((p == 0 && !(g_dbg.shadow_planes & 1)) || (p > 0 && !(g_dbg.shadow_planes & 2))) ? 0 : v;
-        if (p == 0 && a->P.bps == 1) a->P.shadow[0] = 0; // (8-bit super frames carry the UV plane only)
+        if (p == 0 && a->P.bps == 1 && !g_dbg.shadow8) a->P.shadow[0] = 0; // (8-bit super frames carry the UV plane only)
     }
     std::lock_guard<std::mutex> lk(a->guard.mu);
     if (a->dP) HIP_CHECK(hipMemcpy(a->dP, &a->P, sizeof(AParams), hipMemcpyHostToDevice)); // (synchronous: no launch of this handle is reading it concurrently unless the caller races)
@@ -376,26 +378,37 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         // ... except as TEAMS in a launch that leaves the GPU's wave slots empty (r5): there the speculative kernel wins for every shape it can run, row passes or
         // not (132 chains of cfg5: 974 ms serial, 352 ms as teams of four; 128 chains of 8-bit 16x16 blocks: 140 / 43 ms; at ~512 chains it is a tie:
         // profiles/r5_team_other_shapes.txt).  The library's own choice only: any forced "spec" / "team" value keeps its meaning.
-        const bool teamAnyShape = g_dbg.spec == 1 && g_dbg.team < 0 && mvx_team_default(njobs, simds, false, P.bps) > 0;
+        // (r6, ADVICE r5: whether a team FITS is decided here, before anything is sized for the speculative kernel -- a shape without row passes whose team
+        // would not fit the CU's LDS (a very wide frame) stays on the serial kernel with the serial kernel's LDS sizing instead of running the one-wave
+        // speculative kernel, which loses to it: cfg2, cfg4, cfg5 above)
+        const int sStrip = (P.bps == 2 && (P.blkX == 16 || (MVX_STRIP32 && P.blkX == 32))) ? (P.blkX + P.blkX / 2) * 128 : (P.bps == 1 && P.blkX == 16) ? 24 * 64 : 0; // the source strip of a window of blocks: 24 (48) rows x 8 columns (mvx_analyse_spec.h: STRIP_OK)
+        const int sSrc = stripShape8 ? 16 + 768 : fRow < sStrip ? sStrip : fRow; // (8-bit 8x8: 16 bytes of slack + 12 rows x 64 bytes)
+        int sNeed = 0, sTabMax = 0; // per level: row buffer (8 B per block of THAT level) + the table of its search type; the largest SAD table of any level
+        for (int i = 0; i < P.nLevels; i++) {
+            const bool smallest = i == P.nLevels - 1;
+            const int st = smallest ? (P.nLevels == 1 ? P.searchType : P.searchTypeCoarse) : (i == 0 ? P.searchType : P.searchTypeCoarse);
+            const int tabB = (st == SearchHex2 ? SPEC_SLOTS_HEX : SPEC_SLOTS_EXH) * SPEC_STRIDE;
+            const int need = sSrc + ((P.lv[i].nBlkX * 8 + 15) & ~15) + tabB;
+            if (need > sNeed) sNeed = need;
+            if (tabB > sTabMax) sTabMax = tabB;
+        }
+        if (sNeed < sSrc + fBins * 4) sNeed = sSrc + fBins * 4;
+        // the team form's LDS: [64 B control words | row buffer] shared + per wave [source strip / block | SAD table]; the histogram of the global-motion estimate lies over the table
+        const int teamShared = (64 + fMaxBlkX * 8 + 255) & ~255;
+        const int teamPerWave = ((sSrc + sTabMax < sSrc + fBins * 4 ? sSrc + fBins * 4 : sSrc + sTabMax) + 255) & ~255;
+        auto teamThatFits = [&](int team) { // waves per chain after the LDS limit (0: no team)
+            if (team == 1 || team > 8) team = 0;
+            while (team > 1 && teamShared + teamPerWave * team > 160 * 1024) team--;
+            return team > 1 ? team : 0;
+        };
+        const bool teamAnyShape = g_dbg.spec == 1 && g_dbg.team < 0 && teamThatFits(mvx_team_default(njobs, simds, false, P.bps)) > 0;
         const bool useSpec = g_dbg.spec != 0 && (stripShape || g_dbg.spec >= 2 || teamAnyShape);
         const bool useSpecStrips = useSpec && g_dbg.spec != 3 && stripShape;
-        int sTab = 0, sRow = fRow, sTabMax = 0; // (sTabMax: the largest SAD table of any level)
+        int sTab = 0, sRow = fRow;
         if (useSpec) {
-            const bool anyExh = P.searchType == SearchExhaustive || (P.nLevels > 1 && P.searchTypeCoarse == SearchExhaustive);
-            const int sStrip = (P.bps == 2 && (P.blkX == 16 || (MVX_STRIP32 && P.blkX == 32))) ? (P.blkX + P.blkX / 2) * 128 : (P.bps == 1 && P.blkX == 16) ? 24 * 64 : 0; // the source strip of a window of blocks: 24 (48) rows x 8 columns (mvx_analyse_spec.h: STRIP_OK)
-            const int sSrc = stripShape8 ? 16 + 768 : fRow < sStrip ? sStrip : fRow; // (8-bit 8x8: 16 bytes of slack + 12 rows x 64 bytes)
             sRow = sSrc;
             sTab = sSrc + ((fMaxBlkX * 8 + 15) & ~15);
-            fNeed = 0; // per level: row buffer (8 B per block of THAT level) + the table of its search type
-            for (int i = 0; i < P.nLevels; i++) {
-                const bool smallest = i == P.nLevels - 1;
-                const int st = smallest ? (P.nLevels == 1 ? P.searchType : P.searchTypeCoarse) : (i == 0 ? P.searchType : P.searchTypeCoarse);
-                const int need = sSrc + ((P.lv[i].nBlkX * 8 + 15) & ~15) + (st == SearchHex2 ? SPEC_SLOTS_HEX : SPEC_SLOTS_EXH) * SPEC_STRIDE;
-                if (need > fNeed) fNeed = need;
-                const int tabB = (st == SearchHex2 ? SPEC_SLOTS_HEX : SPEC_SLOTS_EXH) * SPEC_STRIDE;
-                if (tabB > sTabMax) sTabMax = tabB;
-            }
-            if (fNeed < sRow + fBins * 4) fNeed = sRow + fBins * 4;
+            fNeed = sNeed;
         }
         const int perChain = (fNeed + 255) & ~255;
         // builds per (sample size, block size): chains per SIMD that exist (mvx_analyse_u8.hip / _u16.hip)
@@ -458,22 +471,20 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
             // TEAM form (r5): the nw waves of a workgroup walk ONE chain.  A chain finishes ~nw times sooner and a launch keeps nw times fewer chains resident
             // per wave slot, so it is the form for launches that do not fill the GPU with one wave per chain (a frame server's look-ahead window); for
             // big batches the choice is measured.  LDS: [64 B control words | row buffer] shared + per wave [source strip | SAD table]
+            const int specSide = (P.blkX == 16 && P.ovX == 0) ? 1 : 0; // 16x16 blocks side by side: the SIDE builds of the speculative kernel (their row passes step by a whole block)
             int team = 0;
             if (useSpec) {
                 team = g_dbg.team >= 0 ? g_dbg.team : mvx_team_default(njobs, simds, useSpecStrips, P.bps);
                 if (team == 1 || team > 8) team = 0;
             }
+            team = teamThatFits(team);
             if (team) {
-                const int shared = (64 + fMaxBlkX * 8 + 255) & ~255;
-                int perWave = sRow + sTabMax; // [source strip / block | SAD table]; the histogram of the global-motion estimate lies over the table
-                if (perWave < sRow + fBins * 4) perWave = sRow + fBins * 4;
-                perWave = (perWave + 255) & ~255;
-                while (team > 1 && shared + perWave * team > 160 * 1024) team--;
+                const int shared = teamShared, perWave = teamPerWave;
                 if (team > 1) {
                     ALaunch TL = L;
                     TL.ldsRow = shared; TL.ldsNeed = perWave; TL.ldsHist = sRow; TL.syncEvery = 0; TL.fast = 2; TL.cpw = 1;
-                    // the table of the job list is NOT padded for this form (one chain per workgroup); padding entries are skipped by the kernel
-                    const ASpecLaunch SL = { TL, sRow, team };
+                    // (the job table may carry padding entries, blob == NULL, from the run padding above: the kernel skips them, `!J.blob`)
+                    const ASpecLaunch SL = { TL, sRow, team, specSide };
                     rc = P.bps == 1 ? mvx_analyse_launch_spec_u8(P, SL) : mvx_analyse_launch_spec_u16(P, SL);
                     if (rc == MVX_OK) {
                         g_lastLaunch[0] = 2; g_lastLaunch[1] = team; g_lastLaunch[2] = 0; g_lastLaunch[3] = ntab; g_lastLaunch[4] = 3;
@@ -484,7 +495,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
                     if (rc != 1) return rc;
                 }
             }
-            if (useSpec) { const ASpecLaunch SL = { L, sTab, 0 }; rc = P.bps == 1 ? mvx_analyse_launch_spec_u8(P, SL) : mvx_analyse_launch_spec_u16(P, SL); }
+            if (useSpec) { const ASpecLaunch SL = { L, sTab, 0, specSide }; rc = P.bps == 1 ? mvx_analyse_launch_spec_u8(P, SL) : mvx_analyse_launch_spec_u16(P, SL); }
             else rc = P.bps == 1 ? mvx_analyse_launch_fast_u8(P, L) : mvx_analyse_launch_fast_u16(P, L);
             if (rc == MVX_OK) {
                 g_lastLaunch[0] = k; g_lastLaunch[1] = cpw; g_lastLaunch[2] = syncEvery; g_lastLaunch[3] = ntab; g_lastLaunch[4] = useSpec ? 2 : 0;

@@ -100,8 +100,7 @@ static inline bool mvx_fast_eligible(const AParams &P) {
             if (v < 0 || v > 0x7fffffffLL) return false;
         }
         if ((long long)L.pel * L.pel * L.pstride[0] >= 0xffffffffLL || (long long)L.pel * L.pel * L.pstride[1] >= 0xffffffffLL) return false; // 32-bit plane offsets
-        if ((long long)L.pel * L.pel * L.pstride[0] + P.shadow[0] >= 0xffffffffLL || 2 * (long long)L.pel * L.pel * L.pstride[1] + P.shadow[1] >= 0xffffffffLL) return false;
-        if (P.shadow[0] && P.bps != 2) return false; // (shadow planes exist for 16-bit clips only)
+        if ((long long)L.pel * L.pel * L.pstride[0] + (P.bps == 1 ? 3 : 1) * P.shadow[0] >= 0xffffffffLL || 2 * (long long)L.pel * L.pel * L.pstride[1] + P.shadow[1] >= 0xffffffffLL) return false;
         if ((L.pw << L.logPel) >= 30000 || (L.ph << L.logPel) >= 30000) return false; // vectors and their squared distances stay well inside int
     }
     return true;

@@ -63,7 +63,7 @@ static __device__ int g_specdbgAt[3];
 #define SPECDBG_HERE() (lvl == g_specdbgAt[0] && blky == g_specdbgAt[1] && c0 == g_specdbgAt[2])
 #endif
 #ifdef MVX_SPEC_STATS
-static __device__ unsigned long long g_specstat[MVX_MAX_LEVELS][4]; // per level: blocks in speculated rows, of them searched live, live because the flag was clear, rescues
+static __device__ unsigned long long g_specstat[MVX_MAX_LEVELS][8]; // per level: blocks in speculated rows, of them searched live, live because the flag was clear, rescues; 16x16 row passes: windows of stage 2 in strip form, in block form, blocks of block-form windows whose centre differs from the window's first block, block-form windows because of the limits alone
 #endif
 
 // SWIN: row loads a lane keeps in flight in the row passes (12 = half a pass; 24 = a whole pass: the builds with 256 registers)
@@ -77,7 +77,9 @@ static __device__ unsigned long long g_specstat[MVX_MAX_LEVELS][4]; // per level
 // and in reference order; the SAD work of nw groups overlaps.  A chain finishes ~nw times sooner, so a launch keeps nw times fewer chains resident for
 // the same number of waves: their live reference rows share the L2 / the Infinity Cache among fewer chains, and small launches (a frame server's
 // look-ahead window) fill the GPU.  Results are those of the single-wave form by construction: every decision in A2 / B is taken with the same inputs.
-template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct SpecSearcher : FastSearcher<BPS, BW, UV, 48> {
+// SIDE (r6; a run-time flag of the level in r5, which cost the overlapped builds registers and 3 % of their launch time): the build for 16x16 blocks SIDE BY SIDE
+// (overlap 0): a block is two columns and steps by two, a window holds four
+template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false, bool SIDE = false> struct SpecSearcher : FastSearcher<BPS, BW, UV, 48> {
     typedef FastSearcher<BPS, BW, UV, 48> F;
     typedef FGeo<BPS, BW> G;
     using F::P; using F::J; using F::lds; using F::ldsRow; using F::ldsHist; using F::histBins;
@@ -102,8 +104,21 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
         for (int i = 0; i < hiE - lo; i++) g = clampAt(g, fwd ? lo + i : hiE - 1 - i);
         return g;
     }
+    // The token protocol rests on two properties of the launch (r6): every wave of the workgroup is RESIDENT while another one spins (a workgroup is
+    // dispatched to one CU as a whole and is never pre-empted wave by wave: the spin cannot starve the wave it waits for), and the waves share the CU's L1
+    // (the library is built without -mtgsplit: in threadgroup-split mode the waves of a workgroup may sit on different CUs, and global `vectors[]` written by one
+    // wave would need an agent-scope release to reach another).  -DMVX_TEAM_WATCHDOG (developer builds): a wait that lasts ~2^26 sleeps traps instead of hanging,
+    // so that an ordering bug shows up as a launch error.
     __device__ __forceinline__ void team_wait_ge(int need) const { // until the results of the first `need` groups of this level are written
-        while (uni(__hip_atomic_load(ctl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(2);
+#ifdef MVX_TEAM_WATCHDOG
+        unsigned spins = 0;
+#endif
+        while (uni(__hip_atomic_load(ctl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) {
+            __builtin_amdgcn_s_sleep(2);
+#ifdef MVX_TEAM_WATCHDOG
+            if (++spins > (1u << 26)) __builtin_trap();
+#endif
+        }
     }
     __device__ __forceinline__ void team_acquire(int myG, int &px, int &py, int &ps) { // the token reaches group myG: the walk's state behind group myG - 1
         team_wait_ge(myG);
@@ -232,6 +247,7 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
     // HC = 16-byte columns per half block (a 32x32 block row is four columns, blocks step by two); a window is eight columns: 7 (3) blocks;
     // block form: LPB lanes per block, LPC per candidate (four candidates: lanes 0..4 * LPC - 1; lanes 56-63 stay free for the zero vector's strip)
     static constexpr int HC = STRIP_OK ? BW / 16 : 1, SW_BLOCKS = 8 / HC - 1, LPB = 2 * HC, LPC = SW_BLOCKS * LPB;
+    static_assert(!SIDE || (STRIP_OK && HC == 1), "blocks side by side: 16x16 row passes only");
     static constexpr int pickSW(int nt, int w) { return w <= 1 ? 1 : (w <= nt && nt % w == 0) ? w : pickSW(nt, w - 1); } // rows in flight: a divisor of the rows of a pass
     static constexpr int SNA = BW, SNB = UV ? BW / 2 : 0, SNT = SNA + SNB, SW = pickSW(SNT, (BW == 32 && SWIN > 12) ? 12 : SWIN), S_UV = SNA * ROWB, SSTG = SNT / 8; // (32x32: 12 in flight -- 24 plus the six staging pieces spill) // rows of a pass, loads in flight, LDS offset of the UV rows, staging pieces per lane
     struct StripPass { v4u r[SW]; unsigned curA, curB, aL, aC; };
@@ -408,7 +424,7 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
             // (16-bit: LPC lanes per block-form candidate -- 14 for 16x16 blocks.  r4 had the 14 written out here, which made the block-form stage 2 of a 32x32 build
             // (LPC = 12) mix two pattern points in the blocks of lanes 12-13, 24-27 and 36-41: the "8K clip that disagreed with the oracle" of r4 -- one block in
             // 128 851, profiles/r5_strip32_mismatch_found.txt)
-            const bool side16 = STRIP_OK && HC == 1 && stepX == BW; // (16x16 blocks side by side: four blocks per window, eight lanes per block-form candidate)
+            constexpr bool side16 = SIDE; // (16x16 blocks side by side: four blocks per window, eight lanes per block-form candidate)
             const int gb = side8 ? l >> 3 : STRIP8_OK ? (l >= 45 ? 3 : l >= 30 ? 2 : l >= 15 ? 1 : 0) : side16 ? min(l >> 3, 3) : min(l / LPC, 3);
             for (int q = 0; q < 8; q++) {
                 int dx, dy;
@@ -419,7 +435,7 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
             }
         }
 #ifdef MVX_SPEC_STATS
-        unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
+        unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, st6 = 0, st7 = 0;
 #endif
 
         int prevX = 0, prevY = 0, prevSad = 0;
@@ -596,7 +612,7 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
 
                         // ======== A: the SADs of every block of the group, nothing serial in between
                         const int nb = hiE - lo;
-                        const bool lumaStrips = STRIP_OK && !UV && !chroma && stripEnabled && (stepX == BW / 2 || (BW == 16 && stepX == BW)); // luma-only search: row passes without UV rows
+                        const bool lumaStrips = STRIP_OK && !UV && !chroma && stripEnabled && stepX == (SIDE ? BW : BW / 2); // luma-only search: row passes without UV rows
                         const bool streamed = (chroma && (hexLevel ? STREAM_HEX : STREAM_EXH)) || lumaStrips;
                         if (streamed) {
                             const int pkZ = pk(0, fieldShift);
@@ -618,9 +634,9 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
                             if constexpr (STRIP_OK) {
                                 // (r5: 16x16 blocks SIDE BY SIDE -- overlap 0, the reference's default -- take the same passes: a block is two columns and steps by TC = two,
                                 // a window holds four; no column sum is shared, the strips stay contiguous)
-                                const bool side = HC == 1 && stepX == BW;
-                                if (stripEnabled && (stepX == BW / 2 || side) && (UV ? chroma != 0 : chroma == 0)) {
-                                    const int TC = side ? 2 : HC, SWB = side ? 4 : SW_BLOCKS, LPCr = SWB * LPB; // columns per block step, blocks per window, lanes per block-form candidate
+                                constexpr bool side = SIDE;
+                                if (stripEnabled && stepX == (side ? BW : BW / 2) && (UV ? chroma != 0 : chroma == 0)) {
+                                    constexpr int TC = side ? 2 : HC, SWB = side ? 4 : SW_BLOCKS, LPCr = SWB * LPB; // columns per block step, blocks per window, lanes per block-form candidate
                                     const int nw = (nb + SWB - 1) / SWB;
                                     const int npat = hexLevel ? 14 : 24;
                                     pbMask = 0;
@@ -712,13 +728,16 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
 #pragma unroll
                                         for (int k = 0; k < SSTG; k++) st_chunk_l(lds + (gS + 8 * k) * ROWB + pS * COLB, stg[k], COLB); // (S_UV = SNA * ROWB: the UV rows follow the luma rows)
                                     };
+                                    // (r6: the two stages WINDOW BY WINDOW -- stage 1, predictor phase, stage 2 of one window before the next window's stage 1, so that stage 2
+                                    // would find stage 1's lines in the L2 -- fetches as much as this order: 1 357 against 1 302 GB per 2046-chain launch, profiles/r6_window_major_ab.txt.
+                                    // On a clip whose vectors are whole pels stage 1 reads the integer-pel plane and stage 2 mostly the three others: little to share)
                                     // (a leading-edge prefetch -- one dword of every line a window two ahead will need, four scattered loads per window --
                                     // was measured and removed: 493 -> 544 ms per 2046-chain launch, profiles/r4_spec_prefetch.txt)
                                     auto widx = [&](int i) { return fwd ? i : nw - 1 - i; }; // windows in walk order
                                     auto npass = [&](int st, int w) { return st == 1 ? 1 : ((stripW >> w) & 1) ? (npat + 7) / 8 : (npat + 3) / 4; };
                                     // one stage: a stream of passes whose loads stay in flight across passes and windows
-                                    auto run_stage = [&](int st) {
-                                        int wi = 0, w = widx(0), q = 0;
+                                    auto run_stage = [&](int st, int wFrom, int wTo) { // the windows wFrom .. wTo - 1 in walk order
+                                        int wi = wFrom, w = widx(wFrom), q = 0;
                                         StripPass T;
                                         int slot, colW, srcCol; bool stripLane; unsigned oA, oB;
                                         roles();
@@ -729,7 +748,7 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
                                             roles();
                                             int wn = w, qn = q + 1, win = wi;
                                             if (qn >= npass(st, w)) { qn = 0; win = wi + 1; wn = widx(win); }
-                                            const bool more = win < nw;
+                                            const bool more = win < wTo;
                                             int slotN = -1, colN = 0, srcN = 0; bool stripN = false; unsigned nA = 0, nB = 0;
                                             SPROF(2);
                                             if (more) w_cand(st, wn, qn, slotN, colN, stripN, srcN, nA, nB); // the pass after this one (its loads refill the window of loads while this one is consumed)
@@ -737,7 +756,7 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
                                             if (q == 0) { // a new window: its source strip (requested one window ahead)
                                                 __builtin_amdgcn_wave_barrier();
                                                 stage_store();
-                                                if (wi + 1 < nw) stage_issue(widx(wi + 1));
+                                                if (wi + 1 < wTo) stage_issue(widx(wi + 1));
                                                 __builtin_amdgcn_wave_barrier();
                                             }
                                             SPROF(12);
@@ -760,7 +779,7 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
                                         }
                                         __builtin_amdgcn_wave_barrier();
                                     };
-                                    run_stage(1);
+                                    run_stage(1, 0, nw);
                                     a2_pred(pBest, pX_, pY_, pSad); // the predictor phase of every block of the group
                                     pkW = pk(pX_, pY_);
 #if MVX_SPEC_ABL == 9
@@ -778,9 +797,13 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
                                             const bool inw = (l >= f) & (l < e);
                                             const int w0 = __builtin_amdgcn_readlane(pkW, f);
                                             if (MVX_SPEC_ABL != 7 && e - f >= 2 && __ballot(inw & ((pkW != w0) | !ok2)) == 0) stripW |= 1u << w; // (ABL 7: block form only)
+#ifdef MVX_SPEC_STATS
+                                            if ((stripW >> w) & 1) st4 += 1;
+                                            else { st5 += 1; st6 += __builtin_popcountll(__ballot(inw & (pkW != w0))); if (__ballot(inw & (pkW != w0)) == 0) st7 += 1; }
+#endif
                                         }
                                     }
-                                    run_stage(2);
+                                    run_stage(2, 0, nw);
                                 }
                             }
 
@@ -1207,7 +1230,7 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
                                 auto totS = [&](int slot) { const v2u t = *(const LDS_AS v2u *)(tcol + slot * SPEC_STRIDE); return uni((int)t[0] + (chroma ? (int)t[1] : 0)); };
                                 const int lamS = __builtin_amdgcn_readlane(lamG, li);
                                 auto mdS = [&](int vx, int vy) { const unsigned dx = (unsigned)(upx(sH) - vx), dy = (unsigned)(upy(sH) - vy); return (int)(((long long)lamS * (int)(dx * dx + dy * dy)) >> 8); };
-                                int best, wx = 0, wy = fieldShift, ws;
+                                int best, wx = 0, wy = fieldShift, ws; (void)ws;
                                 { const int t = totS(slotZB); best = F::sat_add(0, t + (int)(((long long)penaltyZero * t) >> 8)); ws = t; }
                                 { const int t = totS(slotZB + 1); const int cc = F::sat_add(0, t + (int)(((long long)pglobal * t) >> 8)); if (cc < best) { best = cc; wx = upx(sG); wy = upy(sG); ws = t; } }
                                 { const int t = totS(slotZB + 2); const int cc = F::sat_add(0, t); if (cc < best) { best = cc; wx = upx(sH); wy = upy(sH); ws = t; } }
@@ -1324,7 +1347,7 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
             }
         }
 #ifdef MVX_SPEC_STATS
-        if (l == 0) { atomicAdd(&g_specstat[lvl][0], st0); atomicAdd(&g_specstat[lvl][1], st1); atomicAdd(&g_specstat[lvl][2], st2); atomicAdd(&g_specstat[lvl][3], st3); }
+        if (l == 0) { atomicAdd(&g_specstat[lvl][0], st0); atomicAdd(&g_specstat[lvl][1], st1); atomicAdd(&g_specstat[lvl][2], st2); atomicAdd(&g_specstat[lvl][3], st3); atomicAdd(&g_specstat[lvl][4], st4); atomicAdd(&g_specstat[lvl][5], st5); atomicAdd(&g_specstat[lvl][6], st6); atomicAdd(&g_specstat[lvl][7], st7); }
 #endif
         SPROF(7);
         // vectors[] of this level feed the next level's interpolation / global-MV estimate (other lanes read them)
@@ -1337,7 +1360,7 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false> struct Spe
 // The launch shape is analyse_fast_kernel's: workgroups of 4 * WPE chains that are consecutive entries of the (reference-sorted) job table.
 // TEAM: the workgroup's waves walk ONE chain (blockDim.x / 64 of them; workgroup b = entry b of the job table).  LDS: [control words 64 B | the previous block
 // row's results | one area of ldsChain bytes per wave: source strip / block, SAD table]; ldsRow carries the size of the shared part
-template <int BPS, int BW, int WPE, int MAXCPW, bool UV, bool TEAM = false>
+template <int BPS, int BW, int WPE, int MAXCPW, bool UV, bool TEAM = false, bool SIDE = false>
 __global__ __launch_bounds__(64 * MAXCPW, WPE) void analyse_spec_kernel(const AParams *Pp, const AJob *jobs, int njobs, int ldsChain, int syncEvery, int ldsRow, int ldsHist, int histBins, int ldsTab, int flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const AParams &P = *Pp;
@@ -1368,7 +1391,7 @@ __global__ __launch_bounds__(64 * MAXCPW, WPE) void analyse_spec_kernel(const AP
         return;
     }
     if (l == 0 && (!TEAM || wave == 0)) { hdr[0] = P.blobSize; hdr[1] = 1; } // GroupOfPlanes.c:77-85
-    SpecSearcher<BPS, BW, UV, (WPE <= 2 ? 24 : MVX_SPEC_SW3), TEAM> S(P, J);
+    SpecSearcher<BPS, BW, UV, (WPE <= 2 ? 24 : MVX_SPEC_SW3), TEAM, SIDE> S(P, J);
     S.lds = (lds_u8 *)smem + (TEAM ? ldsRow : 0) + wave * ldsChain;
     S.ldsRow = ldsRow; S.ldsHist = ldsHist; S.histBins = histBins; S.ldsTab = ldsTab;
     S.role = wave; S.nw = uni((int)(blockDim.x >> 6)); S.ctl = (LDS_AS int *)((lds_u8 *)smem); S.shRow = (lds_u8 *)smem + 64;
@@ -1402,46 +1425,46 @@ extern "C" __attribute__((visibility("default"))) int mvx_debug_specdbg_at(int l
 #endif
 #if defined(MVX_SPEC_STATS) && defined(MVX_PROF_EXPORT)
 extern "C" __attribute__((visibility("default"))) int mvx_debug_specstats(unsigned long long *out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_specstat), sizeof(unsigned long long) * MVX_MAX_LEVELS * 4) != hipSuccess) return -1;
-    if (reset) { static unsigned long long z[MVX_MAX_LEVELS * 4]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_specstat), z, sizeof(z)) != hipSuccess) return -1; }
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_specstat), sizeof(unsigned long long) * MVX_MAX_LEVELS * 8) != hipSuccess) return -1;
+    if (reset) { static unsigned long long z[MVX_MAX_LEVELS * 8]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_specstat), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
 #endif
 
 // L.ldsRow = offset of the row buffer (8 bytes per block), L.ldsHist = offset of the histogram (lies over row buffer and table: it is
 // only used between levels), L.ldsBytes = offset of the table when L.ldsNeed carries the chain's total
-struct ASpecLaunch { ALaunch L; int ldsTab; int team; }; // team: 0 = one wave per chain, n = the workgroup's n waves walk one chain
-template <int BPS, int BW, int WPE, int MAXCPW, bool UV> static int launch_analyse_spec_uv(const ASpecLaunch &S) {
+struct ASpecLaunch { ALaunch L; int ldsTab; int team; int side; }; // side: 16x16 blocks side by side (overlap 0): the SIDE builds // team: 0 = one wave per chain, n = the workgroup's n waves walk one chain
+template <int BPS, int BW, int WPE, int MAXCPW, bool UV, bool SIDE = false> static int launch_analyse_spec_uv(const ASpecLaunch &S) {
     const ALaunch &L = S.L;
     const int perChain = (L.ldsNeed + 255) & ~255;
     const int cpw = L.cpw < MAXCPW ? L.cpw : MAXCPW;
     int lds = perChain * cpw;
     if (L.ldsBytes > lds && L.ldsBytes <= 160 * 1024) lds = L.ldsBytes; // developer / host option: fewer workgroups per CU
     if (lds > 64 * 1024)
-        HIP_CHECK(hipFuncSetAttribute((const void *)analyse_spec_kernel<BPS, BW, WPE, MAXCPW, UV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL((analyse_spec_kernel<BPS, BW, WPE, MAXCPW, UV>), dim3((L.njobs + cpw - 1) / cpw), dim3(64 * cpw), lds, L.st, L.dP, L.dJobs,
+        HIP_CHECK(hipFuncSetAttribute((const void *)analyse_spec_kernel<BPS, BW, WPE, MAXCPW, UV, false, SIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((analyse_spec_kernel<BPS, BW, WPE, MAXCPW, UV, false, SIDE>), dim3((L.njobs + cpw - 1) / cpw), dim3(64 * cpw), lds, L.st, L.dP, L.dJobs,
                        L.njobs, perChain, L.syncEvery, L.ldsRow, L.ldsHist, L.histBins, S.ldsTab, L.flags);
     return MVX_OK;
 }
-template <int BPS, int BW, int WPE, int MAXCPW> static int launch_analyse_spec(const ASpecLaunch &S) {
-    if (S.L.flags & MVX_FAST_UV) return launch_analyse_spec_uv<BPS, BW, WPE, MAXCPW, true>(S);
-    return launch_analyse_spec_uv<BPS, BW, WPE, MAXCPW, false>(S);
+template <int BPS, int BW, int WPE, int MAXCPW, bool SIDE = false> static int launch_analyse_spec(const ASpecLaunch &S) {
+    if (S.L.flags & MVX_FAST_UV) return launch_analyse_spec_uv<BPS, BW, WPE, MAXCPW, true, SIDE>(S);
+    return launch_analyse_spec_uv<BPS, BW, WPE, MAXCPW, false, SIDE>(S);
 }
 // TEAM: S.team waves per chain, one chain per workgroup; S.L.ldsRow = the shared part (control words + row buffer), S.L.ldsNeed = one wave's own area,
 // S.ldsTab / S.L.ldsHist = offsets of the SAD table / the histogram inside a wave's area
-template <int BPS, int BW, int WPE, int MAXCPW, bool UV> static int launch_analyse_spec_team_uv(const ASpecLaunch &S) {
+template <int BPS, int BW, int WPE, int MAXCPW, bool UV, bool SIDE = false> static int launch_analyse_spec_team_uv(const ASpecLaunch &S) {
     const ALaunch &L = S.L;
     const int nw = S.team < MAXCPW ? S.team : MAXCPW;
     const int perWave = (L.ldsNeed + 255) & ~255;
     int lds = L.ldsRow + perWave * nw;
     if (L.ldsBytes > lds && L.ldsBytes <= 160 * 1024) lds = L.ldsBytes;
     if (lds > 64 * 1024)
-        HIP_CHECK(hipFuncSetAttribute((const void *)analyse_spec_kernel<BPS, BW, WPE, MAXCPW, UV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL((analyse_spec_kernel<BPS, BW, WPE, MAXCPW, UV, true>), dim3(L.njobs), dim3(64 * nw), lds, L.st, L.dP, L.dJobs,
+        HIP_CHECK(hipFuncSetAttribute((const void *)analyse_spec_kernel<BPS, BW, WPE, MAXCPW, UV, true, SIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((analyse_spec_kernel<BPS, BW, WPE, MAXCPW, UV, true, SIDE>), dim3(L.njobs), dim3(64 * nw), lds, L.st, L.dP, L.dJobs,
                        L.njobs, perWave, 0, L.ldsRow, L.ldsHist, L.histBins, S.ldsTab, L.flags);
     return MVX_OK;
 }
-template <int BPS, int BW, int WPE, int MAXCPW> static int launch_analyse_spec_team(const ASpecLaunch &S) {
-    if (S.L.flags & MVX_FAST_UV) return launch_analyse_spec_team_uv<BPS, BW, WPE, MAXCPW, true>(S);
-    return launch_analyse_spec_team_uv<BPS, BW, WPE, MAXCPW, false>(S);
+template <int BPS, int BW, int WPE, int MAXCPW, bool SIDE = false> static int launch_analyse_spec_team(const ASpecLaunch &S) {
+    if (S.L.flags & MVX_FAST_UV) return launch_analyse_spec_team_uv<BPS, BW, WPE, MAXCPW, true, SIDE>(S);
+    return launch_analyse_spec_team_uv<BPS, BW, WPE, MAXCPW, false, SIDE>(S);
 }

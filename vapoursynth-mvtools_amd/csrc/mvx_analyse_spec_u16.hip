@@ -4,6 +4,10 @@
 #include "mvx_analyse_spec.h"
 int mvx_analyse_launch_spec_u16(const AParams &P, const ASpecLaunch &S) {
     const int k = S.L.fast;
+    if (S.side && P.blkX == 16) { // 16x16 blocks side by side: the SIDE builds (256 registers: two chains per SIMD or fewer; teams)
+        if (S.team) return launch_analyse_spec_team<2, 16, 2, 8, true>(S);
+        return launch_analyse_spec<2, 16, 2, 8, true>(S);
+    }
     if (S.team) { // the team form: 256-register builds, up to eight waves per chain
         if (P.blkX == 16) return launch_analyse_spec_team<2, 16, 2, 8>(S);
         if (P.blkX == 32) return launch_analyse_spec_team<2, 32, 2, 8>(S);

@@ -430,16 +430,25 @@ static int super_frames_impl(mvx_super *s, int nframes, const void *const *src, 
 // buffer shifted left by 1 .. n samples (copy k, byte i = plane byte i + k * bps).  A block at a sample position x with
 // x % (4 / bps) == k is then read from copy k at x - k: same samples, dword-aligned address.  mvx_analyse_set_ref_shadow tells
 // a search where the copies are.
-struct ShadowArgs { void *const *planes; long long size[3], stride[3], begin[3]; int nplanes, bps; };
+struct ShadowArgs { void *const *planes; long long size[3], stride[3], begin[3]; int nplanes, bps, copies8; };
 // blockIdx.y = frame * 2 + kind; kind 0: the luma plane shifted left by one sample; kind 1: U and V interleaved sample by sample
 __global__ __launch_bounds__(256) void super_shadow_kernel(ShadowArgs A) {
     const int f = blockIdx.y >> 1, kind = blockIdx.y & 1;
     const long long i = A.begin[kind] + ((long long)blockIdx.x * 256 + threadIdx.x) * 16; // begin: bytes before it were written by the Super kernels themselves
     if (kind == 0) {
-        if (A.bps == 1 || i >= A.size[0]) return; // (8-bit clips keep no shifted luma copy)
+        if ((A.bps == 1 && !A.copies8) || i >= A.size[0]) return; // (8-bit clips keep no shifted luma copy, unless "shadow8" asks for the three)
         unsigned char *base = (unsigned char *)A.planes[f * 3];
         const uint4 a = *(const uint4 *)(base + i);
         const unsigned b = i + 16 < A.size[0] ? *(const unsigned *)(base + i + 16) : 0u;
+        if (A.bps == 1) { // copy k = the plane shifted left by k bytes
+            for (unsigned k = 1; k < 4; k++) {
+                uint4 o;
+                o.x = __builtin_amdgcn_alignbit(a.y, a.x, 8 * k); o.y = __builtin_amdgcn_alignbit(a.z, a.y, 8 * k);
+                o.z = __builtin_amdgcn_alignbit(a.w, a.z, 8 * k); o.w = __builtin_amdgcn_alignbit(b, a.w, 8 * k);
+                *(uint4 *)(base + (long long)k * A.stride[0] + i) = o;
+            }
+            return;
+        }
         const unsigned sh = 8u * A.bps;
         uint4 o;
         o.x = __builtin_amdgcn_alignbit(a.y, a.x, sh); o.y = __builtin_amdgcn_alignbit(a.z, a.y, sh);
@@ -477,10 +486,11 @@ extern "C" __attribute__((visibility("default"))) void mvx_super_shadow_bytes(co
     extra[0] = extra[1] = extra[2] = 0;
     if (!mvx_super_shadow_copies(s)) return;
     if (s->info.bits > 8) extra[0] = (size_t)s->info.plane_height[0] * pitch[0];
+    else if (mvx_debug_value("shadow8", 0)) extra[0] = 3 * (((size_t)s->info.plane_height[0] * pitch[0] + 255) & ~(size_t)255); // (three copies, each at a multiple of the 256-byte rounded plane size)
     if (s->info.num_planes >= 3) extra[1] = 2 * (size_t)s->info.plane_height[1] * pitch[1];
 }
 static int shadow_check(const mvx_super_info &si, const ptrdiff_t pitch[3], const ptrdiff_t copy_stride[3]) {
-    for (int p = si.bits > 8 ? 0 : 1; p < si.num_planes && p < 2; p++) {
+    for (int p = (si.bits > 8 || mvx_debug_value("shadow8", 0)) ? 0 : 1; p < si.num_planes && p < 2; p++) {
         const long long size = (long long)si.plane_height[p] * pitch[p];
         if (pitch[p] % 16 || copy_stride[p] % 16 || copy_stride[p] < size) { mvx_set_error("mvx_super_shadow_frames: pitch and shadow offset must be multiples of 16 bytes, the offset at least one plane"); return MVX_E_ARG; }
     }
@@ -492,9 +502,9 @@ static int shadow_launch(const mvx_super_info &si, int nframes, void *const *dpl
                          const long long begin[2], hipStream_t st) {
     ShadowArgs A;
     memset(&A, 0, sizeof(A));
-    A.nplanes = si.num_planes; A.bps = si.bits > 8 ? 2 : 1; A.planes = dplanes;
+    A.nplanes = si.num_planes; A.bps = si.bits > 8 ? 2 : 1; A.planes = dplanes; A.copies8 = A.bps == 1 && mvx_debug_value("shadow8", 0);
     long long maxsize = 0;
-    for (int p = A.bps == 1 ? 1 : 0; p < si.num_planes && p < 2; p++) {
+    for (int p = (A.bps == 1 && !A.copies8) ? 1 : 0; p < si.num_planes && p < 2; p++) {
         A.size[p] = (long long)si.plane_height[p] * pitch[p]; A.stride[p] = copy_stride[p]; A.begin[p] = begin[p];
         if (A.size[p] - begin[p] > maxsize) maxsize = A.size[p] - begin[p];
     }

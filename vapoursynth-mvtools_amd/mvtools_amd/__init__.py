@@ -171,7 +171,7 @@ def lib():
         # developer / test switches: the library itself never reads the environment (mvx_debug_option is its one hook);
         # this TEST binding forwards the MVX_* variables the tools/ scripts use
         for env, opt in (("MVX_GENERAL", "general"), ("MVX_FAST_WPE", "fast_wpe"), ("MVX_NO_WPE2", "no_wpe2"),
-                         ("MVX_NO_WPE3", "no_wpe3"), ("MVX_WPE3", "wpe3_u16"), ("MVX_FAST_CPW", "fast_cpw"), ("MVX_FAST_FLAGS", "fast_flags"), ("MVX_PAD_RUNS", "pad_runs"), ("MVX_SHADOW_PLANES", "shadow_planes"), ("MVX_DEGRAIN_XCD", "degrain_xcd"), ("MVX_DEGRAIN_SHADOW", "degrain_shadow"), ("MVX_CPW_SYNC", "cpw_sync"), ("MVX_LDS_MIN", "lds_min"), ("MVX_SUPER_ROWS_OFF", "super_rows_off"), ("MVX_ABLATE", "ablate"), ("MVX_FAST_K", "fast_k"), ("MVX_SPEC", "spec"), ("MVX_TEAM", "team"), ("MVX_FAST_LDS_MIN", "fast_lds_min")):
+                         ("MVX_NO_WPE3", "no_wpe3"), ("MVX_WPE3", "wpe3_u16"), ("MVX_FAST_CPW", "fast_cpw"), ("MVX_FAST_FLAGS", "fast_flags"), ("MVX_PAD_RUNS", "pad_runs"), ("MVX_SHADOW_PLANES", "shadow_planes"), ("MVX_DEGRAIN_XCD", "degrain_xcd"), ("MVX_DEGRAIN_SHADOW", "degrain_shadow"), ("MVX_CPW_SYNC", "cpw_sync"), ("MVX_LDS_MIN", "lds_min"), ("MVX_SUPER_ROWS_OFF", "super_rows_off"), ("MVX_ABLATE", "ablate"), ("MVX_FAST_K", "fast_k"), ("MVX_SPEC", "spec"), ("MVX_TEAM", "team"), ("MVX_FAST_LDS_MIN", "fast_lds_min"), ("MVX_SHADOW8", "shadow8")):
             if os.environ.get(env) is not None:
                 L.mvx_debug_option(opt.encode(), int(os.environ[env]))
         if os.environ.get("MVX_CPW") == "1":

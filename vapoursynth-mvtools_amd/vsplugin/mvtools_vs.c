@@ -2059,7 +2059,14 @@ static void VS_CC fpsCreate(const VSMap *in, VSMap *out, void *user, VSCore *cor
 VS_EXTERNAL_API(void) VapourSynthPluginInit2(VSPlugin *plugin, const VSPLUGINAPI *vspapi) {
     /* (the search streams want GPU_MAX_HW_QUEUES >= 12 -- see search_stream_next.  That is a setting of the HOST PROCESS, read once when the HIP
      * runtime initialises: a plugin must not change the process environment behind its host's back, so it is documented in INTEGRATION.md and set
-     * by the mini host / the launch scripts, not here) */
+     * by the mini host / the launch scripts, not here.  r6: an unconfigured host is TOLD once, under MVX_VS_STATS, that its searches will share
+     * the runtime's default four hardware queues) */
+    if (env_long("MVX_VS_STATS", 0)) {
+        const char *q = getenv("GPU_MAX_HW_QUEUES");
+        if (!q || atoi(q) < SEARCH_STREAMS)
+            fprintf(stderr, "mvtools (MI355X): GPU_MAX_HW_QUEUES is %s: the %d search streams of concurrent mv.Analyse instances share the HIP runtime's hardware queues and "
+                            "serialise; export GPU_MAX_HW_QUEUES=16 before starting the host (INTEGRATION.md)\n", q ? q : "unset (runtime default: 4)", SEARCH_STREAMS);
+    }
     vspapi->configPlugin("com.nodame.mvtools", "mv", "MVTools v24", VS_MAKE_VERSION(24, 0), VS_MAKE_VERSION(VAPOURSYNTH_API_MAJOR, VAPOURSYNTH_API_MINOR), 0, plugin);
     vspapi->registerFunction("Super",
                              "clip:vnode;hpad:int:opt;vpad:int:opt;pel:int:opt;levels:int:opt;chroma:int:opt;sharp:int:opt;rfilter:int:opt;pelclip:vnode:opt;opt:int:opt;",
