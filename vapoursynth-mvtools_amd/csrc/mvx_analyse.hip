@@ -381,7 +381,7 @@ extern "C" __attribute__((visibility("default"))) int mvx_analyse_frames(mvx_ana
         // (r6, ADVICE r5: whether a team FITS is decided here, before anything is sized for the speculative kernel -- a shape without row passes whose team
         // would not fit the CU's LDS (a very wide frame) stays on the serial kernel with the serial kernel's LDS sizing instead of running the one-wave
         // speculative kernel, which loses to it: cfg2, cfg4, cfg5 above)
-        const int sStrip = (P.bps == 2 && (P.blkX == 16 || (MVX_STRIP32 && P.blkX == 32))) ? (P.blkX + P.blkX / 2) * 128 : (P.bps == 1 && P.blkX == 16) ? 24 * 64 : 0; // the source strip of a window of blocks: 24 (48) rows x 8 columns (mvx_analyse_spec.h: STRIP_OK)
+        const int sStrip = (P.bps == 2 && P.blkX == 16 && MVX_STRIP_DMA) ? 2 * 24 * 128 /* r6: two strip buffers, filled by LDS-direct loads */ : (P.bps == 2 && (P.blkX == 16 || (MVX_STRIP32 && P.blkX == 32))) ? (P.blkX + P.blkX / 2) * 128 : (P.bps == 1 && P.blkX == 16) ? 24 * 64 : 0; // the source strip of a window of blocks: 24 (48) rows x 8 columns (mvx_analyse_spec.h: STRIP_OK)
         const int sSrc = stripShape8 ? 16 + 768 : fRow < sStrip ? sStrip : fRow; // (8-bit 8x8: 16 bytes of slack + 12 rows x 64 bytes)
         int sNeed = 0, sTabMax = 0; // per level: row buffer (8 B per block of THAT level) + the table of its search type; the largest SAD table of any level
         for (int i = 0; i < P.nLevels; i++) {

@@ -40,6 +40,9 @@
 #ifndef MVX_SPEC_ABL
 #define MVX_SPEC_ABL 0
 #endif
+#ifndef MVX_STRIP_DMA
+#define MVX_STRIP_DMA 1 // r6: the source strip of a window of 16-bit 16x16 blocks goes from global memory straight into LDS (global_load_lds_dwordx4), two buffers
+#endif
 #ifndef MVX_SPEC_SW3
 #define MVX_SPEC_SW3 12 // row loads in flight per lane in the builds for three or more chains per SIMD (168 registers)
 #endif
@@ -262,8 +265,8 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false, bool SIDE 
 #pragma unroll
         for (int k = 0; k < SW; k++) T.r[k] = strip_issue(T, k);
     }
-    template <bool REFILL> __device__ __forceinline__ void strip_run(StripPass &T, int p, unsigned nA, unsigned nB) const {
-        const lds_u8 *sp = lds + p * COLB;
+    template <bool REFILL> __device__ __forceinline__ void strip_run(StripPass &T, int p, unsigned nA, unsigned nB, int bufOff = 0) const {
+        const lds_u8 *sp = lds + bufOff + p * COLB;
         auto src_piece = [&](int k) { return F::template lds_piece<COLB>(sp + (k < SNA ? k * ROWB : S_UV + (k - SNA) * ROWB)); };
         constexpr int D = MVX_SRC_AHEAD;
         v4u a[D];
@@ -714,19 +717,33 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false, bool SIDE 
                                         }
                                     };
                                     // the source strip of window w: lane = (row l >> 3 of 8, column l & 7); luma rows r and r + 8, UV row r
-                                    A4x32 stg[SSTG]; // (rows gS, gS + 8, ...: the luma rows first, then the rows of the UV plane)
-                                    auto stage_issue = [&](int w) {
+                                    // r6, SDMA: sixteen-byte columns, 16x16 blocks -- lane l's piece of rows 8k .. 8k + 7 belongs at byte 16 l of that kilobyte of the strip, which is where
+                                    // global_load_lds_dwordx4 puts it: the strip never passes through registers (twelve fewer live across the passes, no ds_write).  Two buffers: the next
+                                    // window's strip arrives while this window's passes read theirs.  A strip is requested BEFORE the 24 row loads that follow it (the prime, or a pass's
+                                    // refills), so "all but the 24 newest loads have returned" (vmcnt is in order) means it is there
+                                    constexpr bool SDMA = MVX_STRIP_DMA && COLB == 16 && HC == 1 && SW == 24 && SNT == 24;
+                                    constexpr int SBUF = SNT * ROWB; // bytes of one strip buffer (the host sizes the chain's LDS for two)
+                                    int sbuf = 0;                    // the buffer of the window whose passes run
+                                    A4x32 stg[SDMA ? 1 : SSTG]; // (rows gS, gS + 8, ...: the luma rows first, then the rows of the UV plane)
+                                    auto stage_issue = [&](int w, int buf) {
                                         const int f = lo + SWB * w, L = min(SWB, hiE - f), bx0 = hpad + stepX * (c0 + f), pe = min(pS, TC * (L - 1) + 2 * HC - 1) * COLB;
 #pragma unroll
                                         for (int k = 0; k < SSTG; k++) {
                                             const int row = gS + 8 * k;
-                                            if (8 * k < SNA) stg[k] = ld_chunk_g(srcY + (unsigned)(y0 + row) * pitchY + (unsigned)bx0 * BPS + (unsigned)pe, COLB);
-                                            else stg[k] = ld_chunk_g(srcUV + (unsigned)((y0 >> 1) + row - SNA) * 2 * pitchC + (unsigned)(bx0 >> 1) * 2 * BPS + (unsigned)pe, COLB);
+                                            gl_u8 *g = 8 * k < SNA ? srcY + (unsigned)(y0 + row) * pitchY + (unsigned)bx0 * BPS + (unsigned)pe
+                                                                   : srcUV + (unsigned)((y0 >> 1) + row - SNA) * 2 * pitchC + (unsigned)(bx0 >> 1) * 2 * BPS + (unsigned)pe;
+                                            if constexpr (SDMA) {
+                                                const unsigned m0v = (unsigned)(unsigned long long)(lds + buf * SBUF + 8 * k * ROWB); // (wave-uniform: the LDS address of lane 0's piece)
+                                                asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(m0v) : "memory", "m0");
+                                            } else stg[k] = ld_chunk_g(g, COLB);
                                         }
                                     };
                                     auto stage_store = [&]() {
+                                        if constexpr (SDMA) asm volatile("s_waitcnt vmcnt(24)" : : : "memory");
+                                        else {
 #pragma unroll
-                                        for (int k = 0; k < SSTG; k++) st_chunk_l(lds + (gS + 8 * k) * ROWB + pS * COLB, stg[k], COLB); // (S_UV = SNA * ROWB: the UV rows follow the luma rows)
+                                            for (int k = 0; k < SSTG; k++) st_chunk_l(lds + (gS + 8 * k) * ROWB + pS * COLB, stg[k], COLB); // (S_UV = SNA * ROWB: the UV rows follow the luma rows)
+                                        }
                                     };
                                     // (r6: the two stages WINDOW BY WINDOW -- stage 1, predictor phase, stage 2 of one window before the next window's stage 1, so that stage 2
                                     // would find stage 1's lines in the L2 -- fetches as much as this order: 1 357 against 1 302 GB per 2046-chain launch, profiles/r6_window_major_ab.txt.
@@ -742,8 +759,8 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false, bool SIDE 
                                         int slot, colW, srcCol; bool stripLane; unsigned oA, oB;
                                         roles();
                                         w_cand(st, w, q, slot, colW, stripLane, srcCol, oA, oB);
-                                        strip_prime(T, oA, oB);
-                                        stage_issue(w);
+                                        if constexpr (SDMA) { sbuf = 0; stage_issue(w, 0); strip_prime(T, oA, oB); } // (the strip first: see above)
+                                        else { strip_prime(T, oA, oB); stage_issue(w, 0); }
                                         for (;;) {
                                             roles();
                                             int wn = w, qn = q + 1, win = wi;
@@ -756,11 +773,11 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false, bool SIDE 
                                             if (q == 0) { // a new window: its source strip (requested one window ahead)
                                                 __builtin_amdgcn_wave_barrier();
                                                 stage_store();
-                                                if (wi + 1 < wTo) stage_issue(widx(wi + 1));
+                                                if (wi + 1 < wTo) stage_issue(widx(wi + 1), sbuf ^ 1);
                                                 __builtin_amdgcn_wave_barrier();
                                             }
                                             SPROF(12);
-                                            if (more) strip_run<true>(T, srcCol, nA, nB); else strip_run<false>(T, srcCol, 0, 0);
+                                            if (more) strip_run<true>(T, srcCol, nA, nB, SDMA ? sbuf * SBUF : 0); else strip_run<false>(T, srcCol, 0, 0, SDMA ? sbuf * SBUF : 0);
                                             SPROF(13);
                                             // strip lanes: block m = columns m and m + 1; block lanes: the two halves of a block sit in neighbouring lanes
                                             unsigned sL = T.aL + (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aL, 0x101, 0xf, 0xf, true), sC = T.aC + (unsigned)__builtin_amdgcn_update_dpp(0, (int)T.aC, 0x101, 0xf, 0xf, true);
@@ -775,6 +792,7 @@ template <int BPS, int BW, bool UV, int SWIN = 12, bool TEAM = false, bool SIDE 
                                             sprof[15] += 1;
 #endif
                                             if (!more) break;
+                                            if (SDMA && win != wi) sbuf ^= 1;
                                             w = wn; wi = win; q = qn; slot = slotN; colW = colN; stripLane = stripN; srcCol = srcN;
                                         }
                                         __builtin_amdgcn_wave_barrier();
