@@ -73,4 +73,11 @@ r6_k34() {
     done 2>&1 | tee $out/r6_8bit_chains_per_simd.txt
 }
 
+r6_configs() {
+    # every bench configuration, one batch in flight, 3 timed steps each (TAG names the state)
+    for c in cfg3 cfg2 cfg4 hd16 hd16s cfg1 cfg5; do
+        timeout 600 python bench.py --config $c --no-cpu --no-traffic --no-others --no-vs --slots 1 --steps 3 --warmup 1 2>/dev/null | tail -1 | line "$c"
+    done 2>&1 | tee $out/r6_configs_${TAG:-last}.txt
+}
+
 "r6_$1" "${@:2}"
