@@ -332,6 +332,11 @@ int mvx_upload_2d(void *dst, ptrdiff_t dst_pitch, const void *src_host, ptrdiff_
 int mvx_download_2d(void *dst_host, ptrdiff_t dst_pitch, const void *src, ptrdiff_t src_pitch, size_t row_bytes, size_t rows, void *stream);
 int mvx_dev_memset(void *dst, int value, size_t bytes, void *stream); /* asynchronous on `stream` */
 int mvx_set_device(int ordinal);
+/* Start-up work a host can take off its first frame (r6; the VapourSynth shell calls it from a background thread when the plugin is loaded): brings the HIP runtime up on the
+ * current device, loads this library's code objects (a first kernel launch pays ~0.1 s for that) and page-locks `staging_buffers` of the 16 MiB buffers mvx_upload_2d /
+ * mvx_download_2d go through (`staging_buffers` < 0: the runtime only) (page-locking is slow -- ~20 ms per buffer -- and stalls every other HIP call of the process while it lasts).  Idempotent, thread-safe; MVX_OK,
+ * or MVX_E_DEVICE when there is no usable device (nothing else fails because of it). */
+int mvx_warmup(int staging_buffers);
 
 #ifdef __cplusplus
 }

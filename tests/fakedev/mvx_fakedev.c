@@ -88,6 +88,7 @@ API void *mvx_dev_alloc_uninit(size_t bytes) {
 }
 API void mvx_dev_free(void *p) { free(p); }
 API void mvx_dev_pool_limit(size_t bytes) { (void)bytes; }
+API int mvx_warmup(int staging_buffers) { (void)staging_buffers; return MVX_OK; } /* (the plugin's background warm-up at load: nothing to warm here) */
 API void mvx_dev_pool_trim(void) {}
 API int mvx_dev_mem_info(size_t *free_bytes, size_t *total_bytes) {
     /* small on purpose (MVX_FAKEDEV_MEM, default 64 MiB "free"): the shell sizes its frame cache from this, so eviction really happens */

@@ -80,4 +80,26 @@ r6_configs() {
     done 2>&1 | tee $out/r6_configs_${TAG:-last}.txt
 }
 
+r6_final() {
+    # r6 final state: the whole GPU suite, smoke(), the driver's bench command (20 steps like the driver), rocprofv3 kernel stats of the default command, per-kernel HBM traffic,
+    # SQ / TCP / TCC counters of the search kernel
+    timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -12 | tee $out/r6_tests_gpu_final.txt
+    timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $out/r6_smoke.txt
+    t0=$(date +%s)
+    timeout 1500 python bench.py --steps 20 --warmup 5 > $out/r6_bench_default.json 2> $out/r6_bench_default.err || tail -5 $out/r6_bench_default.err
+    echo "bench.py --steps 20 --warmup 5 wall: $(( $(date +%s) - t0 )) s"
+    python - <<'PY'
+import json
+d=json.loads([l for l in open('gpurun_out/r6_bench_default.json') if l.startswith('{')][-1])
+r=d['roofline']
+print('default', round(d['value'],1), 'fps', round(r['avg_launch_ms'],1), 'ms/launch', round(d['ms_per_step'],1), 'ms/step frac', round(r['frac'],4), 'alone', r.get('launch_alone',{}).get('avg_launch_ms'), 'traffic', r['traffic'], 'parity', d['parity_check']['identical'], 'cpu', d['cpu_baseline']['value'], 'one batch', d.get('one_batch_in_flight',{}).get('value'))
+print('others', {k:(round(v.get('fps',0),1) if isinstance(v,dict) else v) for k,v in d.get('other_configs',{}).items()})
+print('vs', {k:d.get('vs_shell',{}).get(k) for k in ('fps_all_inclusive','fps_steady','identical_to_c_abi','graph_construction_s','request_phase_s')}, (d.get('vs_shell',{}).get('lazy_super') or {}).get('fps_all_inclusive'))
+PY
+    TAG=r6 BENCH_ARGS="--no-others --no-vs" bash tools/gpu_session.sh stats traffic > $out/r6_profile_steps.log 2>&1
+    PMC_FILTER=analyse_spec bash tools/pmc.sh "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_BUSY_avr" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" -- python bench.py --no-cpu --no-parity --no-traffic --no-others --no-vs --steps 1 --warmup 0 --slots 1 > /dev/null 2>&1
+    cp $out/pmc_summary.txt $out/r6_search_final_counters.txt
+    head -14 $out/r6_kernel_stats.csv | cut -c1-200
+}
+
 "r6_$1" "${@:2}"

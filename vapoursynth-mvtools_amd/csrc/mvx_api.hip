@@ -186,6 +186,26 @@ void stage_release(Stage *s) {
 // rows of a transfer that fit one staging buffer (device pitch dp; the last row of a chunk needs row_bytes only)
 size_t chunk_rows(ptrdiff_t dp, size_t row_bytes) { const size_t n = (kStageBytes - row_bytes) / (size_t)dp + 1; return n ? n : 1; }
 }
+__global__ void mvx_noop_kernel(int *p) { if (p) *p = 1; }
+// r6: see mvtools_amd.h.  (The staging buffers it page-locks are the pool's own: taken and given back one by one, so a transfer that runs meanwhile is not starved)
+extern "C" __attribute__((visibility("default"))) int mvx_warmup(int staging_buffers) {
+    if (hipFree(nullptr) != hipSuccess) { mvx_set_error("mvx_warmup: no usable HIP device"); return MVX_E_DEVICE; }
+    if (staging_buffers < 0) return MVX_OK; // (the runtime only)
+    hipLaunchKernelGGL(mvx_noop_kernel, dim3(1), dim3(64), 0, 0, (int *)nullptr); // (the first launch loads the library's code objects)
+    if (hipDeviceSynchronize() != hipSuccess) { mvx_set_error("mvx_warmup: first launch failed"); return MVX_E_DEVICE; }
+    if (staging_buffers > kStages) staging_buffers = kStages;
+    for (int i = 0; i < staging_buffers; i++) {
+        Stage *s = nullptr;
+        {
+            std::lock_guard<std::mutex> g(g_stage_mu);
+            for (auto &t : g_stage) if (!t.busy && !t.p) { t.busy = true; s = &t; break; }
+        }
+        if (!s) break; // every buffer exists (or is in use)
+        if (hipHostMalloc(&s->p, kStageBytes, hipHostMallocDefault) != hipSuccess) s->p = nullptr;
+        stage_release(s);
+    }
+    return MVX_OK;
+}
 extern "C" __attribute__((visibility("default"))) int mvx_upload_2d(void *dev, ptrdiff_t dp, const void *host, ptrdiff_t hp, size_t row_bytes, size_t rows, void *stream) {
     if (!rows || !row_bytes) return MVX_OK;
     if (dp < (ptrdiff_t)row_bytes) { mvx_set_error("mvx_upload_2d: device pitch smaller than a row"); return MVX_E_ARG; }

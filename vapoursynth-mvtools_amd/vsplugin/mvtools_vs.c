@@ -783,7 +783,35 @@ static void VS_CC superFree(void *inst, VSCore *core, const VSAPI *vs) {
     free(d);
 }
 
+/* ------------------------------------------------------------------------------------------------ start-up on a background thread (r6)
+ * The HIP runtime (0.25-0.3 s), this library's code objects (~0.1 s at the first launch) and the page-locked staging buffers (~20 ms each) come up on a thread started when the
+ * plugin is loaded, while the host is still reading its script / opening its clips.  Two rules keep that safe: (1) every filter-creation function first waits until the RUNTIME
+ * is up (what a synchronous start would have cost it anyway) -- so a host that exits after a creation error never tears the process down under a thread that is inside the
+ * runtime's initialisation (the runtime's own exit handlers run before any handler registered earlier: measured, a segmentation fault at exit with the error message still in the
+ * stdio buffer); (2) once the runtime is up the thread registers an exit handler -- which therefore runs BEFORE the runtime's -- that waits for the rest of the warm-up.
+ * MVX_VS_WARMUP=0 turns the thread off, MVX_VS_WARM_STAGES = staging buffers to page-lock (default 48 = 768 MiB: what a 4K session allocates within its first second). */
+static pthread_t g_warm_thread;
+static int g_warm_started, g_warm_runtime_up, g_warm_done; /* (atomics: __atomic_*) */
+static void warm_join(void) {
+    if (__atomic_exchange_n(&g_warm_started, 0, __ATOMIC_ACQ_REL)) pthread_join(g_warm_thread, NULL);
+}
+static void *warmup_thread(void *arg) {
+    (void)arg;
+    (void)mvx_warmup(-1);         /* the runtime (no device: the filters report that when they are used) */
+    __atomic_store_n(&g_warm_runtime_up, 1, __ATOMIC_RELEASE);
+    atexit(warm_join);            /* (registered after the runtime's own handlers, so it runs before them) */
+    const char *e = getenv("MVX_VS_WARM_STAGES");
+    (void)mvx_warmup(e ? atoi(e) : 48); /* code objects, staging buffers */
+    __atomic_store_n(&g_warm_done, 1, __ATOMIC_RELEASE);
+    return NULL;
+}
+static void warm_barrier(void) { /* at the top of every *Create: the runtime is up (or no warm-up runs) */
+    while (__atomic_load_n(&g_warm_started, __ATOMIC_ACQUIRE) && !__atomic_load_n(&g_warm_runtime_up, __ATOMIC_ACQUIRE)) { struct timespec t = { 0, 2000000 }; nanosleep(&t, NULL); }
+}
+__attribute__((destructor)) static void warm_unload(void) { warm_join(); } /* (dlclose without exit) */
+
 static void VS_CC superCreate(const VSMap *in, VSMap *out, void *user, VSCore *core, const VSAPI *vs) {
+    warm_barrier();
     (void)user;
     VSNode *node = vs->mapGetNode(in, "clip", 0, 0);
     const VSVideoInfo *vi = vs->getVideoInfo(node);
@@ -874,7 +902,7 @@ typedef struct Combiner {
 #define LA_SLOTS 6
 enum { LW_EMPTY, LW_BUILDING, LW_LAUNCHED, LW_SYNCING, LW_READY, LW_FAILED };
 typedef struct LaWindow { int w, state, first, count, users, rc; void *dblobs; size_t dstride; DevFrame **pins; int npins; void *stream; } LaWindow; /* dblobs: the window's vectors, on the device until the slot is recycled */
-typedef struct LookAhead { int on, B, depth; volatile int degraded; /* a window ran out of device memory: new requests take the per-frame path */ VSNode *srcNode; SuperData *sd; pthread_mutex_t mu; pthread_cond_t cv; LaWindow win[LA_SLOTS]; } LookAhead;
+typedef struct LookAhead { int on, B, depth; volatile int started; /* a window of this instance has been launched (r6: the request that starts the FIRST one starts no window ahead) */ volatile int degraded; /* a window ran out of device memory: new requests take the per-frame path */ VSNode *srcNode; SuperData *sd; pthread_mutex_t mu; pthread_cond_t cv; LaWindow win[LA_SLOTS]; } LookAhead;
 #define LA_DEPTH_MAX 3
 typedef struct LaReq { int legacy, w, hold[1 + LA_DEPTH_MAX], want[1 + LA_DEPTH_MAX]; } LaReq;
 
@@ -1138,7 +1166,10 @@ static const VSFrame *VS_CC analyseGetFrame(int n, int reason, void *inst, void 
                 if (!s0) r->legacy = 1;
                 else {
                     s0->users++; r->hold[0] = 1; r->want[0] = s0->state == LW_EMPTY;
-                    for (int i = 1; i <= d->la.depth && (r->w + i) * d->la.B < d->vi->numFrames; i++) { /* the windows ahead: whoever sees them empty first starts them */
+                    /* (r6: not the request that starts an instance's FIRST window -- mv.DegrainN's creation reads frame 0 of every vector clip, and the windows ahead of
+                     * the first instances' frame 0 kept the GPU from the later instances' first windows: 0.8 s of graph construction for six clips; the windows ahead are
+                     * started by the next request, a moment later) */
+                    for (int i = 1; d->la.started && i <= d->la.depth && (r->w + i) * d->la.B < d->vi->numFrames; i++) { /* the windows ahead: whoever sees them empty first starts them */
                         LaWindow *s1 = la_slot(d, r->w + i);
                         if (s1 && s1->state == LW_EMPTY) { s1->users++; r->hold[i] = 1; r->want[i] = 1; }
                     }
@@ -1171,6 +1202,7 @@ static const VSFrame *VS_CC analyseGetFrame(int n, int reason, void *inst, void 
                 const int lrc = la_launch(d, s, r->w + i, ctx, vs);
                 pthread_mutex_lock(&d->la.mu);
                 s->rc = lrc; s->state = lrc ? LW_FAILED : LW_LAUNCHED;
+                d->la.started = 1;
                 if (lrc == MVX_E_NOMEM) d->la.degraded = 1; /* (the requests already waiting for this window fail -- their reference frames were never asked for -- but nothing after them does) */
                 pthread_cond_broadcast(&d->la.cv);
                 pthread_mutex_unlock(&d->la.mu);
@@ -1279,6 +1311,7 @@ static void VS_CC analyseFree(void *inst, VSCore *core, const VSAPI *vs) {
 }
 
 static void VS_CC analyseCreate(const VSMap *in, VSMap *out, void *user, VSCore *core, const VSAPI *vs) {
+    warm_barrier();
     (void)user;
     static const char *keys[] = { "blksize", "blksizev", "levels", "search", "searchparam", "pelsearch", "isb", "lambda", "chroma", "delta", "truemotion",
                                   "lsad", "plevel", "global", "pnew", "pzero", "pglobal", "overlap", "overlapv", "divide", "badsad", "badrange", "opt",
@@ -1391,6 +1424,7 @@ static void VS_CC finestFree(void *inst, VSCore *core, const VSAPI *vs) {
     vs->freeNode(d->super); mvx_super_destroy(d->sup); free(d);
 }
 static void VS_CC finestCreate(const VSMap *in, VSMap *out, void *user, VSCore *core, const VSAPI *vs) {
+    warm_barrier();
     (void)user;
     VSNode *super = vs->mapGetNode(in, "super", 0, 0);
     const VSVideoInfo *vi = vs->getVideoInfo(super);
@@ -1448,6 +1482,7 @@ static void VS_CC scdFree(void *inst, VSCore *core, const VSAPI *vs) {
     vs->freeNode(d->node); vs->freeNode(d->vectors); free(d);
 }
 static void VS_CC scdCreate(const VSMap *in, VSMap *out, void *user, VSCore *core, const VSAPI *vs) {
+    warm_barrier();
     (void)user;
     ScdData *d = (ScdData *)calloc(1, sizeof(*d));
     char err[1400] = "";
@@ -1546,6 +1581,7 @@ static void VS_CC recalcFree(void *inst, VSCore *core, const VSAPI *vs) {
 }
 
 static void VS_CC recalcCreate(const VSMap *in, VSMap *out, void *user, VSCore *core, const VSAPI *vs) {
+    warm_barrier();
     (void)user;
     static const char *keys[] = { "thsad", "smooth", "blksize", "blksizev", "search", "searchparam", "lambda", "chroma", "truemotion", "pnew", "overlap", "overlapv",
                                   "divide", "meander", "fields", "dct" };
@@ -1591,6 +1627,15 @@ typedef struct DegrainData {
     int blobSize;
     char name[16];
 } DegrainData;
+
+typedef struct FirstFrameReq { const VSAPI *vs; VSNode *node; } FirstFrameReq;
+static void *first_frame_thread(void *arg) { /* (errors are reported by the caller's own read of the frame) */
+    FirstFrameReq *q = (FirstFrameReq *)arg;
+    char msg[256];
+    const VSFrame *f = q->vs->getFrame(0, q->node, msg, sizeof(msg));
+    if (f) q->vs->freeFrame(f);
+    return NULL;
+}
 
 static const VSFrame *VS_CC degrainGetFrame(int n, int reason, void *inst, void **fd, VSFrameContext *ctx, VSCore *core, const VSAPI *vs) {
     (void)fd;
@@ -1675,6 +1720,7 @@ static void VS_CC degrainFree(void *inst, VSCore *core, const VSAPI *vs) {
 }
 
 static void VS_CC degrainCreate(const VSMap *in, VSMap *out, void *user, VSCore *core, const VSAPI *vs) {
+    warm_barrier();
     const int radius = (int)(intptr_t)user;
     static const char *vnames[] = { "mvbw", "mvfw", "mvbw2", "mvfw2", "mvbw3", "mvfw3", "mvbw4", "mvfw4", "mvbw5", "mvfw5", "mvbw6", "mvfw6" };
     DegrainData *d = (DegrainData *)calloc(1, sizeof(*d));
@@ -1690,10 +1736,16 @@ static void VS_CC degrainCreate(const VSMap *in, VSMap *out, void *user, VSCore 
         d->sup = super_from_props(d->super, d->name, err, sizeof(err), vs);
     }
     const int nr = 2 * radius;
-    for (int r = 0; r < nr && !err[0]; r++) {
-        d->vectors[r] = vs->mapGetNode(in, vnames[r], 0, NULL);
-        adata_from_clip(&d->ad[r], d->vectors[r], d->name, vnames[r], err, sizeof(err), vs);
+    for (int r = 0; r < nr && !err[0]; r++) d->vectors[r] = vs->mapGetNode(in, vnames[r], 0, NULL);
+    if (!err[0] && env_long("MVX_VS_PARALLEL_FIRST", 1)) { /* r6: frame 0 of the vector clips is produced CONCURRENTLY (each is a whole look-ahead window of searches: six launches
+                                                             * that share the GPU instead of queueing behind each other); the reads below then find the frames in the host's cache */
+        pthread_t th[12];
+        FirstFrameReq fr[12];
+        int started[12];
+        for (int r = 0; r < nr; r++) { fr[r].vs = vs; fr[r].node = d->vectors[r]; started[r] = pthread_create(&th[r], NULL, first_frame_thread, &fr[r]) == 0; }
+        for (int r = 0; r < nr; r++) if (started[r]) pthread_join(th[r], NULL);
     }
+    for (int r = 0; r < nr && !err[0]; r++) adata_from_clip(&d->ad[r], d->vectors[r], d->name, vnames[r], err, sizeof(err), vs);
     for (int r = 1; r < nr && !err[0]; r++) adata_similar(&d->ad[0], &d->ad[r], d->name, vnames[0], vnames[r], err, sizeof(err));
     if (!err[0]) { /* src/MVDegrains.cpp:606-640 */
         const char *m = NULL;
@@ -1840,6 +1892,7 @@ static void VS_CC compFree(void *inst, VSCore *core, const VSAPI *vs) {
 }
 
 static void VS_CC compCreate(const VSMap *in, VSMap *out, void *user, VSCore *core, const VSAPI *vs) {
+    warm_barrier();
     (void)user;
     CompData *d = (CompData *)calloc(1, sizeof(*d));
     char err[1400] = "";
@@ -1981,6 +2034,7 @@ static void VS_CC fpsFree(void *inst, VSCore *core, const VSAPI *vs) {
 }
 
 static void VS_CC fpsCreate(const VSMap *in, VSMap *out, void *user, VSCore *core, const VSAPI *vs) {
+    warm_barrier();
     (void)user;
     FpsData *d = (FpsData *)calloc(1, sizeof(*d));
     char err[1400] = "";
@@ -2066,6 +2120,15 @@ VS_EXTERNAL_API(void) VapourSynthPluginInit2(VSPlugin *plugin, const VSPLUGINAPI
         if (!q || atoi(q) < SEARCH_STREAMS)
             fprintf(stderr, "mvtools (MI355X): GPU_MAX_HW_QUEUES is %s: the %d search streams of concurrent mv.Analyse instances share the HIP runtime's hardware queues and "
                             "serialise; export GPU_MAX_HW_QUEUES=16 before starting the host (INTEGRATION.md)\n", q ? q : "unset (runtime default: 4)", SEARCH_STREAMS);
+    }
+    /* r6: the HIP runtime, this library's code objects and the page-locked staging buffers come up on a background thread while the host is still reading its
+     * script / opening its clips: 0.3 s + 0.1 s + ~20 ms per buffer that the first frames (mv.DegrainN's creation reads frame 0 of every vector clip) no longer wait for.
+     * (see warmup_thread) */
+    if (env_long("MVX_VS_WARMUP", 1)) {
+        if (!__atomic_load_n(&g_warm_started, __ATOMIC_ACQUIRE)) {
+            __atomic_store_n(&g_warm_started, 1, __ATOMIC_RELEASE);
+            if (pthread_create(&g_warm_thread, NULL, warmup_thread, NULL) != 0) __atomic_store_n(&g_warm_started, 0, __ATOMIC_RELEASE);
+        }
     }
     vspapi->configPlugin("com.nodame.mvtools", "mv", "MVTools v24", VS_MAKE_VERSION(24, 0), VS_MAKE_VERSION(VAPOURSYNTH_API_MAJOR, VAPOURSYNTH_API_MINOR), 0, plugin);
     vspapi->registerFunction("Super",
