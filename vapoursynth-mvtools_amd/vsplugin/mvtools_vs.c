@@ -105,15 +105,28 @@ static void *thread_stream(void) {
 /* the 131 MB downloads of finished super frames (mv.Super's host frames) run on a stream of their own: they only depend on kernels that
  * were waited for already, and on their own stream they overlap the other threads' uploads (PCIe is full duplex) instead of queueing
  * in front of them */
-static void *g_dl_stream;
-static int g_dl_stream_tried;
+/* r6: MVX_VS_DL_STREAMS of them (default 2), taken in turn: one stream is one DMA engine's worth of device-to-host bandwidth (~45 GB/s measured), and the 138 MB of super frame
+ * per output frame that mv.Super's default mode sends to the host make that engine the bound of the whole graph */
+#define DL_STREAMS_MAX 8
+static void *g_dl_stream, *g_dl_streams[DL_STREAMS_MAX];
+static int g_dl_stream_tried, g_dl_nstreams;
+static unsigned g_dl_next;
 static void *download_stream(void) {
     if (!__atomic_load_n(&g_dl_stream_tried, __ATOMIC_ACQUIRE)) {
         pthread_mutex_lock(&g_lock);
-        if (!g_dl_stream_tried) { g_dl_stream = mvx_stream_create_priority(1); __atomic_store_n(&g_dl_stream_tried, 1, __ATOMIC_RELEASE); }
+        if (!g_dl_stream_tried) {
+            const char *e = getenv("MVX_VS_DL_STREAMS");
+            int want = e ? atoi(e) : 2;
+            if (want < 1) want = 1;
+            if (want > DL_STREAMS_MAX) want = DL_STREAMS_MAX;
+            for (int i = 0; i < want; i++) { void *st = mvx_stream_create_priority(1); if (st) g_dl_streams[g_dl_nstreams++] = st; }
+            g_dl_stream = g_dl_nstreams ? g_dl_streams[0] : NULL;
+            __atomic_store_n(&g_dl_stream_tried, 1, __ATOMIC_RELEASE);
+        }
         pthread_mutex_unlock(&g_lock);
     }
-    return g_dl_stream ? g_dl_stream : thread_stream();
+    if (!g_dl_nstreams) return thread_stream();
+    return g_dl_streams[__atomic_fetch_add(&g_dl_next, 1u, __ATOMIC_RELAXED) % (unsigned)g_dl_nstreams];
 }
 /* Error paths: a getFrame that failed after it enqueued work skipped its stream waits, and mvx_dev_free hands a buffer straight to the next
  * caller (no stream ordering in the pool: ADVICE r2) -- so before such a path frees device memory it waits for whatever is still queued on the
@@ -121,7 +134,7 @@ static void *download_stream(void) {
 static void shell_quiesce(int rc) {
     if (!rc) return;
     (void)mvx_stream_sync(thread_stream());
-    if (g_dl_stream) (void)mvx_stream_sync(g_dl_stream);
+    for (int i = 0; i < g_dl_nstreams; i++) (void)mvx_stream_sync(g_dl_streams[i]);
 }
 static int timed_download_on(void *stream, void *dst, ptrdiff_t dp, const void *src, ptrdiff_t sp, size_t rb, size_t rows) {
     const double t0 = prof_now();
@@ -1151,6 +1164,50 @@ static void la_release_req(AnalyseData *d, LaReq *r) {
     free(r);
 }
 
+/* r6: the vectors of a look-ahead window stay on the device until its slot is recycled; a consumer of this plugin (mv.DegrainN) that finds the window of frame n still there
+ * reads them where they are instead of uploading the 2.7 MB property the vector frame carries (six of them per 4K Degrain3 frame).  The vector FRAME is unchanged -- any
+ * other consumer reads its properties as before -- and when the window is gone the consumer falls back on them too.  The registry maps the node the core made for an
+ * mv.Analyse instance to the instance (identity only, like g_supers; a consumer holds a reference to the node for as long as it may ask). */
+#define ANALYSE_REG_MAX 256
+static struct { VSNode *out; AnalyseData *d; } g_analyses[ANALYSE_REG_MAX];
+static void analyse_register(VSNode *out, AnalyseData *d) {
+    pthread_mutex_lock(&g_lock);
+    for (int i = 0; i < ANALYSE_REG_MAX; i++) if (!g_analyses[i].out) { g_analyses[i].out = out; g_analyses[i].d = d; break; }
+    pthread_mutex_unlock(&g_lock);
+}
+static void analyse_unregister(AnalyseData *d) {
+    pthread_mutex_lock(&g_lock);
+    for (int i = 0; i < ANALYSE_REG_MAX; i++) if (g_analyses[i].d == d) { g_analyses[i].out = NULL; g_analyses[i].d = NULL; }
+    pthread_mutex_unlock(&g_lock);
+}
+static AnalyseData *analyse_lookup(VSNode *out) {
+    AnalyseData *d = NULL;
+    pthread_mutex_lock(&g_lock);
+    for (int i = 0; i < ANALYSE_REG_MAX; i++) if (g_analyses[i].out == out) d = g_analyses[i].d;
+    pthread_mutex_unlock(&g_lock);
+    return d;
+}
+/* the device copy of frame n's vectors, its window pinned (la_device_blob_release), or NULL */
+static const void *la_device_blob(AnalyseData *d, int n, LaWindow **held) {
+    *held = NULL;
+    if (!d || !d->la.on) return NULL;
+    const void *p = NULL;
+    pthread_mutex_lock(&d->la.mu);
+    LaWindow *s = &d->la.win[(n / d->la.B) % LA_SLOTS];
+    if (s->w == n / d->la.B && s->state == LW_READY && s->dblobs && n >= s->first && n < s->first + s->count) {
+        s->users++; *held = s;
+        p = (const char *)s->dblobs + s->dstride * (size_t)(n - s->first);
+    }
+    pthread_mutex_unlock(&d->la.mu);
+    return p;
+}
+static void la_device_blob_release(AnalyseData *d, LaWindow *held) {
+    if (!held) return;
+    pthread_mutex_lock(&d->la.mu);
+    held->users--;
+    pthread_mutex_unlock(&d->la.mu);
+}
+
 static const VSFrame *VS_CC analyseGetFrame(int n, int reason, void *inst, void **fd, VSFrameContext *ctx, VSCore *core, const VSAPI *vs) {
     AnalyseData *d = (AnalyseData *)inst;
     const int nref = analyse_nref(d, n);
@@ -1292,6 +1349,7 @@ static const VSFrame *VS_CC analyseGetFrame(int n, int reason, void *inst, void 
 static void VS_CC analyseFree(void *inst, VSCore *core, const VSAPI *vs) {
     (void)core;
     AnalyseData *d = (AnalyseData *)inst;
+    analyse_unregister(d);
     if (d->la.on) { /* the windows' pins go first: freeing the super node may run mv.Super's free callback, which drops its unpinned frames from the cache */
         for (int i = 0; i < LA_SLOTS; i++) {
             LaWindow *s = &d->la.win[i];
@@ -1383,6 +1441,11 @@ static void VS_CC analyseCreate(const VSMap *in, VSMap *out, void *user, VSCore 
         }
     }
     vs->createVideoFilter(out, "Analyse", vi, analyseGetFrame, analyseFree, fmParallel, deps, ndeps, d, core);
+    if (d->la.on) { /* remember the node the core made for this instance (identity only: no reference is kept) */
+        int e = 0;
+        VSNode *o = vs->mapGetNode(out, "clip", 0, &e);
+        if (o && !e) { analyse_register(o, d); vs->freeNode(o); }
+    }
 }
 
 /* ------------------------------------------------------------------------------------------------ mv.Finest */
@@ -1623,6 +1686,7 @@ typedef struct DegrainData {
     mvx_super *sup; SuperGeo geo;
     mvx_degrain *dg;
     mvx_analysis_data ad[12];
+    AnalyseData *an[12]; /* the mv.Analyse instances behind the vector clips, where they are this plugin's (r6: their vectors are read on the device) */
     ptrdiff_t pitch[3]; /* device pitch of clip / output planes */
     int blobSize;
     char name[16];
@@ -1660,7 +1724,8 @@ static const VSFrame *VS_CC degrainGetFrame(int n, int reason, void *inst, void 
     memset(&job, 0, sizeof(job));
     DevRef refs[12];
     void *blobArena[12];
-    memset(refs, 0, sizeof(refs)); memset(blobArena, 0, sizeof(blobArena));
+    LaWindow *blobHeld[12];
+    memset(refs, 0, sizeof(refs)); memset(blobArena, 0, sizeof(blobArena)); memset(blobHeld, 0, sizeof(blobHeld));
     int rc = 0;
     void *srcArena = NULL, *dsrc[3];
     rc = upload_plane_set(dsrc, &srcArena, src, d->pitch, np, bps, vs);
@@ -1670,10 +1735,14 @@ static const VSFrame *VS_CC degrainGetFrame(int n, int reason, void *inst, void 
     if (!rc && (!srcArena || !dstArena)) rc = MVX_E_NOMEM;
     for (int p = 0; p < np && !rc; p++) { job.src[p] = dsrc[p]; job.dst[p] = (char *)dstArena + dstOff[p]; }
     for (int r = 0; r < nr && !rc; r++) {
-        const VSFrame *vf = vs->getFrameFilter(n, d->vectors[r], ctx);
-        rc = blob_to_device(&blobArena[r], NULL, &d->ad[r], vf, vs);
-        job.blobs[r] = blobArena[r];
-        vs->freeFrame(vf);
+        const void *onDevice = la_device_blob(d->an[r], n, &blobHeld[r]);
+        if (onDevice) job.blobs[r] = (void *)onDevice; /* (the window that made the frame's property: the same bytes) */
+        else {
+            const VSFrame *vf = vs->getFrameFilter(n, d->vectors[r], ctx);
+            rc = blob_to_device(&blobArena[r], NULL, &d->ad[r], vf, vs);
+            job.blobs[r] = blobArena[r];
+            vs->freeFrame(vf);
+        }
         const int nref = (r & 1) ? n - d->ad[r].nDeltaFrame : n + d->ad[r].nDeltaFrame;
         if (!rc && nref >= 0 && nref < d->vi->numFrames) {
             const VSFrame *sf = vs->getFrameFilter(nref, d->super, ctx);
@@ -1693,7 +1762,7 @@ static const VSFrame *VS_CC degrainGetFrame(int n, int reason, void *inst, void 
             rc = timed_download_on(download_stream(), vs->getWritePtr(dst, p), vs->getStride(dst, p), job.dst[p], d->pitch[p], (size_t)vs->getFrameWidth(dst, p) * bps, (size_t)vs->getFrameHeight(dst, p));
     }
     shell_quiesce(rc);
-    for (int r = 0; r < nr; r++) { dev_release(&refs[r]); if (blobArena[r]) mvx_dev_free(blobArena[r]); }
+    for (int r = 0; r < nr; r++) { dev_release(&refs[r]); if (blobArena[r]) mvx_dev_free(blobArena[r]); la_device_blob_release(d->an[r], blobHeld[r]); }
     if (srcArena) mvx_dev_free(srcArena);
     if (dstArena) mvx_dev_free(dstArena);
     vs->freeFrame(src);
@@ -1783,6 +1852,7 @@ static void VS_CC degrainCreate(const VSMap *in, VSMap *out, void *user, VSCore 
         else if (d->geo.copies > 1) mvx_degrain_set_ref_shadow(d->dg, d->geo.shadowStride); /* every device super frame of this shell carries its copies */
     }
     if (!err[0]) d->blobSize = mvx_vectors_size(&d->ad[0]);
+    if (!err[0] && env_long("MVX_VS_DEVICE_VECTORS", 1)) for (int r = 0; r < nr; r++) d->an[r] = analyse_lookup(d->vectors[r]);
     if (err[0]) {
         vs->mapSetError(out, err);
         if (d->node) vs->freeNode(d->node);
