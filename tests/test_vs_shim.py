@@ -212,6 +212,79 @@ def test_shell_degrain_matches_oracle(shell, oracle, tmp_path, w, h, bits, radiu
             assert np.array_equal(got[n][p], want[p]), (n, p)
 
 
+FORMATS = {"444": dict(subsampling=(0, 0)), "422": dict(subsampling=(1, 0)), "gray": dict(gray=True)}
+
+
+def _fmt_clip(w, h, bits, nf, fmt, seed):
+    frames = pl.moving_clip(w, h, bits, nf, seed=seed, noise=3, sub=FORMATS[fmt].get("subsampling", (1, 1)))
+    return [[f[0]] for f in frames] if fmt == "gray" else frames
+
+
+def _read_fmt_frames(path, w, h, bits, n, fmt):
+    dt = np.uint8 if bits == 8 else np.uint16
+    sw, sh = FORMATS[fmt].get("subsampling", (1, 1))
+    dims = [(h, w)] if fmt == "gray" else [(h, w), (h >> sh, w >> sw), (h >> sh, w >> sw)]
+    data = np.fromfile(path, dtype=dt)
+    per = sum(a * b for a, b in dims)
+    assert data.size == per * n
+    out = []
+    for i in range(n):
+        d, o, fr = data[i * per:(i + 1) * per], 0, []
+        for a, b in dims:
+            fr.append(d[o:o + a * b].reshape(a, b))
+            o += a * b
+        out.append(fr)
+    return out
+
+
+@pytest.mark.parametrize("fmt,bits,pipeline,aargs,fargs", [
+    ("444", 8, "degrain1", dict(blksize=8, overlap=4), {}),
+    ("444", 16, "degrain2", dict(blksize=16, overlap=8), dict(limit=2000)),
+    ("422", 8, "degrain1", dict(blksize=16, overlap=8), {}),
+    ("422", 16, "degrain1", dict(blksize=8, overlap=4), dict(plane=3)),
+    ("gray", 8, "degrain1", dict(blksize=8, overlap=4), {}),
+    ("gray", 16, "degrain2", dict(blksize=16, overlap=0), {}),
+    ("444", 8, "compensate", dict(blksize=8, overlap=4), dict(thsad=5000)),
+    ("422", 16, "compensate", dict(blksize=16, overlap=8), {}),
+    ("gray", 8, "compensate", dict(blksize=8, overlap=0), {}),
+])
+def test_shell_other_chroma_formats_match_oracle(shell, oracle, tmp_path, fmt, bits, pipeline, aargs, fargs):
+    """r6: the whole graph -- mv.Super -> mv.Analyse -> mv.DegrainN / mv.Compensate -- through the filter shell on 4:4:4, 4:2:2 and Gray clips (MVDegrains.cpp:693-776,
+    MVCompensate.c:543, MVAnalyse.c:463-517 accept them; the C-ABI cases are tests/test_gpu_formats.py)"""
+    w, h = 128, 96
+    radius = int(pipeline[7:]) if pipeline.startswith("degrain") else 1
+    nf = 2 * radius + 2
+    frames = _fmt_clip(w, h, bits, nf, fmt, seed=37)
+    src = tmp_path / "in.raw"
+    _write_clip(src, frames)
+    key = "d" if pipeline.startswith("degrain") else "c"
+    cli = ["a.%s=%s" % kv for kv in aargs.items()] + ["%s.%s=%s" % (key, k, v) for k, v in fargs.items()] + ["x.format=" + fmt]
+    host("run", pipeline, src, w, h, bits, nf, tmp_path / "out.raw", *cli)
+    got = _read_fmt_frames(tmp_path / "out.raw", w, h, bits, nf, fmt)
+    osup = oracle.Super(w, h, bits, **FORMATS[fmt])
+    osf = [osup.frame(f) for f in frames]
+    ans = {(d, isb): oracle.Analyse(osup, num_frames=nf, isb=isb, delta=d, **aargs) for d in range(1, radius + 1) for isb in (1, 0)}
+    if pipeline.startswith("degrain"):
+        odg = oracle.Degrain(radius, osup, ans[(1, 1)].ad, **fargs)
+    else:
+        ocp = oracle.Compensate(osup, ans[(1, 1)].ad, **fargs)
+    for n in range(nf):
+        if pipeline.startswith("degrain"):
+            refs, blobs = [], []
+            for d in range(1, radius + 1):
+                for isb in (1, 0):
+                    nref = n + d if isb else n - d
+                    r = osf[nref] if 0 <= nref < nf else None
+                    refs.append(r)
+                    blobs.append(ans[(d, isb)].frame(osf[n], r))
+            want = odg.frame(frames[n], refs, blobs)
+        else:
+            r = osf[n + 1] if n + 1 < nf else None
+            want = ocp.frame(osf[n], r, ans[(1, 1)].frame(osf[n], r))
+        for p in range(len(want)):
+            assert np.array_equal(got[n][p], want[p]), (fmt, n, p)
+
+
 def test_shell_compensate_matches_oracle(shell, oracle, tmp_path):
     w, h, bits, nf = 128, 96, 8, 4
     aargs = dict(blksize=8, overlap=4)

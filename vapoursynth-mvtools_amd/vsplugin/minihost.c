@@ -12,7 +12,7 @@
  *   mvx_vs_host <plugin.so> error  <Filter> <w> <h> <bits> [f.key=value ...]       -> prints the creation error (or OK)
  *   mvx_vs_host <plugin.so> run <pipeline> <in.raw> <w> <h> <bits> <nframes> <out.raw> [s.|a.|d.|c.key=value ...]
  *       pipeline: super | finest | analyse | scdetection (d.*) | recalculate (r.*) | degrainN | compensate | blockfps (b.*)
- *       in.raw  : nframes x (Y, U, V planes, 4:2:0, tightly packed, little endian)
+ *       in.raw  : nframes x (Y, U, V planes, 4:2:0, tightly packed, little endian); x.format=422 | 444 | gray (one plane): other chroma formats
  *       out.raw : super      -> every super frame (planes tightly packed) ; props of frame 0 on stdout
  *                 analyse    -> per frame: 84-byte MVTools_MVAnalysisData + MVTools_vectors, backward (isb=1) then forward
  *                 degrainN / compensate -> output frames, planes tightly packed
@@ -381,18 +381,28 @@ static void init_api(void) {
 
 static int g_field_order = -1; /* x.fieldorder=0|1: source frame n carries _Field = order ^ (n % 2), like separated fields */
 
+static int g_fmt_ssw = 1, g_fmt_ssh = 1, g_fmt_gray; /* x.format=420 (default) | 422 | 444 | gray: the source clip's chroma format */
+static void format_from_args(int argc, char **argv) {
+    for (int i = 0; i < argc; i++)
+        if (!strncmp(argv[i], "x.format=", 9)) {
+            const char *f = argv[i] + 9;
+            g_fmt_gray = !strcmp(f, "gray");
+            g_fmt_ssw = (!strcmp(f, "444") || g_fmt_gray) ? 0 : 1;
+            g_fmt_ssh = !strcmp(f, "420") ? 1 : 0;
+        }
+}
 static VSNode *source_clip(const char *path, int w, int h, int bits, int nframes) {
     VSNode *n = (VSNode *)calloc(1, sizeof(VSNode));
     n->refs = 1;
-    n->vi.format.colorFamily = cfYUV; n->vi.format.sampleType = stInteger; n->vi.format.bitsPerSample = bits; n->vi.format.bytesPerSample = bits > 8 ? 2 : 1;
-    n->vi.format.subSamplingW = 1; n->vi.format.subSamplingH = 1; n->vi.format.numPlanes = 3;
+    n->vi.format.colorFamily = g_fmt_gray ? cfGray : cfYUV; n->vi.format.sampleType = stInteger; n->vi.format.bitsPerSample = bits; n->vi.format.bytesPerSample = bits > 8 ? 2 : 1;
+    n->vi.format.subSamplingW = g_fmt_ssw; n->vi.format.subSamplingH = g_fmt_ssh; n->vi.format.numPlanes = g_fmt_gray ? 1 : 3;
     n->vi.fpsNum = 24; n->vi.fpsDen = 1; n->vi.width = w; n->vi.height = h; n->vi.numFrames = nframes;
     n->cache = (const VSFrame **)calloc((size_t)nframes, sizeof(VSFrame *));
     FILE *fp = path ? fopen(path, "rb") : NULL;
     if (path && !fp) { fprintf(stderr, "cannot open %s\n", path); exit(2); }
     for (int f = 0; f < nframes; f++) {
         VSFrame *fr = newVideoFrame(&n->vi.format, w, h, NULL, NULL);
-        for (int p = 0; p < 3; p++)
+        for (int p = 0; p < n->vi.format.numPlanes; p++)
             for (int y = 0; y < plane_h(fr, p); y++) {
                 uint8_t *row = fr->data[p] + (size_t)y * fr->stride[p];
                 const size_t rb = (size_t)plane_w(fr, p) * n->vi.format.bytesPerSample;
@@ -538,6 +548,7 @@ int main(int argc, char **argv) {
     const int w = atoi(argv[5]), hh = atoi(argv[6]), bits = atoi(argv[7]), nframes = atoi(argv[8]);
     char **extra = argv + 10; const int nextra = argc - 10;
     int threads = 1;
+    format_from_args(nextra, extra);
     for (int i = 0; i < nextra; i++) if (!strncmp(extra[i], "x.fieldorder=", 13)) g_field_order = atoi(extra[i] + 13);
     for (int i = 0; i < nextra; i++) if (!strncmp(extra[i], "x.threads=", 10)) threads = atoi(extra[i] + 10);
     for (int i = 0; i < nextra; i++) if (!strncmp(extra[i], "x.cache=", 8)) g_cache_limit = atoi(extra[i] + 8);
