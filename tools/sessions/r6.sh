@@ -102,4 +102,26 @@ PY
     head -14 $out/r6_kernel_stats.csv | cut -c1-200
 }
 
+r6_vs_sweep() {
+    # the filter shell on 640 4K16 frames, default mode: download streams x request threads x look-ahead window (the clip file is written once; only the first run is verified against the C ABI)
+    timeout 600 python tools/vs_4k_run.py 640 48 2>&1 | grep -v amdgpu.ids | tail -6
+    for v in "2 48 128 2" "3 48 128 2" "4 48 128 2" "2 64 128 2" "3 64 128 2" "2 96 128 2" "2 48 64 2" "2 48 64 3" "2 48 96 2" "2 48 192 2" "3 64 64 3" "2 48 128 3"; do
+        set -- $v
+        echo "== dl_streams=$1 threads=$2 lookahead=$3 depth=$4"
+        VS_NOVERIFY=1 VS_MARKS=1 MVX_VS_DL_STREAMS=$1 MVX_VS_LOOKAHEAD=$3 MVX_VS_LOOKAHEAD_DEPTH=$4 timeout 300 python tools/vs_4k_run.py 640 $2 2>&1 | grep -E "minihost: (graph built|output clip)|steady state|progress|shell:" | cut -c1-260
+    done 2>&1 | tee $out/r6_vs_sweep.txt
+}
+
+r6_vs_sweep2() {
+    # the same, three repeats per setting (run-to-run noise of the request phase is +-0.2 s): download streams x request threads
+    timeout 600 python tools/vs_4k_run.py 640 48 2>&1 | grep -v amdgpu.ids | tail -3
+    for rep in 1 2 3; do
+        for v in "2 48" "3 48" "4 48" "2 64" "3 64" "4 64" "2 96" "3 96" "4 96"; do
+            set -- $v
+            r=$(VS_NOVERIFY=1 MVX_VS_DL_STREAMS=$1 timeout 300 python tools/vs_4k_run.py 640 $2 2>&1 | grep -E "minihost: output clip" | sed 's/.*order) //')
+            echo "rep $rep dl_streams=$1 threads=$2 request phase $r"
+        done
+    done 2>&1 | tee $out/r6_vs_sweep2.txt
+}
+
 "r6_$1" "${@:2}"
