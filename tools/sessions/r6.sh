@@ -124,4 +124,52 @@ r6_vs_sweep2() {
     done 2>&1 | tee $out/r6_vs_sweep2.txt
 }
 
+r6_degrain() {
+    # Degrain cell kernel: the plan records of a workgroup's tile in LDS (default build) against every thread reading its own (dgnotile), and the chroma kernel of
+    # Degrain3 at seven instead of eight waves per SIMD (dgw4_7): parity subset, then per-kernel durations with ONE batch in flight (nothing overlaps the Degrain kernels)
+    for lib in "$@"; do
+        if [ "$lib" != default ]; then export MVX_LIB=$PWD/$lib; else unset MVX_LIB; fi
+        timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_formats.py -x -q -m gpu -k "degrain or golden or full_size" 2>&1 | tail -2 | sed "s|^|$lib: |"
+        for c in cfg3 cfg2 hd16 cfg5; do
+            (cd /tmp && rm -rf /tmp/kt && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python $OLDPWD/bench.py --config $c --no-cpu --no-parity --no-traffic --no-others --no-vs --slots 1 --steps 3 --warmup 1 > /tmp/kt.log 2>&1)
+            f=$(find /tmp/kt -name '*kernel_stats.csv' | head -1)
+            python - $f "$lib" $c <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if 'degrain' in r['Name'] or 'usable' in r['Name']:
+        print(sys.argv[2], sys.argv[3], r['Name'][:64].ljust(64), 'calls', r['Calls'], 'avg %.3f ms' % (float(r['AverageNs']) / 1e6))
+PY
+            grep '^{' /tmp/kt.log | tail -1 | python -c "import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('$lib $c', round(d['value'],1), d['unit'], round(d['ms_per_step'],1), 'ms/step')"
+        done
+    done 2>&1 | tee $out/r6_degrain_tile_ab.txt
+}
+
+r6_vs_threads() {
+    # request threads of the host beyond 96 (a VapourSynth core starts one worker per logical CPU), two repeats each
+    timeout 600 python tools/vs_4k_run.py 640 96 2>&1 | grep -v amdgpu.ids | tail -3
+    for rep in 1 2; do
+        for t in 96 128 192 256; do
+            r=$(VS_NOVERIFY=1 VS_MARKS=1 timeout 300 python tools/vs_4k_run.py 640 $t 2>&1 | grep -E "minihost: (graph built|output clip)|progress" | sed 's/.*order) //' | tr '\n' ' ')
+            echo "rep $rep threads=$t request phase $r"
+        done
+    done 2>&1 | tee $out/r6_vs_threads.txt
+}
+
+r6_halfslots() {
+    # 8-bit configurations (equally long chains: a full launch frees its wave slots all at once, Super / Degrain of the neighbouring batch have nothing to run under):
+    # launches of HALF the wave slots (batch 512 = 1024 chains = one wave per SIMD, one wave per chain: MVX_TEAM=0) from three or four batches in flight -- two searches
+    # resident, the other batches' Super / Degrain kernels in the registers a finished launch frees
+    for c in cfg2 cfg4 hd16; do
+        timeout 600 python bench.py --config $c --no-cpu --no-traffic --no-others --no-vs --steps 8 --warmup 2 2>/dev/null | grep '^{' | tail -1 | line "$c default (2 x 2048)"
+        for v in "2 512" "3 512" "4 512" "6 512" "4 1024" "8 256"; do
+            set -- $v
+            MVX_TEAM=0 timeout 600 python bench.py --config $c --slots $1 --batch $2 --no-cpu --no-traffic --no-others --no-vs --steps $(( 16 * 2048 / $2 / $1 )) --warmup $1 2>/dev/null | grep '^{' | tail -1 | line "$c slots $1 batch $2 team 0"
+        done
+        timeout 600 python bench.py --config $c --slots 4 --batch 512 --no-cpu --no-traffic --no-others --no-vs --steps 16 --warmup 4 2>/dev/null | grep '^{' | tail -1 | line "$c slots 4 batch 512 library's team choice"
+    done 2>&1 | tee $out/r6_half_occupancy_launches.txt
+}
+
 "r6_$1" "${@:2}"

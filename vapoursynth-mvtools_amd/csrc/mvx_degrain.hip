@@ -377,8 +377,20 @@ template <typename T, int W> __device__ __forceinline__ void dg_store(DG_GL unsi
     else *(DG_GL dg_uh1 *)p = (unsigned short)d[0];
 }
 
+#ifndef MVX_DG_TILE
+#define MVX_DG_TILE 1 // (developer A/B builds: 0 = every thread reads its plan records from global memory, the form of rounds 2-5)
+#endif
+#define DG_TILE_MAX (34 * 6) // plan records of a workgroup's tile (32 cells x 8 rows): 33 block columns x at most 6 block rows (2-sample cell rows: five)
+// blocks of blkW x blkH stepping by stepX x stepY: the records that cover 32 cells x 8 rows fit the tile (always, for the geometries the cell kernel is launched on:
+// a power-of-two step below the block size is half the block size)
+constexpr bool dg_tiled(int nrefs) { return nrefs >= 6; }
+static bool dg_tile_fits(int blkW, int blkH, int stepX, int stepY) { return (31 + (blkW + stepX - 1) / stepX) * (7 / stepY + (blkH + stepY - 1) / stepY + 1) <= DG_TILE_MAX; }
+#ifndef MVX_DG_W4_NR6_WAVES
+#define MVX_DG_W4_NR6_WAVES 7 // (eight needs six spilled registers with the tile: 12.1 against 9.8 ms per 341 4K16 chroma frame pairs, profiles/r6_degrain_tile_ab.txt)
+#endif
+template <int NR, int W> constexpr int dg_cell_waves() { return W <= 2 ? 7 : W == 4 ? (NR <= 4 ? 8 : NR <= 6 ? MVX_DG_W4_NR6_WAVES : 6) : W == 8 ? (NR <= 2 ? 6 : NR <= 6 ? 5 : 4) : (NR <= 8 ? 3 : 2); }
 template <typename T, int NR, int W>
-__global__ __launch_bounds__(256) void degrain_cell_kernel(const DGParams *Pp, const DGJob *jobs, const PlanRecT<NR> *plan, int planeFirst, int planesPerFrame, int xcdOrder) {
+__global__ __launch_bounds__(256, (dg_cell_waves<NR, W>())) void degrain_cell_kernel(const DGParams *Pp, const DGJob *jobs, const PlanRecT<NR> *plan, int planeFirst, int planesPerFrame, int xcdOrder) {
     typedef PlanRecT<NR> PlanRec;
     const DGParams &P = *Pp;
     int bxi = blockIdx.x, byi = blockIdx.y, z = blockIdx.z;
@@ -395,6 +407,34 @@ __global__ __launch_bounds__(256) void degrain_cell_kernel(const DGParams *Pp, c
     const PlaneG &g = P.pl[p];
     const int c = bxi * 32 + (threadIdx.x & 31), y = byi * 8 + (threadIdx.x >> 5);
     const int x0 = c * W;
+    // r6: the plan records of the blocks that cover this workgroup's tile (32 cells x 8 rows: with blocks overlapping by half 33 block columns x 2-5 block
+    // rows) are fetched ONCE, cooperatively, into LDS.  Before, every thread read the records of its <= 4 covering blocks itself: three of the eleven memory
+    // instructions of a block visit (12 of 45 per thread; a 16-byte load costs the texture addresser its 16 cycles whether or not the line is in L1), and each
+    // visit was two dependent round trips (record -> reference rows)
+    // Measured (profiles/r6_degrain_tile_ab.txt, ms per batch, every thread for itself -> tile): six 16-bit references 15.9 -> 14.3 (8-sample cells) and 12.8 -> 9.8
+    // (4-sample cells), twelve 47.2 -> 43.0 / 29.2 -> 25.2; TWO 8-bit references (16-byte records, two loads per visit) lose: 15.5 -> 16.6, 12.7 -> 15.6 -- the tile is
+    // for filters with six or more references (Degrain3-6)
+    constexpr bool TILED = MVX_DG_TILE && dg_tiled(NR);
+    constexpr int RD = (int)sizeof(PlanRec) / 4;
+    __shared__ __attribute__((aligned(16))) unsigned tileD[TILED ? DG_TILE_MAX * RD : 1];
+    int tBx = 0, tBy = 0, tNbx = 0; // (wave-uniform: scalar registers)
+    if (TILED && g.process && P.overlap) { // (uniform over the workgroup; the host launches this kernel only when the tile fits: dg_tile_fits)
+        const int xt = bxi * 32 * W, yt = byi * 8;
+        tBx = __builtin_amdgcn_readfirstlane(xt - g.blkW + 1 <= 0 ? 0 : (xt - g.blkW + g.stepX) / g.stepX);
+        tBy = __builtin_amdgcn_readfirstlane(yt - g.blkH + 1 <= 0 ? 0 : (yt - g.blkH + g.stepY) / g.stepY);
+        const int bxHi = min(bxi * 32 + 31, P.nBlkX - 1), byHi = min((yt + 7) / g.stepY, P.nBlkY - 1);
+        tNbx = __builtin_amdgcn_readfirstlane(bxHi - tBx + 1);
+        const int nby = __builtin_amdgcn_readfirstlane(byHi - tBy + 1);
+        if (tNbx > 0) {
+            const unsigned *src = (const unsigned *)(plan + ((size_t)f * 2 + (p ? 1 : 0)) * P.nBlk);
+            const int rowD = tNbx * RD;
+            for (int r = 0; r < nby; r++) {
+                DG_GL const unsigned *q = (DG_GL const unsigned *)dg_gl((const unsigned char *)(src + ((size_t)(tBy + r) * P.nBlkX + tBx) * RD));
+                for (int k = threadIdx.x; k < rowD; k += 256) tileD[r * rowD + k] = q[k];
+            }
+        }
+        __syncthreads();
+    }
     if (x0 >= g.W || y >= g.H) return;
     const DGJob &J = jobs[f];
     const unsigned char *srow = J.src[p] + (long long)y * g.srcPitch + (long long)x0 * sizeof(T);
@@ -461,21 +501,23 @@ __global__ __launch_bounds__(256) void degrain_cell_kernel(const DGParams *Pp, c
                 const int nv = g.blkW - px;
                 if (nv <= 0) continue;
                 const int wbx = bx == P.nBlkX - 1 ? 2 : (bx == 0 ? 0 : 1);
-                const PlanRec &R = pl[by * P.nBlkX + bx];
+                PlanRec R;
+                if (TILED) __builtin_memcpy(&R, &tileD[((by - tBy) * tNbx + (bx - tBx)) * RD], sizeof(PlanRec));
+                else R = pl[by * P.nBlkX + bx];
                 const int wsrc = R.wsrc;
                 int sum[W];
 #pragma unroll
                 for (int i = 0; i < W; i++) sum[i] = 128 + s[i] * wsrc;
                 const long long rowOff = safe ? (long long)py * g.supPitch + (long long)px * sizeof(T) : 0;
                 const int16_t *wrow = win + (wby + wbx) * g.blkW * g.blkH + py * g.blkW + px;
-                int wv[W];
+                DgRaw<unsigned short, W> wr; // the window taps of this row of the cell, packed (unpacked where they are used: four registers fewer across the weighted sums)
                 if (nv >= W) { // whole cell inside the block: vector loads, ALL of the block's references requested before the first is used
                     // (a reference with weight 0 is loaded too -- from a valid address: refp -- which costs bandwidth the kernel has to
                     // spare; waiting for every load in turn, as a `if (w)` around each one makes the compiler do, cost 4x the round trips)
                     DgRaw<T, W> raw[NR];
 #pragma unroll
                     for (int r = 0; r < NR; r++) raw[r] = dg_load_raw<T, W>(dg_gl(refp[r] + R.off[r] + rowOff));
-                    dg_load<unsigned short, W>(dg_gl((const unsigned char *)wrow), wv);
+                    wr = dg_load_raw<unsigned short, W>(dg_gl((const unsigned char *)wrow));
                     dg_mad_refs<T, NR, W>(raw, R, sum);
                 } else { // partially covered (overlap != block/2): per-sample loads of the covered samples only
 #pragma unroll
@@ -488,12 +530,14 @@ __global__ __launch_bounds__(256) void degrain_cell_kernel(const DGParams *Pp, c
                         }
                     }
 #pragma unroll
-                    for (int i = 0; i < W; i++) wv[i] = i < nv ? (int)wrow[i] : 0;
+                    for (int k = 0; k < (W + 1) / 2; k++) wr.d[k] = 0;
+#pragma unroll
+                    for (int i = 0; i < W; i++) if (i < nv) wr.d[i >> 1] |= (unsigned)(unsigned short)wrow[i] << (16 * (i & 1));
                 }
 #pragma unroll
                 for (int i = 0; i < W; i++) {
                     const int val = (T)(sum[i] >> 8);
-                    if (i < nv) acc[i] += (unsigned)((val * wv[i]) >> 6);
+                    if (i < nv) acc[i] += (unsigned)((val * dg_sample<unsigned short, W>(wr, i)) >> 6);
                 }
             }
         }
@@ -852,7 +896,8 @@ extern "C" __attribute__((visibility("default"))) int mvx_degrain_frames(mvx_deg
     // per-sample gather
     // (r5: blocks side by side take the cell kernel too -- a cell of 8 (4) samples inside one block)
     auto cellW = [&](int p) { const int w = P.pl[p].stepX; return P.overlap ? ((w == 2 || w == 4 || w == 8 || w == 16) ? w : 0) : (P.pl[p].blkW % 8 == 0 ? 8 : P.pl[p].blkW % 4 == 0 ? 4 : 0); };
-    const bool cells = cellW(0) && (P.nplanes == 1 || (cellW(1) && P.pl[1].stepX == P.pl[2].stepX));
+    auto tileOk = [&](int p) { return !MVX_DG_TILE || !dg_tiled(P.nRefs) || !P.overlap || dg_tile_fits(P.pl[p].blkW, P.pl[p].blkH, P.pl[p].stepX, P.pl[p].stepY); };
+    const bool cells = cellW(0) && tileOk(0) && (P.nplanes == 1 || (cellW(1) && P.pl[1].stepX == P.pl[2].stepX && tileOk(1) && tileOk(2)));
     if (cells) {
         for (int cls = 0; cls < (P.nplanes > 1 ? 2 : 1); cls++) {
             const int p0 = cls, npl = cls ? 2 : 1, W = cellW(p0);
