@@ -164,12 +164,21 @@ r6_halfslots() {
     # resident, the other batches' Super / Degrain kernels in the registers a finished launch frees
     for c in cfg2 cfg4 hd16; do
         timeout 600 python bench.py --config $c --no-cpu --no-traffic --no-others --no-vs --steps 8 --warmup 2 2>/dev/null | grep '^{' | tail -1 | line "$c default (2 x 2048)"
-        for v in "2 512" "3 512" "4 512" "6 512" "4 1024" "8 256"; do
+        for v in "2 512" "3 512" "4 512" "6 512" "3 1024"; do  # (MVX_FAST_K=2: the two-waves-per-SIMD build -- the one-wave build takes more than 256 registers, two launches could not share a SIMD)
             set -- $v
-            MVX_TEAM=0 timeout 600 python bench.py --config $c --slots $1 --batch $2 --no-cpu --no-traffic --no-others --no-vs --steps $(( 16 * 2048 / $2 / $1 )) --warmup $1 2>/dev/null | grep '^{' | tail -1 | line "$c slots $1 batch $2 team 0"
+            MVX_TEAM=0 MVX_FAST_K=2 timeout 600 python bench.py --config $c --slots $1 --batch $2 --no-cpu --no-traffic --no-others --no-vs --steps $(( 16 * 2048 / $2 / $1 )) --warmup $1 2>/dev/null | grep '^{' | tail -1 | line "$c slots $1 batch $2 team 0"
         done
-        timeout 600 python bench.py --config $c --slots 4 --batch 512 --no-cpu --no-traffic --no-others --no-vs --steps 16 --warmup 4 2>/dev/null | grep '^{' | tail -1 | line "$c slots 4 batch 512 library's team choice"
+        MVX_FAST_K=2 timeout 600 python bench.py --config $c --slots 4 --batch 512 --no-cpu --no-traffic --no-others --no-vs --steps 16 --warmup 4 2>/dev/null | grep '^{' | tail -1 | line "$c slots 4 batch 512 library team choice"
     done 2>&1 | tee $out/r6_half_occupancy_launches.txt
+}
+
+r6_vs_threads_stats() {
+    # where the shell's time goes with 96 / 128 / 192 request threads (MVX_VS_STATS thread-seconds)
+    timeout 600 python tools/vs_4k_run.py 640 96 2>&1 | grep -v amdgpu.ids | tail -3
+    for t in 96 128 192; do
+        echo "== threads=$t"
+        VS_NOVERIFY=1 VS_MARKS=1 timeout 300 python tools/vs_4k_run.py 640 $t 2>&1 | grep -v amdgpu.ids | tail -8 | cut -c1-1500
+    done 2>&1 | tee $out/r6_vs_threads_stats.txt
 }
 
 "r6_$1" "${@:2}"

@@ -157,8 +157,13 @@ __device__ __forceinline__ unsigned sup_offset(const PlaneG &g, int pel, int log
     return (unsigned)(idx * g.supPlaneStride + (long long)(nY >> logPel) * g.supPitch + (long long)(nX >> logPel) * bps);
 }
 
+// (r6: left alone the register allocator takes 162 registers for six references -- three waves per SIMD; asked for six it needs 71 and spills nothing:
+// 4.41 -> 2.78 ms per 341 4K16 frames, profiles/r6_degrain_window_plan_ab.txt)
+#ifndef MVX_DG_PLAN_WAVES
+#define MVX_DG_PLAN_WAVES(NR) ((NR) <= 6 ? 6 : 4)
+#endif
 template <int NR>
-__global__ __launch_bounds__(256) void degrain_plan_kernel(const DGParams *Pp, const DGJob *jobs, const int *usable, PlanRecT<NR> *plan) {
+__global__ __launch_bounds__(256, MVX_DG_PLAN_WAVES(NR)) void degrain_plan_kernel(const DGParams *Pp, const DGJob *jobs, const int *usable, PlanRecT<NR> *plan) {
     typedef PlanRecT<NR> PlanRec;
     const DGParams &P = *Pp;
     const int f = blockIdx.y;
@@ -418,6 +423,8 @@ __global__ __launch_bounds__(256, (dg_cell_waves<NR, W>())) void degrain_cell_ke
     constexpr int RD = (int)sizeof(PlanRec) / 4;
     __shared__ __attribute__((aligned(16))) unsigned tileD[TILED ? DG_TILE_MAX * RD : 1];
     int tBx = 0, tBy = 0, tNbx = 0; // (wave-uniform: scalar registers)
+    // (the window taps next to the tile -- the nine windows of 16x16 blocks are 4.5 KB -- measured and removed: 14.7 against 14.5 ms, cfg5's 8-sample cells 26.2 against 25.1:
+    // profiles/r6_degrain_window_plan_ab.txt)
     if (TILED && g.process && P.overlap) { // (uniform over the workgroup; the host launches this kernel only when the tile fits: dg_tile_fits)
         const int xt = bxi * 32 * W, yt = byi * 8;
         tBx = __builtin_amdgcn_readfirstlane(xt - g.blkW + 1 <= 0 ? 0 : (xt - g.blkW + g.stepX) / g.stepX);
