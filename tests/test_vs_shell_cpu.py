@@ -53,6 +53,9 @@ def _oracle_degrain(oracle, frames, w, h, bits, radius, blksize, overlap):
     (16, 3, 8, {"MVX_VS_LOOKAHEAD": "8", "MVX_VS_SUPER_LAZY": "1"}),             # r4 opt-in: super frames whose pixels never leave the device
     (8, 2, 8, {"MVX_VS_LOOKAHEAD": "8", "MVX_VS_SUPER_LAZY": "1", "MVX_FAKEDEV_MEM": str(3 << 20)}),  # ... with evictions: consumers rebuild them from the embedded source
     (16, 1, 4, {"MVX_VS_LOOKAHEAD": "0", "MVX_VS_SUPER_LAZY": "1"}),             # ... on the per-frame path
+    (16, 2, 16, {"MVX_VS_LOOKAHEAD": "8", "MVX_VS_MAX_INFLIGHT": "3"}),          # r6 admission gate: sixteen request threads, three output frames admitted at a time
+    (8, 1, 12, {"MVX_VS_LOOKAHEAD": "4", "MVX_VS_MAX_INFLIGHT": "1"}),           # ... one at a time (every other thread waits at arInitial)
+    (8, 1, 8, {"MVX_VS_LOOKAHEAD": "8", "MVX_VS_MAX_INFLIGHT": "0"}),            # ... switched off
 ])
 def test_shell_reproduces_the_oracle_without_a_gpu(tmp_path, oracle, fakedev, bits, radius, threads, env):
     w, h, n = 160, 96, 37

@@ -181,4 +181,34 @@ r6_vs_threads_stats() {
     done 2>&1 | tee $out/r6_vs_threads_stats.txt
 }
 
+r6_vs_gate() {
+    # the admission gate of the consuming filters (MVX_VS_MAX_INFLIGHT, default 96): request threads 48 .. 256 with the gate, the limit itself at 256 threads, and the gate off
+    timeout 900 python -m pytest tests/test_vs_shim.py -x -q -m gpu 2>&1 | tail -2
+    timeout 600 python tools/vs_4k_run.py 640 256 2>&1 | grep -v amdgpu.ids | tail -4 | cut -c1-400
+    for v in "96 48" "96 96" "96 128" "96 192" "96 256" "64 256" "80 256" "112 256" "128 256" "0 96" "0 128" "96 256" "96 96"; do
+        set -- $v
+        r=$(VS_NOVERIFY=1 VS_MARKS=1 MVX_VS_MAX_INFLIGHT=$1 timeout 300 python tools/vs_4k_run.py 640 $2 2>&1 | grep -E "minihost: output clip|progress" | sed 's/.*order) //' | tr '\n' ' ')
+        echo "max_inflight=$1 threads=$2 request phase $r"
+    done 2>&1 | tee $out/r6_vs_gate.txt
+}
+
+r6_cfg5k3() {
+    # cfg5 (8K16, 32x32 blocks, serial lean kernel): three chains per SIMD need a batch of 252 frames, which only fits without the shifted luma copies (MVX_SHADOW=0: 0.52 instead of 1.05 GB per super frame)
+    for v in "1 168" "0 168" "0 252"; do
+        set -- $v
+        MVX_SHADOW=$1 timeout 900 python bench.py --config cfg5 --batch $2 --no-cpu --no-traffic --no-others --no-vs --slots 1 --steps 2 --warmup 1 2>&1 | grep '^{' | tail -1 | line "cfg5 shadow=$1 batch $2"
+    done 2>&1 | tee $out/r6_cfg5_three_per_simd.txt
+}
+
+r6_vs_gate2() {
+    # the gate with one condition variable per waiter (a delivered frame wakes one request, not all): request threads 64 .. 256, two repeats
+    timeout 600 python tools/vs_4k_run.py 640 256 2>&1 | grep -v amdgpu.ids | tail -4 | cut -c1-400
+    for rep in 1 2; do
+        for t in 64 96 128 192 256; do
+            r=$(VS_NOVERIFY=1 VS_MARKS=1 timeout 300 python tools/vs_4k_run.py 640 $t 2>&1 | grep -E "minihost: output clip|progress" | sed 's/.*order) //' | tr '\n' ' ')
+            echo "rep $rep max_inflight=96 threads=$t request phase $r"
+        done
+    done 2>&1 | tee $out/r6_vs_gate2.txt
+}
+
 "r6_$1" "${@:2}"

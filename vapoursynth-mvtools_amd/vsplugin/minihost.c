@@ -247,6 +247,7 @@ static const VSFrame *eval_frame(int n, VSNode *node, char *err, int errsz) {
             if (!ctx.req[i].f) break;
         }
         if (!ctx.error[0]) out = node->getFrame(n, arAllFramesReady, node->inst, &fd, &ctx, NULL, &g_api);
+        else (void)node->getFrame(n, arError, node->inst, &fd, &ctx, NULL, &g_api); /* (a real core tells the filter that the request failed, so that it can drop its frame data) */
     }
     for (int i = 0; i < ctx.nreq; i++) if (ctx.req[i].f) freeFrame(ctx.req[i].f);
     const VSFrame *evict[8];

@@ -1677,6 +1677,66 @@ static void VS_CC recalcCreate(const VSMap *in, VSMap *out, void *user, VSCore *
     vs->createVideoFilter(out, "Recalculate", d->vi, recalcGetFrame, recalcFree, fmParallel, deps, 2, d, core);
 }
 
+/* ------------------------------------------------------------------------------------------------ admission gate of the consuming filters (r6)
+ * A host asks for as many output frames at once as it has worker threads -- a VapourSynth core starts one per logical CPU, 256 on the bench box.  Every output frame
+ * in flight pins its 2 * radius + 1 super frames and pulls the look-ahead windows of the vector clips forward; past ~3/4 of a look-ahead window of frames in flight the
+ * requests span three windows, the device cache turns over and 640 4K16 frames take 3.8-5.2 s (128 threads), 7-9.6 s (192) or 12-14 s (256) instead of 2.5 s (96):
+ * profiles/r6_vs_shell_threads_96_to_256.txt.  So mv.DegrainN / mv.Compensate / mv.BlockFPS admit at most MVX_VS_MAX_INFLIGHT (default 96) of their own output frames
+ * at a time, the lowest frame numbers first; a request beyond that waits at arInitial -- before it has asked for anything -- until an admitted frame is delivered or
+ * fails.  The permit travels in the request's frame data (*fd), so arAllFramesReady / arError of the same request give it back.  One gate per filter instance: a chain of
+ * such filters cannot deadlock on a shared pool. */
+typedef struct GateWaiter { int n; pthread_cond_t cv; } GateWaiter; /* (one condition variable per waiter: a delivered frame wakes the ONE request it admits, not all of them) */
+typedef struct Gate { pthread_mutex_t mu; int limit, inflight, nwait; long done; GateWaiter *waiting[1024]; } Gate;
+static void gate_init(Gate *g) {
+    pthread_mutex_init(&g->mu, NULL);
+    g->limit = (int)env_long("MVX_VS_MAX_INFLIGHT", 96); /* (<= 0: no gate) */
+    g->inflight = g->nwait = 0; g->done = 0;
+}
+static void gate_free(Gate *g) { pthread_mutex_destroy(&g->mu); }
+static GateWaiter *gate_lowest(const Gate *g) { /* mu held */
+    GateWaiter *w = NULL;
+    for (int i = 0; i < g->nwait; i++) if (!w || g->waiting[i]->n < w->n) w = g->waiting[i];
+    return w;
+}
+/* A waiter occupies one of the host's worker threads.  A host that has more requests outstanding than workers could end up with every worker waiting here and none
+ * left for the upstream filters of the admitted frames; so the waiter that is next in line and sees NO admitted frame finish for a quarter of a second -- frames take
+ * milliseconds -- goes on over the limit: slow, as without the gate, never stuck. */
+static void gate_enter(Gate *g, int n, void **fd) {
+    if (g->limit <= 0 || *fd) return;
+    pthread_mutex_lock(&g->mu);
+    if ((g->inflight >= g->limit || g->nwait) && g->nwait < 1024) {
+        GateWaiter me;
+        me.n = n;
+        pthread_cond_init(&me.cv, NULL);
+        g->waiting[g->nwait++] = &me;
+        for (;;) {
+            const int lowest = gate_lowest(g) == &me;
+            if (g->inflight < g->limit && lowest) break;
+            struct timespec ts;
+            clock_gettime(CLOCK_REALTIME, &ts);
+            ts.tv_nsec += 250000000L;
+            if (ts.tv_nsec >= 1000000000L) { ts.tv_nsec -= 1000000000L; ts.tv_sec++; }
+            const long seen = g->done;
+            const int rc = pthread_cond_timedwait(&me.cv, &g->mu, &ts);
+            if (rc == ETIMEDOUT && gate_lowest(g) == &me && g->done == seen) break;
+        }
+        for (int i = 0; i < g->nwait; i++) if (g->waiting[i] == &me) { g->waiting[i] = g->waiting[--g->nwait]; break; }
+        pthread_cond_destroy(&me.cv);
+        g->inflight++;
+        if (g->inflight < g->limit && g->nwait) pthread_cond_signal(&gate_lowest(g)->cv); /* (room for the next one too) */
+    } else g->inflight++;
+    *fd = (void *)g;
+    pthread_mutex_unlock(&g->mu);
+}
+static void gate_leave(Gate *g, void **fd) {
+    if (!*fd) return;
+    *fd = NULL;
+    pthread_mutex_lock(&g->mu);
+    g->inflight--; g->done++;
+    if (g->nwait && g->inflight < g->limit) pthread_cond_signal(&gate_lowest(g)->cv);
+    pthread_mutex_unlock(&g->mu);
+}
+
 /* ------------------------------------------------------------------------------------------------ mv.Degrain1..6 */
 
 typedef struct DegrainData {
@@ -1690,6 +1750,7 @@ typedef struct DegrainData {
     ptrdiff_t pitch[3]; /* device pitch of clip / output planes */
     int blobSize;
     char name[16];
+    Gate gate;
 } DegrainData;
 
 typedef struct FirstFrameReq { const VSAPI *vs; VSNode *node; } FirstFrameReq;
@@ -1701,7 +1762,7 @@ static void *first_frame_thread(void *arg) { /* (errors are reported by the call
     return NULL;
 }
 
-static const VSFrame *VS_CC degrainGetFrame(int n, int reason, void *inst, void **fd, VSFrameContext *ctx, VSCore *core, const VSAPI *vs) {
+static const VSFrame *VS_CC degrainGetFrameUngated(int n, int reason, void *inst, void **fd, VSFrameContext *ctx, VSCore *core, const VSAPI *vs) {
     (void)fd;
     DegrainData *d = (DegrainData *)inst;
     const int nr = 2 * d->radius;
@@ -1778,6 +1839,15 @@ static const VSFrame *VS_CC degrainGetFrame(int n, int reason, void *inst, void 
     return dst;
 }
 
+/* (the admission gate around the filter proper: arInitial takes the permit, whatever ends the request -- the frame, a filter error, arError -- returns it) */
+static const VSFrame *VS_CC degrainGetFrame(int n, int reason, void *inst, void **fd, VSFrameContext *ctx, VSCore *core, const VSAPI *vs) {
+    DegrainData *d = (DegrainData *)inst;
+    if (reason == arInitial) gate_enter(&d->gate, n, fd);
+    const VSFrame *f = degrainGetFrameUngated(n, reason, inst, fd, ctx, core, vs);
+    if (reason != arInitial || f) gate_leave(&d->gate, fd);
+    return f;
+}
+
 static void VS_CC degrainFree(void *inst, VSCore *core, const VSAPI *vs) {
     (void)core;
     DegrainData *d = (DegrainData *)inst;
@@ -1785,6 +1855,7 @@ static void VS_CC degrainFree(void *inst, VSCore *core, const VSAPI *vs) {
     for (int r = 0; r < 2 * d->radius; r++) vs->freeNode(d->vectors[r]);
     mvx_degrain_destroy(d->dg);
     mvx_super_destroy(d->sup);
+    gate_free(&d->gate);
     free(d);
 }
 
@@ -1793,6 +1864,7 @@ static void VS_CC degrainCreate(const VSMap *in, VSMap *out, void *user, VSCore 
     const int radius = (int)(intptr_t)user;
     static const char *vnames[] = { "mvbw", "mvfw", "mvbw2", "mvfw2", "mvbw3", "mvfw3", "mvbw4", "mvfw4", "mvbw5", "mvfw5", "mvbw6", "mvfw6" };
     DegrainData *d = (DegrainData *)calloc(1, sizeof(*d));
+    gate_init(&d->gate);
     d->radius = radius;
     snprintf(d->name, sizeof(d->name), "Degrain%d", radius);
     char err[1400] = "";
@@ -1872,14 +1944,14 @@ static void VS_CC degrainCreate(const VSMap *in, VSMap *out, void *user, VSCore 
 
 /* ------------------------------------------------------------------------------------------------ mv.Compensate */
 
-typedef struct CompData { VSNode *node, *super, *vectors; const VSVideoInfo *vi; mvx_super *sup; SuperGeo geo; mvx_compensate *cp; mvx_analysis_data ad; ptrdiff_t pitch[3]; int blobSize; FieldOpt fo; } CompData;
+typedef struct CompData { VSNode *node, *super, *vectors; const VSVideoInfo *vi; mvx_super *sup; SuperGeo geo; mvx_compensate *cp; mvx_analysis_data ad; ptrdiff_t pitch[3]; int blobSize; FieldOpt fo; Gate gate; } CompData;
 
 static int comp_nref(const CompData *d, int n) { /* src/MVCompensate.c:84-92 */
     if (d->ad.nDeltaFrame > 0) return n + (d->ad.isBackward ? d->ad.nDeltaFrame : -d->ad.nDeltaFrame);
     return -d->ad.nDeltaFrame;
 }
 
-static const VSFrame *VS_CC compGetFrame(int n, int reason, void *inst, void **fd, VSFrameContext *ctx, VSCore *core, const VSAPI *vs) {
+static const VSFrame *VS_CC compGetFrameUngated(int n, int reason, void *inst, void **fd, VSFrameContext *ctx, VSCore *core, const VSAPI *vs) {
     (void)fd;
     CompData *d = (CompData *)inst;
     const int nref = comp_nref(d, n);
@@ -1952,12 +2024,22 @@ static const VSFrame *VS_CC compGetFrame(int n, int reason, void *inst, void **f
     return dst;
 }
 
+/* (the admission gate around the filter proper: arInitial takes the permit, whatever ends the request -- the frame, a filter error, arError -- returns it) */
+static const VSFrame *VS_CC compGetFrame(int n, int reason, void *inst, void **fd, VSFrameContext *ctx, VSCore *core, const VSAPI *vs) {
+    CompData *d = (CompData *)inst;
+    if (reason == arInitial) gate_enter(&d->gate, n, fd);
+    const VSFrame *f = compGetFrameUngated(n, reason, inst, fd, ctx, core, vs);
+    if (reason != arInitial || f) gate_leave(&d->gate, fd);
+    return f;
+}
+
 static void VS_CC compFree(void *inst, VSCore *core, const VSAPI *vs) {
     (void)core;
     CompData *d = (CompData *)inst;
     vs->freeNode(d->node); vs->freeNode(d->super); vs->freeNode(d->vectors);
     mvx_compensate_destroy(d->cp);
     mvx_super_destroy(d->sup);
+    gate_free(&d->gate);
     free(d);
 }
 
@@ -1965,6 +2047,7 @@ static void VS_CC compCreate(const VSMap *in, VSMap *out, void *user, VSCore *co
     warm_barrier();
     (void)user;
     CompData *d = (CompData *)calloc(1, sizeof(*d));
+    gate_init(&d->gate);
     char err[1400] = "";
     mvx_compensate_args a;
     a.scbehavior = opt_int(in, "scbehavior", vs); a.thsad = opt_int64(in, "thsad", vs); a.thscd1 = opt_int64(in, "thscd1", vs); a.thscd2 = opt_int(in, "thscd2", vs);
@@ -2016,11 +2099,11 @@ static void VS_CC compCreate(const VSMap *in, VSMap *out, void *user, VSCore *co
 /* ------------------------------------------------------------------------------------------------ mv.BlockFPS */
 
 typedef struct FpsData { VSNode *node, *super, *mvbw, *mvfw; const VSVideoInfo *oldvi; VSVideoInfo vi; mvx_super *sup; SuperGeo geo; mvx_blockfps *bf;
-                         mvx_analysis_data bw, fw; ptrdiff_t pitch[3]; int blobSize; } FpsData;
+                         mvx_analysis_data bw, fw; ptrdiff_t pitch[3]; int blobSize; Gate gate; } FpsData;
 
 static int fps_min(int a, int b) { return a < b ? a : b; }
 
-static const VSFrame *VS_CC fpsGetFrame(int n, int reason, void *inst, void **fd, VSFrameContext *ctx, VSCore *core, const VSAPI *vs) {
+static const VSFrame *VS_CC fpsGetFrameUngated(int n, int reason, void *inst, void **fd, VSFrameContext *ctx, VSCore *core, const VSAPI *vs) {
     (void)fd;
     FpsData *d = (FpsData *)inst;
     int nleft, nright, time256;
@@ -2094,12 +2177,22 @@ static const VSFrame *VS_CC fpsGetFrame(int n, int reason, void *inst, void **fd
     return dst;
 }
 
+/* (the admission gate around the filter proper: arInitial takes the permit, whatever ends the request -- the frame, a filter error, arError -- returns it) */
+static const VSFrame *VS_CC fpsGetFrame(int n, int reason, void *inst, void **fd, VSFrameContext *ctx, VSCore *core, const VSAPI *vs) {
+    FpsData *d = (FpsData *)inst;
+    if (reason == arInitial) gate_enter(&d->gate, n, fd);
+    const VSFrame *f = fpsGetFrameUngated(n, reason, inst, fd, ctx, core, vs);
+    if (reason != arInitial || f) gate_leave(&d->gate, fd);
+    return f;
+}
+
 static void VS_CC fpsFree(void *inst, VSCore *core, const VSAPI *vs) {
     (void)core;
     FpsData *d = (FpsData *)inst;
     vs->freeNode(d->node); vs->freeNode(d->super); vs->freeNode(d->mvbw); vs->freeNode(d->mvfw);
     mvx_blockfps_destroy(d->bf);
     mvx_super_destroy(d->sup);
+    gate_free(&d->gate);
     free(d);
 }
 
@@ -2107,6 +2200,7 @@ static void VS_CC fpsCreate(const VSMap *in, VSMap *out, void *user, VSCore *cor
     warm_barrier();
     (void)user;
     FpsData *d = (FpsData *)calloc(1, sizeof(*d));
+    gate_init(&d->gate);
     char err[1400] = "";
     mvx_blockfps_args a;
     a.num = opt_int64(in, "num", vs); a.den = opt_int64(in, "den", vs); a.mode = opt_int(in, "mode", vs); a.blend = opt_int(in, "blend", vs);
