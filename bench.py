@@ -467,7 +467,7 @@ def other_configs():
 
 def vs_shell_leg(frames=640, threads=48):
     """The drop-in boundary in the driver's record (r5): the VapourSynth filter shell (libmvtools_vs.so) in the mini host, the cfg3 graph -- mv.Super ->
-    mv.Analyse x 6 -> mv.Degrain3, blksize 16, overlap 8 -- over `frames` 4K16 frames with `threads` request threads (r6: 48 -- a VapourSynth core starts one worker per logical CPU, 256 on the bench box; r5 used 32: MVX_VS_BENCH_THREADS) asking for OUTPUT frames in frame
+    mv.Analyse x 6 -> mv.Degrain3, blksize 16, overlap 8 -- over `frames` 4K16 frames with `threads` request threads (r6: one per logical CPU of the host, at most 256, as a VapourSynth core starts its workers -- 256 on the bench box; the shell's admission gate keeps 96 output frames in flight whatever the host asks for; r5 used 32: MVX_VS_BENCH_THREADS) asking for OUTPUT frames in frame
     order, in a child process of its own (this function IS that child: `bench.py --vs-shell-leg`).  The clip is generated on the device and written to a
     raw file the host reads; `fps_all_inclusive` = frames / wall clock from "clip in host memory" to "last output frame delivered": graph construction
     (which starts the first look-ahead windows), every upload / download over PCIe, and the shell's per-frame work included; `fps_steady` = frames / the
@@ -734,7 +734,7 @@ def main():
     args = ap.parse_args()
 
     if args.vs_shell_leg:
-        print(json.dumps(vs_shell_leg(args.vs_frames, int(os.environ.get("MVX_VS_BENCH_THREADS", "48")))))
+        print(json.dumps(vs_shell_leg(args.vs_frames, int(os.environ.get("MVX_VS_BENCH_THREADS", str(max(8, min(os.cpu_count() or 48, 256))))))))
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))

@@ -211,4 +211,15 @@ r6_vs_gate2() {
     done 2>&1 | tee $out/r6_vs_gate2.txt
 }
 
+r6_vs_build() {
+    # helper threads that upload a look-ahead window's source frames (MVX_VS_BUILD_THREADS, default 4): the bench's own shell leg (graph construction + request phase, default mode; one request thread per logical CPU)
+    for rep in 1 2; do
+        for b in 4 8 16; do
+            MVX_VS_BUILD_THREADS=$b timeout 600 python bench.py --vs-shell-leg 2>/dev/null | python -c "import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); l=d.get('lazy_super',{})
+print('rep $rep build_threads=$b threads', d.get('threads'), 'graph', d.get('graph_construction_s'), 'requests', d.get('request_phase_s'), 'all inclusive', round(d.get('fps_all_inclusive',0),1), 'fps steady', round(d.get('fps_steady',0),1), 'identical', d.get('identical_to_c_abi'), '| lazy', round(l.get('fps_all_inclusive',0),1), l.get('identical_to_c_abi'))"
+        done
+    done 2>&1 | tee $out/r6_vs_build_threads.txt
+}
+
 "r6_$1" "${@:2}"
