@@ -109,7 +109,8 @@ def test_vector_clip_through_the_shell_equals_the_oracle(tmp_path, oracle, faked
 def test_shell_under_sanitizers(tmp_path, oracle, sanitizer):
     """The plugin, the mini host and the test double rebuilt with -fsanitize=thread / =address (the "device" buffers are heap blocks here, so an
     out-of-bounds copy or a use of a freed device frame by the shell is a heap error the sanitizer sees): a Degrain3 graph with look-ahead
-    windows of 8 and a tiny "device" (constant eviction), 8 request threads -- no report, and the same bytes as the plain build's."""
+    windows of 8 and a tiny "device" (constant eviction), 8 request threads, the admission gate admitting three output frames at a time -- no report, and the same
+    bytes as the plain build's."""
     rt = subprocess.run(["gcc", "-print-file-name=lib%s.so" % ("tsan" if sanitizer == "thread" else "asan")], capture_output=True, text=True).stdout.strip()
     if not os.path.isabs(rt):
         pytest.skip("gcc has no %s sanitizer runtime here" % sanitizer)
@@ -126,12 +127,13 @@ def test_shell_under_sanitizers(tmp_path, oracle, sanitizer):
     frames = pl.moving_clip(w, h, bits, n, seed=8, noise=3)
     src, out = str(tmp_path / "in.raw"), str(tmp_path / "out.raw")
     _write_clip(src, frames)
-    env = dict(os.environ, LD_PRELOAD=rt + " " + fake, MVX_VS_LOOKAHEAD="8", MVX_FAKEDEV_MEM=str(3 << 20), MVX_VS_STATS="1",
+    env = dict(os.environ, LD_PRELOAD=rt + " " + fake, MVX_VS_LOOKAHEAD="8", MVX_FAKEDEV_MEM=str(3 << 20), MVX_VS_STATS="1", MVX_VS_MAX_INFLIGHT="3",  # (r6: eight threads at a gate of three)
                TSAN_OPTIONS="halt_on_error=0", ASAN_OPTIONS="detect_leaks=1:halt_on_error=1")  # (the graph is torn down at the end: what is still allocated then is a leak)
     r = subprocess.run([hst, plug, "run", "degrain3", src, str(w), str(h), str(bits), str(n), out, "a.blksize=16", "a.overlap=8", "x.threads=8", "x.order=frame", "x.free=1"],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "FREED" in r.stdout and "DONE" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]  # (x.free=1: every filter's free callback ran)
     assert "Sanitizer" not in r.stderr, r.stderr[-4000:]
+    assert "permits out" not in r.stderr, r.stderr[-2000:]  # (every admitted request returned its permit before the filters were freed)
     got = _read_frames(out, w, h, bits, n)
     want = _oracle_degrain(oracle, frames, w, h, bits, 3, 16, 8)
     assert all(np.array_equal(got[k][p], want[k][p]) for k in range(n) for p in range(3))

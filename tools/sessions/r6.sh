@@ -222,4 +222,16 @@ print('rep $rep build_threads=$b threads', d.get('threads'), 'graph', d.get('gra
     done 2>&1 | tee $out/r6_vs_build_threads.txt
 }
 
+r6_vs_gate_limit() {
+    # the gate's limit in both modes of mv.Super (default: frames to the host, PCIe-bound; lazy: pixels stay on the device), 256 request threads; 48 threads for reference
+    timeout 600 python tools/vs_4k_run.py 640 256 2>&1 | grep -v amdgpu.ids | tail -3 | cut -c1-300
+    for lazy in 0 1; do
+        for v in "32 256" "48 256" "64 256" "96 256" "128 256" "0 48"; do
+            set -- $v
+            r=$(VS_NOVERIFY=1 MVX_VS_SUPER_LAZY=$lazy MVX_VS_MAX_INFLIGHT=$1 timeout 300 python tools/vs_4k_run.py 640 $2 2>&1 | grep -E "minihost: output clip" | sed 's/.*order) //' | tr '\n' ' ')
+            echo "lazy=$lazy max_inflight=$1 threads=$2 request phase $r"
+        done
+    done 2>&1 | tee $out/r6_vs_gate_limit.txt
+}
+
 "r6_$1" "${@:2}"

@@ -1692,7 +1692,10 @@ static void gate_init(Gate *g) {
     g->limit = (int)env_long("MVX_VS_MAX_INFLIGHT", 96); /* (<= 0: no gate) */
     g->inflight = g->nwait = 0; g->done = 0;
 }
-static void gate_free(Gate *g) { pthread_mutex_destroy(&g->mu); }
+static void gate_free(Gate *g) {
+    if (g->inflight || g->nwait) fprintf(stderr, "mvtools_vs: admission gate freed with %d permits out, %d requests waiting\n", g->inflight, g->nwait); /* (a request that never ended: a bug here or in the host) */
+    pthread_mutex_destroy(&g->mu);
+}
 static GateWaiter *gate_lowest(const Gate *g) { /* mu held */
     GateWaiter *w = NULL;
     for (int i = 0; i < g->nwait; i++) if (!w || g->waiting[i]->n < w->n) w = g->waiting[i];
