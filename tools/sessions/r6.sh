@@ -234,4 +234,16 @@ r6_vs_gate_limit() {
     done 2>&1 | tee $out/r6_vs_gate_limit.txt
 }
 
+r6_vs_pad() {
+    # (experiment, removed from the tree: the switch no longer exists) the common source-frame range of a look-ahead window (MVX_VS_LOOKAHEAD_PAD, default 1) against every instance its own range (0): shell tests, then the bench's shell leg, three repeats
+    timeout 900 python -m pytest tests/test_vs_shim.py -x -q -m gpu 2>&1 | tail -2
+    for rep in 1 2 3; do
+        for pad in 1 0; do
+            MVX_VS_LOOKAHEAD_PAD=$pad timeout 600 python bench.py --vs-shell-leg 2>/dev/null | python -c "import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); l=d.get('lazy_super',{})
+print('rep $rep pad=$pad threads', d.get('threads'), 'graph', d.get('graph_construction_s'), 'requests', d.get('request_phase_s'), 'all inclusive', round(d.get('fps_all_inclusive',0),1), 'fps steady', round(d.get('fps_steady',0),1), 'identical', d.get('identical_to_c_abi'), '| lazy graph', l.get('graph_construction_s'), 'requests', l.get('request_phase_s'), 'all inclusive', round(l.get('fps_all_inclusive',0),1), l.get('identical_to_c_abi'))"
+        done
+    done 2>&1 | tee $out/r6_vs_lookahead_pad.txt
+}
+
 "r6_$1" "${@:2}"
