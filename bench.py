@@ -543,7 +543,8 @@ def vs_shell_leg(frames=640, threads=48):
             env = dict(os.environ, MVX_HOST_TIMES="1", GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES", "16"), **extra_env)
             t0 = time.time()
             r = subprocess.run([host, plugin, "run", "degrain3", src, str(w), str(h), str(bits), str(frames), outp, "a.blksize=16", "a.overlap=8",
-                                "x.threads=%d" % threads, "x.order=frame"], capture_output=True, text=True, env=env, timeout=600)
+                                "x.threads=%d" % threads, "x.order=frame"] + (["x.cache=%s" % os.environ["MVX_VS_BENCH_CACHE"]] if os.environ.get("MVX_VS_BENCH_CACHE") else []),
+                               capture_output=True, text=True, env=env, timeout=600)
             d = {"process_wall_s": round(time.time() - t0, 2), "rc": r.returncode}
             if os.environ.get("MVX_VS_KEEP_STDERR"):  # developer: the shell's statistics / window trace (MVX_VS_STATS=1, MVX_VS_TRACE=1) of this run
                 open(os.path.join(os.environ["MVX_VS_KEEP_STDERR"], "vs_shell_stderr_%s.txt" % ("lazy" if extra_env else "default")), "w").write(r.stderr)

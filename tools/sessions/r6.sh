@@ -246,4 +246,29 @@ print('rep $rep pad=$pad threads', d.get('threads'), 'graph', d.get('graph_const
     done 2>&1 | tee $out/r6_vs_lookahead_pad.txt
 }
 
+r6_vs_adata() {
+    # (experiment, removed from the tree: the switch no longer exists) consumers take the analysis data from this plugin's own mv.Analyse instance instead of reading frame 0 at creation (MVX_VS_ADATA_FROM_INSTANCE, default 1) against reading it (0):
+    # shell tests, then the bench's shell leg, three repeats
+    timeout 900 python -m pytest tests/test_vs_shim.py -x -q -m gpu 2>&1 | tail -2
+    for rep in 1 2 3; do
+        for on in 1 0; do
+            MVX_VS_ADATA_FROM_INSTANCE=$on timeout 600 python bench.py --vs-shell-leg 2>/dev/null | python -c "import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); l=d.get('lazy_super',{})
+print('rep $rep from_instance=$on threads', d.get('threads'), 'graph', d.get('graph_construction_s'), 'requests', d.get('request_phase_s'), 'all inclusive', round(d.get('fps_all_inclusive',0),1), 'fps steady', round(d.get('fps_steady',0),1), 'identical', d.get('identical_to_c_abi'), '| lazy graph', l.get('graph_construction_s'), 'requests', l.get('request_phase_s'), 'all inclusive', round(l.get('fps_all_inclusive',0),1), l.get('identical_to_c_abi'))"
+        done
+    done 2>&1 | tee $out/r6_vs_adata_from_instance.txt
+}
+
+r6_vs_cache() {
+    # the mini host's per-node frame cache in the bench's shell leg: unbounded (every one of the 640 131 MB super frames stays in host memory: the default so far) against 160 / 320 frames per node
+    # (a real core's caches are bounded; a recycled frame buffer costs no page faults)
+    for rep in 1 2; do
+        for c in "" 320 160; do
+            MVX_VS_BENCH_CACHE=$c timeout 600 python bench.py --vs-shell-leg 2>/dev/null | python -c "import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); l=d.get('lazy_super',{})
+print('rep $rep cache=${c:-all} threads', d.get('threads'), 'graph', d.get('graph_construction_s'), 'requests', d.get('request_phase_s'), 'all inclusive', round(d.get('fps_all_inclusive',0),1), 'fps steady', round(d.get('fps_steady',0),1), 'identical', d.get('identical_to_c_abi'), '| lazy graph', l.get('graph_construction_s'), 'requests', l.get('request_phase_s'), 'all inclusive', round(l.get('fps_all_inclusive',0),1), l.get('identical_to_c_abi'))"
+        done
+    done 2>&1 | tee $out/r6_vs_host_cache.txt
+}
+
 "r6_$1" "${@:2}"

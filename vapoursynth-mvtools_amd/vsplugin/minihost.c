@@ -203,6 +203,7 @@ static int VS_CC getFrameHeight(const VSFrame *f, int p) { return plane_h(f, p);
 
 struct VSNode { int refs; VSVideoInfo vi; VSFilterGetFrame getFrame; VSFilterFree freeFn; void *inst; const VSFrame **cache; unsigned char *busy; char name[32]; int ncached, lowest; };
 static int g_cache_limit; /* x.cache=N: a node keeps at most N frames (the lowest-numbered ones go first), 0 = all, like the bounded caches of a real core */
+static struct VSNode *g_uncapped; /* the graph's OUTPUT node keeps every frame whatever x.cache says: the result file is written from them after the timed interval (a client of a real core writes them as they arrive) */
 struct VSFrameContext { int n; struct { int n; VSNode *node; const VSFrame *f; } req[1024]; int nreq; char error[1024]; };
 
 static VSAPI g_api;
@@ -255,7 +256,7 @@ static const VSFrame *eval_frame(int n, VSNode *node, char *err, int errsz) {
     pthread_mutex_lock(&g_host_mu);
     if (out && !node->cache[n]) { node->cache[n] = out; ((VSFrame *)out)->refs++; node->ncached++; if (n < node->lowest) node->lowest = n; }
     if (node->busy) node->busy[n] = 0;
-    while (g_cache_limit > 0 && node->ncached > g_cache_limit && nev < 8) { /* drop the oldest frames (this one excepted) */
+    while (g_cache_limit > 0 && node != g_uncapped && node->ncached > g_cache_limit && nev < 8) { /* drop the oldest frames (this one excepted) */
         int i = node->lowest;
         while (i < node->vi.numFrames && (!node->cache[i] || i == n)) i++;
         if (i >= node->vi.numFrames) break;
@@ -679,6 +680,7 @@ int main(int argc, char **argv) {
     if (times) fprintf(stderr, "minihost: graph built at %.2f s after start\n", t0 - g_start);
     int frameOrder = 0; /* x.order=frame: the threads ask for OUTPUT frames only, as a client of a real core does (every upstream request is then made by the filters) */
     for (int i = 0; i < nextra; i++) if (!strcmp(extra[i], "x.order=frame")) frameOrder = 1;
+    if (frameOrder) g_uncapped = out;
     if (threads > 1 && frameOrder) {
         prefetch_parallel(threads, nframes, &out, 1);
         if (times) { fprintf(stderr, "minihost: output clip (frame order) %.2f s\n", now_s() - t0); t0 = now_s(); }
