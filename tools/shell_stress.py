@@ -8,7 +8,7 @@ the fake "device" (i.e. how hard the frame cache is squeezed) are drawn at rando
     python tools/shell_stress.py [--seed S] [--runs N] [--sanitize thread|address]
 
 --sanitize rebuilds plugin, mini host and double with that sanitizer (into a temporary directory) and also fails on any sanitizer report.
-Round 3: 300 plain runs and 80 ThreadSanitizer runs without a finding."""
+Round 3: 300 plain runs and 80 ThreadSanitizer runs without a finding.  Round 6 (with the admission gate drawn at random too): see profiles/r6_shell_stress.txt."""
 import argparse
 import os
 import random
@@ -54,13 +54,14 @@ for it in range(args.runs):
     la, depth, threads = rnd.choice([0, 1, 2, 3, 5, 8, 16, 128]), rnd.choice([1, 2, 3]), rnd.choice([1, 2, 3, 8, 32])
     mem, order, cache = rnd.choice([1 << 20, 3 << 20, 64 << 20]), rnd.choice([True, False]), rnd.choice([None, 4, 16])
     w, h = rnd.choice([(160, 96), (128, 96), (192, 112)])
-    cfg = "%dx%d %d-bit Degrain%d %d frames, look-ahead %d x %d, %d threads%s, host cache %s, device %d MiB" % (
-        w, h, bits, radius, n, la, depth, threads, " (frame order)" if order and threads > 1 else "", cache, mem >> 20)
+    gate = rnd.choice([0, 1, 2, 5, 96])  # r6: the admission gate of the consuming filters (MVX_VS_MAX_INFLIGHT)
+    cfg = "%dx%d %d-bit Degrain%d %d frames, look-ahead %d x %d, %d threads%s, host cache %s, device %d MiB, gate %d" % (
+        w, h, bits, radius, n, la, depth, threads, " (frame order)" if order and threads > 1 else "", cache, mem >> 20, gate)
     frames = pl.moving_clip(w, h, bits, n, seed=1000 * args.seed + it, noise=3)
     src, out = os.path.join(tmp, "in.raw"), os.path.join(tmp, "out.raw")
     _write_clip(src, frames)
     extra = ["a.blksize=16", "a.overlap=8", "x.threads=%d" % threads, "x.free=1"] + (["x.order=frame"] if order and threads > 1 else []) + (["x.cache=%d" % cache] if cache else [])
-    env = dict(os.environ, LD_PRELOAD=preload, MVX_VS_LOOKAHEAD=str(la), MVX_VS_LOOKAHEAD_DEPTH=str(depth), MVX_FAKEDEV_MEM=str(mem), TSAN_OPTIONS="halt_on_error=0",
+    env = dict(os.environ, LD_PRELOAD=preload, MVX_VS_LOOKAHEAD=str(la), MVX_VS_LOOKAHEAD_DEPTH=str(depth), MVX_FAKEDEV_MEM=str(mem), MVX_VS_MAX_INFLIGHT=str(gate), TSAN_OPTIONS="halt_on_error=0",
                ASAN_OPTIONS="detect_leaks=1")
     t0 = time.time()
     try:
@@ -72,6 +73,8 @@ for it in range(args.runs):
         verdict = "FAIL "
     elif "Sanitizer" in r.stderr:
         verdict = "SANIT"
+    elif "permits out" in r.stderr:
+        verdict = "GATE "
     else:
         got, want = _read_frames(out, w, h, bits, n), _oracle_degrain(oracle, frames, w, h, bits, radius, 16, 8)
         if not all(np.array_equal(got[k][p], want[k][p]) for k in range(n) for p in range(3)):
