@@ -330,6 +330,13 @@ DEGRAIN_CASES = [
     (128, 96, 16, 2, {}, dict(blksize=16, overlap=0), dict(limit=2, limitc=4)),
     (128, 96, 16, 1, {}, dict(blksize=16, overlap=0), dict(plane=0)),
     (128, 96, 8, 1, {}, dict(blksize=16, overlap=0), dict(thscd1=20, thscd2=10)),
+    # r6: the plan tile of the cell kernel (six or more references: Degrain3-6) on frames several workgroup tiles wide (a tile is 32 cells x 8 rows: the first block column
+    # of a tile is the one that starts LEFT of its first cell), ragged at the right and bottom edges, 8- and 16-bit, with the limits, one plane, unusable references
+    (544, 168, 8, 3, {}, dict(blksize=16, overlap=8), {}),                     # 68 x 21 cells of 8: three tile columns, the last one partial
+    (548, 172, 16, 3, {}, dict(blksize=8, overlap=4), dict(limit=3, limitc=5)),  # 137 x 43 cells of 4 (chroma: of 2), width and height not multiples of the cell
+    (400, 200, 16, 6, {}, dict(blksize=16, overlap=8), dict(thscd1=20, thscd2=10)),  # twelve references, all unusable: every load goes to the `safe` plane
+    (400, 200, 8, 4, {}, dict(blksize=16, overlap=8), dict(plane=0)),
+    (576, 160, 16, 3, {}, dict(blksize=32, blksizev=16, overlap=16, overlapv=8), {}),  # 16-sample cells, block rows of 8
 ]
 
 
