@@ -271,4 +271,37 @@ print('rep $rep cache=${c:-all} threads', d.get('threads'), 'graph', d.get('grap
     done 2>&1 | tee $out/r6_vs_host_cache.txt
 }
 
+r6_vs_after() {
+    # why the shell leg is ~5 % slower inside the full bench command than on its own: the leg alone, right after another bench child run, the same with a longer pause before the hosts start, after a hot cfg3 run
+    leg() { python bench.py --vs-shell-leg 2>/dev/null | python -c "import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); l=d.get('lazy_super',{})
+print('$1: graph', d.get('graph_construction_s'), 'requests', d.get('request_phase_s'), 'all inclusive', round(d.get('fps_all_inclusive',0),1), '| lazy', round(l.get('fps_all_inclusive',0),1))"; }
+    {
+    leg "alone (fresh box)"
+    timeout 600 python bench.py --config hd16 --no-cpu --no-traffic --no-others --no-vs --steps 8 --warmup 2 > /dev/null 2>&1; leg "right after a hd16 child run"
+    timeout 600 python bench.py --config hd16 --no-cpu --no-traffic --no-others --no-vs --steps 8 --warmup 2 > /dev/null 2>&1; MVX_VS_SETTLE_S=20 leg "after a hd16 child run, 20 s pause before each host"
+    timeout 600 python bench.py --no-cpu --no-traffic --no-others --no-vs --steps 40 --warmup 5 > /dev/null 2>&1; leg "right after 45 cfg3 steps (hot GPU)"
+    leg "alone again"
+    } 2>&1 | tee $out/r6_vs_leg_after_other_runs.txt
+}
+
+r6_vs_order() {
+    # (the MVX_BENCH_VS_FIRST switch was removed from bench.py after this run) the shell leg inside the full bench command: after the other configurations' child runs (the default order) against before them
+    for v in "" 1; do
+        MVX_BENCH_VS_FIRST=$v timeout 1200 python bench.py --steps 5 --warmup 2 2>/dev/null | grep '^{' | tail -1 | python -c "import sys,json
+d=json.loads(sys.stdin.read()); v=d.get('vs_shell',{}); l=v.get('lazy_super',{})
+print('vs first=${v:-0}:', round(d['value'],1), 'fps | shell graph', v.get('graph_construction_s'), 'requests', v.get('request_phase_s'), 'all inclusive', round(v.get('fps_all_inclusive',0),1), '| lazy', round(l.get('fps_all_inclusive',0),1), '| others', {k:round(x.get('fps',0),1) for k,x in d.get('other_configs',{}).items()})"
+    done 2>&1 | tee $out/r6_vs_leg_order_in_bench.txt
+}
+
+r6_vs_trim() {
+    # (the malloc_trim / MVX_BENCH_NO_TRIM code was removed from bench.py after this run) the shell leg inside the full bench command with the parent's freed host memory returned to the kernel first (malloc_trim) against without
+    for v in "" 1; do
+        MVX_BENCH_NO_TRIM=$v timeout 1200 python bench.py --steps 5 --warmup 2 2>/dev/null | grep '^{' | tail -1 | python -c "import sys,json
+d=json.loads(sys.stdin.read()); v=d.get('vs_shell',{}); l=v.get('lazy_super',{})
+print('no trim=${v:-0}:', round(d['value'],1), 'fps | shell graph', v.get('graph_construction_s'), 'requests', v.get('request_phase_s'), 'all inclusive', round(v.get('fps_all_inclusive',0),1), '| lazy', round(l.get('fps_all_inclusive',0),1))"
+        grep -E "MemFree|MemAvailable|^Cached" /proc/meminfo | tr '\n' ' '; echo; numactl --hardware 2>/dev/null | grep -E "available|free" | tr '\n' ' '; echo
+    done 2>&1 | tee $out/r6_vs_leg_parent_trim.txt
+}
+
 "r6_$1" "${@:2}"
