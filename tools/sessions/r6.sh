@@ -304,4 +304,22 @@ print('no trim=${v:-0}:', round(d['value'],1), 'fps | shell graph', v.get('graph
     done 2>&1 | tee $out/r6_vs_leg_parent_trim.txt
 }
 
+r6_vs_ctx() {
+    # does another process that merely HOLDS a HIP context (as bench.py's parent does while its child runs work) slow the shell leg down?
+    leg() { python bench.py --vs-shell-leg 2>/dev/null | python -c "import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); l=d.get('lazy_super',{})
+print('$1: graph', d.get('graph_construction_s'), 'requests', d.get('request_phase_s'), 'all inclusive', round(d.get('fps_all_inclusive',0),1), '| lazy', round(l.get('fps_all_inclusive',0),1))"; }
+    {
+    leg "alone"
+    python -c "import torch,time; x=torch.zeros(1,device='cuda'); s=[torch.cuda.Stream() for _ in range(3)]; [torch.zeros(1,device='cuda') for _ in s]; torch.cuda.synchronize(); time.sleep(400)" &
+    idle=$!
+    sleep 8
+    leg "beside an idle process that holds a HIP context and three streams"
+    leg "the same again"
+    kill $idle
+    sleep 2
+    leg "alone again"
+    } 2>&1 | tee $out/r6_vs_leg_beside_idle_context.txt
+}
+
 "r6_$1" "${@:2}"
